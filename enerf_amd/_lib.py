@@ -1,0 +1,136 @@
+"""ctypes binding of libenerf_hip.so (C ABI in include/enerf_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libenerf_hip.so")
+
+_c = ctypes
+_vp, _u32, _f32, _int, _sz = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c.c_size_t
+
+# name -> argtypes (restype is int for all of these)
+SIGNATURES = {
+    "enerf_near_far_from_aabb": [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
+    "enerf_polar_from_ray": [_vp, _vp, _f32, _u32, _vp, _vp],
+    "enerf_morton3D": [_vp, _u32, _vp, _vp],
+    "enerf_morton3D_invert": [_vp, _u32, _vp, _vp],
+    "enerf_packbits": [_vp, _u32, _f32, _vp, _vp],
+    "enerf_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _u32, _vp],
+    "enerf_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "enerf_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "enerf_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _u32, _vp],
+    "enerf_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "enerf_compact_rays": [_u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "enerf_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int,
+                                  _int, _vp],
+    "enerf_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp,
+                                   _u32, _int, _int, _vp],
+    "enerf_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _int, _vp, _int, _vp],
+    "enerf_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _int, _vp],
+    "enerf_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _int, _vp],
+    "enerf_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _int, _vp],
+    "enerf_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp,
+                             _int, _vp],
+    "enerf_allocate_splitk": [_sz],
+    "enerf_free_splitk": [],
+    "enerf_prof_enable": [_int],
+    "enerf_prof_reset": [],
+    "enerf_prof_read": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],
+    "enerf_abi_version": [],
+}
+
+F32, F16, BF16 = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    """Load libenerf_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"enerf_amd: {LIB_PATH} not found. Build it with `python -m enerf_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the hot path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, sig in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = sig
+            fn.restype = _int
+        l.enerf_last_error.restype = _c.c_char_p
+        l.enerf_last_error.argtypes = []
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().enerf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t):
+    import torch
+    try:
+        return {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}")
+
+
+# ---- tensor argument checks mirroring the reference's CHECK_* macros (gridencoder.cu:15-18 etc.) ----
+def check_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def check_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def check_floating(t, name):
+    import torch
+    if t.dtype not in (torch.float32, torch.float16, torch.float64):
+        raise RuntimeError(f"{name} must be a floating tensor")
+
+
+def check_int(t, name):
+    import torch
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+
+
+def ptr(t):
+    return t.data_ptr()
+
+
+class prof:
+    """Thin Python face of the enerf_prof_* hooks (used by bench.py)."""
+
+    KERNELS = {"grid_fwd": 0, "grid_bwd": 1, "march_train": 2, "composite_fwd": 3, "composite_bwd": 4, "sh_fwd": 5,
+               "ffmlp_fwd": 6, "ffmlp_bwd": 7, "march_infer": 8, "composite_infer": 9}
+
+    @staticmethod
+    def enable(on=True):
+        lib().enerf_prof_enable(1 if on else 0)
+
+    @staticmethod
+    def reset():
+        lib().enerf_prof_reset()
+
+    @staticmethod
+    def read(name):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_uint64(0)
+        check(lib().enerf_prof_read(prof.KERNELS[name], ctypes.byref(ms), ctypes.byref(n)), "prof_read")
+        return ms.value, n.value

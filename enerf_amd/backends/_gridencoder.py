@@ -1,0 +1,47 @@
+"""`_gridencoder`: grid_encode_forward / grid_encode_backward with the reference's pybind signature
+(gridencoder/src/bindings.cpp:5-8), plus keyword-only `layout` (0 = [L,B,C] as the reference, 1 = [B,L*C])."""
+from .. import _lib as L
+
+
+def _chk(t, name, floating=True):
+    L.check_cuda(t, name)
+    L.check_contiguous(t, name)
+    if floating:
+        L.check_floating(t, name)
+    else:
+        L.check_int(t, name)
+    return t.data_ptr()
+
+
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H, calc_grad_inputs, dy_dx, gridtype,
+                        *, layout=0):
+    import torch
+    if inputs.dtype != torch.float32:
+        raise RuntimeError("inputs must be a float32 tensor (gridencoder.cu:437 reads inputs as float*)")
+    dt = L.dtype_code(embeddings)
+    if outputs.dtype != embeddings.dtype or dy_dx.dtype != embeddings.dtype:
+        raise RuntimeError("outputs/dy_dx must have the dtype of embeddings")
+    L.check(L.lib().enerf_grid_encode_forward(_chk(inputs, "inputs"), _chk(embeddings, "embeddings"),
+                                              _chk(offsets, "offsets", False), _chk(outputs, "outputs"), int(B),
+                                              int(D), int(C), int(L_), float(S), int(H), int(bool(calc_grad_inputs)),
+                                              _chk(dy_dx, "dy_dx"), int(gridtype), dt, int(layout),
+                                              L.stream_handle()), "grid_encode_forward")
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L_, S, H, calc_grad_inputs,
+                         dy_dx, grad_inputs, gridtype, *, layout=0):
+    import torch
+    if inputs.dtype != torch.float32:
+        raise RuntimeError("inputs must be a float32 tensor")
+    dt = L.dtype_code(grad)
+    for t, n in ((embeddings, "embeddings"), (grad_embeddings, "grad_embeddings"), (dy_dx, "dy_dx"),
+                 (grad_inputs, "grad_inputs")):
+        if t.dtype != grad.dtype:
+            raise RuntimeError(f"{n} must have the dtype of grad")
+    L.check(L.lib().enerf_grid_encode_backward(_chk(grad, "grad"), _chk(inputs, "inputs"),
+                                               _chk(embeddings, "embeddings"), _chk(offsets, "offsets", False),
+                                               _chk(grad_embeddings, "grad_embeddings"), int(B), int(D), int(C),
+                                               int(L_), float(S), int(H), int(bool(calc_grad_inputs)),
+                                               _chk(dy_dx, "dy_dx"), _chk(grad_inputs, "grad_inputs"),
+                                               int(gridtype), dt, int(layout), L.stream_handle()),
+            "grid_encode_backward")

@@ -1,0 +1,107 @@
+"""`_raymarching`: same 11 functions as raymarching/src/bindings.cpp:5-20 of the reference, same positional
+arguments, tensors pre-allocated by the caller; every call forwards to libenerf_hip.so on torch's current stream."""
+from .. import _lib as L
+
+
+def _f32(t, name):
+    import torch
+    L.check_cuda(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float32 tensor (raymarching wrappers cast_inputs=torch.float32)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    return t.data_ptr()
+
+
+def _i32(t, name):
+    L.check_cuda(t, name)
+    L.check_int(t, name)
+    L.check_contiguous(t, name)
+    return t.data_ptr()
+
+
+def _u8(t, name):
+    import torch
+    L.check_cuda(t, name)
+    if t.dtype != torch.uint8:
+        raise RuntimeError(f"{name} must be a uint8 tensor")
+    L.check_contiguous(t, name)
+    return t.data_ptr()
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+    L.check(L.lib().enerf_near_far_from_aabb(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(aabb, "aabb"),
+                                             int(N), float(min_near), _f32(nears, "nears"), _f32(fars, "fars"),
+                                             L.stream_handle()), "near_far_from_aabb")
+
+
+def polar_from_ray(rays_o, rays_d, radius, N, coords):
+    L.check(L.lib().enerf_polar_from_ray(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), float(radius), int(N),
+                                         _f32(coords, "coords"), L.stream_handle()), "polar_from_ray")
+
+
+def morton3D(coords, N, indices):
+    L.check(L.lib().enerf_morton3D(_i32(coords, "coords"), int(N), _i32(indices, "indices"), L.stream_handle()),
+            "morton3D")
+
+
+def morton3D_invert(indices, N, coords):
+    L.check(L.lib().enerf_morton3D_invert(_i32(indices, "indices"), int(N), _i32(coords, "coords"),
+                                          L.stream_handle()), "morton3D_invert")
+
+
+def packbits(grid, N, density_thresh, bitfield):
+    L.check(L.lib().enerf_packbits(_f32(grid, "grid"), int(N), float(density_thresh), _u8(bitfield, "bitfield"),
+                                   L.stream_handle()), "packbits")
+
+
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                     rays, counter, perturb):
+    L.check(L.lib().enerf_march_rays_train(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
+                                           float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
+                                           int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
+                                           _f32(dirs, "dirs"), _f32(deltas, "deltas"), _i32(rays, "rays"),
+                                           _i32(counter, "counter"), int(perturb), L.stream_handle()),
+            "march_rays_train")
+
+
+def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image):
+    L.check(L.lib().enerf_composite_rays_train_forward(_f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"),
+                                                       _f32(deltas, "deltas"), _i32(rays, "rays"), int(M), int(N),
+                                                       _f32(weights_sum, "weights_sum"), _f32(depth, "depth"),
+                                                       _f32(image, "image"), L.stream_handle()),
+            "composite_rays_train_forward")
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                  grad_sigmas, grad_rgbs):
+    L.check(L.lib().enerf_composite_rays_train_backward(
+        _f32(grad_weights_sum, "grad_weights_sum"), _f32(grad_image, "grad_image"), _f32(sigmas, "sigmas"),
+        _f32(rgbs, "rgbs"), _f32(deltas, "deltas"), _i32(rays, "rays"), _f32(weights_sum, "weights_sum"),
+        _f32(image, "image"), int(M), int(N), _f32(grad_sigmas, "grad_sigmas"), _f32(grad_rgbs, "grad_rgbs"),
+        L.stream_handle()), "composite_rays_train_backward")
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
+               fars, xyzs, dirs, deltas, perturb):
+    L.check(L.lib().enerf_march_rays(int(n_alive), int(n_step), _i32(rays_alive, "rays_alive"),
+                                     _f32(rays_t, "rays_t"), _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"),
+                                     float(bound), float(dt_gamma), int(max_steps), int(C), int(H), _u8(grid, "grid"),
+                                     _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
+                                     _f32(dirs, "dirs"), _f32(deltas, "deltas"), int(perturb), L.stream_handle()),
+            "march_rays")
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    L.check(L.lib().enerf_composite_rays(int(n_alive), int(n_step), _i32(rays_alive, "rays_alive"),
+                                         _f32(rays_t, "rays_t"), _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"),
+                                         _f32(deltas, "deltas"), _f32(weights_sum, "weights_sum"),
+                                         _f32(depth, "depth"), _f32(image, "image"), L.stream_handle()),
+            "composite_rays")
+
+
+def compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter):
+    L.check(L.lib().enerf_compact_rays(int(n_alive), _i32(rays_alive, "rays_alive"),
+                                       _i32(rays_alive_old, "rays_alive_old"), _f32(rays_t, "rays_t"),
+                                       _f32(rays_t_old, "rays_t_old"), _i32(alive_counter, "alive_counter"),
+                                       L.stream_handle()), "compact_rays")

@@ -1,0 +1,81 @@
+// common.h -- shared host/device helpers for libenerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/enerf_hip.h"
+
+namespace enerf {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+inline int check_hip(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define ENERF_BADARG(...)            \
+    do {                             \
+        enerf::set_error(__VA_ARGS__); \
+        return ENERF_E_BADARG;       \
+    } while (0)
+
+#define ENERF_LAUNCH_CHECK(name)                                   \
+    do {                                                           \
+        int _e = enerf::check_hip(hipGetLastError(), name);        \
+        if (_e) return _e;                                         \
+    } while (0)
+
+// ---- per-kernel-family event timing (include/enerf_hip.h: enerf_prof_*) ---
+struct ProfScope {
+    int id;
+    hipStream_t s;
+    void* slot;
+    ProfScope(int kernel_id, hipStream_t stream);
+    ~ProfScope();
+};
+
+// ---- workspace owned by the library (grow-only, per process) --------------
+// Returns a device buffer of at least `bytes`; nullptr on failure.  Slots are independent.
+void* workspace(int slot, size_t bytes);
+enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_SLOTS = 4 };
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- wave-level primitives (wave64) ----------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = (uint32_t)__shfl_up((int)v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
+
+}  // namespace enerf

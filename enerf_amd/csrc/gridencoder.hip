@@ -1,0 +1,416 @@
+// gridencoder.hip -- multiresolution hash / tiled grid encoder for gfx950.
+//
+// Replaces gridencoder/src/gridencoder.cu of the reference (grid_encode_forward / grid_encode_backward).
+//
+// MI355X mapping
+//  * One thread per (point, level), 256 points per workgroup.  The flat workgroup id is decoded so that the
+//    workgroups resident on XCD k (observed placement: id % 8) all work on level k, then on level k+8: each
+//    XCD's private 4 MiB L2 then holds one level's table (hashed levels are exactly 4 MiB of fp32 pairs) while
+//    the 256 MiB Infinity Cache holds the whole 52 MB table.  A different placement changes speed only.
+//  * Per-level scale / resolution are computed on the host (glibc exp2f, ceil) and passed by value, so the
+//    uint32 index arithmetic is identical to the CPU oracle's; the kernel never calls exp2f.
+//  * A corner's C features are fetched with one C*sizeof(T)-byte load (8 B for the fp32 C=2 configuration).
+//  * Backward scatters with hardware float atomics (global_atomic_add_f32, -munsafe-fp-atomics) or packed
+//    half2 atomics for fp16 tables.
+//
+// Compiled with -ffp-contract=off; fused multiply-adds are explicit.
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+#include "common.h"
+
+using namespace enerf;
+
+namespace {
+
+constexpr int kMaxLevels = 32;
+constexpr int kPtsPerBlock = 256;
+
+struct LevelTab {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+template <typename T, int C>
+struct alignas((sizeof(T) * C) > 16 ? 16 : (sizeof(T) * C)) Feat {
+    T v[C];
+};
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(__half v) { return __half2float(v); }
+template <typename T>
+__device__ __forceinline__ T from_f(float v);
+template <>
+__device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
+
+template <int D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t (&p)[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) r ^= p[i] * primes[i];
+    return r;
+}
+
+// row index (not yet multiplied by C) of a grid vertex
+template <int D>
+__device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution,
+                                             const uint32_t (&p)[D]) {
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += p[d] * stride;
+            stride *= (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(p);
+    return index % hashmap_size;
+}
+
+// XCD-aware decode of the flat workgroup id -> (level, chunk of points)
+__device__ __forceinline__ bool decode_block(uint32_t nchunks, uint32_t L, uint32_t& level, uint32_t& chunk) {
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u;
+    const uint32_t j = bid >> 3;
+    level = xcd + 8u * (j / nchunks);
+    chunk = j % nchunks;
+    return level < L;
+}
+
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                           const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+                                                           uint32_t B, uint32_t L, LevelTab tab, bool calc_grad_inputs,
+                                                           T* __restrict__ dy_dx, uint32_t gridtype, int out_layout,
+                                                           uint32_t nchunks) {
+    uint32_t level, chunk;
+    if (!decode_block(nchunks, L, level, chunk)) return;
+    const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
+    if (b >= B) return;
+
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = tab.scale[level];
+    const uint32_t resolution = tab.resolution[level];
+    const Feat<T, C>* __restrict__ rows = reinterpret_cast<const Feat<T, C>*>(grid) + off0;
+
+    float in[D];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        oob |= (in[d] < 0 || in[d] > 1);
+    }
+    Feat<T, C>* out = reinterpret_cast<Feat<T, C>*>(outputs) +
+                      (out_layout == 0 ? (size_t)level * B + b : (size_t)b * L + level);
+    T* jac = calc_grad_inputs ? dy_dx + ((size_t)b * L + level) * D * C : nullptr;
+    if (oob) {
+        Feat<T, C> z;
+#pragma unroll
+        for (int c = 0; c < C; c++) z.v[c] = from_f<T>(0.0f);
+        *out = z;
+        if (jac) {
+#pragma unroll
+            for (int i = 0; i < D * C; i++) jac[i] = from_f<T>(0.0f);
+        }
+        return;
+    }
+
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = fmaf(in[d], scale, 0.5f);
+        const float fl = floorf(pos[d]);
+        pos_grid[d] = (uint32_t)fl;
+        pos[d] -= (float)pos_grid[d];
+    }
+
+    // issue all 2^D gathers before using any of them
+    Feat<T, C> f[1 << D];
+    float w[1 << D];
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float wi = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) {
+                wi *= 1 - pos[d];
+                pgl[d] = pos_grid[d];
+            } else {
+                wi *= pos[d];
+                pgl[d] = pos_grid[d] + 1;
+            }
+        }
+        w[idx] = wi;
+        f[idx] = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+    }
+    float res[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) res[c] = 0;
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) res[c] = fmaf(w[idx], to_f(f[idx].v[c]), res[c]);
+    }
+    Feat<T, C> o;
+#pragma unroll
+    for (int c = 0; c < C; c++) o.v[c] = from_f<T>(res[c]);
+    *out = o;
+
+    if (jac) {
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+            float rg[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) rg[c] = 0;
+#pragma unroll
+            for (int idx = 0; idx < (1 << (D - 1)); idx++) {
+                float wi = scale;
+                uint32_t pgl[D];
+#pragma unroll
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? (nd + 1) : nd;
+                    if ((idx & (1 << nd)) == 0) {
+                        wi *= 1 - pos[d];
+                        pgl[d] = pos_grid[d];
+                    } else {
+                        wi *= pos[d];
+                        pgl[d] = pos_grid[d] + 1;
+                    }
+                }
+                pgl[gd] = pos_grid[gd];
+                const Feat<T, C> fl_ = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+                pgl[gd] = pos_grid[gd] + 1;
+                const Feat<T, C> fr_ = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+#pragma unroll
+                for (int c = 0; c < C; c++) rg[c] = fmaf(wi, to_f(fr_.v[c]) - to_f(fl_.v[c]), rg[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) jac[gd * C + c] = from_f<T>(rg[c]);
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void scatter_add(float* row, float w, const float (&g)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; c++) atomicAdd(row + c, w * g[c]);
+}
+template <int C>
+__device__ __forceinline__ void scatter_add(__half* row, float w, const float (&g)[C]) {
+    if constexpr (C % 2 == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            const __half2 v = __halves2half2(__float2half(w * g[c]), __float2half(w * g[c + 1]));
+            unsafeAtomicAdd(reinterpret_cast<__half2*>(row + c), v);
+        }
+    } else {
+        // C == 1 with a half table: 16-bit CAS on the containing dword (slow path; the reference warns about it too)
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            __half* addr = row + c;
+            unsigned int* base = reinterpret_cast<unsigned int*>(reinterpret_cast<uintptr_t>(addr) & ~uintptr_t(3));
+            const bool hi = (reinterpret_cast<uintptr_t>(addr) & 2) != 0;
+            unsigned int old = *base, assumed;
+            do {
+                assumed = old;
+                const unsigned short cur = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+                const __half sum = __float2half(__half2float(__ushort_as_half(cur)) + w * g[c]);
+                const unsigned int s = (unsigned int)__half_as_ushort(sum);
+                const unsigned int repl = hi ? ((assumed & 0x0000ffffu) | (s << 16)) : ((assumed & 0xffff0000u) | s);
+                old = atomicCAS(base, assumed, repl);
+            } while (old != assumed);
+        }
+    }
+}
+
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                           const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                           uint32_t B, uint32_t L, LevelTab tab, uint32_t gridtype,
+                                                           int grad_layout, uint32_t nchunks) {
+    uint32_t level, chunk;
+    if (!decode_block(nchunks, L, level, chunk)) return;
+    const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
+    if (b >= B) return;
+
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = tab.scale[level];
+    const uint32_t resolution = tab.resolution[level];
+    T* rows = grad_grid + (size_t)off0 * C;
+
+    float in[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        in[d] = inputs[(size_t)b * D + d];
+        if (in[d] < 0 || in[d] > 1) return;  // grad_grid is pre-zeroed
+    }
+    float pos[D];
+    uint32_t pos_grid[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = fmaf(in[d], scale, 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+    }
+    const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(grad)[grad_layout == 0 ? (size_t)level * B + b
+                                                                                     : (size_t)b * L + level];
+    float g[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) g[c] = to_f(gv.v[c]);
+
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float wi = 1;
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) {
+                wi *= 1 - pos[d];
+                pgl[d] = pos_grid[d];
+            } else {
+                wi *= pos[d];
+                pgl[d] = pos_grid[d] + 1;
+            }
+        }
+        const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+        scatter_add<C>(rows + (size_t)row * C, wi, g);
+    }
+}
+
+// grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (gridencoder.cu:314-340)
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ grad, const T* __restrict__ dy_dx,
+                                                        T* __restrict__ grad_inputs, uint32_t B, uint32_t L,
+                                                        int grad_layout) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D;
+    const uint32_t d = t - b * D;
+    const T* jac = dy_dx + (size_t)b * L * D * C;
+    float result = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        const T* g = grad + (grad_layout == 0 ? ((size_t)l * B + b) * C : ((size_t)b * L + l) * C);
+#pragma unroll
+        for (int c = 0; c < C; c++) result = fmaf(to_f(g[c]), to_f(jac[((size_t)l * D + d) * C + c]), result);
+    }
+    grad_inputs[t] = from_f<T>(result);
+}
+
+int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H) {
+    if (L == 0 || L > kMaxLevels) return -1;
+    for (uint32_t l = 0; l < L; l++) {
+        // gridencoder.cu:124-126: fp32 exp2f, fp32 multiply/subtract, ceil
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;
+        tab.scale[l] = scale;
+        tab.resolution[l] = (uint32_t)ceil(scale) + 1;
+    }
+    return 0;
+}
+
+template <typename T, int D>
+int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
+               const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s) {
+    const uint32_t nchunks = div_up(B, kPtsPerBlock);
+    const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
+#define ENERF_GF(CC)                                                                                              \
+    k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, \
+                                                          gridtype, layout, nchunks)
+    switch (C) {
+        case 1: ENERF_GF(1); break;
+        case 2: ENERF_GF(2); break;
+        case 4: ENERF_GF(4); break;
+        case 8: ENERF_GF(8); break;
+        default: ENERF_BADARG("GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+#undef ENERF_GF
+    return 0;
+}
+
+template <typename T, int D>
+int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* grad_emb, uint32_t B, uint32_t C,
+               uint32_t L, const LevelTab& tab, bool calc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
+               int layout, hipStream_t s) {
+    const uint32_t nchunks = div_up(B, kPtsPerBlock);
+    const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
+#define ENERF_GB(CC)                                                                                             \
+    do {                                                                                                         \
+        k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, gridtype, \
+                                                              layout, nchunks);                                  \
+        if (calc)                                                                                                \
+            k_grid_input_bwd<T, D, CC><<<div_up(B * D, 256), 256, 0, s>>>(grad, dy_dx, grad_inputs, B, L, layout); \
+    } while (0)
+    switch (C) {
+        case 1: ENERF_GB(1); break;
+        case 2: ENERF_GB(2); break;
+        case 4: ENERF_GB(4); break;
+        case 8: ENERF_GB(8); break;
+        default: ENERF_BADARG("GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+#undef ENERF_GB
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                              void* dy_dx, uint32_t gridtype, int dtype, int out_layout, enerf_stream_t stream) {
+    if (B == 0) return 0;
+    LevelTab tab;
+    if (fill_level_tab(tab, L, S, H)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
+    if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_GRID_FWD, s);
+    int rc = 0;
+    const bool calc = calc_grad_inputs != 0;
+    if (dtype == ENERF_F32) {
+        if (D == 3) rc = launch_fwd<float, 3>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, calc, (float*)dy_dx, gridtype, out_layout, s);
+        else if (D == 2) rc = launch_fwd<float, 2>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, calc, (float*)dy_dx, gridtype, out_layout, s);
+        else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
+    } else {
+        if (D == 3) rc = launch_fwd<__half, 3>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, C, L, tab, calc, (__half*)dy_dx, gridtype, out_layout, s);
+        else if (D == 2) rc = launch_fwd<__half, 2>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, C, L, tab, calc, (__half*)dy_dx, gridtype, out_layout, s);
+        else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
+    }
+    if (rc) return rc;
+    ENERF_LAUNCH_CHECK("grid_encode_forward");
+    return 0;
+}
+
+int enerf_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                               void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                               int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int dtype,
+                               int grad_layout, enerf_stream_t stream) {
+    (void)embeddings;
+    if (B == 0) return 0;
+    LevelTab tab;
+    if (fill_level_tab(tab, L, S, H)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
+    if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_GRID_BWD, s);
+    int rc = 0;
+    const bool calc = calc_grad_inputs != 0;
+    if (dtype == ENERF_F32) {
+        if (D == 3) rc = launch_bwd<float, 3>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, C, L, tab, calc, (const float*)dy_dx, (float*)grad_inputs, gridtype, grad_layout, s);
+        else if (D == 2) rc = launch_bwd<float, 2>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, C, L, tab, calc, (const float*)dy_dx, (float*)grad_inputs, gridtype, grad_layout, s);
+        else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
+    } else {
+        if (D == 3) rc = launch_bwd<__half, 3>((const __half*)grad, inputs, offsets, (__half*)grad_embeddings, B, C, L, tab, calc, (const __half*)dy_dx, (__half*)grad_inputs, gridtype, grad_layout, s);
+        else if (D == 2) rc = launch_bwd<__half, 2>((const __half*)grad, inputs, offsets, (__half*)grad_embeddings, B, C, L, tab, calc, (const __half*)dy_dx, (__half*)grad_inputs, gridtype, grad_layout, s);
+        else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
+    }
+    if (rc) return rc;
+    ENERF_LAUNCH_CHECK("grid_encode_backward");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,648 @@
+// raymarching.hip -- occupancy-grid ray marching and compositing for gfx950 (wave64).
+//
+// Replaces raymarching/src/raymarching.cu of the reference (11 entry points, see include/enerf_hip.h).
+// Integer outputs (rays, counter, morton codes, bitfield) and the sample positions are bit-exact with
+// oracle/enerf_oracle.c; compositing is evaluated with wave-parallel scans (one wavefront per ray) and
+// agrees with the sequential recurrence to fp32 round-off.
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+#include <float.h>
+
+#include "common.h"
+
+using namespace enerf;
+
+namespace {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+
+__device__ __forceinline__ float signf_(float x) { return copysignf(1.0f, x); }
+__device__ __forceinline__ float clampf_(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton3_inv(uint32_t x) {
+    x = x & 0x49249249;
+    x = (x | (x >> 2)) & 0xc30c30c3;
+    x = (x | (x >> 4)) & 0x0f00f00f;
+    x = (x | (x >> 8)) & 0xff0000ff;
+    x = (x | (x >> 16)) & 0x0000ffff;
+    return x;
+}
+
+// exponent e with |v| in [2^(e-1), 2^e), 0 for v == 0 (== frexpf's exponent), clamped to [0, C-1]
+__device__ __forceinline__ int mip_exponent(float v, uint32_t C) {
+    int e;
+    (void)frexpf(v, &e);
+    return (int)fminf((float)C - 1.0f, fmaxf(0.0f, (float)e));
+}
+
+// PCG32 (XSH-RR 64/32), seed(initstate, initseq) then one next_float()
+__device__ __forceinline__ uint32_t pcg_next(uint64_t& state, uint64_t inc) {
+    const uint64_t old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    const uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+__device__ __forceinline__ float pcg_first_float(uint64_t initstate, uint64_t initseq) {
+    uint64_t state = 0U;
+    const uint64_t inc = (initseq << 1u) | 1u;
+    (void)pcg_next(state, inc);
+    state += initstate;
+    (void)pcg_next(state, inc);
+    const uint32_t u = (pcg_next(state, inc) >> 9) | 0x3f800000u;
+    return __uint_as_float(u) - 1.0f;
+}
+
+struct RayCtx {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max;
+    uint32_t C, H;
+    const uint8_t* grid;
+};
+
+__device__ __forceinline__ void ray_ctx_init(RayCtx& c, const float* o, const float* d, const uint8_t* grid,
+                                             float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    c.ox = o[0]; c.oy = o[1]; c.oz = o[2];
+    c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
+    c.rdx = 1 / c.dx; c.rdy = 1 / c.dy; c.rdz = 1 / c.dz;
+    c.bound = bound; c.dt_gamma = dt_gamma;
+    c.dt_min = 2 * kSqrt3 / max_steps;
+    c.dt_max = 2 * kSqrt3 * (1 << (C - 1)) / H;
+    c.C = C; c.H = H; c.grid = grid;
+}
+
+// One evaluation of the marching loop body at parameter t.  Returns the occupancy bit; on an empty cell
+// t_skip receives t after the voxel-skipping do/while.
+__device__ __forceinline__ bool eval_step(const RayCtx& c, float t, float& x, float& y, float& z, float& dt,
+                                          float& t_skip) {
+    const float bound = c.bound;
+    const uint32_t H = c.H;
+    x = clampf_(fmaf(t, c.dx, c.ox), -bound, bound);
+    y = clampf_(fmaf(t, c.dy, c.oy), -bound, bound);
+    z = clampf_(fmaf(t, c.dz, c.oz), -bound, bound);
+    dt = clampf_(t * c.dt_gamma, c.dt_min, c.dt_max);
+    const int lp = mip_exponent(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), c.C);
+    const int ld = mip_exponent((float)((double)(dt * (float)H) * 0.5), c.C);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf((float)(1 << level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const float hm1 = (float)(H - 1);
+    const int nx = (int)clampf_((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+    const int ny = (int)clampf_((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+    const int nz = (int)clampf_((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
+    const uint32_t index = (uint32_t)level * H * H * H + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const bool occ = (c.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    if (!occ) {
+        const float tx = fmaf(fmaf((nx + 0.5f + 0.5f * signf_(c.dx)) / hm1, 2.0f, -1.0f), mip_bound, -x) * c.rdx;
+        const float ty = fmaf(fmaf((ny + 0.5f + 0.5f * signf_(c.dy)) / hm1, 2.0f, -1.0f), mip_bound, -y) * c.rdy;
+        const float tz = fmaf(fmaf((nz + 0.5f + 0.5f * signf_(c.dz)) / hm1, 2.0f, -1.0f), mip_bound, -z) * c.rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += clampf_(t * c.dt_gamma, c.dt_min, c.dt_max);
+        } while (t < tt);
+        t_skip = t;
+    }
+    return occ;
+}
+
+// ------------------------------------------------------------------ small per-element kernels
+__global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                  const float* __restrict__ aabb, uint32_t N, float min_near,
+                                                  float* nears, float* fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
+    if (near > far) { tmp = near; near = far; far = tmp; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { tmp = near_y; near_y = far_y; far_y = tmp; }
+    if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; return; }
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { tmp = near_z; near_z = far_z; far_z = tmp; }
+    if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; return; }
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    nears[n] = near;
+    fars[n] = far;
+}
+
+__global__ void __launch_bounds__(256) k_polar(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                               float radius, uint32_t N, float* coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+    const float C = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+    const float t = (-B + sqrtf(fmaf(B, B, -(A * C)))) / A;
+    const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+    const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+    const float phi = atan2f(z, x);
+    coords[n * 2] = fmaf(2 * theta, kRPi, -1.0f);
+    coords[n * 2 + 1] = phi * kRPi;
+}
+
+__global__ void __launch_bounds__(256) k_morton3D(const int32_t* __restrict__ coords, uint32_t N, int32_t* indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+
+__global__ void __launch_bounds__(256) k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t N,
+                                                         int32_t* coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int ind = indices[n];
+    coords[n * 3 + 0] = (int32_t)morton3_inv((uint32_t)(ind >> 0));
+    coords[n * 3 + 1] = (int32_t)morton3_inv((uint32_t)(ind >> 1));
+    coords[n * 3 + 2] = (int32_t)morton3_inv((uint32_t)(ind >> 2));
+}
+
+// One thread per output byte: two 16-byte loads in, one byte out (a wave stores 64 contiguous bytes).
+__global__ void __launch_bounds__(256) k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
+                                                  uint8_t* bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4*>(grid)[(size_t)n * 2];
+    const float4 b = reinterpret_cast<const float4*>(grid)[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= a.x > thresh ? 1u : 0u;
+    bits |= a.y > thresh ? 2u : 0u;
+    bits |= a.z > thresh ? 4u : 0u;
+    bits |= a.w > thresh ? 8u : 0u;
+    bits |= b.x > thresh ? 16u : 0u;
+    bits |= b.y > thresh ? 32u : 0u;
+    bits |= b.z > thresh ? 64u : 0u;
+    bits |= b.w > thresh ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------ march_rays_train
+// Pass structure (replaces the reference's count -> 2 global atomics -> write in one thread):
+//   k_march_count : num_steps[n]  (written to rays[n][2])
+//   k_march_scan  : single workgroup exclusive scan -> rays[n] = (n, base + excl, num_steps); counter update
+//   k_march_write : re-march and emit samples at the scanned offset
+// so offsets are those of sequential execution and reproducible run to run.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t march_one_ray(const RayCtx& c, float t0, float far, uint32_t limit, float* xyzs,
+                                                  float* dirs, float* deltas) {
+    float t = t0, last_t = t0, x, y, z, dt, ts = 0.0f;
+    uint32_t step = 0;
+    while (t < far && step < limit) {
+        if (eval_step(c, t, x, y, z, dt, ts)) {
+            t += dt;
+            if (WRITE) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = c.dx; dirs[1] = c.dy; dirs[2] = c.dz;
+                deltas[0] = dt;
+                deltas[1] = t - last_t;
+                last_t = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+            }
+            step++;
+        } else {
+            t = ts;
+        }
+    }
+    return step;
+}
+
+__global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                    int32_t* rays, uint32_t perturb) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
+    float t0 = nears[n];
+    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    rays[(size_t)n * 3 + 2] = (int32_t)march_one_ray<false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr);
+}
+
+__global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* counter, uint32_t N) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = (uint32_t)counter[0];
+    __syncthreads();
+    for (uint32_t base = 0; base < N; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < N ? (uint32_t)rays[(size_t)i * 3 + 2] : 0u;
+        const uint32_t incl = wave_incl_scan_add_u32(v, lane);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; w++) wave_off += wave_tot[w];
+        const uint32_t carry = carry_s;
+        if (i < N) {
+            rays[(size_t)i * 3 + 0] = (int32_t)i;
+            rays[(size_t)i * 3 + 1] = (int32_t)(carry + wave_off + incl - v);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counter[0] = (int32_t)carry_s;
+        counter[1] += (int32_t)N;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_march_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                    float* xyzs, float* dirs, float* deltas,
+                                                    const int32_t* __restrict__ rays, uint32_t perturb) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t point_index = (uint32_t)rays[(size_t)n * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) return;
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
+    float t0 = nears[n];
+    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    (void)march_one_ray<true>(c, t0, fars[n], num_steps, xyzs + (size_t)point_index * 3,
+                              dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
+}
+
+// ------------------------------------------------------------------ composite_rays_train (one wavefront per ray)
+// Lanes take consecutive samples (coalesced 4/8/12-byte-per-lane loads); transmittance is a wave prefix
+// product, the running sums are wave prefix sums, chunk to chunk carries live in every lane.
+struct CompCarry {
+    float T, t, r, g, b, ws, d;
+};
+
+// Processes one chunk of <= 64 samples; returns per-lane inclusive quantities and updates the carry.
+__device__ __forceinline__ void comp_chunk(bool active, float sigma, float dl0, float dl1, float c0, float c1,
+                                           float c2, int lane, CompCarry& k, float& w, float& T_post, float& r_i,
+                                           float& g_i, float& b_i, float& ws_i) {
+    const float alpha = active ? 1.0f - __expf(-sigma * dl0) : 0.0f;
+    const float om = 1.0f - alpha;
+    const float P = wave_incl_scan_mul(om, lane);  // prod_{j<=i} (1 - alpha_j) within the chunk
+    float Pex = __shfl_up(P, 1, 64);
+    if (lane == 0) Pex = 1.0f;
+    w = alpha * (k.T * Pex);
+    T_post = k.T * P;
+    const float tt = k.t + wave_incl_scan_add(active ? dl1 : 0.0f, lane);
+    r_i = k.r + wave_incl_scan_add(w * c0, lane);
+    g_i = k.g + wave_incl_scan_add(w * c1, lane);
+    b_i = k.b + wave_incl_scan_add(w * c2, lane);
+    ws_i = k.ws + wave_incl_scan_add(w, lane);
+    const float d_i = k.d + wave_incl_scan_add(w * tt, lane);
+    k.T = wave_bcast(T_post, 63);
+    k.t = wave_bcast(tt, 63);
+    k.r = wave_bcast(r_i, 63);
+    k.g = wave_bcast(g_i, 63);
+    k.b = wave_bcast(b_i, 63);
+    k.ws = wave_bcast(ws_i, 63);
+    k.d = wave_bcast(d_i, 63);
+}
+
+__global__ void __launch_bounds__(256) k_composite_train_fwd(const float* __restrict__ sigmas,
+                                                             const float* __restrict__ rgbs,
+                                                             const float* __restrict__ deltas,
+                                                             const int32_t* __restrict__ rays, uint32_t M, uint32_t N,
+                                                             float* weights_sum, float* depth, float* image) {
+    const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = lane_id();
+    const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        if (lane == 0) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[(size_t)index * 3] = 0; image[(size_t)index * 3 + 1] = 0; image[(size_t)index * 3 + 2] = 0;
+        }
+        return;
+    }
+    CompCarry k = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t s0 = 0; s0 < num_steps; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool active = s < num_steps;
+        const size_t p = (size_t)offset + (active ? s : 0);
+        const float sigma = sigmas[p];
+        const float2 dl = reinterpret_cast<const float2*>(deltas)[p];
+        const float c0 = rgbs[p * 3], c1 = rgbs[p * 3 + 1], c2 = rgbs[p * 3 + 2];
+        float w, T_post, r_i, g_i, b_i, ws_i;
+        comp_chunk(active, sigma, dl.x, dl.y, c0, c1, c2, lane, k, w, T_post, r_i, g_i, b_i, ws_i);
+    }
+    if (lane == 0) {
+        weights_sum[index] = k.ws; depth[index] = k.d;
+        image[(size_t)index * 3] = k.r; image[(size_t)index * 3 + 1] = k.g; image[(size_t)index * 3 + 2] = k.b;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_composite_train_bwd(
+    const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+    const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
+    const int32_t* __restrict__ rays, const float* __restrict__ weights_sum, const float* __restrict__ image,
+    uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs) {
+    const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = lane_id();
+    const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[(size_t)index * 3], gi1 = grad_image[(size_t)index * 3 + 1],
+                gi2 = grad_image[(size_t)index * 3 + 2];
+    const float r_final = image[(size_t)index * 3], g_final = image[(size_t)index * 3 + 1],
+                b_final = image[(size_t)index * 3 + 2];
+    const float ws_final = weights_sum[index];
+    CompCarry k = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t s0 = 0; s0 < num_steps; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool active = s < num_steps;
+        const size_t p = (size_t)offset + (active ? s : 0);
+        const float sigma = sigmas[p];
+        const float2 dl = reinterpret_cast<const float2*>(deltas)[p];
+        const float c0 = rgbs[p * 3], c1 = rgbs[p * 3 + 1], c2 = rgbs[p * 3 + 2];
+        float w, T, r_i, g_i, b_i, ws_i;
+        comp_chunk(active, sigma, dl.x, dl.y, c0, c1, c2, lane, k, w, T, r_i, g_i, b_i, ws_i);
+        if (active) {
+            grad_rgbs[p * 3] = gi0 * w;
+            grad_rgbs[p * 3 + 1] = gi1 * w;
+            grad_rgbs[p * 3 + 2] = gi2 * w;
+            grad_sigmas[p] = dl.x * (gi0 * (T * c0 - (r_final - r_i)) + gi1 * (T * c1 - (g_final - g_i)) +
+                                     gi2 * (T * c2 - (b_final - b_i)) + gws * (T - (ws_final - ws_i)));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ inference: march / composite / compact
+__global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n_step,
+                                                    const int32_t* __restrict__ rays_alive,
+                                                    const float* __restrict__ rays_t,
+                                                    const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                    uint32_t H, const uint8_t* __restrict__ grid,
+                                                    const float* __restrict__ fars, float* xyzs, float* dirs,
+                                                    float* deltas, uint32_t perturb) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    float t = rays_t[n];
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
+    if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
+    const size_t base = (size_t)n * n_step;
+    (void)march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+}
+
+__global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step,
+                                                        const int32_t* __restrict__ rays_alive, float* rays_t,
+                                                        const float* __restrict__ sigmas,
+                                                        const float* __restrict__ rgbs,
+                                                        const float* __restrict__ deltas, float* weights_sum,
+                                                        float* depth, float* image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    float t = rays_t[n];
+    const float* s = sigmas + (size_t)n * n_step;
+    const float* c = rgbs + (size_t)n * n_step * 3;
+    const float* dl = deltas + (size_t)n * n_step * 2;
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[(size_t)index * 3], g = image[(size_t)index * 3 + 1], b = image[(size_t)index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0) break;
+        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        r = fmaf(weight, c[0], r);
+        g = fmaf(weight, c[1], g);
+        b = fmaf(weight, c[2], b);
+        if ((double)T < 1e-5) break;
+        s++; c += 3; dl += 2; step++;
+    }
+    rays_t[n] = (step < n_step) ? -1.0f : t;
+    weights_sum[index] = weight_sum;
+    depth[index] = d;
+    image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+}
+
+// Stable stream compaction in three small launches: per-block survivor counts (ballot + popcount),
+// one-workgroup scan of the block counts, order-preserving scatter.
+constexpr int kCompactBlock = 1024;
+
+__global__ void __launch_bounds__(kCompactBlock) k_compact_count(uint32_t n_alive, const float* __restrict__ rays_t_old,
+                                                                 uint32_t* block_counts) {
+    __shared__ uint32_t wave_cnt[kCompactBlock / 64];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool keep = n < n_alive && rays_t_old[n] >= 0;
+    const unsigned long long m = __ballot(keep);
+    if (lane_id() == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kCompactBlock / 64; w++) tot += wave_cnt[w];
+        block_counts[blockIdx.x] = tot;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_compact_scan(uint32_t nblocks, uint32_t* block_counts, int32_t* alive_counter) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_counts[i] : 0u;
+        const uint32_t incl = wave_incl_scan_add_u32(v, lane);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; w++) wave_off += wave_tot[w];
+        const uint32_t carry = carry_s;
+        if (i < nblocks) block_counts[i] = carry + wave_off + incl - v;  // exclusive block offset
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) alive_counter[0] += (int32_t)carry_s;
+}
+
+__global__ void __launch_bounds__(kCompactBlock) k_compact_scatter(uint32_t n_alive, int32_t* rays_alive,
+                                                                   const int32_t* __restrict__ rays_alive_old,
+                                                                   float* rays_t, const float* __restrict__ rays_t_old,
+                                                                   const uint32_t* __restrict__ block_offsets,
+                                                                   const uint32_t* __restrict__ base_count) {
+    __shared__ uint32_t wave_cnt[kCompactBlock / 64];
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    const float t = n < n_alive ? rays_t_old[n] : -1.0f;
+    const bool keep = n < n_alive && t >= 0;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = block_offsets[blockIdx.x] + base_count[0];
+    for (int w = 0; w < wid; w++) off += wave_cnt[w];
+    if (keep) {
+        const uint32_t pos = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        rays_alive[pos] = rays_alive_old[n];
+        rays_t[pos] = t;
+    }
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int enerf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                             float* nears, float* fars, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    k_near_far<<<div_up(N, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    ENERF_LAUNCH_CHECK("near_far_from_aabb");
+    return 0;
+}
+
+int enerf_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                         enerf_stream_t stream) {
+    if (N == 0) return 0;
+    k_polar<<<div_up(N, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, radius, N, coords);
+    ENERF_LAUNCH_CHECK("polar_from_ray");
+    return 0;
+}
+
+int enerf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    k_morton3D<<<div_up(N, 256), 256, 0, (hipStream_t)stream>>>(coords, N, indices);
+    ENERF_LAUNCH_CHECK("morton3D");
+    return 0;
+}
+
+int enerf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    k_morton3D_invert<<<div_up(N, 256), 256, 0, (hipStream_t)stream>>>(indices, N, coords);
+    ENERF_LAUNCH_CHECK("morton3D_invert");
+    return 0;
+}
+
+int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    if (((uintptr_t)grid & 15) != 0) ENERF_BADARG("packbits: grid must be 16-byte aligned");
+    k_packbits<<<div_up(N, 256), 256, 0, (hipStream_t)stream>>>(grid, N, density_thresh, bitfield);
+    ENERF_LAUNCH_CHECK("packbits");
+    return 0;
+}
+
+int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                           uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                           const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
+                           int32_t* counter, uint32_t perturb, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays_train: bad C=%u H=%u max_steps=%u", C, H, max_steps);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_MARCH_TRAIN, s);
+    k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars,
+                                               rays, perturb);
+    k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
+    k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
+                                               fars, xyzs, dirs, deltas, rays, perturb);
+    ENERF_LAUNCH_CHECK("march_rays_train");
+    return 0;
+}
+
+int enerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                       const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum, float* depth,
+                                       float* image, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_COMPOSITE_FWD, s);
+    k_composite_train_fwd<<<div_up(N, 4), 256, 0, s>>>(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    ENERF_LAUNCH_CHECK("composite_rays_train_forward");
+    return 0;
+}
+
+int enerf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                        const float* rgbs, const float* deltas, const int32_t* rays,
+                                        const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                        float* grad_sigmas, float* grad_rgbs, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_COMPOSITE_BWD, s);
+    k_composite_train_bwd<<<div_up(N, 4), 256, 0, s>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+                                                       weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    ENERF_LAUNCH_CHECK("composite_rays_train_backward");
+    return 0;
+}
+
+int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                     const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                     uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                     float* dirs, float* deltas, uint32_t perturb, enerf_stream_t stream) {
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return 0;
+    if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays: bad C=%u H=%u max_steps=%u", C, H, max_steps);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_MARCH_INFER, s);
+    k_march_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                      dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    ENERF_LAUNCH_CHECK("march_rays");
+    return 0;
+}
+
+int enerf_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
+                         const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                         float* image, enerf_stream_t stream) {
+    if (n_alive == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_COMPOSITE_INFER, s);
+    k_composite_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas,
+                                                          weights_sum, depth, image);
+    ENERF_LAUNCH_CHECK("composite_rays");
+    return 0;
+}
+
+int enerf_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
+                       const float* rays_t_old, int32_t* alive_counter, enerf_stream_t stream) {
+    if (n_alive == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = div_up(n_alive, kCompactBlock);
+    // slot layout: [0] = alive_counter value at entry (snapshot), [1..nb] = block counts / offsets
+    uint32_t* ws = (uint32_t*)workspace(WS_COMPACT, sizeof(uint32_t) * (nb + 1));
+    if (!ws) return ENERF_E_NOMEM;
+    // snapshot alive_counter[0] so that survivors are appended after any existing entries (reference: atomicAdd)
+    int e = check_hip(hipMemcpyAsync(ws, alive_counter, sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "compact_rays");
+    if (e) return e;
+    k_compact_count<<<nb, kCompactBlock, 0, s>>>(n_alive, rays_t_old, ws + 1);
+    k_compact_scan<<<1, 1024, 0, s>>>(nb, ws + 1, alive_counter);
+    // survivors are appended after alive_counter's entry value (ws[0]); the renderer zeroes it first
+    // (nerf/renderer.py:372), so this is 0 in practice.
+    k_compact_scatter<<<nb, kCompactBlock, 0, s>>>(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, ws + 1, ws);
+    ENERF_LAUNCH_CHECK("compact_rays");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// runtime.hip -- error strings, library-owned workspaces, per-kernel hipEvent timing.
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace enerf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- workspaces -----------------------------------------------------------
+static std::mutex g_ws_mu;
+static void* g_ws_ptr[WS_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+static size_t g_ws_bytes[WS_SLOTS] = {0, 0, 0, 0};
+
+void* workspace(int slot, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (g_ws_bytes[slot] >= bytes && g_ws_ptr[slot]) return g_ws_ptr[slot];
+    size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        set_error("workspace: hipMalloc(%zu) failed", want);
+        return nullptr;
+    }
+    // The old buffer may still be in use by kernels in flight on some stream: drain before freeing.
+    if (g_ws_ptr[slot]) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_ws_ptr[slot]);
+    }
+    g_ws_ptr[slot] = p;
+    g_ws_bytes[slot] = want;
+    return p;
+}
+
+// ---- event timing ---------------------------------------------------------
+struct EvPair {
+    hipEvent_t a, b;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<EvPair> g_prof_ev[ENERF_K_COUNT];
+static const size_t kMaxPairs = 1 << 16;
+
+ProfScope::ProfScope(int kernel_id, hipStream_t stream) : id(kernel_id), s(stream), slot(nullptr) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_ev[id].size() >= kMaxPairs) return;
+    EvPair p;
+    if (hipEventCreate(&p.a) != hipSuccess) return;
+    if (hipEventCreate(&p.b) != hipSuccess) {
+        (void)hipEventDestroy(p.a);
+        return;
+    }
+    (void)hipEventRecord(p.a, s);
+    g_prof_ev[id].push_back(p);
+    slot = (void*)(uintptr_t)g_prof_ev[id].size();  // 1-based index
+}
+
+ProfScope::~ProfScope() {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    size_t i = (size_t)(uintptr_t)slot - 1;
+    if (i < g_prof_ev[id].size()) (void)hipEventRecord(g_prof_ev[id][i].b, s);
+}
+
+}  // namespace enerf
+
+extern "C" {
+
+const char* enerf_last_error(void) { return enerf::g_err; }
+int enerf_abi_version(void) { return 1; }
+
+int enerf_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
+    enerf::g_prof_on = on != 0;
+    return 0;
+}
+
+int enerf_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
+    for (int k = 0; k < ENERF_K_COUNT; k++) {
+        for (auto& p : enerf::g_prof_ev[k]) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        enerf::g_prof_ev[k].clear();
+    }
+    return 0;
+}
+
+int enerf_prof_read(int kernel_id, double* total_ms, uint64_t* launches) {
+    if (kernel_id < 0 || kernel_id >= ENERF_K_COUNT) ENERF_BADARG("prof_read: bad kernel id %d", kernel_id);
+    std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
+    double tot = 0;
+    uint64_t n = 0;
+    for (auto& p : enerf::g_prof_ev[kernel_id]) {
+        if (hipEventSynchronize(p.b) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            tot += ms;
+            n++;
+        }
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return 0;
+}
+
+}  // extern "C"

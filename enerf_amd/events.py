@@ -1,0 +1,143 @@
+"""The event-loss side of the hot path's caller, re-stated from the reference:
+
+  get_rays / get_event_rays     nerf/utils.py:110-174, 184-216
+  rgb_to_luma / lin_log         utils/event_utils.py:23-66
+  event_loss / train_step_events   nerf/utils.py:482-573  (Trainer.train_step_events)
+
+`train_step_events` takes the model plus a plain options object instead of a Trainer, but renders, converts and
+penalises exactly as the reference does (two renders sharing one random background colour; (lin-)log intensity
+difference against polarity * C_thres, or the normalised variant when C_thres == -1).
+"""
+import numpy as np
+import torch
+
+
+def get_rays(poses, intrinsics, H, W, N=-1, inds=None):
+    """poses [B,4,4] cam2world, intrinsics (fx,fy,cx,cy) -> rays_o, rays_d [B,N,3] (+ inds [B,N] when sampled).
+    Pixel centres are integer coordinates (no +0.5), as in the reference."""
+    device = poses.device
+    B = poses.shape[0]
+    fx, fy, cx, cy = intrinsics
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device),
+                          indexing="ij")
+    i = i.t().reshape([1, H * W]).expand([B, H * W])
+    j = j.t().reshape([1, H * W]).expand([B, H * W])
+    results = {}
+    if N > 0:
+        N = min(N, H * W)
+        if inds is None:
+            inds = torch.randint(0, H * W, size=[N], device=device)
+        inds = inds.expand([B, N])
+        i = torch.gather(i, -1, inds)
+        j = torch.gather(j, -1, inds)
+        results["inds"] = inds
+    zs = torch.ones_like(i)
+    xs = (i - cx) / fx * zs
+    ys = (j - cy) / fy * zs
+    directions = torch.stack((xs, ys, zs), dim=-1)
+    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
+    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+    results["rays_o"] = rays_o
+    results["rays_d"] = rays_d
+    return results
+
+
+def get_event_rays(xs, ys, c2w_before, c2w_at, intrinsics):
+    """Per-event ray pairs: pixel (xs, ys) seen from the pose just before and at the event. c2w_* [B,Nevs,3,4]."""
+    fx, fy, cx, cy = intrinsics
+    zs = torch.ones_like(xs)
+    us = (xs - cx) / fx * zs
+    vs = (ys - cy) / fy * zs
+    dirs_cams = torch.stack((us, vs, zs), dim=-1)
+    dirs_cams = dirs_cams / torch.norm(dirs_cams, dim=-1, keepdim=True)
+    return {
+        "rays_evs_o1": c2w_before[..., :3, 3],
+        "rays_evs_d1": torch.sum(dirs_cams[..., None, :] * c2w_before[..., :3, :3], axis=-1),
+        "rays_evs_o2": c2w_at[..., :3, 3],
+        "rays_evs_d2": torch.sum(dirs_cams[..., None, :] * c2w_at[..., :3, :3], axis=-1),
+    }
+
+
+def rgb_to_luma(rgb, esim=True):
+    """[..., 3] -> [..., 1]; BT.601 weights for esim, BT.709 otherwise."""
+    w = (0.299, 0.587, 0.114) if esim else (0.2126, 0.7152, 0.0722)
+    factors = torch.tensor(w, dtype=torch.float32, device=rgb.device)
+    return torch.sum(rgb * factors[None, :], axis=-1)[..., None]
+
+
+def lin_log(color, linlog_thres=20):
+    """Linear below `linlog_thres`, natural log above, continuous at the threshold."""
+    lin_slope = np.log(linlog_thres) / linlog_thres
+    return torch.where(color < linlog_thres, lin_slope * color, torch.log(color))
+
+
+class EventOptions:
+    """The subset of the reference's CLI namespace the event step reads (main_nerf.py:97-185)."""
+
+    def __init__(self, **kw):
+        self.out_dim_color = 3
+        self.use_luma = True
+        self.linlog = True
+        self.log_thres = 1e-7   # nerf/utils.py:349
+        self.C_thres = 0.2
+        self.event_only = True
+        self.weight_loss_rgb = 1.0
+        self.render_kwargs = {}
+        self.__dict__.update(kw)
+
+
+def event_loss(image1, image2, pols, opt):
+    """(lin-)log intensity change between two renders vs polarity; returns (loss, delta_linlog)."""
+    if opt.use_luma:
+        l1 = rgb_to_luma(image1, esim=True)
+        l2 = rgb_to_luma(image2, esim=True)
+    else:
+        l1, l2 = image1, image2
+    if opt.linlog:
+        p1 = lin_log(l1 * 255, linlog_thres=20)
+        p2 = lin_log(l2 * 255, linlog_thres=20)
+    else:
+        thres = torch.as_tensor(opt.log_thres, dtype=l1.dtype, device=l1.device)
+        p1 = torch.log(torch.maximum(l1 * 255, thres))
+        # the reference evaluates the second term on the *first* luma when use_luma is set (nerf/utils.py:500)
+        p2 = torch.log(torch.maximum((l1 if opt.use_luma else l2) * 255, thres))
+    delta = p2 - p1
+    gt_pol = pols[..., None]
+    w = 1.0
+    if opt.C_thres != -1:
+        loss = w * torch.mean((delta - gt_pol * opt.C_thres) ** 2)
+    else:
+        EPS = 1e-9
+        w *= 20
+        if not opt.event_only:
+            w *= 20
+        dn = delta / (torch.linalg.norm(delta, dim=1, keepdim=True) + EPS)
+        pn = gt_pol / (torch.linalg.norm(gt_pol, dim=1, keepdim=True) + EPS)
+        loss = w * torch.mean((dn - pn) ** 2)
+    return loss, delta
+
+
+def train_step_events(model, data, opt, criterion=None):
+    """One event training step's forward: two renders (+ optional frame render) -> loss.  nerf/utils.py:482-546."""
+    images = data["images"]
+    B = images.shape[0]
+    dev = data["rays_evs_o1"].device
+    bg = torch.rand((B, 1, opt.out_dim_color)).to(dev)
+    kw = dict(opt.render_kwargs)
+    kw.setdefault("out_dim_color", opt.out_dim_color)
+    out1 = model.render(data["rays_evs_o1"], data["rays_evs_d1"], staged=False, bg_color=bg, perturb=True, **kw)
+    out2 = model.render(data["rays_evs_o2"], data["rays_evs_d2"], staged=False, bg_color=bg, perturb=True, **kw)
+    loss, delta = event_loss(out1["image"], out2["image"], data["pols"], opt)
+    if not opt.event_only:
+        C = images.shape[-1]
+        if C == 4:
+            bg_color = torch.rand_like(images[..., :opt.out_dim_color])
+            gt = images[..., :opt.out_dim_color] * images[..., opt.out_dim_color:] + \
+                bg_color * (1 - images[..., opt.out_dim_color:])
+        else:
+            bg_color, gt = None, images
+        out = model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True, **kw)
+        crit = criterion if criterion is not None else torch.nn.MSELoss(reduction="none")
+        loss = loss + opt.weight_loss_rgb * crit(out["image"], gt).mean()
+    return loss, delta

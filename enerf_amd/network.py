@@ -1,0 +1,101 @@
+"""`NeRFNetwork` with nn.Linear MLPs -- re-statement of nerf/network.py of the reference (hashgrid -> sigma MLP ->
+trunc_exp; SH(dir) (+) geo_feat -> colour MLP -> sigmoid).  Module / parameter names match the reference so
+checkpoints interchange (`encoder.embeddings`, `encoder.offsets`, `sigma_net.N.weight`, `color_net.N.weight`).
+Quirk kept: the colour MLP's hidden width is `hidden_dim`, not `hidden_dim_color` (network.py:68,73).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .activation import trunc_exp
+from .encoding import get_encoder
+from .renderer import NeRFRenderer
+
+
+def _mlp(in_dim, hidden, out_dim, n):
+    layers = []
+    for l in range(n):
+        layers.append(nn.Linear(in_dim if l == 0 else hidden, out_dim if l == n - 1 else hidden, bias=False))
+    return nn.ModuleList(layers)
+
+
+def _run_mlp(layers, h):
+    for l, layer in enumerate(layers):
+        h = layer(h)
+        if l != len(layers) - 1:
+            h = F.relu(h, inplace=True)
+    return h
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", encoding_bg="hashgrid", num_layers=2,
+                 hidden_dim=64, geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2,
+                 hidden_dim_bg=64, bound=1, disable_view_direction=False, out_dim_color=3, **kwargs):
+        super().__init__(bound, **kwargs)
+        self.disable_view_direction = disable_view_direction
+        self.out_dim_color = out_dim_color
+
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.geo_feat_dim = geo_feat_dim
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.sigma_net = _mlp(self.in_dim, hidden_dim, 1 + geo_feat_dim, num_layers)
+
+        self.num_layers_color = num_layers_color
+        self.hidden_dim_color = hidden_dim_color
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        self.color_net = _mlp(self.in_dim_dir + geo_feat_dim, hidden_dim, out_dim_color, num_layers_color)
+
+        if self.bg_radius > 0:
+            self.num_layers_bg = num_layers_bg
+            self.hidden_dim_bg = hidden_dim_bg
+            self.encoder_bg, self.in_dim_bg = get_encoder(encoding_bg, input_dim=2, num_levels=4,
+                                                          log2_hashmap_size=19, desired_resolution=2048)
+            self.bg_net = _mlp(self.in_dim_bg + self.in_dim_dir, hidden_dim_bg, out_dim_color, num_layers_bg)
+        else:
+            self.bg_net = None
+
+    def _dir_features(self, d):
+        e = self.encoder_dir(d)
+        return e * 0 if self.disable_view_direction else e * 1
+
+    def forward(self, x, d):
+        """x [N,3] in [-bound,bound], d [N,3] -> sigma [N], color [N,out_dim_color]   (network.py:104-132)"""
+        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:]
+        h = _run_mlp(self.color_net, torch.cat([self._dir_features(d), geo_feat], dim=-1))
+        return sigma, torch.sigmoid(h)
+
+    def density(self, x):
+        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def background(self, x, d):
+        h = torch.cat([self._dir_features(d), self.encoder_bg(x)], dim=-1)
+        return torch.sigmoid(_run_mlp(self.bg_net, h))
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """Masked colour query (network.py:171-199): rows where mask is False stay zero."""
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], self.out_dim_color, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
+        h = torch.sigmoid(_run_mlp(self.color_net, torch.cat([self._dir_features(d), geo_feat], dim=-1)))
+        if mask is not None:
+            rgbs[mask] = h.to(rgbs.dtype)
+            return rgbs
+        return h
+
+    def get_params(self, lr):
+        params = [
+            {"params": self.encoder.parameters(), "lr": lr},
+            {"params": self.sigma_net.parameters(), "lr": lr},
+            {"params": self.encoder_dir.parameters(), "lr": lr},
+            {"params": self.color_net.parameters(), "lr": lr},
+        ]
+        if self.bg_radius > 0:
+            params.append({"params": self.encoder_bg.parameters(), "lr": lr})
+            params.append({"params": self.bg_net.parameters(), "lr": lr})
+        return params

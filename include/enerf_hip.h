@@ -1,0 +1,200 @@
+/*
+ * enerf_hip.h -- C ABI of libenerf_hip.so, the MI355X (gfx950) implementation of the
+ * instant-ngp hot path that knelk/enerf sits on.
+ *
+ * This is the drop-in boundary.  The reference binds its native code through four
+ * pybind11 modules (`_raymarching`, `_gridencoder`, `_shencoder`, `_ffmlp`) whose
+ * functions take at::Tensor arguments that the *caller* has already allocated
+ * (and zero-filled where the kernels only partially write).  Each entry point below
+ * replaces exactly one of those bound functions; the argument order is the
+ * reference's, with every tensor flattened to a raw device pointer, followed by
+ *   - explicit dtype selectors where the reference dispatches on tensor dtype,
+ *   - `stream`: the hipStream_t to launch on (the reference uses the legacy default
+ *     stream; pass torch's current stream).
+ * All pointers are DEVICE pointers unless marked [host].  All functions are
+ * asynchronous, allocate nothing the caller can see, and return 0 on success or a
+ * negative ENERF_E_* / positive hipError_t code; enerf_last_error() describes the
+ * failure (the reference throws c10::Error / std::runtime_error at the same places).
+ * enerf_amd/backends/_*.py are the ctypes shims that re-create the reference's
+ * pybind signatures on top of this ABI.
+ *
+ * Reference interfaces replaced (paths relative to the knelk/enerf tree):
+ *   raymarching/src/raymarching.h:7-19, raymarching/src/bindings.cpp:5-20
+ *   gridencoder/src/gridencoder.h:12-13, gridencoder/src/bindings.cpp:5-8
+ *   shencoder/src/shencoder.h:9,12,     shencoder/src/bindings.cpp:5-8
+ *   ffmlp/src/ffmlp.h:8-14,             ffmlp/src/bindings.cpp:5-11
+ */
+#ifndef ENERF_HIP_H
+#define ENERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* enerf_stream_t; /* hipStream_t */
+
+/* error codes (negative; positive values are hipError_t) */
+#define ENERF_OK 0
+#define ENERF_E_BADARG (-1)      /* unsupported D / C / degree / width / dtype ...           */
+#define ENERF_E_NOMEM (-2)       /* internal workspace allocation failed                      */
+#define ENERF_E_UNSUPPORTED (-3) /* feature the reference asserts off as well                 */
+
+/* element types for entry points that the reference dispatches on tensor dtype */
+#define ENERF_F32 0
+#define ENERF_F16 1
+#define ENERF_BF16 2
+
+const char* enerf_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int enerf_abi_version(void);
+
+/* ------------------------------------------------------------------ raymarching
+ * raymarching/src/raymarching.cu; all float tensors are fp32 (the wrappers
+ * custom_fwd(cast_inputs=torch.float32), raymarching/raymarching.py:21,54,131,163). */
+
+/* raymarching.cu:150-158  near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars) */
+int enerf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                             float min_near, float* nears, float* fars, enerf_stream_t stream);
+
+/* raymarching.cu:203-211  polar_from_ray(rays_o, rays_d, radius, N, coords) */
+int enerf_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                         enerf_stream_t stream);
+
+/* raymarching.cu:231-234  morton3D(coords, N, indices) */
+int enerf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, enerf_stream_t stream);
+
+/* raymarching.cu:259-262  morton3D_invert(indices, N, coords) */
+int enerf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, enerf_stream_t stream);
+
+/* raymarching.cu:294-302  packbits(grid, N, density_thresh, bitfield); N = number of output bytes */
+int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, enerf_stream_t stream);
+
+/* raymarching.cu:482-490  march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
+ *                                          nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
+ * xyzs/dirs/deltas must be zero-filled by the caller (raymarching.py:205-207).
+ * Slot allocation is deterministic here: rays[n] = (n, counter[0]@entry + exclusive_scan(num_steps)[n],
+ * num_steps[n]); counter[0] += sum(num_steps); counter[1] += N.  (The reference's atomics give the same
+ * multiset in hardware order.) */
+int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                           float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                           const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                           int32_t* rays, int32_t* counter, uint32_t perturb, enerf_stream_t stream);
+
+/* raymarching.cu:581-589  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
+int enerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                       const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
+                                       float* depth, float* image, enerf_stream_t stream);
+
+/* raymarching.cu:685-693  composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+ *                                                       weights_sum, image, M, N, grad_sigmas, grad_rgbs)
+ * grad_sigmas / grad_rgbs must be zero-filled by the caller (raymarching.py:277-278). */
+int enerf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                        const float* rgbs, const float* deltas, const int32_t* rays,
+                                        const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                        float* grad_sigmas, float* grad_rgbs, enerf_stream_t stream);
+
+/* raymarching.cu:807-813  march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
+ *                                    max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, perturb) */
+int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                     const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                     uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                     float* xyzs, float* dirs, float* deltas, uint32_t perturb, enerf_stream_t stream);
+
+/* raymarching.cu:903-909  composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas,
+ *                                        weights_sum, depth, image)   -- in place */
+int enerf_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
+                         const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                         float* depth, float* image, enerf_stream_t stream);
+
+/* raymarching.cu:933-939  compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter)
+ * Order-preserving (stable) here; alive_counter[0] += number of survivors. */
+int enerf_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* rays_alive_old, float* rays_t,
+                       const float* rays_t_old, int32_t* alive_counter, enerf_stream_t stream);
+
+/* ------------------------------------------------------------------ gridencoder
+ * gridencoder/src/gridencoder.cu:416-471.  `inputs` is always fp32 (gridencoder.cu:437);
+ * embeddings / outputs / dy_dx / grad share `dtype` (ENERF_F32 or ENERF_F16).
+ * out_layout 0 = the reference's [L,B,C]; 1 = [B,L*C] written directly (saves the permute copy of
+ * gridencoder/grid.py:52,70 -- used by enerf_amd's own wrapper, not by the reference's). */
+
+/* grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype) */
+int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                              int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int dtype, int out_layout,
+                              enerf_stream_t stream);
+
+/* grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs,
+ *                      dy_dx, grad_inputs, gridtype); grad_embeddings must be zero-filled (grid.py:72);
+ * grad_layout as out_layout above. */
+int enerf_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                               void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                               uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs,
+                               uint32_t gridtype, int dtype, int grad_layout, enerf_stream_t stream);
+
+/* ------------------------------------------------------------------ shencoder
+ * shencoder/src/shencoder.cu:402-441; `dtype` ENERF_F32 or ENERF_F16 for every tensor. */
+
+/* sh_encode_forward(inputs, outputs, B, D, C, calc_grad_inputs, dy_dx);  D must be 3, 1 <= C <= 8 */
+int enerf_sh_encode_forward(const void* inputs, void* outputs, uint32_t B, uint32_t D, uint32_t C,
+                            int calc_grad_inputs, void* dy_dx, int dtype, enerf_stream_t stream);
+
+/* sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs); accumulates into grad_inputs */
+int enerf_sh_encode_backward(const void* grad, const void* inputs, uint32_t B, uint32_t D, uint32_t C,
+                             const void* dy_dx, void* grad_inputs, int dtype, enerf_stream_t stream);
+
+/* ------------------------------------------------------------------ ffmlp
+ * ffmlp/src/ffmlp.cu:632-895.  16-bit storage (`dtype` ENERF_F16 as the reference, or ENERF_BF16),
+ * fp32 MFMA accumulation (the reference accumulates in fp16).  Weight blob layout
+ * [W_in hid*in | W_h (k-1)*hid*hid | W_out out*hid], each W[out][in] row-major, y = x W^T, no bias.
+ * B must be a multiple of 128 (ffmlp/ffmlp.py:157-159 pads), hidden_dim == 64, input_dim in {16,32,48,64},
+ * output_dim == 16 (ffmlp.py:112-121 pads to 16), activation relu(0)/none(6). */
+
+int enerf_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                        void* forward_buffer, void* outputs, int dtype, enerf_stream_t stream);
+
+int enerf_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                          uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                          uint32_t output_activation, void* inference_buffer, void* outputs, int dtype,
+                          enerf_stream_t stream);
+
+/* grad_weights (same 16-bit dtype, zero-filled by the caller) receives the batch-summed weight gradient;
+ * backward_buffer [k,B,hid] receives the per-layer activation gradients as in the reference. */
+int enerf_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer,
+                         uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                         uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                         int calc_grad_inputs, void* backward_buffer, void* grad_inputs, void* grad_weights,
+                         int dtype, enerf_stream_t stream);
+
+/* ffmlp.cu:723-743: the reference (re)creates its split-K side streams here.  This implementation reduces weight
+ * gradients inside the fused backward kernel, so these only (re)size the fp32 partial-sum workspace. */
+int enerf_allocate_splitk(size_t size);
+int enerf_free_splitk(void);
+
+/* ------------------------------------------------------------------ measurement hooks (not in the reference)
+ * When enabled, every launch of the selected kernel family is bracketed by hipEvents on its own stream so that
+ * bench.py can report the average launch duration of the dominant kernel (roofline.achieved). */
+#define ENERF_K_GRID_FWD 0
+#define ENERF_K_GRID_BWD 1
+#define ENERF_K_MARCH_TRAIN 2
+#define ENERF_K_COMPOSITE_FWD 3
+#define ENERF_K_COMPOSITE_BWD 4
+#define ENERF_K_SH_FWD 5
+#define ENERF_K_FFMLP_FWD 6
+#define ENERF_K_FFMLP_BWD 7
+#define ENERF_K_MARCH_INFER 8
+#define ENERF_K_COMPOSITE_INFER 9
+#define ENERF_K_COUNT 10
+
+int enerf_prof_enable(int on);
+int enerf_prof_reset(void);
+/* Synchronises the recorded events; returns total milliseconds and launch count for `kernel_id`. [host ptrs] */
+int enerf_prof_read(int kernel_id, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENERF_HIP_H */

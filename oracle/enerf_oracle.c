@@ -1,0 +1,843 @@
+/*
+ * enerf_oracle.c -- CPU restatement of the reference's native hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under enerf_amd/ may import, link or call
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker.
+ *
+ * PARITY STATUS: the reference (knelk/enerf) ships no tests, golden vectors or
+ * known-answer fixtures for any of these functions, and its
+ * native code is CUDA (needs cuda_fp16.h / mma.h / an un-vendored CUTLASS), so
+ * it cannot be compiled in this image (oracle/_ref: unbuildable).  This oracle
+ * is therefore pinned by (a) the canonical PCG32 demo stream, (b) golden
+ * fixtures minted by importing the reference's *Python* (NeRFRenderer.run
+ * compositing, gridencoder/grid.py + shencoder + ffmlp wrappers driven through
+ * this oracle, nerf/network.py, train_step_events) -- see oracle/make_golden.py
+ * -- and (c) independent second statements (numpy.packbits, sympy real SH,
+ * torch autograd).  For march_rays_train / march_rays no second statement
+ * exists anywhere: parity for those is "unpinned" beyond this transliteration.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Floating-point convention: nvcc contracts a*b+c into FMA by
+ * default; the expressions where that matters for integer outputs (sample
+ * counts, cell indices) are written with explicit fmaf() here and in the HIP
+ * kernels, and both are compiled with -ffp-contract=off.
+ *
+ * Ordering convention: where the reference allocates output slots with global
+ * atomics (march_rays_train, compact_rays) the order is hardware-dependent;
+ * the oracle uses sequential execution order n = 0..N-1, which is one of the
+ * orders the reference can produce.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <float.h>
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------ */
+/* helpers: raymarching/src/raymarching.cu:21-83                       */
+/* ------------------------------------------------------------------ */
+#define ORC_SQRT3 1.7320508075688772f
+#define ORC_RPI 0.3183098861837907f
+
+static inline float orc_signf(float x) { return copysignf(1.0f, x); }          /* :32-34 */
+static inline float orc_clampf(float x, float lo, float hi) {                  /* :36-38 */
+    return fminf(hi, fmaxf(lo, x));
+}
+
+/* :44-49  frexpf exponent of max|coord|, clamped to [0, C-1] */
+static inline int orc_mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0, (float)exponent));
+}
+
+/* :51-56 */
+static inline int orc_mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (float)((double)(dt * H) * 0.5);   /* `dt * H * 0.5`: float*float then *double literal */
+    int exponent;
+    frexpf(mx, &exponent);
+    return (int)fminf(max_cascade - 1, fmaxf(0, (float)exponent));
+}
+
+/* :58-65 */
+static inline uint32_t orc_expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+/* :67-73 */
+static inline uint32_t orc_morton3D_1(uint32_t x, uint32_t y, uint32_t z) {
+    return orc_expand_bits(x) | (orc_expand_bits(y) << 1) | (orc_expand_bits(z) << 2);
+}
+/* :75-83 */
+static inline uint32_t orc_morton3D_invert_1(uint32_t x) {
+    x = x & 0x49249249;
+    x = (x | (x >> 2)) & 0xc30c30c3;
+    x = (x | (x >> 4)) & 0x0f00f00f;
+    x = (x | (x >> 8)) & 0xff0000ff;
+    x = (x | (x >> 16)) & 0x0000ffff;
+    return x;
+}
+
+/* ------------------------------------------------------------------ */
+/* PCG32: raymarching/src/pcg32.h:31-33 (constants), :57-63 (seed),    */
+/* :66-72 (next_uint), :107-116 (next_float)                           */
+/* ------------------------------------------------------------------ */
+#define ORC_PCG32_MULT 0x5851f42d4c957f2dULL
+typedef struct { uint64_t state, inc; } orc_pcg32;
+
+static inline uint32_t orc_pcg32_next_uint(orc_pcg32* r) {
+    uint64_t oldstate = r->state;
+    r->state = oldstate * ORC_PCG32_MULT + r->inc;
+    uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+static inline void orc_pcg32_seed(orc_pcg32* r, uint64_t initstate, uint64_t initseq) {
+    r->state = 0U;
+    r->inc = (initseq << 1u) | 1u;
+    orc_pcg32_next_uint(r);
+    r->state += initstate;
+    orc_pcg32_next_uint(r);
+}
+static inline float orc_pcg32_next_float(orc_pcg32* r) {
+    union { uint32_t u; float f; } x;
+    x.u = (orc_pcg32_next_uint(r) >> 9) | 0x3f800000u;
+    return x.f - 1.0f;
+}
+
+/* test hook: first `n` uints / floats of pcg32(seed, seq) (two independent generators) */
+void orc_pcg32_stream(uint64_t seed, uint64_t seq, uint32_t n, uint32_t* out_u, float* out_f) {
+    orc_pcg32 a, b;
+    orc_pcg32_seed(&a, seed, seq);
+    orc_pcg32_seed(&b, seed, seq);
+    for (uint32_t i = 0; i < n; i++) {
+        if (out_u) out_u[i] = orc_pcg32_next_uint(&a);
+        if (out_f) out_f[i] = orc_pcg32_next_float(&b);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* near_far_from_aabb: raymarching.cu:94-147                           */
+/* ------------------------------------------------------------------ */
+void orc_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb,
+                            uint32_t N, float min_near, float* nears, float* fars) {
+    for (uint32_t n = 0; n < N; n++) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
+        if (near > far) { tmp = near; near = far; far = tmp; }
+        float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+        if (near_y > far_y) { tmp = near_y; near_y = far_y; far_y = tmp; }
+        if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; continue; }
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+        if (near_z > far_z) { tmp = near_z; near_z = far_z; far_z = tmp; }
+        if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; continue; }
+        if (near_z > near) near = near_z;
+        if (far_z < far) far = far_z;
+        if (near < min_near) near = min_near;
+        nears[n] = near;
+        fars[n] = far;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* polar_from_ray: raymarching.cu:165-200                              */
+/* ------------------------------------------------------------------ */
+void orc_polar_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords) {
+    for (uint32_t n = 0; n < N; n++) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float A = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float B = fmaf(oz, dz, fmaf(oy, dy, ox * dx));
+        const float C = fmaf(oz, oz, fmaf(oy, oy, ox * ox)) - radius * radius;
+        const float t = (-B + sqrtf(fmaf(B, B, -(A * C)))) / A;
+        const float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy), z = fmaf(t, dz, oz);
+        const float theta = atan2f(sqrtf(fmaf(z, z, x * x)), y);
+        const float phi = atan2f(z, x);
+        coords[n * 2] = fmaf(2 * theta, ORC_RPI, -1.0f);
+        coords[n * 2 + 1] = phi * ORC_RPI;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* morton3D / morton3D_invert: raymarching.cu:216-256                  */
+/* ------------------------------------------------------------------ */
+void orc_morton3D(const int* coords, uint32_t N, int* indices) {
+    for (uint32_t n = 0; n < N; n++)
+        indices[n] = (int)orc_morton3D_1((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+void orc_morton3D_invert(const int* indices, uint32_t N, int* coords) {
+    for (uint32_t n = 0; n < N; n++) {
+        const int ind = indices[n];
+        coords[n * 3 + 0] = (int)orc_morton3D_invert_1((uint32_t)(ind >> 0));
+        coords[n * 3 + 1] = (int)orc_morton3D_invert_1((uint32_t)(ind >> 1));
+        coords[n * 3 + 2] = (int)orc_morton3D_invert_1((uint32_t)(ind >> 2));
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* packbits: raymarching.cu:270-291 (strict >, LSB first)              */
+/* ------------------------------------------------------------------ */
+void orc_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield) {
+    for (uint32_t n = 0; n < N; n++) {
+        uint8_t bits = 0;
+        for (int i = 0; i < 8; i++) bits |= grid[(size_t)n * 8 + i] > density_thresh ? (uint8_t)(1u << i) : 0;
+        bitfield[n] = bits;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* one marching step shared by march_rays_train (both passes) and      */
+/* march_rays: raymarching.cu:362-399 == :429-478 == :751-802          */
+/* Returns occupancy; *x,*y,*z = clamped sample, *dt = step at t,      */
+/* if empty, *t_next = t after the do{}while skip loop.                */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bound, dt_gamma, dt_min, dt_max;
+    uint32_t C, H;
+    const uint8_t* grid;
+} orc_ray_ctx;
+
+static inline int orc_eval_step(const orc_ray_ctx* c, float t, float* px, float* py, float* pz, float* pdt, float* t_skip) {
+    const float bound = c->bound;
+    const uint32_t H = c->H;
+    const float x = orc_clampf(fmaf(t, c->dx, c->ox), -bound, bound);
+    const float y = orc_clampf(fmaf(t, c->dy, c->oy), -bound, bound);
+    const float z = orc_clampf(fmaf(t, c->dz, c->oz), -bound, bound);
+    const float dt = orc_clampf(t * c->dt_gamma, c->dt_min, c->dt_max);
+    const int lp = orc_mip_from_pos(x, y, z, (float)c->C);
+    const int ld = orc_mip_from_dt(dt, (float)H, (float)c->C);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf((float)(1 << level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    /* `0.5 * (x * mip_rbound + 1) * H` is evaluated in double (0.5 is a double literal) */
+    const int nx = (int)orc_clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+    const int ny = (int)orc_clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+    const int nz = (int)orc_clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, (float)(H - 1));
+    const uint32_t index = (uint32_t)level * H * H * H + orc_morton3D_1((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const int occ = (c->grid[index / 8] & (1 << (index % 8))) != 0;
+    *px = x; *py = y; *pz = z; *pdt = dt;
+    if (!occ) {
+        /* distance to the voxel exit; note the (H - 1) quirk (:391-393) */
+        const float hm1 = (float)(H - 1);
+        const float tx = fmaf(fmaf((nx + 0.5f + 0.5f * orc_signf(c->dx)) / hm1, 2.0f, -1.0f), mip_bound, -x) * c->rdx;
+        const float ty = fmaf(fmaf((ny + 0.5f + 0.5f * orc_signf(c->dy)) / hm1, 2.0f, -1.0f), mip_bound, -y) * c->rdy;
+        const float tz = fmaf(fmaf((nz + 0.5f + 0.5f * orc_signf(c->dz)) / hm1, 2.0f, -1.0f), mip_bound, -z) * c->rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += orc_clampf(t * c->dt_gamma, c->dt_min, c->dt_max);
+        } while (t < tt);
+        *t_skip = t;
+    }
+    return occ;
+}
+
+static inline void orc_ray_ctx_init(orc_ray_ctx* c, const float* o, const float* d, const uint8_t* grid,
+                                    float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    c->ox = o[0]; c->oy = o[1]; c->oz = o[2];
+    c->dx = d[0]; c->dy = d[1]; c->dz = d[2];
+    c->rdx = 1 / c->dx; c->rdy = 1 / c->dy; c->rdz = 1 / c->dz;
+    c->bound = bound; c->dt_gamma = dt_gamma;
+    c->dt_min = 2 * ORC_SQRT3 / max_steps;                 /* :344 */
+    c->dt_max = 2 * ORC_SQRT3 * (1 << (C - 1)) / H;        /* :345 */
+    c->C = C; c->H = H; c->grid = grid;
+}
+
+/* ------------------------------------------------------------------ */
+/* march_rays_train: raymarching.cu:314-480; sequential-order atomics  */
+/* ------------------------------------------------------------------ */
+void orc_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid,
+                          float bound, float dt_gamma, uint32_t max_steps,
+                          uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                          const float* nears, const float* fars,
+                          float* xyzs, float* dirs, float* deltas,
+                          int* rays, int* counter, uint32_t perturb) {
+    for (uint32_t n = 0; n < N; n++) {
+        orc_ray_ctx c;
+        orc_ray_ctx_init(&c, rays_o + n * 3, rays_d + n * 3, grid, bound, dt_gamma, max_steps, C, H);
+        const float far = fars[n];
+        float t0 = nears[n];
+        if (perturb) {
+            orc_pcg32 rng;
+            orc_pcg32_seed(&rng, (uint64_t)n, 1u);
+            t0 += c.dt_min * orc_pcg32_next_float(&rng);
+        }
+        /* first pass: count */
+        float t = t0, x, y, z, dt, ts = 0;
+        uint32_t num_steps = 0;
+        while (t < far && num_steps < max_steps) {
+            if (orc_eval_step(&c, t, &x, &y, &z, &dt, &ts)) { num_steps++; t += dt; }
+            else t = ts;
+        }
+        /* :405-413 (atomicAdd, sequential order) */
+        const uint32_t point_index = (uint32_t)counter[0]; counter[0] += (int)num_steps;
+        const uint32_t ray_index = (uint32_t)counter[1];   counter[1] += 1;
+        rays[ray_index * 3] = (int)n;
+        rays[ray_index * 3 + 1] = (int)point_index;
+        rays[ray_index * 3 + 2] = (int)num_steps;
+        if (num_steps == 0) continue;
+        if (point_index + num_steps >= M) continue;         /* :416 (>=) */
+        float* px = xyzs + (size_t)point_index * 3;
+        float* pd = dirs + (size_t)point_index * 3;
+        float* pl = deltas + (size_t)point_index * 2;
+        /* second pass: write */
+        t = t0;
+        uint32_t step = 0;
+        float last_t = t;
+        while (t < far && step < num_steps) {
+            if (orc_eval_step(&c, t, &x, &y, &z, &dt, &ts)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                t += dt;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                step++;
+            } else t = ts;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* composite_rays_train_forward: raymarching.cu:501-578                */
+/* (__expf -> expf; accumulations as FMA, the nvcc default)            */
+/* ------------------------------------------------------------------ */
+void orc_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                      const int* rays, uint32_t M, uint32_t N,
+                                      float* weights_sum, float* depth, float* image) {
+    for (uint32_t n = 0; n < N; n++) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps >= M) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[index * 3] = image[index * 3 + 1] = image[index * 3 + 2] = 0;
+            continue;
+        }
+        const float* s = sigmas + offset;
+        const float* c = rgbs + (size_t)offset * 3;
+        const float* dl = deltas + (size_t)offset * 2;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - expf(-s[0] * dl[0]);
+            const float weight = alpha * T;
+            r = fmaf(weight, c[0], r);
+            g = fmaf(weight, c[1], g);
+            b = fmaf(weight, c[2], b);
+            t += dl[1];
+            d = fmaf(weight, t, d);
+            ws += weight;
+            T *= 1.0f - alpha;
+            s++; c += 3; dl += 2;
+        }
+        weights_sum[index] = ws; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* composite_rays_train_backward: raymarching.cu:603-682               */
+/* ------------------------------------------------------------------ */
+void orc_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                       const float* sigmas, const float* rgbs, const float* deltas,
+                                       const int* rays, const float* weights_sum, const float* image,
+                                       uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs) {
+    for (uint32_t n = 0; n < N; n++) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps >= M) continue;
+        const float gws = grad_weights_sum[index];
+        const float* gi = grad_image + (size_t)index * 3;
+        const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
+        const float ws_final = weights_sum[index];
+        const float* s = sigmas + offset;
+        const float* c = rgbs + (size_t)offset * 3;
+        const float* dl = deltas + (size_t)offset * 2;
+        float* gs = grad_sigmas + offset;
+        float* gc = grad_rgbs + (size_t)offset * 3;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float alpha = 1.0f - expf(-s[0] * dl[0]);
+            const float weight = alpha * T;
+            r = fmaf(weight, c[0], r);
+            g = fmaf(weight, c[1], g);
+            b = fmaf(weight, c[2], b);
+            ws += weight;
+            T *= 1.0f - alpha;
+            gc[0] = gi[0] * weight; gc[1] = gi[1] * weight; gc[2] = gi[2] * weight;
+            gs[0] = dl[0] * (gi[0] * (T * c[0] - (r_final - r)) +
+                             gi[1] * (T * c[1] - (g_final - g)) +
+                             gi[2] * (T * c[2] - (b_final - b)) +
+                             gws * (T - (ws_final - ws)));
+            s++; c += 3; dl += 2; gs++; gc += 3;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* march_rays (inference): raymarching.cu:701-804                      */
+/* ------------------------------------------------------------------ */
+void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, const float* rays_t,
+                    const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                    uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                    float* xyzs, float* dirs, float* deltas, uint32_t perturb) {
+    (void)nears;
+    for (uint32_t n = 0; n < n_alive; n++) {
+        const int index = rays_alive[n];
+        float t = rays_t[n];
+        orc_ray_ctx c;
+        orc_ray_ctx_init(&c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
+        const float far = fars[index];
+        float* px = xyzs + (size_t)n * n_step * 3;
+        float* pd = dirs + (size_t)n * n_step * 3;
+        float* pl = deltas + (size_t)n * n_step * 2;
+        if (perturb) {
+            orc_pcg32 rng;
+            orc_pcg32_seed(&rng, (uint64_t)n, (uint64_t)perturb);   /* :743: seed = slot n, stream = perturb */
+            t += c.dt_min * orc_pcg32_next_float(&rng);
+        }
+        float last_t = t, x, y, z, dt, ts = 0;
+        uint32_t step = 0;
+        while (t < far && step < n_step) {
+            if (orc_eval_step(&c, t, &x, &y, &z, &dt, &ts)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                t += dt;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                step++;
+            } else t = ts;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* composite_rays (inference, in place): raymarching.cu:817-900        */
+/* ------------------------------------------------------------------ */
+void orc_composite_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, float* rays_t,
+                        const float* sigmas, const float* rgbs, const float* deltas,
+                        float* weights_sum, float* depth, float* image) {
+    for (uint32_t n = 0; n < n_alive; n++) {
+        const int index = rays_alive[n];
+        float t = rays_t[n];
+        const float* s = sigmas + (size_t)n * n_step;
+        const float* c = rgbs + (size_t)n * n_step * 3;
+        const float* dl = deltas + (size_t)n * n_step * 2;
+        float weight_sum = weights_sum[index], d = depth[index];
+        float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+        uint32_t step = 0;
+        while (step < n_step) {
+            if (dl[0] == 0) break;
+            const float alpha = 1.0f - expf(-s[0] * dl[0]);
+            const float T = 1 - weight_sum;
+            const float weight = alpha * T;
+            weight_sum += weight;
+            t += dl[1];
+            d = fmaf(weight, t, d);
+            r = fmaf(weight, c[0], r);
+            g = fmaf(weight, c[1], g);
+            b = fmaf(weight, c[2], b);
+            if (T < 1e-5) break;       /* double literal: (double)T < 1e-5 */
+            s++; c += 3; dl += 2; step++;
+        }
+        rays_t[n] = (step < n_step) ? -1.0f : t;
+        weights_sum[index] = weight_sum; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* compact_rays: raymarching.cu:913-930 (sequential order)             */
+/* ------------------------------------------------------------------ */
+void orc_compact_rays(uint32_t n_alive, int* rays_alive, const int* rays_alive_old,
+                      float* rays_t, const float* rays_t_old, int* alive_counter) {
+    for (uint32_t n = 0; n < n_alive; n++) {
+        if (rays_t_old[n] >= 0) {
+            const int index = alive_counter[0]++;
+            rays_alive[index] = rays_alive_old[n];
+            rays_t[index] = rays_t_old[n];
+        }
+    }
+}
+
+/* ================================================================== */
+/* gridencoder: gridencoder/src/gridencoder.cu                         */
+/* ================================================================== */
+
+/* :34-50 */
+static inline uint32_t orc_fast_hash(const uint32_t* pos_grid, uint32_t D) {
+    static const uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t result = 0;
+    for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+    return result;
+}
+
+/* :53-71 */
+static inline uint32_t orc_get_grid_index(uint32_t D, uint32_t C, uint32_t gridtype, uint32_t ch,
+                                          uint32_t hashmap_size, uint32_t resolution, const uint32_t* pos_grid) {
+    uint32_t stride = 1, index = 0;
+    for (uint32_t d = 0; d < D && stride <= hashmap_size; d++) {
+        index += pos_grid[d] * stride;
+        stride *= (resolution + 1);
+    }
+    if (gridtype == 0 && stride > hashmap_size) index = orc_fast_hash(pos_grid, D);
+    return (index % hashmap_size) * C + ch;
+}
+
+/* per-level constants: gridencoder.cu:124-126 (fp32 exp2f / ceil) */
+void orc_grid_level_params(uint32_t level, float S, uint32_t H, float* scale, uint32_t* resolution) {
+    const float sc = exp2f(level * S) * H - 1.0f;
+    *scale = sc;
+    *resolution = (uint32_t)ceil(sc) + 1;
+}
+
+/* kernel_grid: gridencoder.cu:74-222.  outputs [L,B,C]; dy_dx [B,L,D,C]. */
+void orc_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets, float* outputs,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             int calc_grad_inputs, float* dy_dx, uint32_t gridtype) {
+    for (uint32_t level = 0; level < L; level++) {
+        const float* grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        orc_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float* in = inputs + (size_t)b * D;
+            float* out = outputs + ((size_t)level * B + b) * C;
+            float* jac = calc_grad_inputs ? dy_dx + ((size_t)b * L + level) * D * C : 0;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) {
+                for (uint32_t ch = 0; ch < C; ch++) out[ch] = 0;
+                if (jac) for (uint32_t i = 0; i < D * C; i++) jac[i] = 0;
+                continue;
+            }
+            float pos[3]; uint32_t pos_grid[3];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                const float fl = floorf(pos[d]);
+                pos_grid[d] = (uint32_t)fl;
+                pos[d] -= (float)pos_grid[d];
+            }
+            float results[8] = {0};
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1; uint32_t pgl[3];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = orc_get_grid_index(D, C, gridtype, 0, hashmap_size, resolution, pgl);
+                for (uint32_t ch = 0; ch < C; ch++) results[ch] = fmaf(w, grid[index + ch], results[ch]);
+            }
+            for (uint32_t ch = 0; ch < C; ch++) out[ch] = results[ch];
+            if (jac) {
+                for (uint32_t gd = 0; gd < D; gd++) {
+                    float rg[8] = {0};
+                    for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                        float w = scale; uint32_t pgl[3];
+                        for (uint32_t nd = 0; nd < D - 1; nd++) {
+                            const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                            if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                            else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                        }
+                        pgl[gd] = pos_grid[gd];
+                        const uint32_t il = orc_get_grid_index(D, C, gridtype, 0, hashmap_size, resolution, pgl);
+                        pgl[gd] = pos_grid[gd] + 1;
+                        const uint32_t ir = orc_get_grid_index(D, C, gridtype, 0, hashmap_size, resolution, pgl);
+                        for (uint32_t ch = 0; ch < C; ch++) rg[ch] = fmaf(w, grid[ir + ch] - grid[il + ch], rg[ch]);
+                    }
+                    for (uint32_t ch = 0; ch < C; ch++) jac[gd * C + ch] = rg[ch];
+                }
+            }
+        }
+    }
+}
+
+/* kernel_grid_backward: gridencoder.cu:225-311 (atomicAdd -> sequential +=, b ascending)
+ * kernel_input_backward: :314-340 */
+void orc_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int* offsets,
+                              float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                              int calc_grad_inputs, const float* dy_dx, float* grad_inputs, uint32_t gridtype) {
+    (void)embeddings;
+    for (uint32_t level = 0; level < L; level++) {
+        float* gg = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        float scale; uint32_t resolution;
+        orc_grid_level_params(level, S, H, &scale, &resolution);
+        for (uint32_t b = 0; b < B; b++) {
+            const float* in = inputs + (size_t)b * D;
+            const float* g = grad + ((size_t)level * B + b) * C;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[3]; uint32_t pos_grid[3];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+            }
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1; uint32_t pgl[3];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                const uint32_t index = orc_get_grid_index(D, C, gridtype, 0, hashmap_size, resolution, pgl);
+                for (uint32_t ch = 0; ch < C; ch++) gg[index + ch] += w * g[ch];
+            }
+        }
+    }
+    if (calc_grad_inputs) {
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t d = 0; d < D; d++) {
+                float result = 0;
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t ch = 0; ch < C; ch++)
+                        result = fmaf(grad[((size_t)l * B + b) * C + ch], dy_dx[(((size_t)b * L + l) * D + d) * C + ch], result);
+                grad_inputs[(size_t)b * D + d] = result;
+            }
+    }
+}
+
+/* ================================================================== */
+/* shencoder: shencoder/src/shencoder.cu:27-383                        */
+/* The reference spells out 64 polynomials + 3x64 partial derivatives  */
+/* as literals (:51-121, :131-351).  They are the real spherical       */
+/* harmonics with Condon-Shortley phase in the form                    */
+/*    Y_l^m = N_l^m * Q_l^m(z) * {Re,Im}(x+iy)^|m|                      */
+/* with Q_l^m(z) = P_l^m(z)/(1-z^2)^{m/2} a polynomial in z only, and   */
+/* x,y,z treated as independent variables (no normalisation).  The      */
+/* oracle evaluates exactly those polynomials by recurrence in double   */
+/* and rounds once; index = l*l + l + m.                                */
+/* ================================================================== */
+static void orc_sh_eval(double x, double y, double z, uint32_t deg, double* Y, double* dYx, double* dYy, double* dYz) {
+    /* A_m + i B_m = (x + i y)^m and partials */
+    double A[8], Bm[8], Ax[8], Ay[8], Bx[8], By[8];
+    A[0] = 1; Bm[0] = 0; Ax[0] = Ay[0] = Bx[0] = By[0] = 0;
+    for (uint32_t m = 1; m < deg; m++) {
+        A[m] = x * A[m - 1] - y * Bm[m - 1];
+        Bm[m] = x * Bm[m - 1] + y * A[m - 1];
+        Ax[m] = m * A[m - 1];  Ay[m] = -(double)m * Bm[m - 1];
+        Bx[m] = m * Bm[m - 1]; By[m] = m * A[m - 1];
+    }
+    for (uint32_t m = 0; m < deg; m++) {
+        /* Q_m^m = (-1)^m (2m-1)!!, Q_{m+1}^m = (2m+1) z Q_m^m, (l-m) Q_l^m = (2l-1) z Q_{l-1}^m - (l+m-1) Q_{l-2}^m */
+        double Q[8], dQ[8];
+        double qmm = 1;
+        for (uint32_t k = 1; k <= m; k++) qmm *= -(2.0 * k - 1.0);
+        Q[m] = qmm; dQ[m] = 0;
+        if (m + 1 < deg) { Q[m + 1] = (2.0 * m + 1.0) * z * qmm; dQ[m + 1] = (2.0 * m + 1.0) * qmm; }
+        for (uint32_t l = m + 2; l < deg; l++) {
+            Q[l] = ((2.0 * l - 1.0) * z * Q[l - 1] - (l + m - 1.0) * Q[l - 2]) / (double)(l - m);
+            dQ[l] = ((2.0 * l - 1.0) * (Q[l - 1] + z * dQ[l - 1]) - (l + m - 1.0) * dQ[l - 2]) / (double)(l - m);
+        }
+        for (uint32_t l = m; l < deg; l++) {
+            /* N_l^m = sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!) * (m ? sqrt2 : 1) */
+            double ratio = 1;
+            for (uint32_t k = l - m + 1; k <= l + m; k++) ratio /= (double)k;
+            double Nlm = sqrt((2.0 * l + 1.0) / (4.0 * M_PI) * ratio);
+            if (m) Nlm *= sqrt(2.0);
+            const uint32_t ip = l * l + l + m, in_ = l * l + l - m;
+            Y[ip] = Nlm * Q[l] * A[m];
+            dYx[ip] = Nlm * Q[l] * Ax[m]; dYy[ip] = Nlm * Q[l] * Ay[m]; dYz[ip] = Nlm * dQ[l] * A[m];
+            if (m) {
+                Y[in_] = Nlm * Q[l] * Bm[m];
+                dYx[in_] = Nlm * Q[l] * Bx[m]; dYy[in_] = Nlm * Q[l] * By[m]; dYz[in_] = Nlm * dQ[l] * Bm[m];
+            }
+        }
+    }
+}
+
+/* kernel_sh: shencoder.cu:27-356. outputs [B, C*C]; dy_dx [B, 3, C*C] */
+void orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                           int calc_grad_inputs, float* dy_dx) {
+    const uint32_t C2 = C * C;
+    for (uint32_t b = 0; b < B; b++) {
+        double Y[64], dx[64], dy[64], dz[64];
+        orc_sh_eval(inputs[(size_t)b * D], inputs[(size_t)b * D + 1], inputs[(size_t)b * D + 2], C, Y, dx, dy, dz);
+        for (uint32_t i = 0; i < C2; i++) outputs[(size_t)b * C2 + i] = (float)Y[i];
+        if (calc_grad_inputs) {
+            float* j = dy_dx + (size_t)b * D * C2;
+            for (uint32_t i = 0; i < C2; i++) { j[i] = (float)dx[i]; j[C2 + i] = (float)dy[i]; j[2 * C2 + i] = (float)dz[i]; }
+        }
+    }
+}
+
+/* kernel_sh_backward: shencoder.cu:359-383 (accumulates into pre-zeroed grad_inputs) */
+void orc_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                            const float* dy_dx, float* grad_inputs) {
+    (void)inputs;
+    const uint32_t C2 = C * C;
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t d = 0; d < D; d++) {
+            float acc = grad_inputs[(size_t)b * D + d];
+            for (uint32_t ch = 0; ch < C2; ch++)
+                acc = fmaf(grad[(size_t)b * C2 + ch], dy_dx[((size_t)b * D + d) * C2 + ch], acc);
+            grad_inputs[(size_t)b * D + d] = acc;
+        }
+}
+
+/* ================================================================== */
+/* ffmlp: ffmlp/src/ffmlp.cu (semantics: layer order, weight layout,   */
+/* ReLU masks; ffmlp.cu:377-403,632; utils.h:424-582 activations).     */
+/* Weight blob: [W_in hid x in | W_h (k-1) x hid x hid | W_out out x hid],*/
+/* each row-major W[out][in]; y = x W^T; no bias.                       */
+/* forward_buffer[l] = post-activation output of matmul l (l=0..k-1).   */
+/* The reference computes in fp16 with fp16 accumulation; this oracle   */
+/* computes in fp32/double-accumulate and optionally rounds storage     */
+/* to bf16 (rnd=1) or fp16 (rnd=2) at the same points the kernels do.   */
+/* ================================================================== */
+static inline float orc_round_bf16(float v) {
+    union { float f; uint32_t u; } x; x.f = v;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return v;           /* NaN */
+    x.u += 0x7fffu + ((x.u >> 16) & 1u);                        /* RNE */
+    x.u &= 0xffff0000u;
+    return x.f;
+}
+/* round-to-nearest-even through IEEE binary16 (gcc 11 has no _Float16 on x86) */
+static inline float orc_round_f16(float v) {
+    union { float f; uint32_t u; } x; x.f = v;
+    const uint32_t sign = x.u & 0x80000000u;
+    const uint32_t a = x.u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return v;                              /* inf / NaN */
+    if (a >= 0x477ff000u) { x.u = sign | 0x7f800000u; return x.f; } /* >= 65520 -> inf */
+    if (a < 0x38800000u) {                                       /* subnormal half: quantum 2^-24 */
+        const float q = 5.9604644775390625e-08f;                 /* 2^-24 */
+        float r = nearbyintf(fabsf(v) / q) * q;
+        return sign ? -r : r;
+    }
+    uint32_t u = a + 0xfffu + ((a >> 13) & 1u);                  /* RNE to 10 mantissa bits */
+    u &= 0xffffe000u;
+    x.u = sign | u;
+    return x.f;
+}
+static inline float orc_rnd(float v, int rnd) { return rnd == 1 ? orc_round_bf16(v) : rnd == 2 ? orc_round_f16(v) : v; }
+
+#define ORC_K_ACT 10.0f   /* ffmlp/src/utils.h:41 */
+static inline float orc_act(float x, uint32_t a) {              /* utils.h:424-470 */
+    switch (a) {
+        case 0: return x > 0 ? x : 0;
+        case 1: return expf(x);
+        case 2: return sinf(x);
+        case 3: return 1.0f / (1.0f + expf(-x));
+        case 4: { float v = x * ORC_K_ACT; return 0.5f * (v + sqrtf(v * v + 4)) / ORC_K_ACT; }
+        case 5: return logf(expf(x * ORC_K_ACT) + 1.0f) / ORC_K_ACT;
+        default: return x;
+    }
+}
+/* utils.h:534-582: gradient transfer given the *post-activation* forward value */
+static inline float orc_act_bwd(float g, float fwd, uint32_t a) {
+    switch (a) {
+        case 0: return fwd > 0 ? g : 0;
+        case 1: return g * fwd;
+        case 3: return g * (fwd * (1.0f - fwd));
+        case 4: { float y = fwd * ORC_K_ACT; return g * (y * y / (y * y + 1)); }
+        case 5: return g * (1.0f - expf(-fwd * ORC_K_ACT));
+        default: return g;     /* None; Sine is unsupported in the reference backward */
+    }
+}
+
+void orc_ffmlp_forward(const float* inputs, const float* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                       uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                       float* forward_buffer /* [k,B,hid] or NULL */, float* outputs /* [B,out] */, int rnd) {
+    float* cur = (float*)malloc(sizeof(float) * hidden_dim);
+    float* nxt = (float*)malloc(sizeof(float) * hidden_dim);
+    const float* W_in = weights;
+    const float* W_h = weights + (size_t)hidden_dim * input_dim;
+    const float* W_out = W_h + (size_t)(num_layers - 1) * hidden_dim * hidden_dim;
+    for (uint32_t b = 0; b < B; b++) {
+        const float* x = inputs + (size_t)b * input_dim;
+        for (uint32_t o = 0; o < hidden_dim; o++) {
+            double acc = 0;
+            for (uint32_t i = 0; i < input_dim; i++) acc += (double)orc_rnd(x[i], rnd) * (double)orc_rnd(W_in[(size_t)o * input_dim + i], rnd);
+            cur[o] = orc_rnd(orc_act((float)acc, activation), rnd);
+        }
+        if (forward_buffer) memcpy(forward_buffer + ((size_t)0 * B + b) * hidden_dim, cur, sizeof(float) * hidden_dim);
+        for (uint32_t l = 1; l < num_layers; l++) {
+            const float* W = W_h + (size_t)(l - 1) * hidden_dim * hidden_dim;
+            for (uint32_t o = 0; o < hidden_dim; o++) {
+                double acc = 0;
+                for (uint32_t i = 0; i < hidden_dim; i++) acc += (double)cur[i] * (double)orc_rnd(W[(size_t)o * hidden_dim + i], rnd);
+                nxt[o] = orc_rnd(orc_act((float)acc, activation), rnd);
+            }
+            float* tmp = cur; cur = nxt; nxt = tmp;
+            if (forward_buffer) memcpy(forward_buffer + ((size_t)l * B + b) * hidden_dim, cur, sizeof(float) * hidden_dim);
+        }
+        for (uint32_t o = 0; o < output_dim; o++) {
+            double acc = 0;
+            for (uint32_t i = 0; i < hidden_dim; i++) acc += (double)cur[i] * (double)orc_rnd(W_out[(size_t)o * hidden_dim + i], rnd);
+            outputs[(size_t)b * output_dim + o] = orc_rnd(orc_act((float)acc, output_activation), rnd);
+        }
+    }
+    free(cur); free(nxt);
+}
+
+/* ffmlp_backward: ffmlp.cu:745-895 + kernel_mlp_fused_backward :410-518.
+ * backward_buffer[j] (j=0..k-1) = dL/d(pre-activation of matmul k-1-j); output activation ignored (:781). */
+void orc_ffmlp_backward(const float* grad, const float* inputs, const float* weights, const float* forward_buffer,
+                        uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                        uint32_t activation, int calc_grad_inputs,
+                        float* backward_buffer /* [k,B,hid] or NULL */, float* grad_inputs /* [B,in] */,
+                        float* grad_weights /* flat, pre-zeroed */, int rnd) {
+    const uint32_t k = num_layers, hid = hidden_dim;
+    const float* W_in = weights;
+    const float* W_h = weights + (size_t)hid * input_dim;
+    const float* W_out = W_h + (size_t)(k - 1) * hid * hid;
+    const size_t nW = (size_t)hid * (input_dim + (size_t)hid * (k - 1) + output_dim);
+    double* gW = (double*)calloc(nW, sizeof(double));
+    double* gW_in = gW;
+    double* gW_h = gW + (size_t)hid * input_dim;
+    double* gW_out = gW_h + (size_t)(k - 1) * hid * hid;
+    float* g = (float*)malloc(sizeof(float) * hid);
+    float* gn = (float*)malloc(sizeof(float) * hid);
+    for (uint32_t b = 0; b < B; b++) {
+        const float* go = grad + (size_t)b * output_dim;
+        const float* fl = forward_buffer + ((size_t)(k - 1) * B + b) * hid;
+        /* output layer: dW_out += go^T fwd_{k-1};  g = (go W_out) * act'(fwd_{k-1}) */
+        for (uint32_t o = 0; o < output_dim; o++)
+            for (uint32_t i = 0; i < hid; i++) gW_out[(size_t)o * hid + i] += (double)orc_rnd(go[o], rnd) * (double)fl[i];
+        for (uint32_t i = 0; i < hid; i++) {
+            double acc = 0;
+            for (uint32_t o = 0; o < output_dim; o++) acc += (double)orc_rnd(go[o], rnd) * (double)orc_rnd(W_out[(size_t)o * hid + i], rnd);
+            g[i] = orc_rnd(orc_act_bwd((float)acc, fl[i], activation), rnd);
+        }
+        if (backward_buffer) memcpy(backward_buffer + ((size_t)0 * B + b) * hid, g, sizeof(float) * hid);
+        /* hidden layers, last to first */
+        for (uint32_t j = 1; j < k; j++) {
+            const uint32_t l = k - j;                      /* matmul index whose weights are W_h[l-1] */
+            const float* W = W_h + (size_t)(l - 1) * hid * hid;
+            double* gWl = gW_h + (size_t)(l - 1) * hid * hid;
+            const float* fprev = forward_buffer + ((size_t)(l - 1) * B + b) * hid;
+            for (uint32_t o = 0; o < hid; o++)
+                for (uint32_t i = 0; i < hid; i++) gWl[(size_t)o * hid + i] += (double)g[o] * (double)fprev[i];
+            for (uint32_t i = 0; i < hid; i++) {
+                double acc = 0;
+                for (uint32_t o = 0; o < hid; o++) acc += (double)g[o] * (double)orc_rnd(W[(size_t)o * hid + i], rnd);
+                gn[i] = orc_rnd(orc_act_bwd((float)acc, fprev[i], activation), rnd);
+            }
+            float* tmp = g; g = gn; gn = tmp;
+            if (backward_buffer) memcpy(backward_buffer + ((size_t)j * B + b) * hid, g, sizeof(float) * hid);
+        }
+        /* input layer */
+        const float* x = inputs + (size_t)b * input_dim;
+        for (uint32_t o = 0; o < hid; o++)
+            for (uint32_t i = 0; i < input_dim; i++) gW_in[(size_t)o * input_dim + i] += (double)g[o] * (double)orc_rnd(x[i], rnd);
+        if (calc_grad_inputs) {
+            for (uint32_t i = 0; i < input_dim; i++) {
+                double acc = 0;
+                for (uint32_t o = 0; o < hid; o++) acc += (double)g[o] * (double)orc_rnd(W_in[(size_t)o * input_dim + i], rnd);
+                grad_inputs[(size_t)b * input_dim + i] = orc_rnd((float)acc, rnd);
+            }
+        }
+    }
+    for (size_t i = 0; i < nW; i++) grad_weights[i] += (float)gW[i];
+    free(gW); free(g); free(gn);
+}

@@ -1,0 +1,311 @@
+"""Mint tests/golden/*.npz by running the reference's own Python (this container only).
+
+    cd /root/repo && python -B -m oracle.make_golden
+
+TEST INFRASTRUCTURE ONLY.  The reference has no tests or golden vectors; what it does have is
+Python that is an independent statement of parts of the hot path.  This script imports that Python (recipe:
+oracle/ref_import.py), drives it on CPU -- the native parts through the reference's own autograd wrappers backed by the
+C oracle -- and stores inputs + outputs as small fixtures.  tests/ then check
+  (a) enerf_amd's re-stated wrappers / networks / renderer.run / event loss against these fixtures (same oracle backend),
+  (b) the oracle's compositing against NeRFRenderer.run's cumprod formula and torch autograd (the only second statement
+      of a native kernel the reference contains).
+Only data (arrays) is stored; no reference source text.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_import
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def det_fill_(params, seed, lo=-1.0, hi=1.0):
+    """Deterministic parameter fill shared with the tests (tests/util.py:det_fill_)."""
+    g = torch.Generator().manual_seed(seed)
+    for p in params:
+        p.data.copy_(torch.rand(p.shape, generator=g) * (hi - lo) + lo)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"  wrote {name}.npz ({', '.join(f'{k}{list(v.shape)}' for k, v in out.items())})")
+
+
+def pts(n, seed, lo=-1.0, hi=1.0, d=3):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, d, generator=g) * (hi - lo) + lo
+
+
+def gold_grid_wrapper():
+    from gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=6, level_dim=2, base_resolution=4, log2_hashmap_size=9,
+                      desired_resolution=96)
+    det_fill_([enc.embeddings], 11)
+    x = pts(96, 12, -1.0, 1.0)
+    x[5] = torch.tensor([1.5, 0.0, 0.0])      # out of range -> zeros
+    x[6] = torch.tensor([1.0, -1.0, 1.0])     # exactly on the boundary
+    x.requires_grad_(True)
+    y = enc(x, bound=1)
+    w = pts(96, 13, -1, 1, d=12)
+    (y * w).sum().backward()
+    save("ref_grid_wrapper", x=x, w=w, y=y, grad_embeddings=enc.embeddings.grad, grad_x=x.grad,
+         offsets=enc.offsets, per_level_scale=np.float64(enc.per_level_scale))
+    # offset tables of the two BASELINE configurations (bound 2 and 3) -- table sizing only
+    for bound in (1, 2, 3):
+        e = GridEncoder(desired_resolution=2048 * bound)
+        save(f"ref_grid_offsets_b{bound}", offsets=e.offsets, per_level_scale=np.float64(e.per_level_scale),
+             n_rows=np.int64(e.embeddings.shape[0]))
+
+
+def gold_sh_wrapper():
+    from shencoder import SHEncoder
+    for deg in (4, 8):
+        enc = SHEncoder(degree=deg)
+        d = pts(40, 20 + deg)
+        d = d / d.norm(dim=-1, keepdim=True)
+        d[3] = d[3] * 0.5     # un-normalised input: kernel must not normalise
+        d.requires_grad_(True)
+        y = enc(d)
+        w = pts(40, 21, d=deg * deg)
+        (y * w).sum().backward()
+        save(f"ref_sh_wrapper_d{deg}", d=d, w=w, y=y, grad_d=d.grad)
+
+
+def gold_ffmlp_wrapper():
+    from ffmlp import FFMLP
+    for (i, o, h, k, B) in ((32, 16, 64, 2, 100), (32, 3, 64, 3, 128)):
+        net = FFMLP(i, o, h, k)
+        w0 = net.weights.detach().clone()
+        net.train()
+        x = pts(B, 30 + k, d=i).requires_grad_(True)
+        y = net(x)
+        gw = pts(B, 31, d=o)
+        (y * gw).sum().backward()
+        net.eval()
+        with torch.no_grad():
+            y_inf = net(x.detach())
+        save(f"ref_ffmlp_wrapper_k{k}", x=x, gw=gw, y=y, y_inf=y_inf, weights=w0, grad_weights=net.weights.grad,
+             grad_x=x.grad)
+
+
+def _rays(n, seed, bound):
+    g = torch.Generator().manual_seed(seed)
+    o = (torch.rand(n, 3, generator=g) - 0.5) * 0.6 * bound
+    o[:, 2] -= 1.6 * bound
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 1.2 * bound
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o.unsqueeze(0), d.unsqueeze(0)
+
+
+def gold_network():
+    from nerf.network import NeRFNetwork
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=False, out_dim_color=3)
+    det_fill_(list(model.parameters()), 41)
+    model.eval()
+    x = pts(80, 42, -2, 2)
+    d = pts(80, 43)
+    d = d / d.norm(dim=-1, keepdim=True)
+    sigma, color = model(x, d)
+    dens = model.density(x)
+    mask = torch.rand(80, generator=torch.Generator().manual_seed(44)) > 0.4
+    cm = model.color(x, d, mask=mask, geo_feat=dens["geo_feat"])
+    save("ref_network", x=x, d=d, sigma=sigma, color=color, geo_feat=dens["geo_feat"], mask=mask, color_masked=cm)
+
+    # NeRFRenderer.run through the reference (eval mode: deterministic upsampling)
+    o, dd = _rays(24, 45, 2)
+    for up in (0, 8):
+        with torch.no_grad():
+            out = model.render(o, dd, staged=False, bg_color=None, perturb=False, num_steps=24, upsample_steps=up,
+                               out_dim_color=3)
+        save(f"ref_run_up{up}", rays_o=o, rays_d=dd, image=out["image"], depth=out["depth"])
+    # training-mode run with gradients (no upsampling: rand-free)
+    model.train()
+    out = model.render(o, dd, staged=False, bg_color=torch.full((3,), 0.25), perturb=False, num_steps=24,
+                       upsample_steps=0, out_dim_color=3)
+    loss = (out["image"] ** 2).sum() + out["depth"].sum()
+    loss.backward()
+    save("ref_run_train", rays_o=o, rays_d=dd, image=out["image"], depth=out["depth"],
+         g_sigma0=model.sigma_net[0].weight.grad, g_color2=model.color_net[2].weight.grad,
+         g_emb_sum=model.encoder.embeddings.grad.abs().sum(),
+         g_emb_l0=model.encoder.embeddings.grad[:4920])
+
+
+def gold_network_ff():
+    from nerf.network_ff import NeRFNetwork
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=False)
+    det_fill_([model.encoder.embeddings], 51)
+    model.eval()
+    x = pts(70, 52, -2, 2)
+    d = pts(70, 53)
+    d = d / d.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        sigma, rgb = model(x, d)
+    save("ref_network_ff", x=x, d=d, sigma=sigma, rgb=rgb, w_sigma=model.sigma_net.weights, w_color=model.color_net.weights)
+
+
+def gold_composite_vs_run():
+    """NeRFRenderer.run's compositing (cumprod formula) on prescribed per-sample sigmas / rgbs, with autograd grads."""
+    from nerf.renderer import NeRFRenderer
+
+    N, T = 37, 29
+    g = torch.Generator().manual_seed(61)
+    sig = (torch.rand(N, T, generator=g) * 6.0).requires_grad_(True)
+    sig.data[3] = 0.0                                  # fully transparent ray
+    sig.data[4] *= 40.0                                # saturating ray
+    rgb = torch.rand(N, T, 3, generator=g).requires_grad_(True)
+
+    class Fake(NeRFRenderer):
+        def density(self, x):
+            return {"sigma": sig.reshape(-1)}
+
+        def color(self, x, d, mask=None, **kw):
+            return rgb.reshape(-1, 3)       # ignore the w>1e-4 mask: the native kernel composites every sample
+
+    m = Fake(bound=1, cuda_ray=False)
+    m.train()
+    o, d = _rays(N, 62, 1)
+    out = m.render(o, d, staged=False, bg_color=torch.zeros(3), perturb=False, num_steps=T, upsample_steps=0,
+                   out_dim_color=3)
+    image = out["image"][0]
+    gi = torch.rand(N, 3, generator=g)
+    (image * gi).sum().backward()
+    # weights_sum through a second pass with rgb == 1 and its own upstream gradient
+    g_sig_img, g_rgb_img = sig.grad.clone(), rgb.grad.clone()
+    sig.grad = None
+    rgb_saved = rgb.data.clone()
+    rgb.data.fill_(1.0)
+    out1 = m.render(o, d, staged=False, bg_color=torch.zeros(3), perturb=False, num_steps=T, upsample_steps=0,
+                    out_dim_color=3)
+    ws = out1["image"][0, :, 0]
+    gws = torch.rand(N, generator=g)
+    (ws * gws).sum().backward()
+    g_sig_ws = sig.grad.clone()
+    rgb.data.copy_(rgb_saved)
+    # the z/delta sequence run() used (renderer.py:166-176, 228-229)
+    from oracle import oracle as O
+    nears, fars = O.near_far_from_aabb(o[0].numpy(), d[0].numpy(), m.aabb_train.numpy(), 0.2)
+    save("ref_composite_vs_run", rays_o=o[0], rays_d=d[0], nears=nears, fars=fars, sigmas=sig, rgbs=rgb, image=image,
+         weights_sum=ws, grad_image=gi, grad_ws=gws, g_sig_img=g_sig_img, g_rgb_img=g_rgb_img, g_sig_ws=g_sig_ws)
+
+
+def gold_events():
+    import argparse as ap
+    from nerf.utils import Trainer, get_rays, get_event_rays
+    from utils.event_utils import rgb_to_luma, lin_log
+
+    g = torch.Generator().manual_seed(71)
+    B, N = 1, 50
+    img1 = torch.rand(B, N, 3, generator=g)
+    img2 = (img1 + 0.2 * (torch.rand(B, N, 3, generator=g) - 0.5)).clamp(0, 1)
+    img3 = torch.rand(B, N, 3, generator=g)
+    pols = torch.sign(torch.rand(B, N, generator=g) - 0.5)
+    frames = torch.rand(B, N, 3, generator=g)
+
+    class FakeModel:
+        def __init__(self):
+            self.calls = 0
+
+        def render(self, o, d, **kw):
+            self.calls += 1
+            im = [img1, img2, img3][(self.calls - 1) % 3].clone().requires_grad_(True)
+            self.last = getattr(self, "last", []) + [im]
+            return {"image": im, "depth": im[..., 0]}
+
+    results = {}
+    cfgs = {
+        "luma_linlog": dict(use_luma=1, linlog=1, C_thres=0.2, event_only=1),
+        "rgb_linlog": dict(use_luma=0, linlog=1, C_thres=0.2, event_only=1),
+        "luma_log": dict(use_luma=1, linlog=0, C_thres=0.2, event_only=1),
+        "rgb_log": dict(use_luma=0, linlog=0, C_thres=0.2, event_only=1),
+        "normed": dict(use_luma=1, linlog=1, C_thres=-1, event_only=1),
+        "both": dict(use_luma=1, linlog=1, C_thres=0.2, event_only=0),
+    }
+    for name, c in cfgs.items():
+        t = Trainer.__new__(Trainer)
+        t.device = torch.device("cpu")
+        t.out_dim_color = 3
+        t.use_luma, t.linlog, t.C_thres, t.event_only = c["use_luma"], c["linlog"], c["C_thres"], c["event_only"]
+        t.log_implicit_C_thres = False
+        t.negative_event_sampling = False
+        t.weight_loss_rgb = 1.0
+        t.epoch, t.epoch_start_noEvLoss = 1, 0
+        t.criterion = torch.nn.MSELoss(reduction="none")
+        if not t.linlog:
+            t.log_thres = torch.Tensor([0.0000001])
+        t.opt = ap.Namespace()
+        t.model = FakeModel()
+        data = {"images": frames, "rays_evs_o1": torch.zeros(B, N, 3), "rays_evs_d1": torch.zeros(B, N, 3),
+                "rays_evs_o2": torch.zeros(B, N, 3), "rays_evs_d2": torch.zeros(B, N, 3), "pols": pols,
+                "rays_o": torch.zeros(B, N, 3), "rays_d": torch.zeros(B, N, 3)}
+        delta, gt_pol, loss, _, losses = t.train_step_events(data)
+        loss.backward()
+        results[f"{name}_loss"] = loss
+        results[f"{name}_delta"] = delta
+        results[f"{name}_g1"] = t.model.last[0].grad if t.model.last[0].grad is not None else torch.zeros_like(img1)
+        results[f"{name}_g2"] = t.model.last[1].grad if t.model.last[1].grad is not None else torch.zeros_like(img1)
+        if not c["event_only"]:
+            results[f"{name}_g3"] = t.model.last[2].grad
+    save("ref_event_loss", img1=img1, img2=img2, img3=img3, pols=pols, frames=frames, **results)
+    x = torch.rand(20, 3, generator=g)
+    save("ref_event_utils", x=x, luma_esim=rgb_to_luma(x, esim=True), luma_v2e=rgb_to_luma(x, esim=False),
+         linlog=lin_log(x * 255, 20))
+
+    # rays
+    H, W = 6, 8
+    intr = (7.5, 7.0, 3.5, 2.5)
+    th = 0.3
+    pose = torch.tensor([[np.cos(th), 0, np.sin(th), 0.1], [0, 1, 0, -0.2], [-np.sin(th), 0, np.cos(th), 0.3],
+                         [0, 0, 0, 1]], dtype=torch.float32).unsqueeze(0)
+    full = get_rays(pose, intr, H, W, -1)
+    xs = torch.tensor([0.0, 3.0, 7.0, 2.0])
+    ys = torch.tensor([0.0, 5.0, 1.0, 2.0])
+    c2w_b = pose[:, :3, :].unsqueeze(1).expand(1, 4, 3, 4).clone()
+    c2w_a = c2w_b.clone()
+    c2w_a[..., :3, 3] += 0.05
+    ev = get_event_rays(xs, ys, c2w_b, c2w_a, intr)
+    save("ref_rays", pose=pose, intr=np.array(intr), H=np.int64(H), W=np.int64(W), rays_o=full["rays_o"],
+         rays_d=full["rays_d"], xs=xs, ys=ys, c2w_b=c2w_b, c2w_a=c2w_a, **{k: v for k, v in ev.items()})
+
+
+def gold_misc():
+    from activation import trunc_exp
+    from encoding import FreqEncoder
+    x = torch.linspace(-20, 20, 41).requires_grad_(True)
+    y = trunc_exp(x)
+    y.sum().backward()
+    f = FreqEncoder(input_dim=3, max_freq_log2=5, N_freqs=6)
+    p = pts(9, 81)
+    save("ref_misc", x=x, trunc_exp=y, trunc_exp_grad=x.grad, p=p, freq=f(p))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    if not sys.dont_write_bytecode:
+        print("re-run with python -B", file=sys.stderr)
+        sys.exit(2)
+    ref_import.install()
+    os.makedirs(OUT, exist_ok=True)
+    jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
+            gold_composite_vs_run, gold_events, gold_misc]
+    for j in jobs:
+        if a.only and a.only not in j.__name__:
+            continue
+        print(j.__name__)
+        j()
+
+
+if __name__ == "__main__":
+    main()
