@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path's headline measurement (BASELINE.json: train rays/sec + render Msamples/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration of BASELINE config 2 (shakeCarpet1-shaped: bound 3, hash grid L16 F2 T2^19,
+HIP march_rays_train, nn.Linear MLPs, fp32, 4096 rays per GPU) on the synthetic scene of enerf_amd/scene.py:
+update_extra_state (every 16 steps) + render + MSE + backward + [RCCL gradient all-reduce] + Adam.  Inputs (ray
+batches, targets) are generated on the device before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant HBM-bound kernel (grid_encode_forward): algorithmic bytes (1164 B/point x points per launch)
+                / mean launch duration measured with hipEvents on the launch stream inside the timed region
+  cpu_baseline  the reference's pure-PyTorch route (NeRFRenderer.run, 512 stratified samples per ray, nn.Linear nets,
+                fwd + bwd + Adam) re-stated in enerf_amd and run on the host cores with the C oracle as the native
+                backend, on a bounded sample (256 rays/step); rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+GRID_FWD_BYTES_PER_POINT = 1164   # 12 in + 16 levels x 8 corners x 8 B + 128 out
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--bound", type=int, default=3)
+    ap.add_argument("--mode", choices=["rgb", "events"], default="rgb")
+    ap.add_argument("--render-frames", type=int, default=1, help="full 640x480 inference frames timed after training")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build_batches(n_batches, n_rays, device, rank, bound):
+    from enerf_amd import scene
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + rank)
+    batches = []
+    for b in range(n_batches):
+        (ro, rd), inds = scene.training_batch(b, n_rays, device, generator=g, rank=rank)
+        # synthetic target colour: a smooth function of the ray (there is no dataset; "data": "synthetic")
+        target = (0.5 + 0.5 * torch.sin(rd * 4.0 + ro)).clamp(0, 1).contiguous()
+        batches.append((ro, rd, target))
+    return batches
+
+
+def cpu_baseline(args):
+    """Reference pure-PyTorch route on the host: run() + nn.Linear + oracle-backed encoders, fwd+bwd+Adam."""
+    import enerf_amd.raymarching as rm
+    import enerf_amd.gridencoder as ge
+    import enerf_amd.shencoder as sh
+    from oracle import backend as ob
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd import scene
+    saved = (rm._backend, rm._DEVICE, ge._backend, sh._backend)
+    rm._backend, rm._DEVICE, ge._backend, sh._backend = (ob.raymarching_backend, "cpu", ob.gridencoder_backend,
+                                                         ob.shencoder_backend)
+    try:
+        # 16 hash-grid levels = 16 OpenMP tasks; more torch threads than that only adds fork/join cost on the
+        # small (131k x 64) GEMMs.  `cores` reports the threads actually used.
+        from oracle import oracle as O
+        cores = min(os.cpu_count() or 1, 16)
+        prev_threads = torch.get_num_threads()
+        torch.set_num_threads(cores)
+        O.set_threads(cores)
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=False, out_dim_color=3)
+        opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        model.train()
+        n, T = args.cpu_rays, 512
+        g = torch.Generator().manual_seed(7)
+        steps, t_total = 0, 0.0
+        for it in range(1 + 64):
+            (ro, rd), _ = scene.training_batch(it, n, "cpu", generator=g)
+            target = (0.5 + 0.5 * torch.sin(rd * 4.0 + ro)).clamp(0, 1)
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            out = model.render(ro, rd, staged=False, bg_color=None, perturb=True, num_steps=T, upsample_steps=0,
+                               out_dim_color=3)
+            loss = torch.nn.functional.mse_loss(out["image"], target)
+            loss.backward()
+            opt.step()
+            dt = time.perf_counter() - t0
+            if it == 0:
+                continue        # warm-up
+            steps += 1
+            t_total += dt
+            if t_total > args.cpu_budget_s or steps >= 16:
+                break
+        rays_s = steps * n / t_total
+        return {"value": rays_s, "unit": "rays/s", "cores": cores, "kind": "port",
+                "network_evals_per_sec": rays_s * T,
+                "sample": f"{steps} steps x {n} rays x {T} stratified samples/ray (NeRFRenderer.run + nn.Linear, "
+                          f"fwd+bwd+Adam, hash grid via the C oracle with one OpenMP task per level), "
+                          f"{t_total:.1f} s of CPU work, torch threads={cores}"}
+    finally:
+        rm._backend, rm._DEVICE, ge._backend, sh._backend = saved
+        torch.set_num_threads(prev_threads)
+
+
+def main():
+    args = parse()
+    from enerf_amd import parallel, _lib
+    from enerf_amd.backends import _gridencoder as gb, _raymarching as rb
+    import torch.distributed as dist
+
+    rank, world, local_rank = parallel.init_from_env()
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    from enerf_amd.events import EventOptions
+
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
+    harness = TrainHarness(model, occupancy="synthetic", world=world)
+    parallel.broadcast_state(model)
+    batches = build_batches(8, args.rays, device, rank, args.bound)
+    ev_opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
+
+    def one_step(i):
+        ro, rd, target = batches[i % len(batches)]
+        if args.mode == "rgb":
+            return harness.step_rgb(ro, rd, target)
+        ro2, rd2, _ = batches[(i + 1) % len(batches)]
+        pols = torch.sign(target[..., 0] - 0.5)
+        data = {"images": target, "rays_evs_o1": ro, "rays_evs_d1": rd, "rays_evs_o2": ro2, "rays_evs_d2": rd2,
+                "pols": pols}
+        return harness.step_events(data, ev_opt)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    sync()
+
+    samples_acc = torch.zeros((), dtype=torch.int64, device=device)
+    gb.STATS.update(fwd_points=0, fwd_calls=0, bwd_points=0, bwd_calls=0)
+    _lib.prof.reset()
+    _lib.prof.enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        one_step(i)
+        samples_acc += model.step_counter[(model.local_step - 1) % 16, 0].to(torch.int64)
+        if args.mode == "events":
+            samples_acc += model.step_counter[(model.local_step - 2) % 16, 0].to(torch.int64)
+    sync()
+    t1 = time.perf_counter()
+    _lib.prof.enable(False)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(samples_acc, op=dist.ReduceOp.SUM)
+    elapsed = float(elapsed.item())
+    total_samples = int(samples_acc.item())
+    renders_per_step = 2 if args.mode == "events" else 1
+    total_rays = world * args.rays * renders_per_step * args.steps
+
+    kernels = {}
+    for name in ("grid_fwd", "grid_bwd", "march_train", "composite_fwd", "composite_bwd", "sh_fwd"):
+        ms, n = _lib.prof.read(name)
+        if n:
+            kernels[name] = {"avg_ms": ms / n, "launches": int(n)}
+    roofline = None
+    if "grid_fwd" in kernels and gb.STATS["fwd_calls"]:
+        pts = gb.STATS["fwd_points"] / gb.STATS["fwd_calls"]
+        achieved = pts * GRID_FWD_BYTES_PER_POINT / (kernels["grid_fwd"]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "grid_encode_forward", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"]}
+        if "grid_bwd" in kernels and gb.STATS["bwd_calls"]:
+            ptsb = gb.STATS["bwd_points"] / gb.STATS["bwd_calls"]
+            roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / \
+                (kernels["grid_bwd"]["avg_ms"] * 1e-3) / 1e9
+
+    # ---- render leg (not part of `value`): full 640x480 frame through the inference loop
+    render = None
+    if args.render_frames > 0:
+        from enerf_amd import scene
+        model.eval()
+        inds = torch.arange(scene.H * scene.W, device=device)
+        ro, rd = scene.pixel_rays(scene.pose(3), inds, device)
+        with torch.no_grad():
+            model.render(ro, rd, staged=False, bg_color=None, perturb=False)      # warm-up
+            torch.cuda.synchronize()
+            rb.STATS.update(infer_samples=0, infer_calls=0)
+            tr0 = time.perf_counter()
+            for _ in range(args.render_frames):
+                model.render(ro, rd, staged=False, bg_color=None, perturb=False)
+            torch.cuda.synchronize()
+            tr = time.perf_counter() - tr0
+        render = {"msamples_per_sec": rb.STATS["infer_samples"] / tr / 1e6, "frames": args.render_frames,
+                  "rays_per_frame": scene.H * scene.W, "ms_per_frame": tr / args.render_frames * 1e3,
+                  "march_iterations_per_frame": rb.STATS["infer_calls"] / args.render_frames}
+        model.train()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        out = {
+            "metric": "train_rays_per_sec",
+            "value": total_rays / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: shakeCarpet1-shaped train step, bound={args.bound}, hashgrid "
+                                   f"L16 F2 T2^19 + HIP march_rays_train, nn.Linear MLPs fp32, {args.rays} rays/GPU, "
+                                   f"mode={args.mode}",
+                       "rays_per_gpu": args.rays, "global_rays": world * args.rays,
+                       "parallelism": f"ray-sharded dp{world}" if world > 1 else "single"},
+            "train_ray_samples_per_sec": total_samples / elapsed,
+            "samples_per_step_per_gpu": total_samples / args.steps / world,
+            "render": render,
+            "kernels": kernels,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

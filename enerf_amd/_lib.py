@@ -57,6 +57,10 @@ def lib():
             raise RuntimeError(
                 f"enerf_amd: {LIB_PATH} not found. Build it with `python -m enerf_amd.build` "
                 "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the hot path.")
+        # torch bundles its own libamdhip64.so (soname libamdhip64.so.7, requested by torch as "libamdhip64.so").
+        # It must be in the process before this library is, so that both resolve to ONE HIP runtime (one set of
+        # streams / queues): loaded the other way round the process ends up with two runtimes.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, sig in SIGNATURES.items():
             fn = getattr(l, name)

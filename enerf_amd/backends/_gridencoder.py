@@ -2,6 +2,9 @@
 (gridencoder/src/bindings.cpp:5-8), plus keyword-only `layout` (0 = [L,B,C] as the reference, 1 = [B,L*C])."""
 from .. import _lib as L
 
+# points processed per entry point since the last reset (bench.py: algorithmic bytes = 1164 B/point)
+STATS = {"fwd_points": 0, "fwd_calls": 0, "bwd_points": 0, "bwd_calls": 0}
+
 
 def _chk(t, name, floating=True):
     L.check_cuda(t, name)
@@ -18,6 +21,8 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H,
     import torch
     if inputs.dtype != torch.float32:
         raise RuntimeError("inputs must be a float32 tensor (gridencoder.cu:437 reads inputs as float*)")
+    STATS["fwd_points"] += int(B)
+    STATS["fwd_calls"] += 1
     dt = L.dtype_code(embeddings)
     if outputs.dtype != embeddings.dtype or dy_dx.dtype != embeddings.dtype:
         raise RuntimeError("outputs/dy_dx must have the dtype of embeddings")
@@ -33,6 +38,8 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     import torch
     if inputs.dtype != torch.float32:
         raise RuntimeError("inputs must be a float32 tensor")
+    STATS["bwd_points"] += int(B)
+    STATS["bwd_calls"] += 1
     dt = L.dtype_code(grad)
     for t, n in ((embeddings, "embeddings"), (grad_embeddings, "grad_embeddings"), (dy_dx, "dy_dx"),
                  (grad_inputs, "grad_inputs")):

@@ -2,6 +2,9 @@
 arguments, tensors pre-allocated by the caller; every call forwards to libenerf_hip.so on torch's current stream."""
 from .. import _lib as L
 
+# inference samples marched since the last reset (bench.py: render Msamples/s)
+STATS = {"infer_samples": 0, "infer_calls": 0}
+
 
 def _f32(t, name):
     import torch
@@ -84,6 +87,8 @@ def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, de
 
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
                fars, xyzs, dirs, deltas, perturb):
+    STATS["infer_samples"] += int(n_alive) * int(n_step)
+    STATS["infer_calls"] += 1
     L.check(L.lib().enerf_march_rays(int(n_alive), int(n_step), _i32(rays_alive, "rays_alive"),
                                      _f32(rays_t, "rays_t"), _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"),
                                      float(bound), float(dt_gamma), int(max_steps), int(C), int(H), _u8(grid, "grid"),

@@ -29,7 +29,10 @@ constexpr int kPtsPerBlock = 256;
 struct LevelTab {
     float scale[kMaxLevels];
     uint32_t resolution[kMaxLevels];
+    uint32_t level_mask;   // profiling aid (enerf_debug_grid_level_mask): levels whose bit is clear are skipped
 };
+
+uint32_t g_level_mask = 0xffffffffu;
 
 template <typename T, int C>
 struct alignas((sizeof(T) * C) > 16 ? 16 : (sizeof(T) * C)) Feat {
@@ -79,6 +82,9 @@ __device__ __forceinline__ bool decode_block(uint32_t nchunks, uint32_t L, uint3
     chunk = j % nchunks;
     return level < L;
 }
+__device__ __forceinline__ bool level_enabled(const LevelTab& tab, uint32_t level) {
+    return (tab.level_mask >> level) & 1u;
+}
 
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restrict__ inputs, const T* __restrict__ grid,
@@ -88,6 +94,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
                                                            uint32_t nchunks) {
     uint32_t level, chunk;
     if (!decode_block(nchunks, L, level, chunk)) return;
+    if (!level_enabled(tab, level)) return;
     const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
     if (b >= B) return;
 
@@ -229,6 +236,12 @@ __device__ __forceinline__ void scatter_add(__half* row, float w, const float (&
     }
 }
 
+// Backward scatter.  Device-scope float atomics top out at ~21 G/s on MI355X whatever the footprint or XCD affinity
+// (tools/atomic_rate.hip), so the kernel's job is to issue as few of them as possible.  Lanes of a wavefront hold
+// consecutive samples, i.e. consecutive points along a ray: at every level whose cell is larger than the marching
+// step they fall into the same cell in runs.  A run's 2^D corner contributions are summed in-wave (segmented suffix
+// sum keyed on the cell coordinates) and only the head lane of the run issues atomics.  Levels with no adjacent
+// sharing (wave-uniform ballot test) skip the reduction.
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                            const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
@@ -236,8 +249,9 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
                                                            int grad_layout, uint32_t nchunks) {
     uint32_t level, chunk;
     if (!decode_block(nchunks, L, level, chunk)) return;
+    if (!level_enabled(tab, level)) return;
     const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
-    if (b >= B) return;
+    const int lane = lane_id();
 
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -245,11 +259,12 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
     const uint32_t resolution = tab.resolution[level];
     T* rows = grad_grid + (size_t)off0 * C;
 
+    bool valid = b < B;
     float in[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        in[d] = inputs[(size_t)b * D + d];
-        if (in[d] < 0 || in[d] > 1) return;  // grad_grid is pre-zeroed
+        in[d] = valid ? inputs[(size_t)b * D + d] : 0.0f;
+        valid = valid && !(in[d] < 0 || in[d] > 1);   // out-of-range points contribute nothing (grad_grid pre-zeroed)
     }
     float pos[D];
     uint32_t pos_grid[D];
@@ -259,28 +274,67 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
         pos_grid[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pos_grid[d];
     }
-    const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(grad)[grad_layout == 0 ? (size_t)level * B + b
-                                                                                     : (size_t)b * L + level];
     float g[C];
+    if (valid) {
+        const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(grad)[grad_layout == 0 ? (size_t)level * B + b
+                                                                                         : (size_t)b * L + level];
 #pragma unroll
-    for (int c = 0; c < C; c++) g[c] = to_f(gv.v[c]);
+        for (int c = 0; c < C; c++) g[c] = to_f(gv.v[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = 0.0f;
+    }
 
+    // per-corner contributions w_idx * g[c]
+    float v[(1 << D) * C];
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float wi = 1;
-        uint32_t pgl[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            if ((idx & (1 << d)) == 0) {
-                wi *= 1 - pos[d];
-                pgl[d] = pos_grid[d];
-            } else {
-                wi *= pos[d];
-                pgl[d] = pos_grid[d] + 1;
+        for (int d = 0; d < D; d++) wi *= ((idx >> d) & 1) ? pos[d] : 1 - pos[d];
+#pragma unroll
+        for (int c = 0; c < C; c++) v[idx * C + c] = wi * g[c];
+    }
+
+    // run detection: same cell as the previous lane
+    bool same = lane > 0 && valid;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const uint32_t prev = (uint32_t)__shfl_up((int)pos_grid[d], 1, 64);
+        same = same && (prev == pos_grid[d]);
+    }
+    const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
+    same = same && prev_valid;
+    const unsigned long long same_mask = __ballot(same);
+    bool head = valid;
+    if (same_mask != 0ull) {
+        head = valid && !same;
+        // a run ends right before the next lane that is not a continuation (head or invalid)
+        const unsigned long long cont = same_mask >> 1;                 // bit i: lane i+1 continues lane i's run
+        const unsigned long long stop = ~cont >> lane;                  // first zero of cont at or above my lane
+        const int end = lane + (stop ? __builtin_ctzll(stop) : 64 - lane) + 1;   // one past my run's last lane
+        for (int o = 1; o < 64; o <<= 1) {
+            const bool take = lane + o < end;
+            if (__ballot(take) == 0ull) break;
+#pragma unroll
+            for (int k = 0; k < (1 << D) * C; k++) {
+                const float t = __shfl_down(v[k], o, 64);
+                if (take) v[k] += t;
             }
         }
+    }
+    if (!head) return;
+
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1);
         const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
-        scatter_add<C>(rows + (size_t)row * C, wi, g);
+        float gg[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) gg[c] = v[idx * C + c];
+        scatter_add<C>(rows + (size_t)row * C, 1.0f, gg);
     }
 }
 
@@ -311,6 +365,7 @@ int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H) {
         tab.scale[l] = scale;
         tab.resolution[l] = (uint32_t)ceil(scale) + 1;
     }
+    tab.level_mask = g_level_mask;
     return 0;
 }
 
@@ -360,6 +415,12 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
 }  // namespace
 
 extern "C" {
+
+// profiling aid, not part of the reference surface: restrict both grid kernels to the levels set in `mask`
+int enerf_debug_grid_level_mask(uint32_t mask) {
+    g_level_mask = mask;
+    return 0;
+}
 
 int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,

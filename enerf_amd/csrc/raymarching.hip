@@ -82,10 +82,9 @@ __device__ __forceinline__ void ray_ctx_init(RayCtx& c, const float* o, const fl
     c.C = C; c.H = H; c.grid = grid;
 }
 
-// One evaluation of the marching loop body at parameter t.  Returns the occupancy bit; on an empty cell
-// t_skip receives t after the voxel-skipping do/while.
-__device__ __forceinline__ bool eval_step(const RayCtx& c, float t, float& x, float& y, float& z, float& dt,
-                                          float& t_skip) {
+// One evaluation of the marching loop body at parameter t: sample position, step size, occupancy bit of the cell and,
+// for an empty cell, the parameter `tt` of the cell's exit face (with the reference's (H - 1) quirk).
+__device__ __forceinline__ bool eval_cell(const RayCtx& c, float t, float& x, float& y, float& z, float& dt, float& tt) {
     const float bound = c.bound;
     const uint32_t H = c.H;
     x = clampf_(fmaf(t, c.dx, c.ox), -bound, bound);
@@ -103,11 +102,19 @@ __device__ __forceinline__ bool eval_step(const RayCtx& c, float t, float& x, fl
     const int nz = (int)clampf_((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)H), 0.0f, hm1);
     const uint32_t index = (uint32_t)level * H * H * H + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
     const bool occ = (c.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    const float tx = fmaf(fmaf((nx + 0.5f + 0.5f * signf_(c.dx)) / hm1, 2.0f, -1.0f), mip_bound, -x) * c.rdx;
+    const float ty = fmaf(fmaf((ny + 0.5f + 0.5f * signf_(c.dy)) / hm1, 2.0f, -1.0f), mip_bound, -y) * c.rdy;
+    const float tz = fmaf(fmaf((nz + 0.5f + 0.5f * signf_(c.dz)) / hm1, 2.0f, -1.0f), mip_bound, -z) * c.rdz;
+    tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    return occ;
+}
+
+// Sequential form (one thread per ray): on an empty cell t_skip receives t after the voxel-skipping do/while.
+__device__ __forceinline__ bool eval_step(const RayCtx& c, float t, float& x, float& y, float& z, float& dt,
+                                          float& t_skip) {
+    float tt;
+    const bool occ = eval_cell(c, t, x, y, z, dt, tt);
     if (!occ) {
-        const float tx = fmaf(fmaf((nx + 0.5f + 0.5f * signf_(c.dx)) / hm1, 2.0f, -1.0f), mip_bound, -x) * c.rdx;
-        const float ty = fmaf(fmaf((ny + 0.5f + 0.5f * signf_(c.dy)) / hm1, 2.0f, -1.0f), mip_bound, -y) * c.rdy;
-        const float tz = fmaf(fmaf((nz + 0.5f + 0.5f * signf_(c.dz)) / hm1, 2.0f, -1.0f), mip_bound, -z) * c.rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
         do {
             t += clampf_(t * c.dt_gamma, c.dt_min, c.dt_max);
         } while (t < tt);
@@ -222,6 +229,137 @@ __device__ __forceinline__ uint32_t march_one_ray(const RayCtx& c, float t0, flo
         }
     }
     return step;
+}
+
+// ------------------------------------------------------------------ wave-per-ray "lattice" marcher (dt_gamma == 0)
+// With dt_gamma == 0 every update of t in the reference's loop -- the occupied step and each iteration of the
+// empty-voxel skip loop alike -- is t += dt_min, so the values t can take form a fixed lattice t_0, t_1 = fl(t_0 + dt),
+// ... that does not depend on occupancy; occupancy only decides which lattice points are evaluated and which are
+// emitted.  Inside one binade of t, fl(t + dt) - t is the same multiple of ulp(t) for every t (ties excepted, which
+// are detected), so 64 consecutive lattice points are t_base + lane * delta EXACTLY and all 64 lanes of a wavefront
+// evaluate their cells in parallel.  The sequential control flow (emit on occupied, jump to the first lattice point
+// >= the voxel exit on empty) is then replayed on wave-uniform bit masks: runs of occupied lanes are emitted whole,
+// empty lanes jump through a precomputed per-lane "next" index.  The emitted samples, their count and their
+// positions are bit-identical to the one-thread-per-ray loop above; the work per ray is spread over 64 lanes
+// instead of one latency-bound thread.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, float far, uint32_t limit, float* xyzs,
+                                                  float* dirs, float* deltas) {
+    const int lane = lane_id();
+    const float dt = c.dt_min;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes strictly below mine
+    float base = t0;                              // wave-uniform: first lattice point of the current chunk
+    float tt_pending = -__builtin_huge_valf();    // exit parameter of a skip that ran past the previous chunk
+    float last_t = t0;                            // t after the previously emitted sample's step
+    uint32_t count = 0;
+    while (base < far && count < limit) {
+        // increment of the arithmetic progression starting at `base`, and how far it is valid
+        const float delta = (base + dt) - base;
+        const float delta2 = ((base + delta) + dt) - (base + delta);
+        int e;
+        (void)frexpf(base, &e);
+        const float bin_top = ldexpf(1.0f, e);                                  // base in [bin_top/2, bin_top)
+        const bool progression = base >= 2.0f * dt && delta2 == delta;
+        const float ti = progression ? fmaf((float)lane, delta, base) : base;   // exact within the binade
+        const bool ok = lane == 0 || (progression && ti < bin_top);
+        const unsigned long long okm = __ballot(ok && ti < far);
+        const int nvalid = okm == ~0ull ? 64 : __builtin_ctzll(~okm);           // leading run of usable lanes (>= 1)
+        const unsigned long long vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+
+        float x, y, z, dts, tt;
+        const bool occ = eval_cell(c, ti, x, y, z, dts, tt);
+        const float t_next = ti + dt;                                           // the true next lattice value
+        // per-lane jump target for an empty cell: first lattice index j > lane with !(t_j < tt)
+        int nxt = lane + 1;
+        if (progression && ti < tt) {
+            int j = lane + (int)fminf(fmaxf(ceilf((tt - ti) / delta), 1.0f), 64.0f);
+            while (j - 1 > lane && !(fmaf((float)(j - 1), delta, base) < tt)) j--;
+            while (j < 64 && fmaf((float)j, delta, base) < tt) j++;
+            nxt = j;
+        }
+        const unsigned long long occm = __ballot(occ) & vmask;
+        // first lattice point of this chunk not skipped by a pending voxel exit
+        const unsigned long long reach = __ballot(!(ti < tt_pending)) & vmask;
+        int cur = reach ? __builtin_ctzll(reach) : nvalid;
+        if (cur < nvalid) tt_pending = -__builtin_huge_valf();
+        unsigned long long emit = 0ull;
+        uint32_t room = limit - count;
+        while (cur < nvalid && room > 0) {
+            if ((occm >> cur) & 1ull) {
+                const unsigned long long rest = ~(occm >> cur);
+                uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : (uint32_t)(64 - cur);
+                if (run > room) run = room;
+                emit |= (run == 64 ? ~0ull : ((1ull << run) - 1ull)) << cur;
+                cur += (int)run;
+                room -= run;
+            } else {
+                const int j = __builtin_amdgcn_readlane(nxt, cur);
+                if (j >= nvalid) {
+                    tt_pending = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt), cur));
+                    cur = nvalid;
+                } else {
+                    cur = j;
+                }
+            }
+        }
+        const uint32_t nemit = (uint32_t)__popcll(emit);
+        if (nemit) {
+            const int top = 63 - __builtin_clzll(emit);
+            if (WRITE) {
+                const unsigned long long before = emit & below;
+                const int prev = before ? 63 - __builtin_clzll(before) : 0;
+                const float prev_next = __shfl(t_next, prev, 64);
+                if ((emit >> lane) & 1ull) {
+                    const size_t k = (size_t)count + (uint32_t)__popcll(before);
+                    xyzs[k * 3] = x; xyzs[k * 3 + 1] = y; xyzs[k * 3 + 2] = z;
+                    dirs[k * 3] = c.dx; dirs[k * 3 + 1] = c.dy; dirs[k * 3 + 2] = c.dz;
+                    deltas[k * 2] = dts;
+                    deltas[k * 2 + 1] = t_next - (before ? prev_next : last_t);
+                }
+            }
+            last_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_next), top));
+            count += nemit;
+        }
+        base = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_next), nvalid - 1));
+    }
+    return count;
+}
+
+__global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__ rays_o,
+                                                       const float* __restrict__ rays_d,
+                                                       const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
+                                                       uint32_t N, uint32_t C, uint32_t H,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars,
+                                                       int32_t* rays, uint32_t perturb) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (n >= N) return;
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
+    float t0 = nears[n];
+    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    const uint32_t cnt = lattice_march<false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr);
+    if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
+}
+
+__global__ void __launch_bounds__(256) k_march_write_w(const float* __restrict__ rays_o,
+                                                       const float* __restrict__ rays_d,
+                                                       const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
+                                                       uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars,
+                                                       float* xyzs, float* dirs, float* deltas,
+                                                       const int32_t* __restrict__ rays, uint32_t perturb) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (n >= N) return;
+    const uint32_t point_index = (uint32_t)rays[(size_t)n * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) return;
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
+    float t0 = nears[n];
+    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    (void)lattice_march<true>(c, t0, fars[n], num_steps, xyzs + (size_t)point_index * 3,
+                              dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
 }
 
 __global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -565,11 +703,20 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays_train: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
-    k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars,
-                                               rays, perturb);
-    k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
-    k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
-                                               fars, xyzs, dirs, deltas, rays, perturb);
+    if (dt_gamma == 0.0f) {
+        // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
+        k_march_count_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays,
+                                                     perturb);
+        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
+        k_march_write_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars,
+                                                     xyzs, dirs, deltas, rays, perturb);
+    } else {
+        k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
+                                                   fars, rays, perturb);
+        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
+        k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
+                                                   fars, xyzs, dirs, deltas, rays, perturb);
+    }
     ENERF_LAUNCH_CHECK("march_rays_train");
     return 0;
 }

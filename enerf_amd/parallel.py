@@ -1,0 +1,91 @@
+"""Ray-sharded data parallelism for the train step: one process per GPU, every rank holds a full
+replica (hash table + MLPs + occupancy state), renders its own slice of the step's rays, and the gradients are
+averaged with ONE collective exchange per step over RCCL/xGMI (`torch.distributed`, backend "nccl" on ROCm; "gloo"
+in the CPU tests).  There is no collective in the forward/backward data path itself.
+
+Bucketing: the hash-table gradient (52 MB fp32 at bound 3) is reduced in place as its own bucket; all MLP gradients
+(37 KB) are flattened into a second bucket so that two collectives are issued per step regardless of layer count.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank); a single-process run needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_range(n, rank, world):
+    """Contiguous slice [lo, hi) of n rays owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradAverager:
+    """Averages gradients of `params` across ranks with two buckets (big tensors in place, small ones flattened)."""
+
+    def __init__(self, params, big_threshold=1 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.big = [p for p in self.params if p.numel() >= big_threshold]
+        self.small = [p for p in self.params if p.numel() < big_threshold]
+        self._flat = None
+
+    def __call__(self):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        works = []
+        for p in self.big:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        small = [p for p in self.small]
+        if small:
+            n = sum(p.numel() for p in small)
+            if self._flat is None or self._flat.numel() != n or self._flat.device != small[0].device:
+                self._flat = torch.empty(n, dtype=torch.float32, device=small[0].device)
+            off = 0
+            for p in small:
+                k = p.numel()
+                if p.grad is None:
+                    self._flat[off:off + k].zero_()
+                else:
+                    self._flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+            works.append(dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        inv = 1.0 / world
+        for p in self.big:
+            p.grad.mul_(inv)
+        if small:
+            off = 0
+            for p in small:
+                k = p.numel()
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(self._flat[off:off + k].view_as(p)).mul_(inv)
+                off += k
+
+
+def broadcast_state(model, src=0):
+    """Make replicas identical (parameters and buffers, incl. the occupancy grid / bitfield)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src)

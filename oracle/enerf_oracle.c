@@ -33,6 +33,18 @@
 #include <string.h>
 #include <float.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* number of OpenMP threads used by the level-parallel grid loops (bench.py cpu_baseline) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------ */
 /* helpers: raymarching/src/raymarching.cu:21-83                       */
@@ -504,6 +516,8 @@ void orc_grid_level_params(uint32_t level, float S, uint32_t H, float* scale, ui
 void orc_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets, float* outputs,
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              int calc_grad_inputs, float* dy_dx, uint32_t gridtype) {
+    /* levels are independent: one OpenMP task per level (used by bench.py's cpu_baseline on all host cores) */
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t level = 0; level < L; level++) {
         const float* grid = embeddings + (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
@@ -567,6 +581,7 @@ void orc_grid_encode_backward(const float* grad, const float* inputs, const floa
                               float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                               int calc_grad_inputs, const float* dy_dx, float* grad_inputs, uint32_t gridtype) {
     (void)embeddings;
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t level = 0; level < L; level++) {
         float* gg = grad_embeddings + (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);

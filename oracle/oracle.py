@@ -20,6 +20,7 @@ _u32p = _c.POINTER(_c.c_uint32)
 _u32, _f32, _int, _u64 = _c.c_uint32, _c.c_float, _c.c_int, _c.c_uint64
 
 _SIGS = {
+    "orc_set_threads": [_int],
     "orc_pcg32_stream": [_u64, _u64, _u32, _u32p, _f32p],
     "orc_near_far_from_aabb": [_f32p, _f32p, _f32p, _u32, _f32, _f32p, _f32p],
     "orc_polar_from_ray": [_f32p, _f32p, _f32, _u32, _f32p],
@@ -67,6 +68,10 @@ def lib():
             fn.argtypes = sig
             fn.restype = None
     return _lib
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
 
 
 def _p(a, ct):

@@ -1,0 +1,445 @@
+"""Parity of the HIP path (through the C ABI: enerf_amd/backends -> libenerf_hip.so) against the CPU oracle on the
+same seeded inputs.  Integer / index outputs and marched sample positions must be bit-exact; floating-point
+compositing / encodings within the stated tolerance (north_star: 1e-4 rel fp32)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from util import synthetic_density_grid, camera_rays, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+H = 128
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.fixture(scope="module")
+def rm():
+    from enerf_amd.backends import _raymarching
+    return _raymarching
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    out = {}
+    for bound in (1, 2, 3):
+        grid = synthetic_density_grid(bound, H)
+        bits = O.packbits(grid.reshape(-1), 0.01)
+        out[bound] = (grid, bits, 1 + math.ceil(math.log2(bound)))
+    return out
+
+
+def _rays(n, seed, bound):
+    o, d = camera_rays(n, seed, bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    return o, d, aabb
+
+
+# ------------------------------------------------------------------ small integer kernels: bit-exact
+def test_near_far_bit_exact(rm):
+    o, d, aabb = _rays(5000, 1, 2)
+    d[10] = [1, 0, 0]; d[11] = [0, -1, 0]; d[12] = [0, 0, 1]          # axis-parallel: 1/0 = inf paths
+    o[13] = [5, 5, 5]                                                     # outside, pointing away
+    n_ref, f_ref = O.near_far_from_aabb(o, d, aabb, 0.2)
+    nears = torch.empty(len(o), device=DEV); fars = torch.empty(len(o), device=DEV)
+    rm.near_far_from_aabb(cu(o), cu(d), cu(aabb), len(o), 0.2, nears, fars)
+    assert np.array_equal(nears.cpu().numpy(), n_ref) and np.array_equal(fars.cpu().numpy(), f_ref)
+
+
+def test_morton_and_packbits_bit_exact(rm, scenes):
+    rng = np.random.default_rng(2)
+    c = rng.integers(0, 128, (100003, 3)).astype(np.int32)
+    idx = torch.empty(len(c), dtype=torch.int32, device=DEV)
+    rm.morton3D(cu(c), len(c), idx)
+    assert np.array_equal(idx.cpu().numpy(), O.morton3D(c))
+    back = torch.empty(len(c), 3, dtype=torch.int32, device=DEV)
+    rm.morton3D_invert(idx, len(c), back)
+    assert np.array_equal(back.cpu().numpy(), c)
+    grid, bits, C = scenes[3]                                            # full size: 3 x 128^3 cells
+    g = grid.copy(); g[0, :8] = 0.01; g[1, 8:16] = -1
+    out = torch.empty(g.size // 8, dtype=torch.uint8, device=DEV)
+    rm.packbits(cu(g), g.size // 8, 0.01, out)
+    assert np.array_equal(out.cpu().numpy(), O.packbits(g.reshape(-1), 0.01))
+    assert np.array_equal(out.cpu().numpy(), np.packbits(g.reshape(-1) > 0.01, bitorder="little"))
+
+
+def test_polar_from_ray(rm):
+    o, d, _ = _rays(1000, 3, 1)
+    ref = O.polar_from_ray(o * 0.3, d, 4.0)
+    out = torch.empty(1000, 2, device=DEV)
+    rm.polar_from_ray(cu(o * 0.3), cu(d), 4.0, 1000, out)
+    assert_close(out, ref, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ march_rays_train: rays/counter/samples bit-exact
+def _gpu_march_train(rm, o, d, bits, bound, dt_gamma, C, M, nears, fars, perturb, max_steps=1024):
+    N = len(o)
+    xyzs = torch.zeros(M, 3, device=DEV); dirs = torch.zeros(M, 3, device=DEV); deltas = torch.zeros(M, 2, device=DEV)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    rm.march_rays_train(cu(o), cu(d), cu(bits), bound, dt_gamma, max_steps, N, C, H, M, cu(nears), cu(fars), xyzs, dirs,
+                        deltas, rays, counter, perturb)
+    torch.cuda.synchronize()
+    return [x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)]
+
+
+@pytest.mark.parametrize("bound,perturb,dt_gamma,N", [(1, 0, 0.0, 300), (2, 1, 0.0, 1000), (3, 1, 0.0, 4096),
+                                                      (3, 0, 1.0 / 128, 500), (2, 1, 1.0 / 256, 257)])
+def test_march_rays_train_bit_exact(rm, scenes, bound, perturb, dt_gamma, N):
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(N, 10 + bound, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    M = N * 1024
+    ref = O.march_rays_train(o, d, bits, bound, dt_gamma, 1024, C, H, M, nears, fars, perturb)
+    got = _gpu_march_train(rm, o, d, bits, bound, dt_gamma, C, M, nears, fars, perturb)
+    assert np.array_equal(got[4], ref[4]), (got[4], ref[4])             # counter
+    assert np.array_equal(got[3], ref[3])                               # rays (index, offset, num_steps)
+    tot = int(ref[4][0])
+    assert tot > 1000
+    for a, b, name in zip(got[:3], ref[:3], ("xyzs", "dirs", "deltas")):
+        assert np.array_equal(a[:tot], b[:tot]), name
+        assert not a[tot:].any()
+
+
+def test_march_rays_train_overflow_drop_rule(rm, scenes):
+    bound = 2
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(512, 21, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    tot = int(O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, 512 * 1024, nears, fars, 1)[4][0])
+    M = tot // 3
+    M += 128 - M % 128
+    ref = O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, M, nears, fars, 1)
+    got = _gpu_march_train(rm, o, d, bits, bound, 0.0, C, M, nears, fars, 1)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    assert got[4][0] == tot
+
+
+# ------------------------------------------------------------------ composite_rays_train: 1e-4 rel
+@pytest.mark.parametrize("bound,N", [(1, 200), (3, 4096)])
+def test_composite_rays_train_fwd_bwd(rm, scenes, bound, N):
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(N, 30 + bound, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    xyzs, dirs, deltas, rays, counter = O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, N * 1024, nears, fars, 1)
+    tot = int(counter[0]); M = tot + 128 - tot % 128
+    rng = np.random.default_rng(4)
+    sig = (rng.random(M) * 25).astype(np.float32)
+    sig[rng.random(M) < 0.1] = 0
+    rgb = rng.random((M, 3)).astype(np.float32)
+    dl = deltas[:M]
+    ws, depth, image = O.composite_rays_train_forward(sig, rgb, dl, rays)
+    g_ws = torch.empty(N, device=DEV); g_d = torch.empty(N, device=DEV); g_im = torch.empty(N, 3, device=DEV)
+    rm.composite_rays_train_forward(cu(sig), cu(rgb), cu(dl), cu(rays), M, N, g_ws, g_d, g_im)
+    assert_close(g_ws, ws, rtol=1e-4, atol=1e-6)
+    assert_close(g_im, image, rtol=1e-4, atol=1e-6)
+    assert_close(g_d, depth, rtol=1e-4, atol=1e-5)
+    gws = rng.normal(size=N).astype(np.float32); gim = rng.normal(size=(N, 3)).astype(np.float32)
+    gs_ref, gc_ref = O.composite_rays_train_backward(gws, gim, sig, rgb, dl, rays, ws, image)
+    gs = torch.zeros(M, device=DEV); gc = torch.zeros(M, 3, device=DEV)
+    rm.composite_rays_train_backward(cu(gws), cu(gim), cu(sig), cu(rgb), cu(dl), cu(rays), g_ws, g_im, M, N, gs, gc)
+    assert_close(gc, gc_ref, rtol=1e-4, atol=1e-6)
+    # grad_sigma involves the cancellation (final - running): compare at the scale of the per-ray gradient
+    scale = np.abs(gs_ref).max()
+    assert np.abs(gs.cpu().numpy() - gs_ref).max() < 2e-5 * max(scale, 1.0)
+
+
+def test_composite_rays_train_dropped_and_empty_rays(rm):
+    # rays = (index, offset, count): empty ray, overflowing ray (offset+count >= M), permuted indices
+    M = 64
+    rays = np.array([[2, 0, 10], [0, 10, 0], [1, 10, 54], [3, 10, 53]], np.int32)
+    rng = np.random.default_rng(5)
+    sig = rng.random(M).astype(np.float32) * 5; rgb = rng.random((M, 3)).astype(np.float32)
+    dl = np.full((M, 2), 0.01, np.float32)
+    ws, depth, image = O.composite_rays_train_forward(sig, rgb, dl, rays)
+    a = torch.full((4,), 7.0, device=DEV); b = torch.full((4,), 7.0, device=DEV); c = torch.full((4, 3), 7.0, device=DEV)
+    rm.composite_rays_train_forward(cu(sig), cu(rgb), cu(dl), cu(rays), M, 4, a, b, c)
+    assert_close(a, ws, rtol=1e-5, atol=1e-7); assert_close(c, image, rtol=1e-5, atol=1e-7)
+    assert ws[1] == 0 and ws[0] == 0 and ws[2] > 0       # ray index 1 overflows (10+54 >= 64), index 0 is empty
+
+
+# ------------------------------------------------------------------ inference trio
+def test_inference_loop_march_composite_compact(rm, scenes):
+    bound = 2
+    grid, bits, C = scenes[bound]
+    N = 3000
+    o, d, aabb = _rays(N, 40, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    rng = np.random.default_rng(6)
+    # oracle state
+    ws = np.zeros(N, np.float32); dp = np.zeros(N, np.float32); im = np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32); rt = nears.copy()
+    # gpu state
+    g_ws = torch.zeros(N, device=DEV); g_dp = torch.zeros(N, device=DEV); g_im = torch.zeros(N, 3, device=DEV)
+    g_alive = torch.zeros(2, N, dtype=torch.int32, device=DEV); g_rt = torch.zeros(2, N, device=DEV)
+    g_alive[0] = torch.arange(N, dtype=torch.int32, device=DEV); g_rt[0] = cu(nears)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    co, cd, cb, cn, cf = cu(o), cu(d), cu(bits), cu(nears), cu(fars)
+    n_alive, i, step = N, 0, 0
+    for it in range(200):
+        if it > 0:
+            new_alive, new_t, n_new = O.compact_rays(n_alive, alive, rt)
+            cnt.zero_()
+            rm.compact_rays(n_alive, g_alive[i % 2], g_alive[(i + 1) % 2], g_rt[i % 2], g_rt[(i + 1) % 2], cnt)
+            assert int(cnt.item()) == n_new
+            assert np.array_equal(g_alive[i % 2][:n_new].cpu().numpy(), new_alive[:n_new])     # stable order
+            alive, rt, n_alive = new_alive[:n_new].copy(), new_t[:n_new].copy(), n_new
+            # keep both sides' t identical so the marcher inputs stay bit-equal
+            g_rt[i % 2][:n_new] = cu(rt)
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        Mi = n_alive * n_step; Mi += 128 - Mi % 128
+        x, dd, dl = O.march_rays(n_alive, n_step, alive, rt, o, d, bound, 0.0, 1024, C, H, bits, nears, fars, Mi, 0)
+        gx = torch.zeros(Mi, 3, device=DEV); gd = torch.zeros(Mi, 3, device=DEV); gl = torch.zeros(Mi, 2, device=DEV)
+        rm.march_rays(n_alive, n_step, g_alive[i % 2], g_rt[i % 2], co, cd, bound, 0.0, 1024, C, H, cb, cn, cf, gx, gd,
+                      gl, 0)
+        assert np.array_equal(gx.cpu().numpy(), x) and np.array_equal(gl.cpu().numpy(), dl)
+        assert np.array_equal(gd.cpu().numpy(), dd)
+        sig = (rng.random(Mi) * 30).astype(np.float32); rgb = rng.random((Mi, 3)).astype(np.float32)
+        rt_o = rt.copy()
+        O.composite_rays(n_alive, n_step, alive, rt_o, sig, rgb, dl, ws, dp, im)
+        rm.composite_rays(n_alive, n_step, g_alive[i % 2], g_rt[i % 2], cu(sig), cu(rgb), gl, g_ws, g_dp, g_im)
+        got_t = g_rt[i % 2][:n_alive].cpu().numpy()
+        assert np.array_equal(got_t < 0, rt_o < 0)                       # same rays terminate
+        np.testing.assert_allclose(got_t, rt_o, rtol=1e-6, atol=1e-6)
+        rt = rt_o
+        step += n_step; i += 1
+    assert it > 5
+    assert_close(g_ws, ws, rtol=1e-4, atol=1e-6)
+    assert_close(g_im, im, rtol=1e-4, atol=1e-6)
+    assert_close(g_dp, dp, rtol=1e-4, atol=1e-5)
+
+
+def test_inference_march_perturb_seed_bit_exact(rm, scenes):
+    bound = 3
+    grid, bits, C = scenes[bound]
+    N = 700
+    o, d, aabb = _rays(N, 41, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    alive = np.random.default_rng(7).permutation(N).astype(np.int32)[:500]
+    rt = nears[alive]
+    M = 500 * 4
+    x, dd, dl = O.march_rays(500, 4, alive, rt, o, d, bound, 1.0 / 256, 1024, C, H, bits, nears, fars, M, 5)
+    gx = torch.zeros(M, 3, device=DEV); gd = torch.zeros(M, 3, device=DEV); gl = torch.zeros(M, 2, device=DEV)
+    rm.march_rays(500, 4, cu(alive), cu(rt), cu(o), cu(d), bound, 1.0 / 256, 1024, C, H, cu(bits), cu(nears), cu(fars),
+                  gx, gd, gl, 5)
+    assert np.array_equal(gx.cpu().numpy(), x) and np.array_equal(gl.cpu().numpy(), dl)
+
+
+# ------------------------------------------------------------------ grid encoder
+def _table(offsets, C, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+
+
+@pytest.mark.parametrize("D,C,gridtype", [(3, 2, 0), (3, 1, 0), (3, 4, 0), (3, 8, 1), (2, 2, 0)])
+def test_grid_encode_forward_backward_small(D, C, gridtype):
+    from enerf_amd.backends import _gridencoder as ge
+    offsets, pls = O.grid_offsets(input_dim=D, num_levels=8, level_dim=C, base_resolution=4, log2_hashmap_size=10,
+                                  desired_resolution=160)
+    S = float(np.log2(pls)); Hb = 4; L = 8; B = 777
+    emb = _table(offsets, C, 50 + C)
+    rng = np.random.default_rng(51)
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0] = 0.0; x[1] = 1.0; x[2, 0] = 1.2; x[3, 1] = -0.1           # corners + out-of-range
+    ref_out, ref_jac = O.grid_encode_forward(x, emb, offsets, S, Hb, True, gridtype)
+    for layout in (0, 1):
+        out = torch.empty((L, B, C) if layout == 0 else (B, L * C), device=DEV)
+        jac = torch.empty(B, L * D * C, device=DEV)
+        ge.grid_encode_forward(cu(x), cu(emb), cu(offsets), out, B, D, C, L, S, Hb, True, jac, gridtype, layout=layout)
+        got = out.cpu().numpy() if layout == 0 else out.cpu().numpy().reshape(B, L, C).transpose(1, 0, 2)
+        np.testing.assert_allclose(got, ref_out, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(jac.cpu().numpy(), ref_jac, rtol=1e-4, atol=2e-4)
+        g = rng.normal(size=(L, B, C)).astype(np.float32)
+        ge_ref, gi_ref = O.grid_encode_backward(g, x, emb, offsets, S, Hb, ref_jac, gridtype)
+        gemb = torch.zeros(emb.shape, device=DEV); gin = torch.zeros(B, D, device=DEV)
+        gg = cu(g) if layout == 0 else cu(np.ascontiguousarray(g.transpose(1, 0, 2).reshape(B, L * C)))
+        ge.grid_encode_backward(gg, cu(x), cu(emb), cu(offsets), gemb, B, D, C, L, S, Hb, True, jac, gin, gridtype,
+                                layout=layout)
+        np.testing.assert_allclose(gemb.cpu().numpy(), ge_ref, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(gin.cpu().numpy(), gi_ref, rtol=1e-4, atol=2e-4)
+
+
+def test_grid_encode_half_table():
+    from enerf_amd.backends import _gridencoder as ge
+    offsets, pls = O.grid_offsets(num_levels=8, base_resolution=4, log2_hashmap_size=10, desired_resolution=160)
+    S = float(np.log2(pls)); L = 8; B = 500; C = 2
+    emb = _table(offsets, C, 60).astype(np.float16)
+    x = np.random.default_rng(61).uniform(0, 1, (B, 3)).astype(np.float32)
+    ref, _ = O.grid_encode_forward(x, emb.astype(np.float32), offsets, S, 4)
+    out = torch.empty(L, B, C, device=DEV, dtype=torch.half)
+    dummy = torch.empty(1, device=DEV, dtype=torch.half)
+    ge.grid_encode_forward(cu(x), cu(emb), cu(offsets), out, B, 3, C, L, S, 4, False, dummy, 0)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3)
+    g = np.random.default_rng(62).normal(size=(L, B, C)).astype(np.float16)
+    ge_ref, _ = O.grid_encode_backward(g.astype(np.float32), x, emb.astype(np.float32), offsets, S, 4)
+    gemb = torch.zeros(emb.shape, device=DEV, dtype=torch.half)
+    ge.grid_encode_backward(cu(g), cu(x), cu(emb), cu(offsets), gemb, B, 3, C, L, S, 4, False, dummy, dummy, 0)
+    np.testing.assert_allclose(gemb.float().cpu().numpy(), ge_ref, atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("bound", [2, 3])
+def test_grid_encode_full_size_tables(bound):
+    """BASELINE table sizes (6.3M / 6.5M rows, L=16, C=2, T=2^19): direct comparison on 100k points plus the
+    size-independent properties: linearity in the table and sum(grad_embeddings) == sum(grad) (weights sum to 1)."""
+    from enerf_amd.backends import _gridencoder as ge
+    offsets, pls = O.grid_offsets(desired_resolution=2048 * bound)
+    S = float(np.log2(pls)); L = 16; C = 2; B = 100000
+    rng = np.random.default_rng(70 + bound)
+    emb1 = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    emb2 = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    x = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    ref, _ = O.grid_encode_forward(x, emb1, offsets, S, 16)
+    cx, co = cu(x), cu(offsets)
+    dummy = torch.empty(1, device=DEV)
+
+    def enc(e):
+        out = torch.empty(L, B, C, device=DEV)
+        ge.grid_encode_forward(cx, e, co, out, B, 3, C, L, S, 16, False, dummy, 0)
+        return out
+    e1, e2 = cu(emb1), cu(emb2)
+    y1 = enc(e1)
+    np.testing.assert_allclose(y1.cpu().numpy(), ref, rtol=1e-5, atol=3e-6)
+    assert_close(enc(e1 + 2 * e2), y1 + 2 * enc(e2), rtol=1e-4, atol=1e-5)
+    g = rng.normal(size=(L, B, C)).astype(np.float32)
+    gemb = torch.zeros_like(e1)
+    ge.grid_encode_backward(cu(g), cx, e1, co, gemb, B, 3, C, L, S, 16, False, dummy, dummy, 0)
+    for l in range(L):
+        a, b = int(offsets[l]), int(offsets[l + 1])
+        np.testing.assert_allclose(gemb[a:b].sum(0).cpu().numpy(), g[l].sum(0), rtol=1e-3, atol=2e-2)
+    ge_ref, _ = O.grid_encode_backward(g, x, emb1, offsets, S, 16)
+    np.testing.assert_allclose(gemb.cpu().numpy(), ge_ref, rtol=1e-4, atol=1e-4)
+
+
+def test_grid_encode_2d_vs_torch():
+    from enerf_amd.backends import _gridencoder as ge
+    offsets, pls = O.grid_offsets(input_dim=2, num_levels=4, base_resolution=16, log2_hashmap_size=19,
+                                  desired_resolution=2048)
+    S = float(np.log2(pls)); L = 4; C = 2; B = 1000
+    rng = np.random.default_rng(80)
+    emb = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    x = rng.uniform(0, 1, (B, 2)).astype(np.float32)
+    out = torch.empty(L, B, C, device=DEV); dummy = torch.empty(1, device=DEV)
+    ge.grid_encode_forward(cu(x), cu(emb), cu(offsets), out, B, 2, C, L, S, 16, False, dummy, 0)
+    got = out.cpu().numpy()
+    for l in range(L):
+        scale, res = O.grid_level_params(l, np.float32(S), 16)
+        size = int(offsets[l + 1] - offsets[l])
+        pos = x.astype(np.float64) * scale + 0.5
+        pg = np.floor(pos).astype(np.int64); fr = pos - pg
+        acc = np.zeros((B, C))
+        for idx in range(4):
+            cxs = pg[:, 0] + (idx & 1); cys = pg[:, 1] + ((idx >> 1) & 1)
+            w = (fr[:, 0] if idx & 1 else 1 - fr[:, 0]) * (fr[:, 1] if idx & 2 else 1 - fr[:, 1])
+            stride, index = 1, np.zeros(B, np.int64)
+            for cc in (cxs, cys):
+                if stride <= size:
+                    index = index + cc * stride
+                    stride *= res + 1
+            if stride > size:
+                index = (cxs * 1) ^ ((cys * 2654435761) & 0xffffffff)
+            index = (index & 0xffffffff) % size
+            acc += w[:, None] * emb[offsets[l] + index]
+        np.testing.assert_allclose(got[l], acc, atol=max(3e-5, scale * 1.2e-7))   # fp32 pos = x*scale+0.5
+    ref, _ = O.grid_encode_forward(x, emb, offsets, S, 16)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------ SH encoder
+@pytest.mark.parametrize("deg", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_encode(deg):
+    from enerf_amd.backends import _shencoder as sh
+    rng = np.random.default_rng(90 + deg)
+    B = 1001
+    v = rng.normal(size=(B, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[5] *= 0.5
+    ref, jref = O.sh_encode_forward(v, deg, True)
+    out = torch.empty(B, deg * deg, device=DEV); jac = torch.empty(B, 3 * deg * deg, device=DEV)
+    sh.sh_encode_forward(cu(v), out, B, 3, deg, True, jac)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * deg)
+    np.testing.assert_allclose(jac.cpu().numpy(), jref, rtol=1e-4, atol=2e-5 * deg * deg)
+    out2 = torch.empty(B, deg * deg, device=DEV)
+    sh.sh_encode_forward(cu(v), out2, B, 3, deg, False, torch.empty(1, device=DEV))
+    assert torch.equal(out, out2)
+    g = rng.normal(size=(B, deg * deg)).astype(np.float32)
+    gi_ref = O.sh_encode_backward(g, v, deg, jref)
+    gi = torch.zeros(B, 3, device=DEV)
+    sh.sh_encode_backward(cu(g), cu(v), B, 3, deg, jac, gi)
+    np.testing.assert_allclose(gi.cpu().numpy(), gi_ref, rtol=1e-3, atol=1e-4 * deg * deg)
+
+
+def test_sh_encode_half():
+    from enerf_amd.backends import _shencoder as sh
+    v = np.random.default_rng(99).normal(size=(300, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    vh = v.astype(np.float16)
+    ref, _ = O.sh_encode_forward(vh.astype(np.float32), 4)
+    out = torch.empty(300, 16, device=DEV, dtype=torch.half)
+    sh.sh_encode_forward(cu(vh), out, 300, 3, 4, False, torch.empty(1, device=DEV, dtype=torch.half))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3)
+
+
+# ------------------------------------------------------------------ end to end: renderer on the HIP path vs the
+# same renderer on the CPU oracle backend (same weights, same rays)
+def _cpu_model_and_outputs(bound, o, d, bits, train, monkeypatch):
+    import enerf_amd.raymarching as rmod, enerf_amd.gridencoder as gmod, enerf_amd.shencoder as smod
+    from oracle import backend as ob
+    from enerf_amd.network import NeRFNetwork
+    with monkeypatch.context() as mp:
+        mp.setattr(rmod, "_backend", ob.raymarching_backend); mp.setattr(rmod, "_DEVICE", "cpu")
+        mp.setattr(gmod, "_backend", ob.gridencoder_backend); mp.setattr(smod, "_backend", ob.shencoder_backend)
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3)
+        g = torch.Generator().manual_seed(5)
+        model.encoder.embeddings.data.copy_(torch.rand(model.encoder.embeddings.shape, generator=g) * 2 - 1)
+        model.density_bitfield.copy_(torch.from_numpy(bits))
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        model.train(train)
+        ro, rd = torch.from_numpy(o)[None], torch.from_numpy(d)[None]
+        if train:
+            out = model.render(ro, rd, staged=False, bg_color=torch.full((3,), 0.3), perturb=True, force_all_rays=True)
+            ((out["image"] ** 2).sum() + out["depth"].sum()).backward()
+            grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+            return state, out, grads, model.step_counter.clone()
+        with torch.no_grad():
+            out = model.render(ro, rd, staged=False, bg_color=None, perturb=False)
+        return state, out, None, None
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_render_end_to_end_vs_cpu_oracle(scenes, monkeypatch, train):
+    from enerf_amd.network import NeRFNetwork
+    bound = 2
+    grid, bits, C = scenes[bound]
+    o, d, _ = _rays(192, 55, bound)
+    state, ref, ref_grads, ref_counter = _cpu_model_and_outputs(bound, o, d, bits, train, monkeypatch)
+    model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3)
+    model.load_state_dict(state)
+    model.to(DEV).train(train)
+    ro, rd = cu(o)[None], cu(d)[None]
+    if train:
+        out = model.render(ro, rd, staged=False, bg_color=torch.full((3,), 0.3, device=DEV), perturb=True,
+                           force_all_rays=True)
+        ((out["image"] ** 2).sum() + out["depth"].sum()).backward()
+        assert torch.equal(model.step_counter.cpu(), ref_counter)            # sample counts bit-exact
+        assert_close(out["image"], ref["image"], rtol=1e-4, atol=2e-5)
+        assert_close(out["depth"], ref["depth"], rtol=1e-4, atol=2e-5)
+        for n, p in model.named_parameters():
+            r = ref_grads[n]
+            tol = 2e-4 * float(r.abs().max()) + 1e-7
+            assert float((p.grad.cpu() - r).abs().max()) < tol, n
+    else:
+        with torch.no_grad():
+            out = model.render(ro, rd, staged=False, bg_color=None, perturb=False)
+        assert_close(out["image"], ref["image"], rtol=1e-4, atol=2e-5)
+        assert_close(out["depth"], ref["depth"], rtol=1e-4, atol=2e-5)
