@@ -1,0 +1,401 @@
+// mlp32.hip -- fused fp32 MLP (64-wide hidden layers, no bias) on the fp32 matrix-core path of gfx950.
+//
+// The reference's default networks (nerf/network.py: sigma_net 32->64->16, color_net 31->64->64->3) are nn.Linear
+// stacks; on MI355X the skinny fp32 GEMMs they turn into dominate a 4096-ray training step.  This file evaluates such
+// a stack -- forward, activation gradients, weight gradients -- in fused kernels built on
+// v_mfma_f32_32x32x2_f32, whose result is bit-for-bit an fp32 fmaf chain (MI355X_MICROARCH.md), so sigma / rgb stay
+// within fp32 round-off of the nn.Linear statement (parity target 1e-4 rel).  It is not part of the reference's
+// native surface; enerf_amd/network.py routes its MLPs here (enerf_amd/fused_mlp.py), state_dict unchanged.
+//
+// Orientation as in ffmlp.hip: D[neuron][sample].  With one fp32 per lane per operand the D tile of one layer is the
+// B operand of the next layer *as is* (MFMA q of input block ib consumes accumulator register q); the weight-gradient
+// kernel reads its operands straight from the row-major [B,64] buffers (a wavefront reads two 128-byte row segments
+// per MFMA), no transposes anywhere.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+using namespace enerf;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int HID = 64;
+constexpr int IN = 32;
+
+__device__ __forceinline__ f32x16 mma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// neuron (within a 32-block) held in accumulator register q by lane half h
+__device__ __forceinline__ int nrow(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+__device__ __forceinline__ float act_fwd(float x, uint32_t a) { return a == 0 ? (x > 0 ? x : 0.0f) : x; }
+__device__ __forceinline__ float act_bwd(float g, float fwd, uint32_t a) { return a == 0 ? (fwd > 0 ? g : 0.0f) : g; }
+
+// blob: [W0 64 x 32 | Wh (NH-1) x 64 x 64 | Wout out_dim x 64], row-major W[out][in]
+__device__ __forceinline__ uint32_t blob_size(int NH, uint32_t out_dim) {
+    return HID * IN + (NH - 1) * HID * HID + out_dim * HID;
+}
+
+__device__ __forceinline__ void stage(float* wl, const float* __restrict__ w, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+}
+
+// store / load a D-tile-shaped [32 samples][32 neurons] block of a row-major [B,64] fp32 buffer (16 B per g)
+__device__ __forceinline__ void store_tile(float* rowptr, int ib, int h, const f32x16& v) {
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        *reinterpret_cast<float4*>(rowptr + 32 * ib + 8 * g + 4 * h) =
+            make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+__device__ __forceinline__ void load_tile(const float* rowptr, int ib, int h, f32x16& v) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 t = *reinterpret_cast<const float4*>(rowptr + 32 * ib + 8 * g + 4 * h);
+        v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+    }
+}
+
+// ================================================================== forward
+template <int NH, bool TRAIN>
+__global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                   float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
+                                                   uint32_t out_dim, uint32_t act, uint32_t out_act) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    stage(wl, W, blob_size(NH, out_dim));
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+
+    // layer 0 contraction pairs (p, 16 + p): lane half h reads the contiguous input columns 16h .. 16h+15
+    float w0[2][16], wh[NH > 1 ? NH - 1 : 1][2][2][16], wo[2][16];
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int p = 0; p < 16; p++) w0[ob][p] = wl[(32 * ob + j) * IN + 16 * h + p];
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    wh[l][ob][ib][q] = wl[HID * IN + l * HID * HID + (32 * ob + j) * HID + 32 * ib + nrow(q, h)];
+    {
+        const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) wo[ib][q] = (uint32_t)j < out_dim ? wout[j * HID + 32 * ib + nrow(q, h)] : 0.0f;
+    }
+
+    const uint32_t ntiles = B / 32;
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const size_t s = (size_t)tile * 32 + j;
+        float x[16];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float4 t = *reinterpret_cast<const float4*>(X + s * IN + 16 * h + 4 * v);
+            x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
+        }
+        f32x16 a[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++) {
+            a[ob] = (f32x16)(0.0f);
+#pragma unroll
+            for (int p = 0; p < 16; p++) a[ob] = mma(w0[ob][p], x[p], a[ob]);
+#pragma unroll
+            for (int q = 0; q < 16; q++) a[ob][q] = act_fwd(a[ob][q], act);
+            if (TRAIN) store_tile(fb + s * HID, ob, h, a[ob]);
+        }
+#pragma unroll
+        for (int l = 1; l < NH; l++) {
+            f32x16 n[2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {
+                n[ob] = (f32x16)(0.0f);
+#pragma unroll
+                for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) n[ob] = mma(wh[l - 1][ob][ib][q], a[ib][q], n[ob]);
+#pragma unroll
+                for (int q = 0; q < 16; q++) n[ob][q] = act_fwd(n[ob][q], act);
+                if (TRAIN) store_tile(fb + ((size_t)l * B + s) * HID, ob, h, n[ob]);
+            }
+            a[0] = n[0];
+            a[1] = n[1];
+        }
+        f32x16 o = (f32x16)(0.0f);
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) o = mma(wo[ib][q], a[ib][q], o);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t r = (uint32_t)nrow(q, h);
+            if (r < out_dim) Y[s * out_dim + r] = act_fwd(o[q], out_act);
+        }
+    }
+}
+
+// ================================================================== backward: activation gradients
+// KPO = number of contraction pairs covering the output dimension (out_dim <= 2 * KPO): pair p = (p, KPO + p)
+template <int NH, int KPO>
+__global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__ dY, const float* __restrict__ W,
+                                                       const float* __restrict__ fb, float* __restrict__ bb,
+                                                       float* __restrict__ dX, uint32_t B, uint32_t out_dim,
+                                                       uint32_t act) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    stage(wl, W, blob_size(NH, out_dim));
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
+
+    float woT[2][KPO], whT[NH > 1 ? NH - 1 : 1][2][2][16], wiT[2][16];
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+        for (int p = 0; p < KPO; p++) {
+            const uint32_t o = (uint32_t)(p + KPO * h);
+            woT[ib][p] = o < out_dim ? wout[o * HID + 32 * ib + j] : 0.0f;
+        }
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)          // block of INPUT neurons of the layer (rows of the transposed operand)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    whT[l][ib][ob][q] = wl[HID * IN + l * HID * HID + (32 * ob + nrow(q, h)) * HID + 32 * ib + j];
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) wiT[ob][q] = wl[(32 * ob + nrow(q, h)) * IN + j];
+
+    const uint32_t ntiles = B / 32;
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const size_t s = (size_t)tile * 32 + j;
+        float dy[KPO];
+#pragma unroll
+        for (int p = 0; p < KPO; p++) {
+            const uint32_t o = (uint32_t)(p + KPO * h);
+            dy[p] = o < out_dim ? dY[s * out_dim + o] : 0.0f;
+        }
+        f32x16 g[2];
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+            g[ib] = (f32x16)(0.0f);
+#pragma unroll
+            for (int p = 0; p < KPO; p++) g[ib] = mma(woT[ib][p], dy[p], g[ib]);
+            f32x16 fw;
+            load_tile(fb + ((size_t)(NH - 1) * B + s) * HID, ib, h, fw);
+#pragma unroll
+            for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(g[ib][q], fw[q], act);
+            store_tile(bb + s * HID, ib, h, g[ib]);
+        }
+#pragma unroll
+        for (int jj = 1; jj < NH; jj++) {
+            const int l = NH - jj;
+            f32x16 n[2];
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                n[ib] = (f32x16)(0.0f);
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) n[ib] = mma(whT[l - 1][ib][ob][q], g[ob][q], n[ib]);
+                f32x16 fw;
+                load_tile(fb + ((size_t)(l - 1) * B + s) * HID, ib, h, fw);
+#pragma unroll
+                for (int q = 0; q < 16; q++) n[ib][q] = act_bwd(n[ib][q], fw[q], act);
+                store_tile(bb + ((size_t)jj * B + s) * HID, ib, h, n[ib]);
+            }
+            g[0] = n[0];
+            g[1] = n[1];
+        }
+        if (dX) {
+            f32x16 d = (f32x16)(0.0f);
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) d = mma(wiT[ob][q], g[ob][q], d);
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++)
+                *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) =
+                    make_float4(d[4 * gq], d[4 * gq + 1], d[4 * gq + 2], d[4 * gq + 3]);
+        }
+    }
+}
+
+// ================================================================== backward: weight gradients
+// dW[o][i] = sum_s dOut[s][o] * In[s][i]; MFMA p of a 32-sample tile contracts samples (2p, 2p+1): lane half h of the
+// A operand reads row 2p+h of dOut (32 consecutive floats per half-wave), likewise the B operand of In.
+template <int NH>
+__global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ dY, const float* __restrict__ X,
+                                                     const float* __restrict__ fb, const float* __restrict__ bb,
+                                                     float* __restrict__ partial, uint32_t B, uint32_t out_dim) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const uint32_t NW = blob_size(NH, out_dim);
+    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) red[i] = 0.0f;
+    __syncthreads();
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+
+    f32x16 aw0[2], awh[NH > 1 ? NH - 1 : 1][2][2], awo[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        aw0[a] = (f32x16)(0.0f);
+        awo[a] = (f32x16)(0.0f);
+#pragma unroll
+        for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) awh[l][a][b] = (f32x16)(0.0f);
+    }
+    const uint32_t ntiles = B / 32;
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const size_t s0 = (size_t)tile * 32;
+#pragma unroll 4
+        for (int p = 0; p < 16; p++) {
+            const size_t s = s0 + 2 * p + h;
+            // input layer
+            const float xin = X[s * IN + j];
+            const float* g0 = bb + ((size_t)(NH - 1) * B + s) * HID;
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) aw0[ob] = mma(g0[32 * ob + j], xin, aw0[ob]);
+            // hidden layers
+#pragma unroll
+            for (int m = 1; m < NH; m++) {
+                const float* in = fb + ((size_t)(m - 1) * B + s) * HID;
+                const float* go = bb + ((size_t)(NH - 1 - m) * B + s) * HID;
+                const float i0 = in[j], i1 = in[32 + j], o0 = go[j], o1 = go[32 + j];
+                awh[m - 1][0][0] = mma(o0, i0, awh[m - 1][0][0]);
+                awh[m - 1][0][1] = mma(o0, i1, awh[m - 1][0][1]);
+                awh[m - 1][1][0] = mma(o1, i0, awh[m - 1][1][0]);
+                awh[m - 1][1][1] = mma(o1, i1, awh[m - 1][1][1]);
+            }
+            // output layer
+            const float* in = fb + ((size_t)(NH - 1) * B + s) * HID;
+            const float dyv = (uint32_t)j < out_dim ? dY[s * out_dim + j] : 0.0f;
+            awo[0] = mma(dyv, in[j], awo[0]);
+            awo[1] = mma(dyv, in[32 + j], awo[1]);
+        }
+    }
+    auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t o = (uint32_t)(32 * ob + nrow(q, h));
+            if (o < nrows) red[base + o * ld + 32 * nb + j] += a[q];
+        }
+    };
+    const int wid = threadIdx.x >> 6;
+    for (int turn = 0; turn < 4; turn++) {      // fixed order: deterministic sums
+        if (wid == turn) {
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID);
+#pragma unroll
+            for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID);
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim);
+        }
+        __syncthreads();
+    }
+    float* dst = partial + (size_t)blockIdx.x * NW;
+    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
+}
+
+__global__ void __launch_bounds__(256) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
+                                                        float* __restrict__ gw) {
+    // 64 weights per workgroup; the 4 waves each sum a quarter of the partial blocks (fixed order), then combine
+    __shared__ float acc[4][64];
+    const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t part = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (i < NW)
+        for (uint32_t b = part; b < nblocks; b += 4) s += partial[(size_t)b * NW + i];
+    acc[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && i < NW) gw[i] += (acc[0][threadIdx.x] + acc[1][threadIdx.x]) + (acc[2][threadIdx.x] + acc[3][threadIdx.x]);
+}
+
+uint32_t pgrid(uint32_t B, uint32_t cap) {
+    const uint32_t blocks = div_up(B / 32, 4);
+    return blocks < cap ? blocks : cap;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Fused fp32 MLP: X [B,32] -> (64 x num_hidden, ReLU/none) -> Y [B,out_dim], out_dim <= 32, no bias.
+// weights: [W0 64x32 | Wh (num_hidden-1) x 64x64 | Wout out_dim x 64]; fb [num_hidden,B,64] or NULL (inference).
+int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
+                        uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
+                        enerf_stream_t stream) {
+    if (B == 0) return 0;
+    if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32 (pad the input), got %u", in_dim);
+    if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
+    if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
+    if (B % 32 != 0) ENERF_BADARG("mlp32: batch must be a multiple of 32, got %u", B);
+    if (activation != 0 && activation != 6) ENERF_BADARG("mlp32: activation must be relu (0) or none (6)");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_FFMLP_FWD, s);
+    const uint32_t grid = pgrid(B, 1024);
+    const size_t lds = sizeof(float) * (HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID);
+#define MLP32_FWD(NHV)                                                                                         \
+    do {                                                                                                       \
+        if (fb) k_mlp32_fwd<NHV, true><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation); \
+        else k_mlp32_fwd<NHV, false><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation);   \
+    } while (0)
+    if (num_hidden == 1) MLP32_FWD(1);
+    else if (num_hidden == 2) MLP32_FWD(2);
+    else MLP32_FWD(3);
+#undef MLP32_FWD
+    ENERF_LAUNCH_CHECK("mlp32_forward");
+    return 0;
+}
+
+// dY [B,out_dim], fb from the forward; bb [num_hidden,B,64] scratch (written); dX [B,32] or NULL;
+// dW (fp32 blob) is ACCUMULATED into (+=).
+int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const float* fb, uint32_t B, uint32_t in_dim,
+                         uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
+                         enerf_stream_t stream) {
+    if (B == 0) return 0;
+    if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32, got %u", in_dim);
+    if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
+    if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
+    if (B % 32 != 0) ENERF_BADARG("mlp32: batch must be a multiple of 32, got %u", B);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_FFMLP_BWD, s);
+    const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
+    const size_t lds = sizeof(float) * NW;
+    const uint32_t grid = pgrid(B, 1024), wgrid = pgrid(B, 256);
+    float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NW);
+    if (!partial) return ENERF_E_NOMEM;
+#define MLP32_BA(NHV, KPOV) k_mlp32_bwd_act<NHV, KPOV><<<grid, 256, lds, s>>>(dY, W, fb, bb, dX, B, out_dim, activation)
+#define MLP32_BWD(NHV)                                                                   \
+    do {                                                                                 \
+        if (out_dim <= 4) MLP32_BA(NHV, 2);                                              \
+        else if (out_dim <= 16) MLP32_BA(NHV, 8);                                        \
+        else MLP32_BA(NHV, 16);                                                          \
+        k_mlp32_bwd_w<NHV><<<wgrid, 256, lds, s>>>(dY, X, fb, bb, partial, B, out_dim);  \
+    } while (0)
+    if (num_hidden == 1) MLP32_BWD(1);
+    else if (num_hidden == 2) MLP32_BWD(2);
+    else MLP32_BWD(3);
+#undef MLP32_BWD
+#undef MLP32_BA
+    k_mlp32_reduce_w<<<div_up(NW, 64), 256, 0, s>>>(partial, wgrid, NW, dW);
+    ENERF_LAUNCH_CHECK("mlp32_backward");
+    return 0;
+}
+
+}  // extern "C"

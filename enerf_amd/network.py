@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_mlp
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .renderer import NeRFRenderer
@@ -20,6 +21,11 @@ def _mlp(in_dim, hidden, out_dim, n):
 
 
 def _run_mlp(layers, h):
+    """relu(... relu(h W0^T) ...) W_last^T.  CUDA fp32 inputs take the fused matrix-core path (same parameters, same
+    math to fp32 round-off); everything else is the plain nn.Linear loop of the reference."""
+    weights = [layer.weight for layer in layers]
+    if h.dim() == 2 and fused_mlp.supported(h, weights):
+        return fused_mlp.fused_mlp(h, weights, "relu")
     for l, layer in enumerate(layers):
         h = layer(h)
         if l != len(layers) - 1:

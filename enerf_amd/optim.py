@@ -1,0 +1,46 @@
+"""`FusedAdam`: torch.optim.Adam semantics (no weight decay, no amsgrad) with one fused HIP pass per parameter
+(csrc/optim.hip).  Drop-in for `torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)` of the
+reference (main_nerf.py:211); param_groups / lr schedulers / state_dict work as for any torch optimizer.
+Parameters that are not CUDA fp32 fall back to the same update written in torch ops."""
+import math
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            lr, eps = float(group["lr"]), float(group["eps"])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad
+                if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() \
+                        and g.dtype == torch.float32:
+                    L.check(L.lib().enerf_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                    st["exp_avg_sq"].data_ptr(), p.numel(), lr, b1, b2, eps,
+                                                    st["step"], 0, L.stream_handle()), "adam_step")
+                else:
+                    m, v, t = st["exp_avg"], st["exp_avg_sq"], st["step"]
+                    m.lerp_(g, 1 - b1)
+                    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                    denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+                    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+        return loss

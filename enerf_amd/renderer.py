@@ -300,7 +300,10 @@ class NeRFRenderer(nn.Module):
             for xs in X:
                 for ys in Y:
                     for zs in Z:
-                        xx, yy, zz = _meshgrid_ij(xs, ys, zs)
+                        # same cell set as the reference's meshgrid(xs, ys, zs), enumerated with x fastest: consecutive
+                        # query points are then x-neighbours, i.e. neighbouring rows of every level of the hash grid
+                        # (dense levels index x + y*R + z*R^2; hashed levels x ^ const) -> coalesced gathers
+                        zz, yy, xx = _meshgrid_ij(zs, ys, xs)
                         coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
                         indices = raymarching.morton3D(coords).long()
                         xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
@@ -314,9 +317,10 @@ class NeRFRenderer(nn.Module):
                 occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
                 rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
                 occ_indices = occ_indices[rand_mask]
-                occ_coords = raymarching.morton3D_invert(occ_indices)
                 indices = torch.cat([indices, occ_indices], dim=0)
-                coords = torch.cat([coords, occ_coords], dim=0)
+                # spatially sorted (morton) evaluation order: same cells, cache-friendly gathers
+                indices = torch.sort(indices)[0]
+                coords = raymarching.morton3D_invert(indices)
                 xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
                 tmp_grid[cas, indices] = self._cell_density(xyzs, cas)
 

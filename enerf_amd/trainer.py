@@ -11,13 +11,15 @@ random-init weights.
 import torch
 
 from . import scene
+from .optim import FusedAdam
 from .parallel import GradAverager
 
 
 class TrainHarness:
     def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16):
         self.model = model
-        self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
+        adam = FusedAdam if next(model.parameters()).is_cuda else torch.optim.Adam
+        self.opt = adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.occupancy = occupancy
         self.update_interval = update_interval
         self.global_step = 0

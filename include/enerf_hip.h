@@ -174,6 +174,28 @@ int enerf_ffmlp_backward(const void* grad, const void* inputs, const void* weigh
 int enerf_allocate_splitk(size_t size);
 int enerf_free_splitk(void);
 
+/* ------------------------------------------------------------------ extensions beyond the reference's native surface
+ * (callers of the hot path: the nn.Linear MLPs of nerf/network.py:40-77 and the optimizer of main_nerf.py:211) */
+
+/* Fused fp32 MLP on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains): X [B,32] -> 64-wide hidden x num_hidden (1..3) ->
+ * Y [B,out_dim <= 32], no bias; W = [W0 64x32 | Wh (num_hidden-1)x64x64 | Wout out_dim x 64], each W[out][in].
+ * fb [num_hidden,B,64] receives the post-activation hidden states (NULL = inference).  B % 32 == 0. */
+int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
+                        uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
+                        enerf_stream_t stream);
+/* bb [num_hidden,B,64] is scratch (written); dX [B,32] or NULL; dW (fp32 blob) is accumulated into (+=). */
+int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const float* fb, uint32_t B, uint32_t in_dim,
+                         uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
+                         enerf_stream_t stream);
+
+/* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
+ * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */
+int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                    uint32_t step, int zero_grad, enerf_stream_t stream);
+
+/* profiling aid: restrict grid_encode_forward/backward to the levels whose bit is set (default all) */
+int enerf_debug_grid_level_mask(uint32_t mask);
+
 /* ------------------------------------------------------------------ measurement hooks (not in the reference)
  * When enabled, every launch of the selected kernel family is bracketed by hipEvents on its own stream so that
  * bench.py can report the average launch duration of the dominant kernel (roofline.achieved). */
