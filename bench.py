@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--render-frames", type=int, default=1, help="full 640x480 inference frames timed after training")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256)
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
+    # development aids: exercise the N > 1 code path on a single-GPU box (gloo all-reduce, every rank on one device)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend override (default: nccl = RCCL)")
+    ap.add_argument("--force-device", type=int, default=None, help="put every rank on this device index")
     return ap.parse_args()
 
 
@@ -58,6 +61,20 @@ def build_batches(n_batches, n_rays, device, rank, bound):
         target = (0.5 + 0.5 * torch.sin(rd * 4.0 + ro)).clamp(0, 1).contiguous()
         batches.append((ro, rd, target))
     return batches
+
+
+def pmc_traffic(points_per_launch):
+    """HBM bytes per grid_encode_forward launch from the committed rocprofv3 PMC passes (profiles/
+    r01_pmc_hbm_kernels.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/bench_kernels.py at
+    137 856 points), scaled per point.  FETCH_SIZE is in KB and, per MI355X_MICROARCH.md (HBM), counts 64 B per
+    128-byte request on gfx950, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).  None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_kernels.json")) as f:
+            d = json.load(f)["k_grid_fwd<float, 3, 2> grid=2207744"]
+        per_point = (2.0 * d["FETCH_SIZE_KB_avg"] + d["WRITE_SIZE_KB_avg"]) * 1024.0 / 137856.0
+        return per_point * points_per_launch
+    except Exception:
+        return None
 
 
 def cpu_baseline(args):
@@ -86,7 +103,7 @@ def cpu_baseline(args):
         n, T = args.cpu_rays, 512
         g = torch.Generator().manual_seed(7)
         steps, t_total = 0, 0.0
-        for it in range(1 + 64):
+        for it in range(1 + 512):
             (ro, rd), _ = scene.training_batch(it, n, "cpu", generator=g)
             target = (0.5 + 0.5 * torch.sin(rd * 4.0 + ro)).clamp(0, 1)
             t0 = time.perf_counter()
@@ -101,7 +118,7 @@ def cpu_baseline(args):
                 continue        # warm-up
             steps += 1
             t_total += dt
-            if t_total > args.cpu_budget_s or steps >= 16:
+            if t_total > args.cpu_budget_s:
                 break
         rays_s = steps * n / t_total
         return {"value": rays_s, "unit": "rays/s", "cores": cores, "kind": "port",
@@ -120,7 +137,9 @@ def main():
     from enerf_amd.backends import _gridencoder as gb, _raymarching as rb
     import torch.distributed as dist
 
-    rank, world, local_rank = parallel.init_from_env()
+    rank, world, local_rank = parallel.init_from_env(backend=args.backend)
+    if args.force_device is not None:
+        local_rank = args.force_device
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -193,7 +212,7 @@ def main():
         pts = gb.STATS["fwd_points"] / gb.STATS["fwd_calls"]
         achieved = pts * GRID_FWD_BYTES_PER_POINT / (kernels["grid_fwd"]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "grid_encode_forward", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pts),
                     "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"]}
         if "grid_bwd" in kernels and gb.STATS["bwd_calls"]:
             ptsb = gb.STATS["bwd_points"] / gb.STATS["bwd_calls"]

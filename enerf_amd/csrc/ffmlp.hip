@@ -70,6 +70,42 @@ __device__ __forceinline__ float act_bwd(float g, float fwd, uint32_t a) {   // 
     }
 }
 
+// Whole-tile activation with the switch OUTSIDE the element loop: the relu / none paths used by the NeRF nets are a
+// handful of instructions; the transcendental variants live in their own (cold) blocks instead of being expanded and
+// branched over per element.
+__device__ __forceinline__ void apply_act(f32x16& t, uint32_t a) {
+    if (a == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = fmaxf(t[q], 0.0f);
+    } else if (a != 6) {
+#define ENERF_ACT_CASE(ID)                                    \
+    case ID:                                                  \
+        _Pragma("unroll") for (int q = 0; q < 16; q++) t[q] = act_fwd(t[q], ID); \
+        break;
+        switch (a) {
+            ENERF_ACT_CASE(1) ENERF_ACT_CASE(2) ENERF_ACT_CASE(3) ENERF_ACT_CASE(4) ENERF_ACT_CASE(5)
+            default: break;
+        }
+#undef ENERF_ACT_CASE
+    }
+}
+__device__ __forceinline__ void apply_act_bwd(f32x16& g, const float (&fw)[16], uint32_t a) {
+    if (a == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) g[q] = fw[q] > 0.0f ? g[q] : 0.0f;
+    } else if (a != 6) {
+#define ENERF_ACTB_CASE(ID)                                   \
+    case ID:                                                  \
+        _Pragma("unroll") for (int q = 0; q < 16; q++) g[q] = act_bwd(g[q], fw[q], ID); \
+        break;
+        switch (a) {
+            ENERF_ACTB_CASE(1) ENERF_ACTB_CASE(3) ENERF_ACTB_CASE(4) ENERF_ACTB_CASE(5)
+            default: break;
+        }
+#undef ENERF_ACTB_CASE
+    }
+}
+
 // ---- weight-fragment builders (from the LDS copy of the blob) -------------------------------------------------
 // natural K order: element e of K-block kb, lane half h  <->  column 16*kb + 8*h + e          (operand fed from memory)
 // permuted K order: K-block (ib,kbb), element e           <->  column 32*ib + 16*kbb + 4*h + (e&3) + 8*(e>>2)
@@ -108,12 +144,12 @@ __device__ __forceinline__ typename V<E>::x8 frag_col_perm(const E* m, int ld, i
 }
 
 // D tile (fp32, lane = sample) -> two permuted-order K-blocks of 16-bit operands, with an elementwise map
-template <typename E, typename F>
-__device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::x8 (&out)[2], F f) {
+template <typename E>
+__device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::x8 (&out)[2]) {
 #pragma unroll
     for (int kbb = 0; kbb < 2; kbb++)
 #pragma unroll
-        for (int e = 0; e < 8; e++) out[kbb][e] = (E)f(acc[8 * kbb + e], 8 * kbb + e);
+        for (int e = 0; e < 8; e++) out[kbb][e] = (E)acc[8 * kbb + e];
 }
 
 // store / load one [32 samples][32 neurons] D-tile-shaped block of a row-major [B,64] 16-bit buffer:
@@ -203,7 +239,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
         }
 #pragma unroll
         for (int ob = 0; ob < 2; ob++) {
-            tile_to_frags<E>(acc[ob], hb[ob], [&](float v, int) { return act_fwd(v, act); });
+            apply_act(acc[ob], act);
+            tile_to_frags<E>(acc[ob], hb[ob]);
             if (TRAIN) store_tile<E>(fb + s * HID, ob, h, hb[ob]);
         }
 #pragma unroll
@@ -217,7 +254,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
             x8 nb[2][2];
 #pragma unroll
             for (int ob = 0; ob < 2; ob++) {
-                tile_to_frags<E>(acc[ob], nb[ob], [&](float v, int) { return act_fwd(v, act); });
+                apply_act(acc[ob], act);
+                tile_to_frags<E>(acc[ob], nb[ob]);
                 if (TRAIN) store_tile<E>(fb + ((size_t)l * B + s) * HID, ob, h, nb[ob]);
             }
 #pragma unroll
@@ -228,12 +266,13 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
         f32x16 ao = (f32x16)(0.0f);
 #pragma unroll
         for (int blk = 0; blk < 4; blk++) ao = mma(wo[blk], hb[blk >> 1][blk & 1], ao);
+        apply_act(ao, out_act);
         // rows 0..15 of the tile: registers 0..7 (g = 0, 1): outputs 8*g + 4*h + r
 #pragma unroll
         for (int g = 0; g < 2; g++) {
             x4 q;
 #pragma unroll
-            for (int r = 0; r < 4; r++) q[r] = (E)act_fwd(ao[4 * g + r], out_act);
+            for (int r = 0; r < 4; r++) q[r] = (E)ao[4 * g + r];
             *reinterpret_cast<x4*>(Y + s * OUT + 8 * g + 4 * h) = q;
         }
     }
@@ -291,7 +330,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY,
             f32x16 a = mma(woT[ib], dyb, (f32x16)(0.0f));
             float fw[16];
             load_tile_f32<E>(fb + ((size_t)(NL - 1) * B + s) * HID, ib, h, fw);
-            tile_to_frags<E>(a, gb[ib], [&](float v, int q) { return act_bwd(v, fw[q], act); });
+            apply_act_bwd(a, fw, act);
+            tile_to_frags<E>(a, gb[ib]);
             store_tile<E>(bb + s * HID, ib, h, gb[ib]);
         }
 #pragma unroll
@@ -305,7 +345,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY,
                 for (int blk = 0; blk < 4; blk++) a = mma(whT[l - 1][ib][blk], gb[blk >> 1][blk & 1], a);
                 float fw[16];
                 load_tile_f32<E>(fb + ((size_t)(l - 1) * B + s) * HID, ib, h, fw);
-                tile_to_frags<E>(a, ng[ib], [&](float v, int q) { return act_bwd(v, fw[q], act); });
+                apply_act_bwd(a, fw, act);
+                tile_to_frags<E>(a, ng[ib]);
                 store_tile<E>(bb + ((size_t)jj * B + s) * HID, ib, h, ng[ib]);
             }
 #pragma unroll

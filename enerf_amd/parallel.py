@@ -25,6 +25,7 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver stack
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 

