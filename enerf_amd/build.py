@@ -1,47 +1,78 @@
 """Build recipe for libenerf_hip.so: hipcc, gfx950 only, in-tree output (enerf_amd/lib/).
 
 No hipify, no torch cpp_extension: the device sources are hand-written HIP and the library has a plain C ABI
-(include/enerf_hip.h), so a single hipcc invocation is the whole build.
+(include/enerf_hip.h).  Every .hip file is compiled to an object (in parallel, rebuilt only when it or a header
+changed) and the objects are linked into one shared library.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libenerf_hip.so")
-SOURCES = ["runtime.hip", "raymarching.hip", "gridencoder.hip", "shencoder.hip", "ffmlp.hip", "mlp32.hip", "optim.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+SOURCES = ["runtime.hip", "raymarching.hip", "gridencoder.hip", "shencoder.hip", "ffmlp.hip", "ffmlp_wgrad.hip",
+           "mlp32.hip", "optim.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
+         "-Wno-unused-function"]
+# Per-file extras.  ffmlp.hip (forward + dgrad) keeps its MFMA accumulators in arch VGPRs: every accumulator is
+# post-processed by VALU code (activation, 16-bit conversion) right away, and the default AGPR form costs a
+# v_accvgpr_read/write pair per element.  The weight-gradient kernels hold up to 192 accumulator registers and need
+# the AGPR half of the register file, so they live in their own translation unit without the flag.
+EXTRA = {"ffmlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ffmlp_common.h"),
+           os.path.join(_HERE, "..", "include", "enerf_hip.h")]
 
 
 def _hipcc():
-    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
-        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
             return cand
     return "hipcc"
 
 
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _stale(obj, src):
+    t = _mtime(obj)
+    return t == 0.0 or _mtime(src) > t or any(_mtime(h) > t for h in HEADERS) or _mtime(__file__) > t
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "enerf_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in srcs]
+    return not os.path.exists(LIB) or any(_stale(o, os.path.join(CSRC, s)) for o, s in zip(objs, srcs)) \
+        or any(_mtime(o) > _mtime(LIB) for o in objs)
 
 
 def build(force=False, verbose=True):
-    """Compile every HIP source into enerf_amd/lib/libenerf_hip.so (cross-compiles without a GPU)."""
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc()] + FLAGS + srcs + ["-o", LIB + ".tmp"]
-    if verbose:
-        print("[enerf_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    """Compile every HIP source for gfx950 and link enerf_amd/lib/libenerf_hip.so (cross-compiles without a GPU)."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = []
+    for s in srcs:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        if force or _stale(obj, src):
+            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print("[enerf_amd.build]", " ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in srcs]
+    if force or jobs or not os.path.exists(LIB) or any(_mtime(o) > _mtime(LIB) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"])
+        os.replace(LIB + ".tmp", LIB)
     return LIB
 
 

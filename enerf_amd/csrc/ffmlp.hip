@@ -17,172 +17,11 @@
 //    over the whole batch slab; per-workgroup partial sums go to a workspace and are reduced by a final pass
 //    (deterministic; replaces the reference's per-layer split-K CUTLASS GEMMs on side streams).
 //  * fp32 accumulation everywhere (the reference accumulates in fp16).
-#include <hip/hip_runtime.h>
+#include "ffmlp_common.h"
 
-#include "common.h"
-
-using namespace enerf;
+using namespace enerf_ffmlp;
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int HID = 64;
-constexpr int OUT = 16;
-constexpr int MAX_NL = 4;
-
-
-template <typename E> struct V;
-template <> struct V<__bf16> { using x8 = bf16x8; using x4 = bf16x4; };
-template <> struct V<_Float16> { using x8 = f16x8; using x4 = f16x4; };
-
-__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-#define K_ACT 10.0f
-__device__ __forceinline__ float act_fwd(float x, uint32_t a) {   // ffmlp/src/utils.h:424-470
-    switch (a) {
-        case 0: return x > 0 ? x : 0.0f;
-        case 1: return __expf(x);
-        case 2: return __sinf(x);
-        case 3: return 1.0f / (1.0f + __expf(-x));
-        case 4: { const float v = x * K_ACT; return 0.5f * (v + sqrtf(v * v + 4)) / K_ACT; }
-        case 5: return __logf(__expf(x * K_ACT) + 1.0f) / K_ACT;
-        default: return x;
-    }
-}
-__device__ __forceinline__ float act_bwd(float g, float fwd, uint32_t a) {   // utils.h:534-582 (post-activation input)
-    switch (a) {
-        case 0: return fwd > 0 ? g : 0.0f;
-        case 1: return g * fwd;
-        case 3: return g * (fwd * (1.0f - fwd));
-        case 4: { const float y = fwd * K_ACT; return g * (y * y / (y * y + 1)); }
-        case 5: return g * (1.0f - __expf(-fwd * K_ACT));
-        default: return g;
-    }
-}
-
-// Whole-tile activation with the switch OUTSIDE the element loop: the relu / none paths used by the NeRF nets are a
-// handful of instructions; the transcendental variants live in their own (cold) blocks instead of being expanded and
-// branched over per element.
-__device__ __forceinline__ void apply_act(f32x16& t, uint32_t a) {
-    if (a == 0) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) t[q] = fmaxf(t[q], 0.0f);
-    } else if (a != 6) {
-#define ENERF_ACT_CASE(ID)                                    \
-    case ID:                                                  \
-        _Pragma("unroll") for (int q = 0; q < 16; q++) t[q] = act_fwd(t[q], ID); \
-        break;
-        switch (a) {
-            ENERF_ACT_CASE(1) ENERF_ACT_CASE(2) ENERF_ACT_CASE(3) ENERF_ACT_CASE(4) ENERF_ACT_CASE(5)
-            default: break;
-        }
-#undef ENERF_ACT_CASE
-    }
-}
-__device__ __forceinline__ void apply_act_bwd(f32x16& g, const float (&fw)[16], uint32_t a) {
-    if (a == 0) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) g[q] = fw[q] > 0.0f ? g[q] : 0.0f;
-    } else if (a != 6) {
-#define ENERF_ACTB_CASE(ID)                                   \
-    case ID:                                                  \
-        _Pragma("unroll") for (int q = 0; q < 16; q++) g[q] = act_bwd(g[q], fw[q], ID); \
-        break;
-        switch (a) {
-            ENERF_ACTB_CASE(1) ENERF_ACTB_CASE(3) ENERF_ACTB_CASE(4) ENERF_ACTB_CASE(5)
-            default: break;
-        }
-#undef ENERF_ACTB_CASE
-    }
-}
-
-// ---- weight-fragment builders (from the LDS copy of the blob) -------------------------------------------------
-// natural K order: element e of K-block kb, lane half h  <->  column 16*kb + 8*h + e          (operand fed from memory)
-// permuted K order: K-block (ib,kbb), element e           <->  column 32*ib + 16*kbb + 4*h + (e&3) + 8*(e>>2)
-//                                                              (operand fed from the previous layer's D tile)
-template <typename E>
-__device__ __forceinline__ typename V<E>::x8 frag_row_nat(const E* m, int ld, int row, int kb, int h) {
-    typename V<E>::x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) f[e] = m[row * ld + 16 * kb + 8 * h + e];
-    return f;
-}
-template <typename E>
-__device__ __forceinline__ typename V<E>::x8 frag_row_perm(const E* m, int ld, int row, int blk, int h) {
-    typename V<E>::x8 f;   // blk = 2*ib + kbb
-#pragma unroll
-    for (int e = 0; e < 8; e++) f[e] = m[row * ld + 16 * blk + 4 * h + (e & 3) + 8 * (e >> 2)];
-    return f;
-}
-// transposed: A[i = column `col` of m][k = row index]; natural / permuted order over the ROW index
-template <typename E>
-__device__ __forceinline__ typename V<E>::x8 frag_col_nat(const E* m, int ld, int col, int kb, int h, int nrows) {
-    typename V<E>::x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int r = 16 * kb + 8 * h + e;
-        f[e] = r < nrows ? m[r * ld + col] : (E)0.0f;
-    }
-    return f;
-}
-template <typename E>
-__device__ __forceinline__ typename V<E>::x8 frag_col_perm(const E* m, int ld, int col, int blk, int h) {
-    typename V<E>::x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) f[e] = m[(16 * blk + 4 * h + (e & 3) + 8 * (e >> 2)) * ld + col];
-    return f;
-}
-
-// D tile (fp32, lane = sample) -> two permuted-order K-blocks of 16-bit operands, with an elementwise map
-template <typename E>
-__device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::x8 (&out)[2]) {
-#pragma unroll
-    for (int kbb = 0; kbb < 2; kbb++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) out[kbb][e] = (E)acc[8 * kbb + e];
-}
-
-// store / load one [32 samples][32 neurons] D-tile-shaped block of a row-major [B,64] 16-bit buffer:
-// lane (j, h) owns neurons 32*ib + 8*g + 4*h + r  (g = 0..3, r = 0..3)  <->  4 consecutive elements per g
-template <typename E>
-__device__ __forceinline__ void store_tile(E* rowptr /* row of sample j */, int ib, int h,
-                                           const typename V<E>::x8 (&fr)[2]) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        typename V<E>::x4 q;
-#pragma unroll
-        for (int r = 0; r < 4; r++) q[r] = fr[g >> 1][(g & 1) * 4 + r];
-        *reinterpret_cast<typename V<E>::x4*>(rowptr + 32 * ib + 8 * g + 4 * h) = q;
-    }
-}
-template <typename E>
-__device__ __forceinline__ void load_tile_f32(const E* rowptr, int ib, int h, float (&v)[16]) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const typename V<E>::x4 q = *reinterpret_cast<const typename V<E>::x4*>(rowptr + 32 * ib + 8 * g + 4 * h);
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[4 * g + r] = (float)q[r];
-    }
-}
-
-template <typename E>
-__device__ __forceinline__ void stage_weights(E* wl, const E* __restrict__ w, uint32_t n) {
-    // n is a multiple of 8 elements (hidden = 64, input_dim % 16 == 0)
-    const uint4* src = reinterpret_cast<const uint4*>(w);
-    uint4* dst = reinterpret_cast<uint4*>(wl);
-    for (uint32_t i = threadIdx.x; i < n / 8; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
-}
 
 // ================================================================== forward / inference
 template <typename E, int IN_KB, int NL, bool TRAIN>
@@ -220,60 +59,99 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
         }
     }
 
-    const uint32_t ntiles = B / 32;
+    // Two 32-sample tiles (64 consecutive samples) per iteration: two independent MFMA dependency chains per layer,
+    // and the next iteration's inputs are already in flight while this one computes (B % 128 == 0 => pairs are whole).
+    constexpr int T = 2;
+    const uint32_t npairs = B / (32 * T);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
-        const size_t s = (size_t)tile * 32 + j;
-        x8 xb[IN_KB];
+    x8 xn[T][IN_KB];
+    if (gw < npairs) {
 #pragma unroll
-        for (int kb = 0; kb < IN_KB; kb++) xb[kb] = *reinterpret_cast<const x8*>(X + s * IN + 16 * kb + 8 * h);
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int kb = 0; kb < IN_KB; kb++)
+                xn[t][kb] = *reinterpret_cast<const x8*>(X + ((size_t)(gw * T + t) * 32 + j) * IN + 16 * kb + 8 * h);
+    }
+    for (uint32_t pair = gw; pair < npairs; pair += nw) {
+        x8 xb[T][IN_KB];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int kb = 0; kb < IN_KB; kb++) xb[t][kb] = xn[t][kb];
+        if (pair + nw < npairs) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int kb = 0; kb < IN_KB; kb++)
+                    xn[t][kb] = *reinterpret_cast<const x8*>(X + ((size_t)((pair + nw) * T + t) * 32 + j) * IN + 16 * kb + 8 * h);
+        }
+        size_t s[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) s[t] = (size_t)(pair * T + t) * 32 + j;
 
-        f32x16 acc[2];
-        x8 hb[2][2];
+        f32x16 acc[T][2];
+        x8 hb[T][2][2];
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++) {
-            acc[ob] = (f32x16)(0.0f);
+        for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-            for (int kb = 0; kb < IN_KB; kb++) acc[ob] = mma(w0[ob][kb], xb[kb], acc[ob]);
-        }
+            for (int t = 0; t < T; t++) {
+                acc[t][ob] = (f32x16)(0.0f);
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++) {
-            apply_act(acc[ob], act);
-            tile_to_frags<E>(acc[ob], hb[ob]);
-            if (TRAIN) store_tile<E>(fb + s * HID, ob, h, hb[ob]);
-        }
+                for (int kb = 0; kb < IN_KB; kb++) acc[t][ob] = mma(w0[ob][kb], xb[t][kb], acc[t][ob]);
+            }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {
+                apply_act(acc[t][ob], act);
+                tile_to_frags<E>(acc[t][ob], hb[t][ob]);
+                if (TRAIN) store_tile<E>(fb + s[t] * HID, ob, h, hb[t][ob]);
+            }
 #pragma unroll
         for (int l = 1; l < NL; l++) {
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) {
-                acc[ob] = (f32x16)(0.0f);
-#pragma unroll
-                for (int blk = 0; blk < 4; blk++) acc[ob] = mma(wh[l - 1][ob][blk], hb[blk >> 1][blk & 1], acc[ob]);
-            }
-            x8 nb[2][2];
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) {
-                apply_act(acc[ob], act);
-                tile_to_frags<E>(acc[ob], nb[ob]);
-                if (TRAIN) store_tile<E>(fb + ((size_t)l * B + s) * HID, ob, h, nb[ob]);
-            }
-#pragma unroll
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-                for (int kbb = 0; kbb < 2; kbb++) hb[ob][kbb] = nb[ob][kbb];
+                for (int t = 0; t < T; t++) {
+                    acc[t][ob] = (f32x16)(0.0f);
+#pragma unroll
+                    for (int blk = 0; blk < 4; blk++)
+                        acc[t][ob] = mma(wh[l - 1][ob][blk], hb[t][blk >> 1][blk & 1], acc[t][ob]);
+                }
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                x8 nb[2][2];
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++) {
+                    apply_act(acc[t][ob], act);
+                    tile_to_frags<E>(acc[t][ob], nb[ob]);
+                    if (TRAIN) store_tile<E>(fb + ((size_t)l * B + s[t]) * HID, ob, h, nb[ob]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int kbb = 0; kbb < 2; kbb++) hb[t][ob][kbb] = nb[ob][kbb];
+            }
         }
-        f32x16 ao = (f32x16)(0.0f);
+        f32x16 ao[T];
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++) ao = mma(wo[blk], hb[blk >> 1][blk & 1], ao);
-        apply_act(ao, out_act);
-        // rows 0..15 of the tile: registers 0..7 (g = 0, 1): outputs 8*g + 4*h + r
+        for (int t = 0; t < T; t++) ao[t] = (f32x16)(0.0f);
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-            x4 q;
+        for (int blk = 0; blk < 4; blk++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) q[r] = (E)ao[4 * g + r];
-            *reinterpret_cast<x4*>(Y + s * OUT + 8 * g + 4 * h) = q;
+            for (int t = 0; t < T; t++) ao[t] = mma(wo[blk], hb[t][blk >> 1][blk & 1], ao[t]);
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            apply_act(ao[t], out_act);
+            // rows 0..15 of the tile: registers 0..7 (g = 0, 1): outputs 8*g + 4*h + r
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                x4 q;
+#pragma unroll
+                for (int r = 0; r < 4; r++) q[r] = (E)ao[t][4 * g + r];
+                *reinterpret_cast<x4*>(Y + s[t] * OUT + 8 * g + 4 * h) = q;
+            }
         }
     }
 }
@@ -375,167 +253,14 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY,
     }
 }
 
-// ================================================================== backward: weight gradients
-// dW_l[o][i] = sum_s dOut_l[s][o] * In_l[s][i].   Both operands live in memory as row-major [B, F] 16-bit buffers.
-// A [32 samples][32 features] tile is loaded "lane = sample" (16 B per lane), flipped to "lane = feature, registers =
-// samples" by D = tile x I on the matrix core (exact), and fed to the MFMA whose contraction index is the sample.
-template <typename E>
-__device__ __forceinline__ void flip_tile(const E* base /* row of sample j, feature 32*nb */, int h, int nfeat,
-                                          const typename V<E>::x8 (&ident)[2], typename V<E>::x8 (&q)[2]) {
-    using x8 = typename V<E>::x8;
-    f32x16 t = (f32x16)(0.0f);
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-        if (16 * kb < nfeat) {
-            const x8 a = *reinterpret_cast<const x8*>(base + 16 * kb + 8 * h);
-            t = mma(a, ident[kb], t);
-        }
-    }
-#pragma unroll
-    for (int kbs = 0; kbs < 2; kbs++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) q[kbs][e] = (E)t[8 * kbs + e];
-}
-
-template <typename E, int IN_KB, int NL>
-__global__ void __launch_bounds__(256) k_ffmlp_bwd_w(const E* __restrict__ dY, const E* __restrict__ X,
-                                                     const E* __restrict__ fb, const E* __restrict__ bb,
-                                                     float* __restrict__ partial, uint32_t B) {
-    using x8 = typename V<E>::x8;
-    constexpr int IN = 16 * IN_KB;
-    constexpr int IN_NB = (IN + 31) / 32;
-    constexpr uint32_t NW = HID * (IN + HID * (NL - 1) + OUT);
-    __shared__ float red[NW];
-    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) red[i] = 0.0f;
-    __syncthreads();
-
-    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
-    x8 ident[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) ident[kb][e] = (16 * kb + 8 * h + e == j) ? (E)1.0f : (E)0.0f;
-
-    // accumulators: input layer [2 x IN_NB], hidden layers [NL-1][2 x 2], output layer [1 x 2]
-    f32x16 aw0[2][IN_NB], awh[NL - 1][2][2], awo[2];
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-#pragma unroll
-        for (int b = 0; b < IN_NB; b++) aw0[a][b] = (f32x16)(0.0f);
-#pragma unroll
-        for (int l = 0; l < NL - 1; l++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) awh[l][a][b] = (f32x16)(0.0f);
-        awo[a] = (f32x16)(0.0f);
-    }
-
-    const uint32_t ntiles = B / 32;
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
-        const size_t s = (size_t)tile * 32 + j;
-        // activation gradients of every matmul, flipped: gq[m][ob] = dL/d(pre-act of matmul m), m = 0..NL-1,
-        // stored in backward_buffer[NL-1-m]
-        x8 prev[2][2];    // flipped INPUT of the current matmul (features in 2 blocks of 32)
-        // ---- input layer: In = X
-        {
-            x8 xq[IN_NB][2];
-#pragma unroll
-            for (int nb = 0; nb < IN_NB; nb++) flip_tile<E>(X + s * IN + 32 * nb, h, IN - 32 * nb, ident, xq[nb]);
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) {
-                x8 gq[2];
-                flip_tile<E>(bb + ((size_t)(NL - 1) * B + s) * HID + 32 * ob, h, 32, ident, gq);
-#pragma unroll
-                for (int nb = 0; nb < IN_NB; nb++)
-#pragma unroll
-                    for (int kbs = 0; kbs < 2; kbs++) aw0[ob][nb] = mma(gq[kbs], xq[nb][kbs], aw0[ob][nb]);
-            }
-        }
-        // ---- hidden layers: matmul m (1..NL-1), In = forward_buffer[m-1], dOut = backward_buffer[NL-1-m]
-#pragma unroll
-        for (int m = 1; m < NL; m++) {
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++)
-                flip_tile<E>(fb + ((size_t)(m - 1) * B + s) * HID + 32 * nb, h, 32, ident, prev[nb]);
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) {
-                x8 gq[2];
-                flip_tile<E>(bb + ((size_t)(NL - 1 - m) * B + s) * HID + 32 * ob, h, 32, ident, gq);
-#pragma unroll
-                for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-                    for (int kbs = 0; kbs < 2; kbs++)
-                        awh[m - 1][ob][nb] = mma(gq[kbs], prev[nb][kbs], awh[m - 1][ob][nb]);
-            }
-        }
-        // ---- output layer: In = forward_buffer[NL-1], dOut = dY (16 features)
-        {
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++)
-                flip_tile<E>(fb + ((size_t)(NL - 1) * B + s) * HID + 32 * nb, h, 32, ident, prev[nb]);
-            x8 gq[2];
-            flip_tile<E>(dY + s * OUT, h, OUT, ident, gq);
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-                for (int kbs = 0; kbs < 2; kbs++) awo[nb] = mma(gq[kbs], prev[nb][kbs], awo[nb]);
-        }
-    }
-
-    // D tile: lane (col j = input neuron within block nb, half h), register q -> output neuron 32*ob + (q&3) + 8*(q>>2) + 4*h.
-    // The four waves add their tiles into the LDS copy one after the other (fixed order => run-to-run deterministic).
-    auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, int nrows, int ncols) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int o = 32 * ob + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const int i = 32 * nb + j;
-            if (o < nrows && i < ncols) red[base + o * ld + i] += a[q];
-        }
-    };
-    const int wid = threadIdx.x >> 6;
-    for (int turn = 0; turn < 4; turn++) {
-        if (wid == turn) {
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++)
-#pragma unroll
-                for (int nb = 0; nb < IN_NB; nb++) flush(aw0[ob][nb], 0, IN, ob, nb, HID, IN);
-#pragma unroll
-            for (int l = 0; l < NL - 1; l++)
-#pragma unroll
-                for (int ob = 0; ob < 2; ob++)
-#pragma unroll
-                    for (int nb = 0; nb < 2; nb++)
-                        flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID, HID);
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NL - 1) * HID * HID, HID, 0, nb, OUT, HID);
-        }
-        __syncthreads();
-    }
-    float* dst = partial + (size_t)blockIdx.x * NW;
-    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
-}
-
-template <typename E>
-__global__ void __launch_bounds__(256) k_ffmlp_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                                        E* __restrict__ gw) {
-    __shared__ float acc[4][64];
-    const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t part = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (i < NW)
-        for (uint32_t b = part; b < nblocks; b += 4) s += partial[(size_t)b * NW + i];
-    acc[part][threadIdx.x & 63] = s;
-    __syncthreads();
-    // grad_weights arrives zero-filled; accumulate like the reference's beta = 0/1 GEMMs
-    if (part == 0 && i < NW)
-        gw[i] = (E)((float)gw[i] + ((acc[0][threadIdx.x] + acc[1][threadIdx.x]) + (acc[2][threadIdx.x] + acc[3][threadIdx.x])));
-}
-
 // ------------------------------------------------------------------ host dispatch
 uint32_t persistent_grid(uint32_t B) {
     const uint32_t tiles = B / 32;
     const uint32_t blocks = div_up(tiles, 4);
+    return blocks < 512u ? blocks : 512u;
+}
+uint32_t persistent_grid_fwd(uint32_t B) {      // forward walks 64-sample pairs
+    const uint32_t blocks = div_up(B / 64, 4);
     return blocks < 512u ? blocks : 512u;
 }
 
@@ -551,24 +276,10 @@ int check_shape(uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hi
     return 0;
 }
 
-#define FFMLP_DISPATCH(E, CALL)                                                     \
-    switch (input_dim * 10 + num_layers) {                                          \
-        case 162: { constexpr int KB = 1, NL = 2; CALL; } break;                    \
-        case 163: { constexpr int KB = 1, NL = 3; CALL; } break;                    \
-        case 164: { constexpr int KB = 1, NL = 4; CALL; } break;                    \
-        case 322: { constexpr int KB = 2, NL = 2; CALL; } break;                    \
-        case 323: { constexpr int KB = 2, NL = 3; CALL; } break;                    \
-        case 324: { constexpr int KB = 2, NL = 4; CALL; } break;                    \
-        case 642: { constexpr int KB = 4, NL = 2; CALL; } break;                    \
-        case 643: { constexpr int KB = 4, NL = 3; CALL; } break;                    \
-        case 644: { constexpr int KB = 4, NL = 4; CALL; } break;                    \
-        default: ENERF_BADARG("ffmlp: unsupported input_dim/num_layers");           \
-    }
-
 template <typename E, bool TRAIN>
 int run_fwd(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t num_layers, uint32_t act,
             uint32_t out_act, void* buffer, void* outputs, hipStream_t s) {
-    const uint32_t grid = persistent_grid(B);
+    const uint32_t grid = persistent_grid_fwd(B);
     FFMLP_DISPATCH(E, (k_ffmlp_fwd<E, KB, NL, TRAIN><<<grid, 256, 0, s>>>((const E*)inputs, (const E*)weights, (E*)buffer,
                                                                             (E*)outputs, B, act, out_act)));
     return 0;
@@ -577,19 +288,12 @@ int run_fwd(const void* inputs, const void* weights, uint32_t B, uint32_t input_
 template <typename E>
 int run_bwd(const void* grad, const void* inputs, const void* weights, const void* fb, uint32_t B, uint32_t input_dim,
             uint32_t num_layers, uint32_t act, bool calc_grad_inputs, void* bb, void* grad_inputs, void* grad_weights,
-            hipStream_t s) {
+            int dtype, hipStream_t s) {
     const uint32_t grid = persistent_grid(B);
-    const uint32_t NWn = HID * (input_dim + HID * (num_layers - 1) + OUT);
-    const uint32_t wgrid = grid < 256u ? grid : 256u;
-    float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NWn);
-    if (!partial) return ENERF_E_NOMEM;
     FFMLP_DISPATCH(E, (k_ffmlp_bwd_act<E, KB, NL><<<grid, 256, 0, s>>>((const E*)grad, (const E*)weights, (const E*)fb,
                                                                         (E*)bb, calc_grad_inputs ? (E*)grad_inputs : nullptr,
                                                                         B, act)));
-    FFMLP_DISPATCH(E, (k_ffmlp_bwd_w<E, KB, NL><<<wgrid, 256, 0, s>>>((const E*)grad, (const E*)inputs, (const E*)fb,
-                                                                       (const E*)bb, partial, B)));
-    k_ffmlp_reduce_w<E><<<div_up(NWn, 64), 256, 0, s>>>(partial, wgrid, NWn, (E*)grad_weights);
-    return 0;
+    return ffmlp_wgrad_launch(dtype, grad, inputs, fb, bb, B, input_dim, num_layers, grad_weights, s);
 }
 
 }  // namespace
@@ -641,8 +345,8 @@ int enerf_ffmlp_backward(const void* grad, const void* inputs, const void* weigh
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_BWD, s);
     rc = dtype == ENERF_BF16
-             ? run_bwd<__bf16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, calc_grad_inputs != 0, backward_buffer, grad_inputs, grad_weights, s)
-             : run_bwd<_Float16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, calc_grad_inputs != 0, backward_buffer, grad_inputs, grad_weights, s);
+             ? run_bwd<__bf16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, calc_grad_inputs != 0, backward_buffer, grad_inputs, grad_weights, dtype, s)
+             : run_bwd<_Float16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, calc_grad_inputs != 0, backward_buffer, grad_inputs, grad_weights, dtype, s);
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("ffmlp_backward");
     return 0;

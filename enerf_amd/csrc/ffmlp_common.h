@@ -1,0 +1,194 @@
+// ffmlp_common.h -- types, MFMA wrappers, fragment builders and tile I/O shared by ffmlp.hip (forward + dgrad, MFMA
+// accumulators in arch VGPRs) and ffmlp_wgrad.hip (weight gradients, accumulators in AGPRs).  See ffmlp.hip for the
+// design notes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace enerf_ffmlp {
+using namespace enerf;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HID = 64;
+constexpr int OUT = 16;
+constexpr int MAX_NL = 4;
+
+
+template <typename E> struct V;
+template <> struct V<__bf16> { using x8 = bf16x8; using x4 = bf16x4; };
+template <> struct V<_Float16> { using x8 = f16x8; using x4 = f16x4; };
+
+__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+#define K_ACT 10.0f
+__device__ __forceinline__ float act_fwd(float x, uint32_t a) {   // ffmlp/src/utils.h:424-470
+    switch (a) {
+        case 0: return x > 0 ? x : 0.0f;
+        case 1: return __expf(x);
+        case 2: return __sinf(x);
+        case 3: return 1.0f / (1.0f + __expf(-x));
+        case 4: { const float v = x * K_ACT; return 0.5f * (v + sqrtf(v * v + 4)) / K_ACT; }
+        case 5: return __logf(__expf(x * K_ACT) + 1.0f) / K_ACT;
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_bwd(float g, float fwd, uint32_t a) {   // utils.h:534-582 (post-activation input)
+    switch (a) {
+        case 0: return fwd > 0 ? g : 0.0f;
+        case 1: return g * fwd;
+        case 3: return g * (fwd * (1.0f - fwd));
+        case 4: { const float y = fwd * K_ACT; return g * (y * y / (y * y + 1)); }
+        case 5: return g * (1.0f - __expf(-fwd * K_ACT));
+        default: return g;
+    }
+}
+
+// Whole-tile activation.  relu / none (the only ones the NeRF nets use) are inline; every other activation goes through
+// a NOINLINE function: left inline, hipcc if-converts the uniform switch into straight-line code that evaluates every
+// transcendental variant for every element and selects (seen in the ISA: 384 v_exp + 128 v_sin + 768 v_div_scale per
+// tile), which made the kernel 3x slower than its MFMA + memory time.
+// (by value in / out: a by-reference accumulator would be forced into scratch memory by the call ABI)
+static __device__ __attribute__((noinline)) f32x16 apply_act_generic(f32x16 t, uint32_t a) {
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 16; q++) r[q] = act_fwd(t[q], a);
+    return r;
+}
+static __device__ __attribute__((noinline)) f32x16 apply_act_bwd_generic(f32x16 g, f32x16 fw, uint32_t a) {
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 16; q++) r[q] = act_bwd(g[q], fw[q], a);
+    return r;
+}
+__device__ __forceinline__ void apply_act(f32x16& t, uint32_t a) {
+    if (a == 0) {
+        // relu as a signed-integer max on the bit pattern: one v_max_i32 per element, no fmaxf canonicalisation pass
+        // (negative floats, -0.0 and negative NaNs are negative integers -> +0.0; everything else is unchanged)
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = __int_as_float(max(__float_as_int(t[q]), 0));
+    } else if (a != 6) {
+        t = apply_act_generic(t, a);
+    }
+}
+__device__ __forceinline__ void apply_act_bwd(f32x16& g, const float (&fw)[16], uint32_t a) {
+    if (a == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) g[q] = fw[q] > 0.0f ? g[q] : 0.0f;
+    } else if (a != 6) {
+        f32x16 f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) f[q] = fw[q];
+        g = apply_act_bwd_generic(g, f, a);
+    }
+}
+
+// ---- weight-fragment builders (from the LDS copy of the blob) -------------------------------------------------
+// natural K order: element e of K-block kb, lane half h  <->  column 16*kb + 8*h + e          (operand fed from memory)
+// permuted K order: K-block (ib,kbb), element e           <->  column 32*ib + 16*kbb + 4*h + (e&3) + 8*(e>>2)
+//                                                              (operand fed from the previous layer's D tile)
+template <typename E>
+__device__ __forceinline__ typename V<E>::x8 frag_row_nat(const E* m, int ld, int row, int kb, int h) {
+    typename V<E>::x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = m[row * ld + 16 * kb + 8 * h + e];
+    return f;
+}
+template <typename E>
+__device__ __forceinline__ typename V<E>::x8 frag_row_perm(const E* m, int ld, int row, int blk, int h) {
+    typename V<E>::x8 f;   // blk = 2*ib + kbb
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = m[row * ld + 16 * blk + 4 * h + (e & 3) + 8 * (e >> 2)];
+    return f;
+}
+// transposed: A[i = column `col` of m][k = row index]; natural / permuted order over the ROW index
+template <typename E>
+__device__ __forceinline__ typename V<E>::x8 frag_col_nat(const E* m, int ld, int col, int kb, int h, int nrows) {
+    typename V<E>::x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int r = 16 * kb + 8 * h + e;
+        f[e] = r < nrows ? m[r * ld + col] : (E)0.0f;
+    }
+    return f;
+}
+template <typename E>
+__device__ __forceinline__ typename V<E>::x8 frag_col_perm(const E* m, int ld, int col, int blk, int h) {
+    typename V<E>::x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = m[(16 * blk + 4 * h + (e & 3) + 8 * (e >> 2)) * ld + col];
+    return f;
+}
+
+// D tile (fp32, lane = sample) -> two permuted-order K-blocks of 16-bit operands, with an elementwise map
+template <typename E>
+__device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::x8 (&out)[2]) {
+#pragma unroll
+    for (int kbb = 0; kbb < 2; kbb++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) out[kbb][e] = (E)acc[8 * kbb + e];
+}
+
+// store / load one [32 samples][32 neurons] D-tile-shaped block of a row-major [B,64] 16-bit buffer:
+// lane (j, h) owns neurons 32*ib + 8*g + 4*h + r  (g = 0..3, r = 0..3)  <->  4 consecutive elements per g
+template <typename E>
+__device__ __forceinline__ void store_tile(E* rowptr /* row of sample j */, int ib, int h,
+                                           const typename V<E>::x8 (&fr)[2]) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        typename V<E>::x4 q;
+#pragma unroll
+        for (int r = 0; r < 4; r++) q[r] = fr[g >> 1][(g & 1) * 4 + r];
+        *reinterpret_cast<typename V<E>::x4*>(rowptr + 32 * ib + 8 * g + 4 * h) = q;
+    }
+}
+template <typename E>
+__device__ __forceinline__ void load_tile_f32(const E* rowptr, int ib, int h, float (&v)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const typename V<E>::x4 q = *reinterpret_cast<const typename V<E>::x4*>(rowptr + 32 * ib + 8 * g + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[4 * g + r] = (float)q[r];
+    }
+}
+
+template <typename E>
+__device__ __forceinline__ void stage_weights(E* wl, const E* __restrict__ w, uint32_t n) {
+    // n is a multiple of 8 elements (hidden = 64, input_dim % 16 == 0)
+    const uint4* src = reinterpret_cast<const uint4*>(w);
+    uint4* dst = reinterpret_cast<uint4*>(wl);
+    for (uint32_t i = threadIdx.x; i < n / 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+#define FFMLP_DISPATCH(E, CALL)                                                     \
+    switch (input_dim * 10 + num_layers) {                                          \
+        case 162: { constexpr int KB = 1, NL = 2; CALL; } break;                    \
+        case 163: { constexpr int KB = 1, NL = 3; CALL; } break;                    \
+        case 164: { constexpr int KB = 1, NL = 4; CALL; } break;                    \
+        case 322: { constexpr int KB = 2, NL = 2; CALL; } break;                    \
+        case 323: { constexpr int KB = 2, NL = 3; CALL; } break;                    \
+        case 324: { constexpr int KB = 2, NL = 4; CALL; } break;                    \
+        case 642: { constexpr int KB = 4, NL = 2; CALL; } break;                    \
+        case 643: { constexpr int KB = 4, NL = 3; CALL; } break;                    \
+        case 644: { constexpr int KB = 4, NL = 4; CALL; } break;                    \
+        default: ENERF_BADARG("ffmlp: unsupported input_dim/num_layers");           \
+    }
+
+
+// weight-gradient pass (ffmlp_wgrad.hip): dW from dY / X / forward_buffer / backward_buffer, accumulated into the
+// caller's zero-filled 16-bit grad_weights
+int ffmlp_wgrad_launch(int dtype, const void* dY, const void* X, const void* fb, const void* bb, uint32_t B,
+                       uint32_t input_dim, uint32_t num_layers, void* grad_weights, hipStream_t s);
+
+}  // namespace enerf_ffmlp
