@@ -40,7 +40,11 @@ def parse():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--bound", type=int, default=3)
     ap.add_argument("--mode", choices=["rgb", "events"], default="rgb")
-    ap.add_argument("--render-frames", type=int, default=1, help="full 640x480 inference frames timed after training")
+    ap.add_argument("--render-frames", type=int, default=2, help="full 640x480 inference frames timed after training")
+    ap.add_argument("--render-batch-mult", type=int, default=8,
+                    help="samples per inference iteration relative to the reference schedule (image is identical)")
+    ap.add_argument("--net", choices=["linear", "ff"], default="linear",
+                    help="linear = nerf/network.py (BASELINE configs[1-3]); ff = nerf/network_ff.py FFMLP bf16 (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
@@ -148,12 +152,16 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    from enerf_amd.network import NeRFNetwork
+    if args.net == "ff":
+        from enerf_amd.network_ff import NeRFNetwork
+    else:
+        from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
     from enerf_amd.events import EventOptions
 
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
+    model.infer_batch_mult = args.render_batch_mult
     harness = TrainHarness(model, occupancy="synthetic", world=world)
     parallel.broadcast_state(model)
     batches = build_batches(8, args.rays, device, rank, args.bound)
@@ -236,6 +244,7 @@ def main():
             torch.cuda.synchronize()
             tr = time.perf_counter() - tr0
         render = {"msamples_per_sec": rb.STATS["infer_samples"] / tr / 1e6, "frames": args.render_frames,
+                  "batch_mult": args.render_batch_mult, "net": args.net,
                   "rays_per_frame": scene.H * scene.W, "ms_per_frame": tr / args.render_frames * 1e3,
                   "march_iterations_per_frame": rb.STATS["infer_calls"] / args.render_frames}
         model.train()
@@ -259,7 +268,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: shakeCarpet1-shaped train step, bound={args.bound}, hashgrid "
-                                   f"L16 F2 T2^19 + HIP march_rays_train, nn.Linear MLPs fp32, {args.rays} rays/GPU, "
+                                   f"L16 F2 T2^19 + HIP march_rays_train, {'nn.Linear MLPs fp32' if args.net == 'linear' else 'FFMLP bf16'}, {args.rays} rays/GPU, "
                                    f"mode={args.mode}",
                        "rays_per_gpu": args.rays, "global_rays": world * args.rays,
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single"},

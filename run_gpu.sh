@@ -1,6 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_ffmlp.py -m gpu -x -q > gpurun_out/pytest_ffmlp.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_ffmlp.log
-timeout 600 python tools/bench_ffmlp.py > gpurun_out/ffmlp.log 2>&1
-tail -3 gpurun_out/pytest_ffmlp.log; grep -v amdgpu gpurun_out/ffmlp.log
+timeout 1500 python -m pytest tests/test_gpu_training.py -m gpu -x -q -s > gpurun_out/pytest_train.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_train.log
+tail -15 gpurun_out/pytest_train.log

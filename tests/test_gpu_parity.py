@@ -443,3 +443,21 @@ def test_render_end_to_end_vs_cpu_oracle(scenes, monkeypatch, train):
             out = model.render(ro, rd, staged=False, bg_color=None, perturb=False)
         assert_close(out["image"], ref["image"], rtol=1e-4, atol=2e-5)
         assert_close(out["depth"], ref["depth"], rtol=1e-4, atol=2e-5)
+
+
+def test_inference_batch_mult_gives_identical_image(scenes):
+    """The K-times-larger inference batches (enerf_amd extension) only change the chunking: image bit-identical."""
+    from enerf_amd.network import NeRFNetwork
+    bound = 2
+    grid, bits, C = scenes[bound]
+    torch.manual_seed(1)
+    m = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3).to(DEV).eval()
+    m.encoder.embeddings.data.uniform_(-1, 1)
+    m.density_bitfield.copy_(torch.from_numpy(bits))
+    o, d, _ = _rays(5000, 77, bound)
+    ro, rd = cu(o)[None], cu(d)[None]
+    with torch.no_grad():
+        a = m.render(ro, rd, staged=False, bg_color=None, perturb=False)
+        m.infer_batch_mult = 8
+        b = m.render(ro, rd, staged=False, bg_color=None, perturb=False)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
