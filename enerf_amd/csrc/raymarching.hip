@@ -550,6 +550,26 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     (void)march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
 }
 
+// wave-per-ray variant (dt_gamma == 0): same lattice marcher as training; pays off once rays are few or n_step is
+// large, i.e. when the one-thread-per-ray loop is latency-bound
+__global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t n_step,
+                                                      const int32_t* __restrict__ rays_alive,
+                                                      const float* __restrict__ rays_t,
+                                                      const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                      float bound, uint32_t max_steps, uint32_t C, uint32_t H,
+                                                      const uint8_t* __restrict__ grid, const float* __restrict__ fars,
+                                                      float* xyzs, float* dirs, float* deltas, uint32_t perturb) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    float t = rays_t[n];
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, 0.0f, max_steps, C, H);
+    if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
+    const size_t base = (size_t)n * n_step;
+    (void)lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+}
+
 __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step,
                                                         const int32_t* __restrict__ rays_alive, float* rays_t,
                                                         const float* __restrict__ sigmas,
@@ -754,8 +774,15 @@ int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_aliv
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_INFER, s);
-    k_march_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
-                                                      dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    // Same samples either way (bit-identical).  One thread per ray wins while there are enough rays to fill the chip with
+    // short loops; one wavefront per ray wins when rays are few or each must produce many samples.
+    if (dt_gamma == 0.0f && (n_alive <= 65536u || n_step >= 16u))
+        k_march_rays_w<<<div_up(n_alive, 4), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                          max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+    else
+        k_march_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+                                                          dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
+                                                          perturb);
     ENERF_LAUNCH_CHECK("march_rays");
     return 0;
 }

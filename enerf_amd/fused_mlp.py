@@ -20,28 +20,33 @@ def supported(x, weights):
         return False
     if weights[0].shape[0] != 64 or weights[0].shape[1] > 32 or weights[-1].shape[0] > 32:
         return False
+    if x.shape[1] != weights[0].shape[1] and x.shape[1] != 32:
+        return False
     return all(tuple(w.shape) == (64, 64) for w in weights[1:-1]) and weights[-1].shape[1] == 64
 
 
 class _FusedMLP32(Function):
     @staticmethod
     def forward(ctx, x, activation, *weights):
-        B0, in_dim = x.shape
+        B0 = x.shape[0]
+        in_dim = weights[0].shape[1]          # x may already be padded to 32 columns (extra columns are ignored)
         num_hidden = len(weights) - 1
         out_dim = weights[-1].shape[0]
         dev = x.device
         # pad the batch to a multiple of 32 and the input width to 32 (zero columns / zero weight columns)
         B = (B0 + 31) // 32 * 32
-        if B != B0 or in_dim != 32 or not x.is_contiguous():
+        if B != B0 or x.shape[1] != 32 or not x.is_contiguous():
             xp = torch.zeros(B, 32, dtype=torch.float32, device=dev)
-            xp[:B0, :in_dim] = x
+            xp[:B0, :in_dim] = x[:, :in_dim]
         else:
             xp = x
         w0 = weights[0]
         if in_dim != 32:
             w0 = torch.nn.functional.pad(w0, (0, 32 - in_dim))
         blob = torch.cat([w0.reshape(-1)] + [w.reshape(-1) for w in weights[1:]]).contiguous()
-        train = any(t.requires_grad for t in (x,) + tuple(weights))
+        # hidden activations are only written out when a backward pass can follow (under no_grad every
+        # needs_input_grad entry is False)
+        train = any(ctx.needs_input_grad)
         fb = torch.empty(num_hidden, B, 64, dtype=torch.float32, device=dev) if train else None
         y = torch.empty(B, out_dim, dtype=torch.float32, device=dev)
         L.check(L.lib().enerf_mlp32_forward(xp.data_ptr(), blob.data_ptr(), B, 32, out_dim, num_hidden, activation, 6,
@@ -50,13 +55,13 @@ class _FusedMLP32(Function):
         if train:
             ctx.save_for_backward(xp, blob, fb)
             ctx.meta = (B0, in_dim, out_dim, num_hidden, activation, [tuple(w.shape) for w in weights],
-                        x.requires_grad)
+                        ctx.needs_input_grad[0], x.shape[1])
         return y[:B0] if B != B0 else y
 
     @staticmethod
     def backward(ctx, gy):
         xp, blob, fb = ctx.saved_tensors
-        B0, in_dim, out_dim, num_hidden, activation, shapes, need_dx = ctx.meta
+        B0, in_dim, out_dim, num_hidden, activation, shapes, need_dx, x_cols = ctx.meta
         B = xp.shape[0]
         dev = xp.device
         if B != B0:
@@ -81,7 +86,7 @@ class _FusedMLP32(Function):
                 gw = dw[off:off + n].view(shp)
                 off += n
             grads.append(gw)
-        gx = dx[:B0, :in_dim] if need_dx else None
+        gx = dx[:B0, :x_cols] if need_dx else None      # columns >= in_dim carry zero weight -> zero gradient
         return (gx, None) + tuple(grads)
 
 

@@ -61,6 +61,15 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self.bg_net = None
 
+    def _color_input(self, d, geo_feat):
+        """[dir encoding | geo_feat] (network.py:123); on the fused CUDA path the 31 columns are written straight into a
+        32-wide buffer (one zero column) so the fused MLP needs no extra padding pass."""
+        e = self._dir_features(d)
+        if e.dim() == 2 and e.shape[1] + geo_feat.shape[1] == 31 and e.dtype == geo_feat.dtype \
+                and fused_mlp.supported(e.new_empty((0, 32)), [layer.weight for layer in self.color_net]):
+            return torch.cat([e, geo_feat, torch.zeros_like(geo_feat[:, :1])], dim=-1)
+        return torch.cat([e, geo_feat], dim=-1)
+
     def _dir_features(self, d):
         e = self.encoder_dir(d)
         return e * 0 if self.disable_view_direction else e * 1
@@ -70,7 +79,7 @@ class NeRFNetwork(NeRFRenderer):
         h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
-        h = _run_mlp(self.color_net, torch.cat([self._dir_features(d), geo_feat], dim=-1))
+        h = _run_mlp(self.color_net, self._color_input(d, geo_feat))
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
@@ -88,7 +97,7 @@ class NeRFNetwork(NeRFRenderer):
             if not mask.any():
                 return rgbs
             x, d, geo_feat = x[mask], d[mask], geo_feat[mask]
-        h = torch.sigmoid(_run_mlp(self.color_net, torch.cat([self._dir_features(d), geo_feat], dim=-1)))
+        h = torch.sigmoid(_run_mlp(self.color_net, self._color_input(d, geo_feat)))
         if mask is not None:
             rgbs[mask] = h.to(rgbs.dtype)
             return rgbs
