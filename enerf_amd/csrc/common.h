@@ -47,7 +47,7 @@ struct ProfScope {
 void* workspace(int slot, size_t bytes);
 enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_SLOTS = 4 };
 
-inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // ---- wave-level primitives (wave64) ----------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

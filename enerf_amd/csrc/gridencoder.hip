@@ -3,13 +3,21 @@
 // Replaces gridencoder/src/gridencoder.cu of the reference (grid_encode_forward / grid_encode_backward).
 //
 // MI355X mapping
-//  * One thread per (point, level), 256 points per workgroup.  The flat workgroup id is decoded so that the
-//    workgroups resident on XCD k (observed placement: id % 8) all work on level k, then on level k+8: each
-//    XCD's private 4 MiB L2 then holds one level's table (hashed levels are exactly 4 MiB of fp32 pairs) while
-//    the 256 MiB Infinity Cache holds the whole 52 MB table.  A different placement changes speed only.
+//  * One thread per (point, level), 256 points per workgroup.  The forward kernel decodes the flat workgroup id so
+//    that each pair of XCDs (observed placement: id % 8) owns a quarter of the levels -- dealt in snake order from the
+//    finest level down, so every pair gets the same mix of expensive fine and cheap coarse levels -- and walks them
+//    one at a time, the two XCDs splitting each level's points.  An XCD's private 4 MiB L2 then holds one level's
+//    table at a time (hashed levels are exactly 4 MiB of fp32 pairs) while the 256 MiB Infinity Cache holds the
+//    whole 52 MB table.  A different placement changes speed only.
+//  * The gather is bound by the number of distinct cache lines a wavefront touches, not by bytes: the two corners
+//    that differ in x sit in adjacent rows on every dense level and, on hashed levels, whenever x is even (the x
+//    prime is 1, so the row index just flips bit 0) -- those lanes fetch both with one double-width load.
 //  * Per-level scale / resolution are computed on the host (glibc exp2f, ceil) and passed by value, so the
 //    uint32 index arithmetic is identical to the CPU oracle's; the kernel never calls exp2f.
-//  * A corner's C features are fetched with one C*sizeof(T)-byte load (8 B for the fp32 C=2 configuration).
+//  * A corner's C features are fetched with one C*sizeof(T)-byte load (8 B for the fp32 C=2 configuration),
+//    an adjacent corner pair with one 2*C*sizeof(T)-byte load.
+//  * Output layouts: [L,B,C] (the reference's), [B,L*C] (what its Python wrapper permutes to) and [L,Bp,C] with
+//    Bp = B rounded up to 32 and zeroed pad rows, which the fused MLP (mlp32.hip) consumes directly.
 //  * Backward scatters with hardware float atomics (global_atomic_add_f32, -munsafe-fp-atomics) or packed
 //    half2 atomics for fp16 tables.
 //
@@ -37,6 +45,12 @@ uint32_t g_level_mask = 0xffffffffu;
 template <typename T, int C>
 struct alignas((sizeof(T) * C) > 16 ? 16 : (sizeof(T) * C)) Feat {
     T v[C];
+};
+
+// two adjacent rows; only the row alignment is guaranteed (wide loads tolerate it on gfx950)
+template <typename T, int C>
+struct __attribute__((packed, aligned((sizeof(T) * C) > 16 ? 16 : (sizeof(T) * C)))) FeatPair {
+    Feat<T, C> a, b;
 };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
@@ -73,7 +87,23 @@ __device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, uint32_t hashmap
     return index % hashmap_size;
 }
 
-// XCD-aware decode of the flat workgroup id -> (level, chunk of points)
+// forward: XCD-pair groups.  Group g = XCDs (2g, 2g+1); round r deals levels L-1-4r .. L-4-4r to the groups in
+// alternating direction; the two members take alternate chunks of every level.
+constexpr uint32_t kGroupXcds = 2, kGroups = 8 / kGroupXcds;
+__device__ __forceinline__ bool decode_block_fwd(uint32_t nchunks, uint32_t L, uint32_t& level, uint32_t& chunk) {
+    const uint32_t bid = blockIdx.x;
+    const uint32_t xcd = bid & 7u, j = bid >> 3;
+    const uint32_t group = xcd / kGroupXcds, member = xcd % kGroupXcds;
+    const uint32_t per = div_up(nchunks, kGroupXcds);
+    const uint32_t round = j / per;
+    chunk = (j % per) * kGroupXcds + member;
+    const uint32_t dealt = round * kGroups + ((round & 1u) ? (kGroups - 1 - group) : group);
+    level = L - 1 - dealt;
+    return dealt < L && chunk < nchunks;
+}
+inline uint32_t fwd_blocks(uint32_t nchunks, uint32_t L) { return 8u * div_up(nchunks, kGroupXcds) * div_up(L, kGroups); }
+
+// backward (atomic-rate bound, placement irrelevant): XCD k takes level k, then k+8
 __device__ __forceinline__ bool decode_block(uint32_t nchunks, uint32_t L, uint32_t& level, uint32_t& chunk) {
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u;
@@ -93,10 +123,19 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
                                                            T* __restrict__ dy_dx, uint32_t gridtype, int out_layout,
                                                            uint32_t nchunks) {
     uint32_t level, chunk;
-    if (!decode_block(nchunks, L, level, chunk)) return;
+    if (!decode_block_fwd(nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
     const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
-    if (b >= B) return;
+    const uint32_t Bp = (B + 31u) & ~31u;
+    if (b >= B) {
+        if (out_layout == 2 && b < Bp) {     // zeroed pad rows of the [L,Bp,C] layout
+            Feat<T, C> z;
+#pragma unroll
+            for (int c = 0; c < C; c++) z.v[c] = from_f<T>(0.0f);
+            reinterpret_cast<Feat<T, C>*>(outputs)[(size_t)level * Bp + b] = z;
+        }
+        return;
+    }
 
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -112,7 +151,8 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
         oob |= (in[d] < 0 || in[d] > 1);
     }
     Feat<T, C>* out = reinterpret_cast<Feat<T, C>*>(outputs) +
-                      (out_layout == 0 ? (size_t)level * B + b : (size_t)b * L + level);
+                      (out_layout == 0 ? (size_t)level * B + b
+                                       : out_layout == 1 ? (size_t)b * L + level : (size_t)level * Bp + b);
     T* jac = calc_grad_inputs ? dy_dx + ((size_t)b * L + level) * D * C : nullptr;
     if (oob) {
         Feat<T, C> z;
@@ -136,25 +176,61 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
         pos[d] -= (float)pos_grid[d];
     }
 
-    // issue all 2^D gathers before using any of them
+    // issue all gathers before using any of them
     Feat<T, C> f[1 << D];
     float w[1 << D];
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float wi = 1;
-        uint32_t pgl[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            if ((idx & (1 << d)) == 0) {
-                wi *= 1 - pos[d];
-                pgl[d] = pos_grid[d];
-            } else {
-                wi *= pos[d];
-                pgl[d] = pos_grid[d] + 1;
+        for (int d = 0; d < D; d++) wi *= (idx & (1 << d)) ? pos[d] : 1 - pos[d];
+        w[idx] = wi;
+    }
+    if constexpr (2 * sizeof(Feat<T, C>) <= 16) {
+        // corners 2k (x) and 2k+1 (x+1): one double-width load when their rows are adjacent, else the aligned pair
+        // holding the first row plus a single-row load of the second (hashed levels, odd x).  hashmap_size is a
+        // multiple of 8, so the aligned pair never leaves the level.
+        constexpr int H = 1 << (D - 1);
+        uint32_t r0[H], r1[H];
+        bool adj[H];
+        FeatPair<T, C> q[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            uint32_t pgl[D];
+#pragma unroll
+            for (int d = 1; d < D; d++) pgl[d] = pos_grid[d] + ((k >> (d - 1)) & 1);
+            pgl[0] = pos_grid[0];
+            r0[k] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+            pgl[0] = pos_grid[0] + 1;
+            r1[k] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+            adj[k] = ((r0[k] ^ r1[k]) == 1u) || (r1[k] == r0[k] + 1u);
+            const uint32_t lo = r0[k] < r1[k] ? r0[k] : r1[k];
+            q[k] = *reinterpret_cast<const FeatPair<T, C>*>(rows + (adj[k] ? lo : (r0[k] & ~1u)));
+        }
+        Feat<T, C> e[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+#pragma unroll
+            for (int c = 0; c < C; c++) e[k].v[c] = from_f<T>(0.0f);
+            if (!adj[k]) e[k] = rows[r1[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const bool first = adj[k] ? (r0[k] < r1[k]) : ((r0[k] & 1u) == 0u);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                f[2 * k].v[c] = first ? q[k].a.v[c] : q[k].b.v[c];
+                f[2 * k + 1].v[c] = adj[k] ? (first ? q[k].b.v[c] : q[k].a.v[c]) : e[k].v[c];
             }
         }
-        w[idx] = wi;
-        f[idx] = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+    } else {
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            uint32_t pgl[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1);
+            f[idx] = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+        }
     }
     float res[C];
 #pragma unroll
@@ -276,8 +352,9 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
     }
     float g[C];
     if (valid) {
-        const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(grad)[grad_layout == 0 ? (size_t)level * B + b
-                                                                                         : (size_t)b * L + level];
+        const uint32_t Bp = (B + 31u) & ~31u;
+        const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(
+            grad)[grad_layout == 0 ? (size_t)level * B + b : grad_layout == 1 ? (size_t)b * L + level : (size_t)level * Bp + b];
 #pragma unroll
         for (int c = 0; c < C; c++) g[c] = to_f(gv.v[c]);
     } else {
@@ -350,7 +427,9 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ gr
     const T* jac = dy_dx + (size_t)b * L * D * C;
     float result = 0;
     for (uint32_t l = 0; l < L; l++) {
-        const T* g = grad + (grad_layout == 0 ? ((size_t)l * B + b) * C : ((size_t)b * L + l) * C);
+        const T* g = grad + (grad_layout == 0 ? ((size_t)l * B + b) * C
+                                              : grad_layout == 1 ? ((size_t)b * L + l) * C
+                                                                 : ((size_t)l * ((B + 31u) & ~31u) + b) * C);
 #pragma unroll
         for (int c = 0; c < C; c++) result = fmaf(to_f(g[c]), to_f(jac[((size_t)l * D + d) * C + c]), result);
     }
@@ -372,8 +451,8 @@ int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H) {
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
                const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s) {
-    const uint32_t nchunks = div_up(B, kPtsPerBlock);
-    const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
+    const uint32_t nchunks = div_up(layout == 2 ? ((B + 31u) & ~31u) : B, kPtsPerBlock);
+    const uint32_t nblocks = fwd_blocks(nchunks, L);
 #define ENERF_GF(CC)                                                                                              \
     k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, \
                                                           gridtype, layout, nchunks)
@@ -429,6 +508,7 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
     LevelTab tab;
     if (fill_level_tab(tab, L, S, H)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
+    if (out_layout < 0 || out_layout > 2) ENERF_BADARG("GridEncoding: out_layout must be 0, 1 or 2, got %d", out_layout);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_FWD, s);
     int rc = 0;
@@ -456,6 +536,7 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
     LevelTab tab;
     if (fill_level_tab(tab, L, S, H)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
+    if (grad_layout < 0 || grad_layout > 2) ENERF_BADARG("GridEncoding: grad_layout must be 0, 1 or 2, got %d", grad_layout);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_BWD, s);
     int rc = 0;

@@ -11,6 +11,12 @@
 // B operand of the next layer *as is* (MFMA q of input block ib consumes accumulator register q); the weight-gradient
 // kernel reads its operands straight from the row-major [B,64] buffers (a wavefront reads two 128-byte row segments
 // per MFMA), no transposes anywhere.
+//
+// Batches are ragged: B is the number of valid samples, every scratch buffer (fb, bb) and the level-major input has
+// Bp = B rounded up to 32 rows, and samples >= B carry zeros through every kernel, so callers never pad or copy.
+// Input layouts (XL): 0 = row-major [B,32]; 1 = level-major [16,Bp,2], exactly what the grid encoder writes with
+// out_layout 2 (gridencoder.hip), so the encoding never has to be transposed into rows: a wavefront reads / writes
+// 256 contiguous bytes per level.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -57,21 +63,29 @@ __device__ __forceinline__ void load_tile(const float* rowptr, int ib, int h, f3
     }
 }
 
+// layer-0 contraction index handled by MFMA p of lane half h
+//   XL 0: pairs (p, 16 + p): lane half h reads the contiguous input columns 16h .. 16h+15
+//   XL 1: lane half h reads the float2 of level 2q + h (q = 0..7): MFMA 2q + c contracts columns 4q + c and 4q + 2 + c
+template <int XL>
+__device__ __forceinline__ int kmap(int p, int h) {
+    return XL == 0 ? 16 * h + p : 4 * (p >> 1) + 2 * h + (p & 1);
+}
+
 // ================================================================== forward
-template <int NH, bool TRAIN>
+template <int NH, bool TRAIN, int XL>
 __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                    float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
                                                    uint32_t out_dim, uint32_t act, uint32_t out_act) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     stage(wl, W, blob_size(NH, out_dim));
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    const uint32_t Bp = (B + 31u) & ~31u;
 
-    // layer 0 contraction pairs (p, 16 + p): lane half h reads the contiguous input columns 16h .. 16h+15
     float w0[2][16], wh[NH > 1 ? NH - 1 : 1][2][2][16], wo[2][16];
 #pragma unroll
     for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-        for (int p = 0; p < 16; p++) w0[ob][p] = wl[(32 * ob + j) * IN + 16 * h + p];
+        for (int p = 0; p < 16; p++) w0[ob][p] = wl[(32 * ob + j) * IN + kmap<XL>(p, h)];
 #pragma unroll
     for (int l = 0; l < NH - 1; l++)
 #pragma unroll
@@ -89,16 +103,30 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             for (int q = 0; q < 16; q++) wo[ib][q] = (uint32_t)j < out_dim ? wout[j * HID + 32 * ib + nrow(q, h)] : 0.0f;
     }
 
-    const uint32_t ntiles = B / 32;
+    const uint32_t ntiles = Bp / 32;
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s = (size_t)tile * 32 + j;
+        const bool valid = s < B;
         float x[16];
+        if (XL == 0) {
+            const size_t sc = valid ? s : (size_t)B - 1;
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const float4 t = *reinterpret_cast<const float4*>(X + s * IN + 16 * h + 4 * v);
-            x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
+            for (int v = 0; v < 4; v++) {
+                const float4 t = *reinterpret_cast<const float4*>(X + sc * IN + 16 * h + 4 * v);
+                x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float2 t = *reinterpret_cast<const float2*>(X + ((size_t)(2 * q + h) * Bp + s) * 2);
+                x[2 * q] = t.x; x[2 * q + 1] = t.y;
+            }
+        }
+        if (!valid) {
+#pragma unroll
+            for (int p = 0; p < 16; p++) x[p] = 0.0f;
         }
         f32x16 a[2];
 #pragma unroll
@@ -122,7 +150,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                     for (int q = 0; q < 16; q++) n[ob] = mma(wh[l - 1][ob][ib][q], a[ib][q], n[ob]);
 #pragma unroll
                 for (int q = 0; q < 16; q++) n[ob][q] = act_fwd(n[ob][q], act);
-                if (TRAIN) store_tile(fb + ((size_t)l * B + s) * HID, ob, h, n[ob]);
+                if (TRAIN) store_tile(fb + ((size_t)l * Bp + s) * HID, ob, h, n[ob]);
             }
             a[0] = n[0];
             a[1] = n[1];
@@ -132,17 +160,19 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
             for (int q = 0; q < 16; q++) o = mma(wo[ib][q], a[ib][q], o);
+        if (valid) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t r = (uint32_t)nrow(q, h);
-            if (r < out_dim) Y[s * out_dim + r] = act_fwd(o[q], out_act);
+            for (int q = 0; q < 16; q++) {
+                const uint32_t r = (uint32_t)nrow(q, h);
+                if (r < out_dim) Y[s * out_dim + r] = act_fwd(o[q], out_act);
+            }
         }
     }
 }
 
 // ================================================================== backward: activation gradients
 // KPO = number of contraction pairs covering the output dimension (out_dim <= 2 * KPO): pair p = (p, KPO + p)
-template <int NH, int KPO>
+template <int NH, int KPO, int XL>
 __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__ dY, const float* __restrict__ W,
                                                        const float* __restrict__ fb, float* __restrict__ bb,
                                                        float* __restrict__ dX, uint32_t B, uint32_t out_dim,
@@ -151,6 +181,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
     stage(wl, W, blob_size(NH, out_dim));
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
+    const uint32_t Bp = (B + 31u) & ~31u;
 
     float woT[2][KPO], whT[NH > 1 ? NH - 1 : 1][2][2][16], wiT[2][16];
 #pragma unroll
@@ -174,16 +205,17 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
 #pragma unroll
         for (int q = 0; q < 16; q++) wiT[ob][q] = wl[(32 * ob + nrow(q, h)) * IN + j];
 
-    const uint32_t ntiles = B / 32;
+    const uint32_t ntiles = Bp / 32;
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s = (size_t)tile * 32 + j;
+        const bool valid = s < B;
         float dy[KPO];
 #pragma unroll
         for (int p = 0; p < KPO; p++) {
             const uint32_t o = (uint32_t)(p + KPO * h);
-            dy[p] = o < out_dim ? dY[s * out_dim + o] : 0.0f;
+            dy[p] = (valid && o < out_dim) ? dY[s * out_dim + o] : 0.0f;
         }
         f32x16 g[2];
 #pragma unroll
@@ -192,7 +224,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
 #pragma unroll
             for (int p = 0; p < KPO; p++) g[ib] = mma(woT[ib][p], dy[p], g[ib]);
             f32x16 fw;
-            load_tile(fb + ((size_t)(NH - 1) * B + s) * HID, ib, h, fw);
+            load_tile(fb + ((size_t)(NH - 1) * Bp + s) * HID, ib, h, fw);
 #pragma unroll
             for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(g[ib][q], fw[q], act);
             store_tile(bb + s * HID, ib, h, g[ib]);
@@ -209,10 +241,10 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
 #pragma unroll
                     for (int q = 0; q < 16; q++) n[ib] = mma(whT[l - 1][ib][ob][q], g[ob][q], n[ib]);
                 f32x16 fw;
-                load_tile(fb + ((size_t)(l - 1) * B + s) * HID, ib, h, fw);
+                load_tile(fb + ((size_t)(l - 1) * Bp + s) * HID, ib, h, fw);
 #pragma unroll
                 for (int q = 0; q < 16; q++) n[ib][q] = act_bwd(n[ib][q], fw[q], act);
-                store_tile(bb + ((size_t)jj * B + s) * HID, ib, h, n[ib]);
+                store_tile(bb + ((size_t)jj * Bp + s) * HID, ib, h, n[ib]);
             }
             g[0] = n[0];
             g[1] = n[1];
@@ -223,10 +255,22 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
                 for (int q = 0; q < 16; q++) d = mma(wiT[ob][q], g[ob][q], d);
+            if (XL == 0) {
+                if (valid) {
 #pragma unroll
-            for (int gq = 0; gq < 4; gq++)
-                *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) =
-                    make_float4(d[4 * gq], d[4 * gq + 1], d[4 * gq + 2], d[4 * gq + 3]);
+                    for (int gq = 0; gq < 4; gq++)
+                        *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) =
+                            make_float4(d[4 * gq], d[4 * gq + 1], d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            } else {
+                // registers 4gq .. 4gq+3 hold input columns 8gq + 4h + {0,1,2,3} = levels 4gq + 2h and 4gq + 2h + 1
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const size_t lv = (size_t)(4 * gq + 2 * h);
+                    *reinterpret_cast<float2*>(dX + (lv * Bp + s) * 2) = make_float2(d[4 * gq], d[4 * gq + 1]);
+                    *reinterpret_cast<float2*>(dX + ((lv + 1) * Bp + s) * 2) = make_float2(d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            }
         }
     }
 }
@@ -234,7 +278,10 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
 // ================================================================== backward: weight gradients
 // dW[o][i] = sum_s dOut[s][o] * In[s][i]; MFMA p of a 32-sample tile contracts samples (2p, 2p+1): lane half h of the
 // A operand reads row 2p+h of dOut (32 consecutive floats per half-wave), likewise the B operand of In.
-template <int NH>
+// With a level-major X (XL 1) each wave first copies its tile's 16 x 256-byte level segments into LDS (row stride 66
+// floats: the 32 lanes of a half-wave then read 32 distinct banks) and takes the B operand from there.
+constexpr int XT_LD = 66;
+template <int NH, int XL>
 __global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ dY, const float* __restrict__ X,
                                                      const float* __restrict__ fb, const float* __restrict__ bb,
                                                      float* __restrict__ partial, uint32_t B, uint32_t out_dim) {
@@ -243,6 +290,8 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ d
     for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) red[i] = 0.0f;
     __syncthreads();
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    const uint32_t Bp = (B + 31u) & ~31u;
+    float* xt = red + ((NW + 3u) & ~3u) + (threadIdx.x >> 6) * (16 * XT_LD);
 
     f32x16 aw0[2], awh[NH > 1 ? NH - 1 : 1][2][2], awo[2];
 #pragma unroll
@@ -254,24 +303,38 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ d
 #pragma unroll
             for (int b = 0; b < 2; b++) awh[l][a][b] = (f32x16)(0.0f);
     }
-    const uint32_t ntiles = B / 32;
+    const uint32_t ntiles = Bp / 32;
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s0 = (size_t)tile * 32;
+        if (XL == 1) {
+            // tile-local flat index f = level * 64 + 2 * sample + c; a lane moves four 16-byte pieces
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int f = t * 256 + lane * 4, lv = f >> 6, off = f & 63;
+                const float4 v = *reinterpret_cast<const float4*>(X + ((size_t)lv * Bp + s0) * 2 + off);
+                *reinterpret_cast<float2*>(xt + lv * XT_LD + off) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(xt + lv * XT_LD + off + 2) = make_float2(v.z, v.w);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
 #pragma unroll 4
         for (int p = 0; p < 16; p++) {
-            const size_t s = s0 + 2 * p + h;
+            const size_t s = s0 + 2 * p + h;      // < Bp; rows >= B of fb / bb / level-major X hold zeros
             // input layer
-            const float xin = X[s * IN + j];
-            const float* g0 = bb + ((size_t)(NH - 1) * B + s) * HID;
+            float xin;
+            if (XL == 0) xin = s < B ? X[s * IN + j] : 0.0f;
+            else xin = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
+            const float* g0 = bb + ((size_t)(NH - 1) * Bp + s) * HID;
 #pragma unroll
             for (int ob = 0; ob < 2; ob++) aw0[ob] = mma(g0[32 * ob + j], xin, aw0[ob]);
             // hidden layers
 #pragma unroll
             for (int m = 1; m < NH; m++) {
-                const float* in = fb + ((size_t)(m - 1) * B + s) * HID;
-                const float* go = bb + ((size_t)(NH - 1 - m) * B + s) * HID;
+                const float* in = fb + ((size_t)(m - 1) * Bp + s) * HID;
+                const float* go = bb + ((size_t)(NH - 1 - m) * Bp + s) * HID;
                 const float i0 = in[j], i1 = in[32 + j], o0 = go[j], o1 = go[32 + j];
                 awh[m - 1][0][0] = mma(o0, i0, awh[m - 1][0][0]);
                 awh[m - 1][0][1] = mma(o0, i1, awh[m - 1][0][1]);
@@ -279,8 +342,8 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ d
                 awh[m - 1][1][1] = mma(o1, i1, awh[m - 1][1][1]);
             }
             // output layer
-            const float* in = fb + ((size_t)(NH - 1) * B + s) * HID;
-            const float dyv = (uint32_t)j < out_dim ? dY[s * out_dim + j] : 0.0f;
+            const float* in = fb + ((size_t)(NH - 1) * Bp + s) * HID;
+            const float dyv = ((uint32_t)j < out_dim && s < B) ? dY[s * out_dim + j] : 0.0f;
             awo[0] = mma(dyv, in[j], awo[0]);
             awo[1] = mma(dyv, in[32 + j], awo[1]);
         }
@@ -327,7 +390,7 @@ __global__ void __launch_bounds__(256) k_mlp32_reduce_w(const float* __restrict_
 }
 
 uint32_t pgrid(uint32_t B, uint32_t cap) {
-    const uint32_t blocks = div_up(B / 32, 4);
+    const uint32_t blocks = div_up(div_up(B, 32), 4);
     return blocks < cap ? blocks : cap;
 }
 
@@ -335,63 +398,80 @@ uint32_t pgrid(uint32_t B, uint32_t cap) {
 
 extern "C" {
 
-// Fused fp32 MLP: X [B,32] -> (64 x num_hidden, ReLU/none) -> Y [B,out_dim], out_dim <= 32, no bias.
-// weights: [W0 64x32 | Wh (num_hidden-1) x 64x64 | Wout out_dim x 64]; fb [num_hidden,B,64] or NULL (inference).
+// Fused fp32 MLP: X -> (64 x num_hidden, ReLU/none) -> Y [B,out_dim], out_dim <= 32, no bias.  B is ragged; with
+// Bp = B rounded up to 32: X is [B,32] row-major (x_layout 0) or [16,Bp,2] level-major (x_layout 1);
+// weights: [W0 64x32 | Wh (num_hidden-1) x 64x64 | Wout out_dim x 64]; fb [num_hidden,Bp,64] or NULL (inference).
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
-                        enerf_stream_t stream) {
+                        uint32_t x_layout, enerf_stream_t stream) {
     if (B == 0) return 0;
     if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32 (pad the input), got %u", in_dim);
     if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
-    if (B % 32 != 0) ENERF_BADARG("mlp32: batch must be a multiple of 32, got %u", B);
     if (activation != 0 && activation != 6) ENERF_BADARG("mlp32: activation must be relu (0) or none (6)");
+    if (x_layout > 1) ENERF_BADARG("mlp32: x_layout must be 0 (row-major) or 1 (level-major), got %u", x_layout);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_FWD, s);
     const uint32_t grid = pgrid(B, 1024);
     const size_t lds = sizeof(float) * (HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID);
-#define MLP32_FWD(NHV)                                                                                         \
-    do {                                                                                                       \
-        if (fb) k_mlp32_fwd<NHV, true><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation); \
-        else k_mlp32_fwd<NHV, false><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation);   \
+#define MLP32_FWD2(NHV, TR, XLV) \
+    k_mlp32_fwd<NHV, TR, XLV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation)
+#define MLP32_FWD(NHV)                                        \
+    do {                                                      \
+        if (fb) {                                             \
+            if (x_layout == 0) MLP32_FWD2(NHV, true, 0);      \
+            else MLP32_FWD2(NHV, true, 1);                    \
+        } else {                                              \
+            if (x_layout == 0) MLP32_FWD2(NHV, false, 0);     \
+            else MLP32_FWD2(NHV, false, 1);                   \
+        }                                                     \
     } while (0)
     if (num_hidden == 1) MLP32_FWD(1);
     else if (num_hidden == 2) MLP32_FWD(2);
     else MLP32_FWD(3);
 #undef MLP32_FWD
+#undef MLP32_FWD2
     ENERF_LAUNCH_CHECK("mlp32_forward");
     return 0;
 }
 
-// dY [B,out_dim], fb from the forward; bb [num_hidden,B,64] scratch (written); dX [B,32] or NULL;
-// dW (fp32 blob) is ACCUMULATED into (+=).
+// dY [B,out_dim], fb from the forward; bb [num_hidden,Bp,64] scratch (written); dX NULL, [B,32] (x_layout 0) or
+// [16,Bp,2] (x_layout 1, pad rows written as zeros); dW (fp32 blob) is ACCUMULATED into (+=).
 int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const float* fb, uint32_t B, uint32_t in_dim,
                          uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
-                         enerf_stream_t stream) {
+                         uint32_t x_layout, enerf_stream_t stream) {
     if (B == 0) return 0;
     if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32, got %u", in_dim);
     if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
-    if (B % 32 != 0) ENERF_BADARG("mlp32: batch must be a multiple of 32, got %u", B);
+    if (x_layout > 1) ENERF_BADARG("mlp32: x_layout must be 0 (row-major) or 1 (level-major), got %u", x_layout);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_BWD, s);
     const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
     const size_t lds = sizeof(float) * NW;
+    const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
     const uint32_t grid = pgrid(B, 1024), wgrid = pgrid(B, 256);
     float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NW);
     if (!partial) return ENERF_E_NOMEM;
-#define MLP32_BA(NHV, KPOV) k_mlp32_bwd_act<NHV, KPOV><<<grid, 256, lds, s>>>(dY, W, fb, bb, dX, B, out_dim, activation)
-#define MLP32_BWD(NHV)                                                                   \
-    do {                                                                                 \
-        if (out_dim <= 4) MLP32_BA(NHV, 2);                                              \
-        else if (out_dim <= 16) MLP32_BA(NHV, 8);                                        \
-        else MLP32_BA(NHV, 16);                                                          \
-        k_mlp32_bwd_w<NHV><<<wgrid, 256, lds, s>>>(dY, X, fb, bb, partial, B, out_dim);  \
+#define MLP32_BA(NHV, KPOV, XLV) \
+    k_mlp32_bwd_act<NHV, KPOV, XLV><<<grid, 256, lds, s>>>(dY, W, fb, bb, dX, B, out_dim, activation)
+#define MLP32_BWD2(NHV, XLV)                                                                      \
+    do {                                                                                          \
+        if (out_dim <= 4) MLP32_BA(NHV, 2, XLV);                                                  \
+        else if (out_dim <= 16) MLP32_BA(NHV, 8, XLV);                                            \
+        else MLP32_BA(NHV, 16, XLV);                                                              \
+        k_mlp32_bwd_w<NHV, XLV><<<wgrid, 256, lds_w, s>>>(dY, X, fb, bb, partial, B, out_dim);    \
+    } while (0)
+#define MLP32_BWD(NHV)                          \
+    do {                                        \
+        if (x_layout == 0) MLP32_BWD2(NHV, 0);  \
+        else MLP32_BWD2(NHV, 1);                \
     } while (0)
     if (num_hidden == 1) MLP32_BWD(1);
     else if (num_hidden == 2) MLP32_BWD(2);
     else MLP32_BWD(3);
 #undef MLP32_BWD
+#undef MLP32_BWD2
 #undef MLP32_BA
     k_mlp32_reduce_w<<<div_up(NW, 64), 256, 0, s>>>(partial, wgrid, NW, dW);
     ENERF_LAUNCH_CHECK("mlp32_backward");

@@ -27,8 +27,10 @@ def _supports_layout():
 class _grid_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0):
-        """inputs [B,D] fp32 in [0,1]; embeddings [rows,C]; offsets [L+1] int32 -> [B, L*C]   (grid.py:19-58)"""
+                gridtype=0, level_major=False):
+        """inputs [B,D] fp32 in [0,1]; embeddings [rows,C]; offsets [L+1] int32 -> [B, L*C]   (grid.py:19-58)
+        level_major=True (HIP backend only) returns the kernel-native [L, Bp, C] tensor instead, Bp = B rounded up
+        to 32 with zero pad rows -- the input format of fused_mlp(..., x_layout=1)."""
         inputs = inputs.float().contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -42,7 +44,11 @@ class _grid_encode(Function):
         embeddings = embeddings.contiguous()
 
         direct = _supports_layout()
-        if direct:
+        if level_major:
+            if not direct:
+                raise RuntimeError("level_major output needs a grid backend with layout support")
+            outputs = torch.empty(L, (B + 31) // 32 * 32, C, device=inputs.device, dtype=embeddings.dtype)
+        elif direct:
             outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
         else:
             outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
@@ -53,7 +59,7 @@ class _grid_encode(Function):
 
         if direct:
             _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs,
-                                         dy_dx, gridtype, layout=1)
+                                         dy_dx, gridtype, layout=2 if level_major else 1)
         else:
             _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs,
                                          dy_dx, gridtype)
@@ -63,6 +69,7 @@ class _grid_encode(Function):
         ctx.dims = (B, D, C, L, S, H, gridtype)
         ctx.calc_grad_inputs = calc_grad_inputs
         ctx.direct = direct
+        ctx.level_major = level_major
         return outputs
 
     @staticmethod
@@ -81,15 +88,16 @@ class _grid_encode(Function):
         if ctx.direct:
             grad = grad.contiguous()
             _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
-                                          calc_grad_inputs, dy_dx, grad_inputs, gridtype, layout=1)
+                                          calc_grad_inputs, dy_dx, grad_inputs, gridtype,
+                                          layout=2 if ctx.level_major else 1)
         else:
             grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
             _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
                                           calc_grad_inputs, dy_dx, grad_inputs, gridtype)
 
         if calc_grad_inputs:
-            return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None
-        return None, grad_embeddings, None, None, None, None, None
+            return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
+        return None, grad_embeddings, None, None, None, None, None, None
 
 
 grid_encode = _grid_encode.apply
@@ -155,3 +163,12 @@ class GridEncoder(nn.Module):
         outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                               inputs.requires_grad, self.gridtype_id)
         return outputs.view(prefix_shape + [self.output_dim])
+
+    def forward_level_major(self, inputs, bound=1):
+        """inputs [B, input_dim] in [-bound, bound] -> ([num_levels, Bp, level_dim], B): the same features as
+        forward(), in the kernel's own level-major order with the batch padded to a multiple of 32 (zero rows).
+        Feeds enerf_amd.fused_mlp.fused_mlp(..., x_layout=1, batch=B) without a transpose in either direction."""
+        inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, True)
+        return outputs, inputs.shape[0]

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from . import fused_mlp
 from .activation import trunc_exp
 from .encoding import get_encoder
+from .gridencoder import GridEncoder, _supports_layout
 from .renderer import NeRFRenderer
 
 
@@ -61,6 +62,17 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self.bg_net = None
 
+    def _sigma_mlp(self, x):
+        """sigma_net(encoder(x)).  On the fused CUDA path the 16 x 2 hash-grid features stay in the gather kernel's
+        level-major order all the way into the matrix-core MLP (and their gradient all the way back)."""
+        enc = self.encoder
+        weights = [layer.weight for layer in self.sigma_net]
+        if isinstance(enc, GridEncoder) and enc.num_levels == 16 and enc.level_dim == 2 and x.dim() == 2 \
+                and fused_mlp.supported_level_major(x.device, enc.embeddings.dtype, weights) and _supports_layout():
+            feats, n = enc.forward_level_major(x, bound=self.bound)
+            return fused_mlp.fused_mlp(feats, weights, "relu", x_layout=1, batch=n)
+        return _run_mlp(self.sigma_net, enc(x, bound=self.bound))
+
     def _color_input(self, d, geo_feat):
         """[dir encoding | geo_feat] (network.py:123); on the fused CUDA path the 31 columns are written straight into a
         32-wide buffer (one zero column) so the fused MLP needs no extra padding pass."""
@@ -76,14 +88,14 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d):
         """x [N,3] in [-bound,bound], d [N,3] -> sigma [N], color [N,out_dim_color]   (network.py:104-132)"""
-        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        h = self._sigma_mlp(x)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
         h = _run_mlp(self.color_net, self._color_input(d, geo_feat))
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
-        h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
+        h = self._sigma_mlp(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def background(self, x, d):

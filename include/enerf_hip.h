@@ -118,7 +118,8 @@ int enerf_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* ray
  * gridencoder/src/gridencoder.cu:416-471.  `inputs` is always fp32 (gridencoder.cu:437);
  * embeddings / outputs / dy_dx / grad share `dtype` (ENERF_F32 or ENERF_F16).
  * out_layout 0 = the reference's [L,B,C]; 1 = [B,L*C] written directly (saves the permute copy of
- * gridencoder/grid.py:52,70 -- used by enerf_amd's own wrapper, not by the reference's). */
+ * gridencoder/grid.py:52,70 -- used by enerf_amd's own wrapper, not by the reference's); 2 = [L,Bp,C] with
+ * Bp = B rounded up to a multiple of 32 and the pad rows zero-filled (the level-major input of enerf_mlp32_*). */
 
 /* grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype) */
 int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
@@ -177,16 +178,19 @@ int enerf_free_splitk(void);
 /* ------------------------------------------------------------------ extensions beyond the reference's native surface
  * (callers of the hot path: the nn.Linear MLPs of nerf/network.py:40-77 and the optimizer of main_nerf.py:211) */
 
-/* Fused fp32 MLP on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains): X [B,32] -> 64-wide hidden x num_hidden (1..3) ->
+/* Fused fp32 MLP on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains): X -> 64-wide hidden x num_hidden (1..3) ->
  * Y [B,out_dim <= 32], no bias; W = [W0 64x32 | Wh (num_hidden-1)x64x64 | Wout out_dim x 64], each W[out][in].
- * fb [num_hidden,B,64] receives the post-activation hidden states (NULL = inference).  B % 32 == 0. */
+ * B is ragged; Bp = B rounded up to a multiple of 32.  x_layout 0: X is [B,32] row-major; x_layout 1: X is the
+ * level-major [16,Bp,2] tensor enerf_grid_encode_forward writes with out_layout 2 (column k = 2*level + c).
+ * fb [num_hidden,Bp,64] receives the post-activation hidden states (NULL = inference). */
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
-                        enerf_stream_t stream);
-/* bb [num_hidden,B,64] is scratch (written); dX [B,32] or NULL; dW (fp32 blob) is accumulated into (+=). */
+                        uint32_t x_layout, enerf_stream_t stream);
+/* dY [B,out_dim]; bb [num_hidden,Bp,64] is scratch (written); dX NULL or laid out like X (x_layout 1: pad rows are
+ * written as zeros, ready for enerf_grid_encode_backward with grad_layout 2); dW (fp32 blob) is accumulated (+=). */
 int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const float* fb, uint32_t B, uint32_t in_dim,
                          uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
-                         enerf_stream_t stream);
+                         uint32_t x_layout, enerf_stream_t stream);
 
 /* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
  * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */

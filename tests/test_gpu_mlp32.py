@@ -45,6 +45,60 @@ def test_fused_mlp_forward_backward(dims, B):
     assert torch.equal(y2, y.detach())
 
 
+@pytest.mark.parametrize("B", [1, 31, 4097, 70000])
+def test_level_major_encoder_into_fused_mlp(B):
+    """Grid encoder (out_layout 2, [16,Bp,2]) -> fused MLP (x_layout 1) -> and back: same values / gradients as the
+    row-major route, bit for bit on the encoding and to fp32 round-off through the MLP."""
+    from enerf_amd.fused_mlp import fused_mlp, pad32
+    from enerf_amd.gridencoder import GridEncoder
+    torch.manual_seed(B)
+    enc = GridEncoder(desired_resolution=4096).to(DEV)
+    enc.embeddings.data.uniform_(-1, 1)
+    ws = [(torch.rand(o, i, device=DEV) * 2 - 1) * (3.0 / i) ** 0.5 for o, i in ((64, 32), (16, 64))]
+    x = (torch.rand(B, 3, device=DEV) * 2 - 1)
+    x[0] = 1.5                                   # one out-of-range point: zero features, zero gradient
+    g = torch.randn(B, 16, device=DEV)
+
+    feats_rows = enc(x, bound=1)
+    lm, n = enc.forward_level_major(x, bound=1)
+    assert n == B and tuple(lm.shape) == (16, pad32(B), 2)
+    assert torch.equal(lm[:, :B].permute(1, 0, 2).reshape(B, 32), feats_rows)
+    assert float(lm[:, B:].abs().sum()) == 0.0   # pad rows are written as zeros
+
+    def run(level_major):
+        enc.zero_grad()
+        wa = [w.clone().requires_grad_(True) for w in ws]
+        xa = x.clone().requires_grad_(True)
+        if level_major:
+            f, nn_ = enc.forward_level_major(xa, bound=1)
+            y = fused_mlp(f, wa, x_layout=1, batch=nn_)
+        else:
+            y = fused_mlp(enc(xa, bound=1), wa)
+        (y * g).sum().backward()
+        return y.detach(), enc.embeddings.grad.clone(), xa.grad.clone(), [w.grad.clone() for w in wa]
+
+    y1, ge1, gx1, gw1 = run(True)
+    y0, ge0, gx0, gw0 = run(False)
+    sc = max(float(y0.abs().max()), 1.0)
+    assert float((y1 - y0).abs().max()) < 2e-6 * sc
+    # fp64 statement of the MLP on the exact encoder output
+    pre = feats_rows.double() @ ws[0].double().t()
+    h = torch.relu(pre) @ ws[1].double().t()
+    assert float((y1.double() - h).abs().max()) < 2e-6 * sc
+    # The two layouts sum the first layer in different orders, so a pre-activation within round-off of zero may
+    # take the other side of the ReLU kink; such a sample legitimately changes its own gradients (8 rows per level
+    # of the embedding gradient, its input gradient, one term of each weight gradient).
+    kink = ((pre.abs() < 2e-6) & (pre != 0)).any(dim=1)      # exact zeros (out-of-range point) are not kinks
+    n_kink = int(kink.sum())
+    assert n_kink <= 3 + B // 1000
+    bad_rows = ((ge1 - ge0).abs().max(dim=1).values > 2e-5 * float(ge0.abs().max()) + 1e-12).sum()
+    assert int(bad_rows) <= 128 * n_kink
+    ok = ~kink
+    assert float((gx1[ok] - gx0[ok]).abs().max()) <= 2e-5 * float(gx0.abs().max()) + 1e-12
+    for a, b in zip(gw1, gw0):
+        assert float((a - b).abs().max()) <= (2e-5 + 1e-3 * n_kink) * float(b.abs().max()) + 1e-12
+
+
 def test_network_uses_fused_path_and_matches_linear_loop(monkeypatch):
     from enerf_amd import fused_mlp as fm
     from enerf_amd.network import NeRFNetwork
@@ -62,6 +116,7 @@ def test_network_uses_fused_path_and_matches_linear_loop(monkeypatch):
     g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
     m.zero_grad()
     monkeypatch.setattr(fm, "supported", lambda *a: False)
+    monkeypatch.setattr(fm, "supported_level_major", lambda *a: False)
     s2, c2 = m(x, d)
     (s2.sum() + c2.sum()).backward()
     assert float(((s1 - s2).abs() / s2.abs().clamp(min=1e-6)).max()) < 1e-4
