@@ -68,14 +68,17 @@ def build_batches(n_batches, n_rays, device, rank, bound):
 
 
 def pmc_traffic(points_per_launch):
-    """HBM bytes per grid_encode_forward launch from the committed rocprofv3 PMC passes (profiles/
-    r01_pmc_hbm_kernels.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/bench_kernels.py at
-    137 856 points), scaled per point.  FETCH_SIZE is in KB and, per MI355X_MICROARCH.md (HBM), counts 64 B per
-    128-byte request on gfx950, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).  None if absent."""
+    """HBM-side bytes per grid_encode_forward launch from the committed rocprofv3 PMC passes (profiles/
+    r01_pmc_hbm_bench.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this very command, averaged over
+    every k_grid_fwd dispatch -- training batches and density-grid updates alike, the same mix `achieved` is
+    averaged over), rescaled by points per launch.  FETCH_SIZE is in KB and, per MI355X_MICROARCH.md (HBM), counts
+    64 B per 128-byte request on gfx950, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).  None if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_kernels.json")) as f:
-            d = json.load(f)["k_grid_fwd<float, 3, 2> grid=2207744"]
-        per_point = (2.0 * d["FETCH_SIZE_KB_avg"] + d["WRITE_SIZE_KB_avg"]) * 1024.0 / 137856.0
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_bench.json")) as f:
+            j = json.load(f)
+        d = j["k_grid_fwd<float, 3, 2>"]
+        ref_pts = float(j["_meta"]["grid_fwd_points_per_launch"])
+        per_point = (2.0 * d["FETCH_SIZE_avg"] + d["WRITE_SIZE_avg"]) * 1024.0 / ref_pts
         return per_point * points_per_launch
     except Exception:
         return None

@@ -25,6 +25,8 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 using namespace enerf;
@@ -41,6 +43,40 @@ struct LevelTab {
 };
 
 uint32_t g_level_mask = 0xffffffffu;
+uint32_t g_tiled_min_batch = 16384;      // enerf_debug_grid_bwd_tiled
+uint32_t g_tiled_min_tiles = 8;
+
+// fork / join of a library-owned side stream around work that may overlap with `s` (event based: also capturable)
+hipStream_t g_side_stream = nullptr;
+hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;
+int fork_side_stream(hipStream_t s, hipStream_t* side) {
+    if (!g_side_stream) {
+        if (hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) != hipSuccess) return -1;
+    }
+    if (hipEventRecord(g_fork_event, s) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(g_side_stream, g_fork_event, 0) != hipSuccess) return -1;
+    *side = g_side_stream;
+    return 0;
+}
+int join_side_stream(hipStream_t s, hipStream_t side) {
+    if (hipEventRecord(g_join_event, side) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(s, g_join_event, 0) != hipSuccess) return -1;
+    return 0;
+}
+
+uint32_t num_cus() {
+    static uint32_t n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n = (uint32_t)cus;
+    }
+    return n;
+}
 
 template <typename T, int C>
 struct alignas((sizeof(T) * C) > 16 ? 16 : (sizeof(T) * C)) Feat {
@@ -71,20 +107,92 @@ __device__ __forceinline__ uint32_t fast_hash(const uint32_t (&p)[D]) {
     return r;
 }
 
-// row index (not yet multiplied by C) of a grid vertex
+// Row index (not yet multiplied by C) of a grid vertex, gridencoder.cu:60-84: dimensions are folded in while the
+// running uint32 stride (which may wrap, as in the reference) is <= the level size; a hash level (stride ran past the
+// size) uses the xor-prime hash instead; the result is reduced modulo the size.  Everything that depends only on the
+// level is resolved once per thread into a LevelGeom (wave-uniform), so the per-vertex work is a few integer ops:
+// dense levels need no reduction at all (largest index < size), power-of-two sizes (every hashed level) reduce with
+// a mask, and only the remaining cases (tiled grids that overflow) pay for an integer modulo.
 template <int D>
-__device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution,
-                                             const uint32_t (&p)[D]) {
-    uint32_t stride = 1, index = 0;
+struct LevelGeom {
+    uint32_t size, mask;
+    uint32_t stride[D];     // 0 for dimensions the reference's loop skips
+    bool hash;
+    int wrap;               // 0: none needed, 1: & mask, 2: % size
+};
+template <int D>
+__device__ __forceinline__ LevelGeom<D> make_geom(uint32_t gridtype, uint32_t size, uint32_t resolution) {
+    LevelGeom<D> g;
+    g.size = size;
+    g.mask = size - 1u;
+    uint32_t stride = 1;
+    unsigned long long max_index = 0;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        if (stride <= hashmap_size) {
-            index += p[d] * stride;
+        if (stride <= size) {
+            g.stride[d] = stride;
+            max_index += (unsigned long long)resolution * stride;     // vertex coordinates are <= resolution
             stride *= (resolution + 1);
+        } else {
+            g.stride[d] = 0;
         }
     }
-    if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(p);
-    return index % hashmap_size;
+    g.hash = gridtype == 0 && stride > size;
+    g.wrap = (size & (size - 1u)) == 0u ? 1 : ((!g.hash && max_index < size) ? 0 : 2);
+    return g;
+}
+template <int D>
+__device__ __forceinline__ uint32_t grid_row(const LevelGeom<D>& g, const uint32_t (&p)[D]) {
+    uint32_t index;
+    if (g.hash) {
+        index = fast_hash<D>(p);
+    } else {
+        index = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) index += p[d] * g.stride[d];
+    }
+    return g.wrap == 0 ? index : (g.wrap == 1 ? (index & g.mask) : index % g.size);
+}
+
+// Rows of all 2^D corners of a cell (corner idx adds bit d of idx to coordinate d): the level-mode branches are taken
+// once per cell, hashed corners share the per-dimension products (p+1)*prime = p*prime + prime, dense corners are the
+// base row plus wave-uniform offsets.  Same values as grid_row on each corner.
+template <int D>
+__device__ __forceinline__ void corner_rows(const LevelGeom<D>& g, const uint32_t (&p)[D], uint32_t (&rows)[1 << D]) {
+    if (g.hash) {
+        constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+        uint32_t h[D][2];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            h[d][0] = p[d] * primes[d];
+            h[d][1] = h[d][0] + primes[d];
+        }
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) r ^= h[d][(idx >> d) & 1];
+            rows[idx] = r;
+        }
+    } else {
+        uint32_t base = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) base += p[d] * g.stride[d];
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            uint32_t off = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) off += ((idx >> d) & 1) ? g.stride[d] : 0u;
+            rows[idx] = base + off;
+        }
+    }
+    if (g.wrap == 1) {
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) rows[idx] &= g.mask;
+    } else if (g.wrap == 2) {
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) rows[idx] %= g.size;
+    }
 }
 
 // forward: XCD-pair groups.  Group g = XCDs (2g, 2g+1); round r deals levels L-1-4r .. L-4-4r to the groups in
@@ -142,6 +250,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
     const float scale = tab.scale[level];
     const uint32_t resolution = tab.resolution[level];
     const Feat<T, C>* __restrict__ rows = reinterpret_cast<const Feat<T, C>*>(grid) + off0;
+    const LevelGeom<D> geom = make_geom<D>(gridtype, hashmap_size, resolution);
 
     float in[D];
     bool oob = false;
@@ -191,18 +300,14 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
         // holding the first row plus a single-row load of the second (hashed levels, odd x).  hashmap_size is a
         // multiple of 8, so the aligned pair never leaves the level.
         constexpr int H = 1 << (D - 1);
-        uint32_t r0[H], r1[H];
+        uint32_t cr[1 << D], r0[H], r1[H];
+        corner_rows<D>(geom, pos_grid, cr);
         bool adj[H];
         FeatPair<T, C> q[H];
 #pragma unroll
         for (int k = 0; k < H; k++) {
-            uint32_t pgl[D];
-#pragma unroll
-            for (int d = 1; d < D; d++) pgl[d] = pos_grid[d] + ((k >> (d - 1)) & 1);
-            pgl[0] = pos_grid[0];
-            r0[k] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
-            pgl[0] = pos_grid[0] + 1;
-            r1[k] = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
+            r0[k] = cr[2 * k];
+            r1[k] = cr[2 * k + 1];
             adj[k] = ((r0[k] ^ r1[k]) == 1u) || (r1[k] == r0[k] + 1u);
             const uint32_t lo = r0[k] < r1[k] ? r0[k] : r1[k];
             q[k] = *reinterpret_cast<const FeatPair<T, C>*>(rows + (adj[k] ? lo : (r0[k] & ~1u)));
@@ -224,13 +329,10 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
             }
         }
     } else {
+        uint32_t cr[1 << D];
+        corner_rows<D>(geom, pos_grid, cr);
 #pragma unroll
-        for (int idx = 0; idx < (1 << D); idx++) {
-            uint32_t pgl[D];
-#pragma unroll
-            for (int d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1);
-            f[idx] = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
-        }
+        for (int idx = 0; idx < (1 << D); idx++) f[idx] = rows[cr[idx]];
     }
     float res[C];
 #pragma unroll
@@ -267,9 +369,9 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
                     }
                 }
                 pgl[gd] = pos_grid[gd];
-                const Feat<T, C> fl_ = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+                const Feat<T, C> fl_ = rows[grid_row<D>(geom, pgl)];
                 pgl[gd] = pos_grid[gd] + 1;
-                const Feat<T, C> fr_ = rows[grid_row<D>(gridtype, hashmap_size, resolution, pgl)];
+                const Feat<T, C> fr_ = rows[grid_row<D>(geom, pgl)];
 #pragma unroll
                 for (int c = 0; c < C; c++) rg[c] = fmaf(wi, to_f(fr_.v[c]) - to_f(fl_.v[c]), rg[c]);
             }
@@ -312,45 +414,27 @@ __device__ __forceinline__ void scatter_add(__half* row, float w, const float (&
     }
 }
 
-// Backward scatter.  Device-scope float atomics top out at ~21 G/s on MI355X whatever the footprint or XCD affinity
-// (tools/atomic_rate.hip), so the kernel's job is to issue as few of them as possible.  Lanes of a wavefront hold
-// consecutive samples, i.e. consecutive points along a ray: at every level whose cell is larger than the marching
-// step they fall into the same cell in runs.  A run's 2^D corner contributions are summed in-wave (segmented suffix
-// sum keyed on the cell coordinates) and only the head lane of the run issues atomics.  Levels with no adjacent
-// sharing (wave-uniform ballot test) skip the reduction.
+// Backward scatter.  Device-scope float atomics execute memory-side on MI355X (every one is a 32-byte fabric
+// transaction) and top out at ~21 G/s whatever the footprint or XCD affinity (tools/atomic_rate.hip), so both
+// backward kernels work at issuing few of them.  Lanes of a wavefront hold consecutive samples, i.e. consecutive
+// points along a ray: at every level whose cell is larger than the marching step they fall into the same cell in
+// runs.  A run's 2^D corner contributions are summed in-wave (segmented suffix sum keyed on the cell coordinates)
+// and only the head lane of the run scatters.  Levels with no adjacent sharing (wave-uniform ballot test) skip the
+// reduction.
+//
+// Building blocks shared by the two backward kernels (all 64 lanes of a wave call them together):
+//   load_sample     position + upstream gradient of sample b at one level; returns whether it contributes
+//   corner_contrib  cell coordinates and the 2^D * C per-corner contributions v[idx*C+c] = w_idx * g[c]
+//   aggregate_runs  in-wave run aggregation; returns whether this lane is the head of its run (only heads scatter)
 template <typename T, int D, int C>
-__global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                           const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
-                                                           uint32_t B, uint32_t L, LevelTab tab, uint32_t gridtype,
-                                                           int grad_layout, uint32_t nchunks) {
-    uint32_t level, chunk;
-    if (!decode_block(nchunks, L, level, chunk)) return;
-    if (!level_enabled(tab, level)) return;
-    const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
-    const int lane = lane_id();
-
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float scale = tab.scale[level];
-    const uint32_t resolution = tab.resolution[level];
-    T* rows = grad_grid + (size_t)off0 * C;
-
-    bool valid = b < B;
-    float in[D];
+__device__ __forceinline__ bool load_sample(uint32_t b, bool valid, const T* __restrict__ grad,
+                                            const float* __restrict__ inputs, uint32_t level, uint32_t B, uint32_t L,
+                                            int grad_layout, float (&in)[D], float (&g)[C]) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
         in[d] = valid ? inputs[(size_t)b * D + d] : 0.0f;
-        valid = valid && !(in[d] < 0 || in[d] > 1);   // out-of-range points contribute nothing (grad_grid pre-zeroed)
+        valid = valid && !(in[d] < 0 || in[d] > 1);   // out-of-range points contribute nothing
     }
-    float pos[D];
-    uint32_t pos_grid[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        pos[d] = fmaf(in[d], scale, 0.5f);
-        pos_grid[d] = (uint32_t)floorf(pos[d]);
-        pos[d] -= (float)pos_grid[d];
-    }
-    float g[C];
     if (valid) {
         const uint32_t Bp = (B + 31u) & ~31u;
         const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(
@@ -361,9 +445,21 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
 #pragma unroll
         for (int c = 0; c < C; c++) g[c] = 0.0f;
     }
+    return valid;
+}
 
-    // per-corner contributions w_idx * g[c]
-    float v[(1 << D) * C];
+template <int D>
+__device__ __forceinline__ void cell_of(const float (&in)[D], float scale, uint32_t (&pos_grid)[D], float (&pos)[D]) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        pos[d] = fmaf(in[d], scale, 0.5f);
+        pos_grid[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pos_grid[d];
+    }
+}
+
+template <int D, int C>
+__device__ __forceinline__ void corner_contrib(const float (&pos)[D], const float (&g)[C], float (&v)[(1 << D) * C]) {
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
         float wi = 1;
@@ -372,7 +468,11 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
 #pragma unroll
         for (int c = 0; c < C; c++) v[idx * C + c] = wi * g[c];
     }
+}
 
+template <int D, int C>
+__device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint32_t (&pos_grid)[D],
+                                               float (&v)[(1 << D) * C]) {
     // run detection: same cell as the previous lane
     bool same = lane > 0 && valid;
 #pragma unroll
@@ -400,18 +500,154 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
             }
         }
     }
-    if (!head) return;
+    return head;
+}
 
+// Large fp32 batches split the levels between two kernels that run side by side (see k_grid_bwd_tiled below):
+// the finest levels -- no runs, the bulk of the atomics -- go to the owner-computes kernel, as many as fit one tile
+// per CU; the rest stay with the atomic kernel.  Both derive the same split from `offsets` on the device.
+constexpr uint32_t kTileFloats = 32768;      // 128 KiB of the CU's 160 KiB LDS
+constexpr uint32_t kTiledThreads = 1024;
+__device__ __forceinline__ uint32_t tiled_first_level(const int32_t* __restrict__ offsets, uint32_t L, uint32_t rows_per_tile,
+                                                      uint32_t min_tiles, uint32_t max_tiles) {
+    uint32_t used = 0, first = L;
+    for (uint32_t li = 0; li < L; li++) {
+        const uint32_t lv = L - 1 - li;
+        const uint32_t tiles = div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), rows_per_tile);
+        if (tiles < min_tiles || used + tiles > max_tiles) break;
+        used += tiles;
+        first = lv;
+    }
+    return first;
+}
+
+// One thread per (sample, level), global atomics from run heads.  tiled_max_tiles != 0: skip the levels the
+// owner-computes kernel takes.
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                           const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                           uint32_t B, uint32_t L, LevelTab tab, uint32_t gridtype,
+                                                           int grad_layout, uint32_t nchunks, uint32_t tiled_min_tiles,
+                                                           uint32_t tiled_max_tiles) {
+    uint32_t level, chunk;
+    if (!decode_block(nchunks, L, level, chunk)) return;
+    if (!level_enabled(tab, level)) return;
+    if (tiled_max_tiles != 0 &&
+        level >= tiled_first_level(offsets, L, kTileFloats / C, tiled_min_tiles, tiled_max_tiles))
+        return;
+    const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
+    const int lane = lane_id();
+
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const LevelGeom<D> geom = make_geom<D>(gridtype, hashmap_size, tab.resolution[level]);
+    T* rows = grad_grid + (size_t)off0 * C;
+
+    float in[D], g[C], pos[D], v[(1 << D) * C];
+    uint32_t pos_grid[D];
+    const bool valid = load_sample<T, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, in, g);
+    cell_of<D>(in, tab.scale[level], pos_grid, pos);
+    corner_contrib<D, C>(pos, g, v);
+    if (!aggregate_runs<D, C>(valid, lane, pos_grid, v)) return;
+
+    uint32_t cr[1 << D];
+    corner_rows<D>(geom, pos_grid, cr);
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
-        uint32_t pgl[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) pgl[d] = pos_grid[d] + ((idx >> d) & 1);
-        const uint32_t row = grid_row<D>(gridtype, hashmap_size, resolution, pgl);
         float gg[C];
 #pragma unroll
         for (int c = 0; c < C; c++) gg[c] = v[idx * C + c];
-        scatter_add<C>(rows + (size_t)row * C, 1.0f, gg);
+        scatter_add<C>(rows + (size_t)cr[idx] * C, 1.0f, gg);
+    }
+}
+
+// Owner-computes backward for the finest levels of large fp32 batches.  The gradient table is cut into tiles of
+// kTileFloats / C consecutive rows of one level; a 1024-thread workgroup owns a tile, keeps it in LDS (128 KiB), scans
+// the whole batch, adds every corner contribution that lands in its tile with LDS atomics and finally adds the tile
+// into the table with plain coalesced read-modify-writes: no global atomics, at the price of every owner re-deriving
+// the corner rows of every sample (a few dozen integer ops).  One workgroup per tile, at most one tile per CU.
+template <int D, int C>
+__global__ void __launch_bounds__(kTiledThreads) k_grid_bwd_tiled(const float* __restrict__ grad,
+                                                                  const float* __restrict__ inputs,
+                                                                  const int32_t* __restrict__ offsets,
+                                                                  float* __restrict__ grad_grid, uint32_t B, uint32_t L,
+                                                                  LevelTab tab, uint32_t gridtype, int grad_layout,
+                                                                  uint32_t min_tiles) {
+    __shared__ __attribute__((aligned(16))) float acc[kTileFloats];
+    constexpr uint32_t R = kTileFloats / C;          // rows per tile
+    const int lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+
+    const uint32_t first = tiled_first_level(offsets, L, R, min_tiles, gridDim.x);
+    uint32_t level = L, tile = 0, rem = blockIdx.x;
+    for (uint32_t lv = L; lv-- > first;) {           // finest level first
+        const uint32_t tiles = div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
+        if (rem < tiles) {
+            level = lv;
+            tile = rem;
+            break;
+        }
+        rem -= tiles;
+    }
+    if (level == L || !level_enabled(tab, level)) return;
+
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const LevelGeom<D> geom = make_geom<D>(gridtype, hashmap_size, tab.resolution[level]);
+    const float scale = tab.scale[level];
+    const uint32_t row0 = tile * R;
+    const uint32_t nrows = hashmap_size - row0 < R ? hashmap_size - row0 : R;
+
+    for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTiledThreads * 4)
+        *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    // software-pipelined scan: the next sample's position / gradient are in flight while this one is scattered
+    float in_n[D], g_n[C];
+    uint32_t b0 = wave * 64;
+    bool valid_n = b0 < B && load_sample<float, D, C>(b0 + lane, b0 + lane < B, grad, inputs, level, B, L, grad_layout,
+                                                      in_n, g_n);
+    for (; b0 < B; b0 += kTiledThreads) {
+        float in[D], g[C];
+#pragma unroll
+        for (int d = 0; d < D; d++) in[d] = in_n[d];
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = g_n[c];
+        const bool valid = valid_n;
+        const uint32_t bn = b0 + kTiledThreads;
+        valid_n = bn < B && load_sample<float, D, C>(bn + lane, bn + lane < B, grad, inputs, level, B, L, grad_layout,
+                                                     in_n, g_n);
+        float pos[D], v[(1 << D) * C];
+        uint32_t pos_grid[D], cr[1 << D];
+        cell_of<D>(in, scale, pos_grid, pos);
+        corner_rows<D>(geom, pos_grid, cr);
+        bool mine = false;
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            cr[idx] -= row0;
+            mine = mine || cr[idx] < nrows;
+        }
+        if (__ballot(valid && mine) == 0ull) continue;       // (ray-ordered samples on a dense level: most waves)
+        corner_contrib<D, C>(pos, g, v);
+        if (!aggregate_runs<D, C>(valid, lane, pos_grid, v)) continue;
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            if (cr[idx] < nrows) {
+#pragma unroll
+                for (int c = 0; c < C; c++) atomicAdd(acc + cr[idx] * C + c, v[idx * C + c]);
+            }
+        }
+    }
+    __syncthreads();
+
+    float* dst = grad_grid + ((size_t)off0 + row0) * C;     // level offsets are multiples of 8 rows: 16-byte aligned
+    for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTiledThreads * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(acc + i);
+        if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
+            float4 o = *reinterpret_cast<float4*>(dst + i);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            *reinterpret_cast<float4*>(dst + i) = o;
+        }
     }
 }
 
@@ -473,10 +709,21 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
                int layout, hipStream_t s) {
     const uint32_t nchunks = div_up(B, kPtsPerBlock);
     const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
+    // fp32 tables and enough samples to amortise a pass over the table: the finest levels go to the owner-computes
+    // kernel on this stream while the atomic kernel handles the other levels on a side stream, joined before return
+    const bool tiled = std::is_same<T, float>::value && B >= g_tiled_min_batch;
+    hipStream_t side = s;
+    if (tiled && fork_side_stream(s, &side)) ENERF_BADARG("GridEncoding: could not set up the side stream");
+    const uint32_t max_tiles = tiled ? num_cus() : 0u;
 #define ENERF_GB(CC)                                                                                             \
     do {                                                                                                         \
-        k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, gridtype, \
-                                                              layout, nchunks);                                  \
+        k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, side>>>(grad, inputs, offsets, grad_emb, B, L, tab, gridtype, \
+                                                                 layout, nchunks, g_tiled_min_tiles, max_tiles); \
+        if constexpr (std::is_same<T, float>::value) {                                                           \
+            if (tiled)                                                                                           \
+                k_grid_bwd_tiled<D, CC><<<max_tiles, kTiledThreads, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, \
+                                                                            gridtype, layout, g_tiled_min_tiles); \
+        }                                                                                                        \
         if (calc)                                                                                                \
             k_grid_input_bwd<T, D, CC><<<div_up(B * D, 256), 256, 0, s>>>(grad, dy_dx, grad_inputs, B, L, layout); \
     } while (0)
@@ -488,6 +735,7 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
         default: ENERF_BADARG("GridEncoding: C must be 1, 2, 4, or 8.");
     }
 #undef ENERF_GB
+    if (tiled && join_side_stream(s, side)) ENERF_BADARG("GridEncoding: could not join the side stream");
     return 0;
 }
 
@@ -498,6 +746,15 @@ extern "C" {
 // profiling aid, not part of the reference surface: restrict both grid kernels to the levels set in `mask`
 int enerf_debug_grid_level_mask(uint32_t mask) {
     g_level_mask = mask;
+    return 0;
+}
+
+// testing / profiling aid: fp32 batches of at least `min_batch` samples hand their finest levels (those with at least
+// `min_tiles` 128-KiB tiles, as many levels as fit one tile per CU) to the owner-computes backward kernel; everything
+// else takes the global-atomic kernel.  Defaults 16384 / 8; min_batch 0xffffffff disables the owner-computes kernel.
+int enerf_debug_grid_bwd_tiled(uint32_t min_batch, uint32_t min_tiles) {
+    g_tiled_min_batch = min_batch;
+    g_tiled_min_tiles = min_tiles ? min_tiles : 1u;
     return 0;
 }
 

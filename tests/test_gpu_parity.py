@@ -269,6 +269,51 @@ def test_grid_encode_forward_backward_small(D, C, gridtype):
         np.testing.assert_allclose(gin.cpu().numpy(), gi_ref, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("D,C,gridtype", [(3, 2, 0), (3, 1, 0), (3, 4, 1), (2, 2, 0), (3, 8, 0)])
+def test_grid_backward_owner_computes_kernel(D, C, gridtype):
+    """The LDS-tiled (owner-computes) backward, forced on a small table so that every branch runs: several tiles per
+    level, split batches on the coarse levels, ray-ordered samples (in-wave run aggregation), all three gradient
+    layouts, accumulation into a non-zero gradient buffer."""
+    from enerf_amd import _lib
+    from enerf_amd.backends import _gridencoder as ge
+    offsets, pls = O.grid_offsets(input_dim=D, num_levels=10, level_dim=C, base_resolution=4, log2_hashmap_size=16,
+                                  desired_resolution=512)
+    S = float(np.log2(pls)); Hb = 4; L = 10; B = 20011
+    emb = _table(offsets, C, 55 + C)
+    rng = np.random.default_rng(56)
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    t = np.arange(6000, dtype=np.float32)[:, None] % 60          # 100 "rays" of 60 closely spaced samples
+    o = np.repeat(rng.uniform(0.2, 0.6, (100, D)), 60, 0); d = np.repeat(rng.uniform(-1, 1, (100, D)), 60, 0)
+    x[:6000] = (o + d * t * 0.002).astype(np.float32)
+    x[7] = 1.5
+    g = rng.normal(size=(L, B, C)).astype(np.float32)
+    ge_ref, _ = O.grid_encode_backward(g, x, emb, offsets, S, Hb, None, gridtype)
+    Bp = (B + 31) // 32 * 32
+    dummy = torch.empty(1, device=DEV)
+    lib = _lib.lib()
+    try:
+        for layout in (0, 1, 2):
+            if layout == 0:
+                gg = cu(g)
+            elif layout == 1:
+                gg = cu(np.ascontiguousarray(g.transpose(1, 0, 2).reshape(B, L * C)))
+            else:
+                gp = np.zeros((L, Bp, C), np.float32); gp[:, :B] = g
+                gg = cu(gp)
+            res = []
+            for min_batch in (0, 0xffffffff):                     # owner-computes kernel, global-atomic kernel
+                lib.enerf_debug_grid_bwd_tiled(min_batch, 1)
+                gemb = torch.full(emb.shape, 0.5, device=DEV)
+                ge.grid_encode_backward(gg, cu(x), cu(emb), cu(offsets), gemb, B, D, C, L, S, Hb, False, dummy, dummy,
+                                        gridtype, layout=layout)
+                res.append(gemb.cpu().numpy() - 0.5)
+            scale = np.abs(ge_ref).max()
+            np.testing.assert_allclose(res[0], ge_ref, rtol=1e-4, atol=2e-5 * scale)
+            np.testing.assert_allclose(res[1], ge_ref, rtol=1e-4, atol=2e-5 * scale)
+    finally:
+        lib.enerf_debug_grid_bwd_tiled(16384, 8)
+
+
 def test_grid_encode_half_table():
     from enerf_amd.backends import _gridencoder as ge
     offsets, pls = O.grid_offsets(num_levels=8, base_resolution=4, log2_hashmap_size=10, desired_resolution=160)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for profiles/ on the GPU box:  bash tools/profile_round.sh r01
+# (kernel-trace stats and each PMC counter set in its own pass; nothing else traced)
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $R/bench.py --no-cpu-baseline"
+
+rm -rf /tmp/p_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $BENCH > $OUT/bench_under_stats.log 2>&1
+find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_$C; timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$C -o c -- $BENCH --render-frames 0 > $OUT/bench_under_$C.log 2>&1
+done
+PTS=$(tail -1 $OUT/bench_under_FETCH_SIZE.log | python -c "import json,sys; print(json.loads(sys.stdin.readline())['roofline']['points_per_launch'])" 2>/dev/null)
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_bench.json --meta "command=bench.py --no-cpu-baseline --render-frames 0" --meta "grid_fwd_points_per_launch=$PTS" \
+  $(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv")
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/k_$C; timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/k_$C -o c -- python $R/tools/bench_kernels.py > $OUT/kernels_under_$C.log 2>&1
+done
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_kernels.json --by-grid --meta "command=tools/bench_kernels.py" \
+  $(find /tmp/k_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/k_WRITE_SIZE -name "*counter_collection.csv")
+
+rm -rf /tmp/p_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma -o c -- python $R/tools/bench_ffmlp.py > $OUT/ffmlp_under_mfma.log 2>&1
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_mfma_ffmlp.json --by-grid --meta "command=tools/bench_ffmlp.py" $(find /tmp/p_mfma -name "*counter_collection.csv")
+ls -la $OUT
