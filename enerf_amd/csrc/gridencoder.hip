@@ -43,28 +43,12 @@ struct LevelTab {
 };
 
 uint32_t g_level_mask = 0xffffffffu;
-uint32_t g_tiled_min_batch = 16384;      // enerf_debug_grid_bwd_tiled
-uint32_t g_tiled_min_tiles = 8;
+uint32_t g_binned_min_batch = 16384;     // enerf_debug_grid_bwd_binned
+uint32_t g_binned_min_tiles = 8;
 
-// fork / join of a library-owned side stream around work that may overlap with `s` (event based: also capturable)
-hipStream_t g_side_stream = nullptr;
-hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;
-int fork_side_stream(hipStream_t s, hipStream_t* side) {
-    if (!g_side_stream) {
-        if (hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess) return -1;
-        if (hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming) != hipSuccess) return -1;
-        if (hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming) != hipSuccess) return -1;
-    }
-    if (hipEventRecord(g_fork_event, s) != hipSuccess) return -1;
-    if (hipStreamWaitEvent(g_side_stream, g_fork_event, 0) != hipSuccess) return -1;
-    *side = g_side_stream;
-    return 0;
-}
-int join_side_stream(hipStream_t s, hipStream_t side) {
-    if (hipEventRecord(g_join_event, side) != hipSuccess) return -1;
-    if (hipStreamWaitEvent(s, g_join_event, 0) != hipSuccess) return -1;
-    return 0;
-}
+uint32_t* g_bin_cursors = nullptr;
+
+uint32_t* bin_cursors();
 
 uint32_t num_cus() {
     static uint32_t n = 0;
@@ -503,38 +487,41 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
     return head;
 }
 
-// Large fp32 batches split the levels between two kernels that run side by side (see k_grid_bwd_tiled below):
-// the finest levels -- no runs, the bulk of the atomics -- go to the owner-computes kernel, as many as fit one tile
-// per CU; the rest stay with the atomic kernel.  Both derive the same split from `offsets` on the device.
-constexpr uint32_t kTileFloats = 32768;      // 128 KiB of the CU's 160 KiB LDS
-constexpr uint32_t kTiledThreads = 1024;
-__device__ __forceinline__ uint32_t tiled_first_level(const int32_t* __restrict__ offsets, uint32_t L, uint32_t rows_per_tile,
-                                                      uint32_t min_tiles, uint32_t max_tiles) {
-    uint32_t used = 0, first = L;
-    for (uint32_t li = 0; li < L; li++) {
-        const uint32_t lv = L - 1 - li;
-        const uint32_t tiles = div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), rows_per_tile);
-        if (tiles < min_tiles || used + tiles > max_tiles) break;
-        used += tiles;
-        first = lv;
-    }
-    return first;
+// Large fp32 batches take the *binned* backward: pass A (k_grid_bwd_bin) computes each run head's 2^D corner
+// contributions once and appends them, as (row-in-tile, values) records, to the record list of the table tile they
+// fall in; pass B (k_grid_bwd_tile) gives every list to one workgroup that sums its records into an LDS-resident tile
+// (kTileElems / C rows of fp64 accumulators, 128 KiB) and adds the tile into the table with plain coalesced
+// read-modify-writes -- a counting sort by tile in place of ~100 memory-side float atomics per sample.  The LDS
+// accumulators are fp64 because ds_add_f64 runs at ~0.45 cycles per lane on gfx950 while ds_add_f32 takes ~3.1
+// (tools/lds_atomic_rate.hip); the sums are rounded to fp32 once, when the tile is added into the table.  A level smaller than `min_tiles`
+// tiles keeps several replica lists per tile (filled by different workgroups, flushed with a few atomics) so that
+// its records do not pile up on one CU.  Everything that depends on the table geometry is derived from `offsets`
+// on the device.  Levels with more than kMaxBins lists (tables beyond 2^24 rows per level) stay with the atomic kernel.
+constexpr uint32_t kTileElems = 16384;       // fp64 accumulators: 128 KiB of the CU's 160 KiB LDS
+constexpr uint32_t kTileThreads = 1024;
+constexpr uint32_t kMaxBins = 1024;          // record lists per level
+struct BinPlan {
+    uint32_t tiles, replicas, bins;          // bins = tiles * replicas (0: level not binned)
+};
+__device__ __forceinline__ BinPlan bin_plan(const int32_t* __restrict__ offsets, uint32_t level, uint32_t rows_per_tile,
+                                            uint32_t min_tiles) {
+    BinPlan p;
+    p.tiles = div_up((uint32_t)(offsets[level + 1] - offsets[level]), rows_per_tile);
+    p.replicas = p.tiles >= min_tiles ? 1u : div_up(min_tiles, p.tiles);
+    p.bins = p.tiles * p.replicas <= kMaxBins ? p.tiles * p.replicas : 0u;
+    return p;
 }
 
-// One thread per (sample, level), global atomics from run heads.  tiled_max_tiles != 0: skip the levels the
-// owner-computes kernel takes.
+// One thread per (sample, level), global atomics from run heads.  binned_min_tiles != 0: skip the binned levels.
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                            const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
                                                            uint32_t B, uint32_t L, LevelTab tab, uint32_t gridtype,
-                                                           int grad_layout, uint32_t nchunks, uint32_t tiled_min_tiles,
-                                                           uint32_t tiled_max_tiles) {
+                                                           int grad_layout, uint32_t nchunks, uint32_t binned_min_tiles) {
     uint32_t level, chunk;
     if (!decode_block(nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
-    if (tiled_max_tiles != 0 &&
-        level >= tiled_first_level(offsets, L, kTileFloats / C, tiled_min_tiles, tiled_max_tiles))
-        return;
+    if (binned_min_tiles != 0 && bin_plan(offsets, level, kTileElems / C, binned_min_tiles).bins != 0) return;
     const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
     const int lane = lane_id();
 
@@ -561,93 +548,202 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
     }
 }
 
-// Owner-computes backward for the finest levels of large fp32 batches.  The gradient table is cut into tiles of
-// kTileFloats / C consecutive rows of one level; a 1024-thread workgroup owns a tile, keeps it in LDS (128 KiB), scans
-// the whole batch, adds every corner contribution that lands in its tile with LDS atomics and finally adds the tile
-// into the table with plain coalesced read-modify-writes: no global atomics, at the price of every owner re-deriving
-// the corner rows of every sample (a few dozen integer ops).  One workgroup per tile, at most one tile per CU.
+// Pass A of the binned path: 256 samples of one level per workgroup.  Level l owns `region` records of `recs`, cut
+// evenly between its lists (capacity = region / bins, at least twice the expected load); a list stores its records as
+// 1 + C arrays of `capacity` dwords (key = row within the tile, then the C values); `cursors[l][list]` counts the
+// records appended.  The workgroup ranks its records per list in LDS, stages them sorted by list, reserves a range
+// in every list it feeds with one integer atomic, and copies the staged records out in runs of consecutive slots.
+// A record that does not fit (pathologically skewed input) is added to the table with float atomics right here.
 template <int D, int C>
-__global__ void __launch_bounds__(kTiledThreads) k_grid_bwd_tiled(const float* __restrict__ grad,
-                                                                  const float* __restrict__ inputs,
-                                                                  const int32_t* __restrict__ offsets,
-                                                                  float* __restrict__ grad_grid, uint32_t B, uint32_t L,
-                                                                  LevelTab tab, uint32_t gridtype, int grad_layout,
-                                                                  uint32_t min_tiles) {
-    __shared__ __attribute__((aligned(16))) float acc[kTileFloats];
-    constexpr uint32_t R = kTileFloats / C;          // rows per tile
+__global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd_bin(const float* __restrict__ grad,
+                                                               const float* __restrict__ inputs,
+                                                               const int32_t* __restrict__ offsets,
+                                                               float* __restrict__ grad_grid, uint32_t B, uint32_t L,
+                                                               LevelTab tab, uint32_t gridtype, int grad_layout,
+                                                               uint32_t nchunks, uint32_t min_tiles,
+                                                               uint32_t* __restrict__ recs, uint32_t* __restrict__ cursors,
+                                                               uint32_t region) {
+    constexpr uint32_t R = kTileElems / C;
+    constexpr uint32_t NREC = kPtsPerBlock << D;
+    __shared__ uint32_t s_ofs[kMaxBins];         // records per list, then exclusive offset of the list in the staging area
+    __shared__ uint32_t s_gbase[kMaxBins];       // first global slot reserved in the list
+    __shared__ uint32_t s_key[NREC];             // row within tile | list << 16
+    __shared__ float s_val[C][NREC];
+    __shared__ uint32_t s_wave[kPtsPerBlock / 64 + 1];
+    uint32_t level, chunk;
+    if (!decode_block(nchunks, L, level, chunk)) return;
+    if (!level_enabled(tab, level)) return;
+    const BinPlan plan = bin_plan(offsets, level, R, min_tiles);
+    if (plan.bins == 0) return;
+    const uint32_t cap = region / plan.bins;
+    const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
     const int lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t replica = chunk % plan.replicas;
 
-    const uint32_t first = tiled_first_level(offsets, L, R, min_tiles, gridDim.x);
-    uint32_t level = L, tile = 0, rem = blockIdx.x;
-    for (uint32_t lv = L; lv-- > first;) {           // finest level first
-        const uint32_t tiles = div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
-        if (rem < tiles) {
-            level = lv;
-            tile = rem;
-            break;
-        }
-        rem -= tiles;
-    }
-    if (level == L || !level_enabled(tab, level)) return;
+    for (uint32_t t = threadIdx.x; t < plan.bins; t += kPtsPerBlock) s_ofs[t] = 0;
+    __syncthreads();
 
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     const LevelGeom<D> geom = make_geom<D>(gridtype, hashmap_size, tab.resolution[level]);
-    const float scale = tab.scale[level];
-    const uint32_t row0 = tile * R;
-    const uint32_t nrows = hashmap_size - row0 < R ? hashmap_size - row0 : R;
 
-    for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTiledThreads * 4)
-        *reinterpret_cast<float4*>(acc + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    // software-pipelined scan: the next sample's position / gradient are in flight while this one is scattered
-    float in_n[D], g_n[C];
-    uint32_t b0 = wave * 64;
-    bool valid_n = b0 < B && load_sample<float, D, C>(b0 + lane, b0 + lane < B, grad, inputs, level, B, L, grad_layout,
-                                                      in_n, g_n);
-    for (; b0 < B; b0 += kTiledThreads) {
-        float in[D], g[C];
-#pragma unroll
-        for (int d = 0; d < D; d++) in[d] = in_n[d];
-#pragma unroll
-        for (int c = 0; c < C; c++) g[c] = g_n[c];
-        const bool valid = valid_n;
-        const uint32_t bn = b0 + kTiledThreads;
-        valid_n = bn < B && load_sample<float, D, C>(bn + lane, bn + lane < B, grad, inputs, level, B, L, grad_layout,
-                                                     in_n, g_n);
-        float pos[D], v[(1 << D) * C];
-        uint32_t pos_grid[D], cr[1 << D];
-        cell_of<D>(in, scale, pos_grid, pos);
-        corner_rows<D>(geom, pos_grid, cr);
-        bool mine = false;
+    float in[D], g[C], pos[D], v[(1 << D) * C];
+    uint32_t pos_grid[D], cr[1 << D], bin[1 << D], rank[1 << D];
+    const bool valid = load_sample<float, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, in, g);
+    cell_of<D>(in, tab.scale[level], pos_grid, pos);
+    corner_contrib<D, C>(pos, g, v);
+    const bool head = aggregate_runs<D, C>(valid, lane, pos_grid, v);
+    corner_rows<D>(geom, pos_grid, cr);
+    if (head) {
 #pragma unroll
         for (int idx = 0; idx < (1 << D); idx++) {
-            cr[idx] -= row0;
-            mine = mine || cr[idx] < nrows;
-        }
-        if (__ballot(valid && mine) == 0ull) continue;       // (ray-ordered samples on a dense level: most waves)
-        corner_contrib<D, C>(pos, g, v);
-        if (!aggregate_runs<D, C>(valid, lane, pos_grid, v)) continue;
-#pragma unroll
-        for (int idx = 0; idx < (1 << D); idx++) {
-            if (cr[idx] < nrows) {
-#pragma unroll
-                for (int c = 0; c < C; c++) atomicAdd(acc + cr[idx] * C + c, v[idx * C + c]);
-            }
+            bin[idx] = (cr[idx] / R) * plan.replicas + replica;      // R is a power of two
+            rank[idx] = atomicAdd(&s_ofs[bin[idx]], 1u);
         }
     }
     __syncthreads();
 
-    float* dst = grad_grid + ((size_t)off0 + row0) * C;     // level offsets are multiples of 8 rows: 16-byte aligned
-    for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTiledThreads * 4) {
-        const float4 a = *reinterpret_cast<const float4*>(acc + i);
-        if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
-            float4 o = *reinterpret_cast<float4*>(dst + i);
-            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-            *reinterpret_cast<float4*>(dst + i) = o;
+    // exclusive scan of the per-list counts (thread t owns `per` consecutive lists) + global reservation
+    const uint32_t per = div_up(plan.bins, kPtsPerBlock);
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t t = threadIdx.x * per + k;
+        if (t < plan.bins) mine += s_ofs[t];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += s_wave[w];
+    if (threadIdx.x == kPtsPerBlock - 1) s_wave[kPtsPerBlock / 64] = before + mine;      // total records
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t t = threadIdx.x * per + k;
+        if (t < plan.bins) {
+            const uint32_t n = s_ofs[t];
+            s_ofs[t] = before;
+            before += n;
+            if (n) s_gbase[t] = atomicAdd(&cursors[level * kMaxBins + t], n);
         }
+    }
+    __syncthreads();
+
+    if (head) {
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            const uint32_t p = s_ofs[bin[idx]] + rank[idx];
+            s_key[p] = (cr[idx] & (R - 1u)) | (bin[idx] << 16);
+#pragma unroll
+            for (int c = 0; c < C; c++) s_val[c][p] = v[idx * C + c];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t total = s_wave[kPtsPerBlock / 64];
+    uint32_t* lrecs = recs + (size_t)level * region * (1 + C);
+    for (uint32_t j = threadIdx.x; j < total; j += kPtsPerBlock) {
+        const uint32_t key = s_key[j], list = key >> 16, loc = key & 0xffffu;
+        const uint32_t slot = s_gbase[list] + (j - s_ofs[list]);
+        if (slot < cap) {
+            uint32_t* r = lrecs + (size_t)list * cap * (1 + C) + slot;
+            r[0] = loc;
+#pragma unroll
+            for (int c = 0; c < C; c++) r[(size_t)(1 + c) * cap] = __float_as_uint(s_val[c][j]);
+        } else {
+            float gg[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) gg[c] = s_val[c][j];
+            scatter_add<C>(grad_grid + ((size_t)off0 + (size_t)(list / plan.replicas) * R + loc) * C, 1.0f, gg);
+        }
+    }
+}
+
+// Pass B: persistent workgroups (one per CU: the tile takes 128 KiB of LDS) walk the record lists, finest level
+// first.  Sum the list's records into the LDS tile, add the non-zero part into the table (plain read-modify-write
+// when the tile has a single list, float atomics for replica lists), reset the list's cursor for the next call.
+template <int C>
+__global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* __restrict__ offsets,
+                                                                float* __restrict__ grad_grid, uint32_t L, LevelTab tab,
+                                                                uint32_t min_tiles, const uint32_t* __restrict__ recs,
+                                                                uint32_t* __restrict__ cursors, uint32_t region) {
+    __shared__ __attribute__((aligned(16))) double acc[kTileElems];
+    __shared__ uint32_t s_n;
+    constexpr uint32_t R = kTileElems / C;
+    constexpr int U = 4;                         // records in flight per thread
+    uint32_t total = 0;
+    for (uint32_t lv = 0; lv < L; lv++) total += bin_plan(offsets, lv, R, min_tiles).bins;
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t level = 0, list = 0, rem = item;
+        BinPlan plan;
+        for (uint32_t lv = L; lv-- > 0;) {
+            plan = bin_plan(offsets, lv, R, min_tiles);
+            if (rem < plan.bins) {
+                level = lv;
+                list = rem;
+                break;
+            }
+            rem -= plan.bins;
+        }
+        const uint32_t cap = region / plan.bins;
+        if (threadIdx.x == 0) {
+            const uint32_t n = cursors[level * kMaxBins + list];
+            s_n = n < cap ? n : cap;
+            cursors[level * kMaxBins + list] = 0;
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n != 0 && level_enabled(tab, level)) {
+            const uint32_t off0 = (uint32_t)offsets[level];
+            const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+            const uint32_t row0 = (list / plan.replicas) * R;
+            const uint32_t nrows = hashmap_size - row0 < R ? hashmap_size - row0 : R;
+            for (uint32_t i = threadIdx.x * 2; i < nrows * C; i += kTileThreads * 2)
+                *reinterpret_cast<double2*>(acc + i) = make_double2(0.0, 0.0);
+            __syncthreads();
+            const uint32_t* r = recs + ((size_t)level * region + (size_t)list * cap) * (1 + C);
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kTileThreads * U) {
+                uint32_t loc[U];
+                float val[U][C];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t i = i0 + u * kTileThreads;
+                    const uint32_t ic = i < n ? i : n - 1;
+                    loc[u] = r[ic];
+#pragma unroll
+                    for (int c = 0; c < C; c++) val[u][c] = __uint_as_float(r[(size_t)(1 + c) * cap + ic]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (i0 + u * kTileThreads < n) {
+#pragma unroll
+                        for (int c = 0; c < C; c++) atomicAdd(acc + loc[u] * C + c, (double)val[u][c]);
+                    }
+                }
+            }
+            __syncthreads();
+            float* dst = grad_grid + ((size_t)off0 + row0) * C;     // level offsets are multiples of 8 rows: 16-byte aligned
+            if (plan.replicas == 1) {
+                for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTileThreads * 4) {
+                    const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
+                    const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
+                    if (a0.x != 0.0 || a0.y != 0.0 || a1.x != 0.0 || a1.y != 0.0) {
+                        float4 o = *reinterpret_cast<float4*>(dst + i);
+                        o.x += (float)a0.x; o.y += (float)a0.y; o.z += (float)a1.x; o.w += (float)a1.y;
+                        *reinterpret_cast<float4*>(dst + i) = o;
+                    }
+                }
+            } else {
+                for (uint32_t i = threadIdx.x; i < nrows * C; i += kTileThreads) {
+                    const double a = acc[i];
+                    if (a != 0.0) atomicAdd(dst + i, (float)a);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -670,6 +766,15 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ gr
         for (int c = 0; c < C; c++) result = fmaf(to_f(g[c]), to_f(jac[((size_t)l * D + d) * C + c]), result);
     }
     grad_inputs[t] = from_f<T>(result);
+}
+
+uint32_t* bin_cursors() {
+    if (!g_bin_cursors) {
+        const size_t bytes = sizeof(uint32_t) * kMaxLevels * kMaxBins;
+        if (hipMalloc((void**)&g_bin_cursors, bytes) != hipSuccess) return nullptr;
+        if (hipMemset(g_bin_cursors, 0, bytes) != hipSuccess) return nullptr;
+    }
+    return g_bin_cursors;
 }
 
 int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H) {
@@ -709,20 +814,29 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
                int layout, hipStream_t s) {
     const uint32_t nchunks = div_up(B, kPtsPerBlock);
     const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
-    // fp32 tables and enough samples to amortise a pass over the table: the finest levels go to the owner-computes
-    // kernel on this stream while the atomic kernel handles the other levels on a side stream, joined before return
-    const bool tiled = std::is_same<T, float>::value && B >= g_tiled_min_batch;
-    hipStream_t side = s;
-    if (tiled && fork_side_stream(s, &side)) ENERF_BADARG("GridEncoding: could not set up the side stream");
-    const uint32_t max_tiles = tiled ? num_cus() : 0u;
+    // fp32 tables and enough samples: the binned path (the atomic kernel then only sees levels it cannot bin)
+    const bool binned = std::is_same<T, float>::value && B >= g_binned_min_batch;
+    uint32_t* recs = nullptr;
+    uint32_t* cursors = nullptr;
+    const uint32_t region = 2u * (1u << D) * B;      // records per level: twice the 2^D * B a level can produce
+    if (binned) {
+        recs = (uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C));
+        cursors = bin_cursors();
+        if (!recs || !cursors) return ENERF_E_NOMEM;
+    }
+    const uint32_t min_tiles = binned ? g_binned_min_tiles : 0u;
 #define ENERF_GB(CC)                                                                                             \
     do {                                                                                                         \
-        k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, side>>>(grad, inputs, offsets, grad_emb, B, L, tab, gridtype, \
-                                                                 layout, nchunks, g_tiled_min_tiles, max_tiles); \
+        k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, gridtype, \
+                                                              layout, nchunks, min_tiles);                       \
         if constexpr (std::is_same<T, float>::value) {                                                           \
-            if (tiled)                                                                                           \
-                k_grid_bwd_tiled<D, CC><<<max_tiles, kTiledThreads, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, \
-                                                                            gridtype, layout, g_tiled_min_tiles); \
+            if (binned) {                                                                                        \
+                k_grid_bwd_bin<D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, \
+                                                                       gridtype, layout, nchunks, min_tiles, recs, \
+                                                                       cursors, region);                         \
+                k_grid_bwd_tile<CC><<<num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, recs, \
+                                                                       cursors, region);                         \
+            }                                                                                                    \
         }                                                                                                        \
         if (calc)                                                                                                \
             k_grid_input_bwd<T, D, CC><<<div_up(B * D, 256), 256, 0, s>>>(grad, dy_dx, grad_inputs, B, L, layout); \
@@ -735,7 +849,6 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
         default: ENERF_BADARG("GridEncoding: C must be 1, 2, 4, or 8.");
     }
 #undef ENERF_GB
-    if (tiled && join_side_stream(s, side)) ENERF_BADARG("GridEncoding: could not join the side stream");
     return 0;
 }
 
@@ -749,12 +862,12 @@ int enerf_debug_grid_level_mask(uint32_t mask) {
     return 0;
 }
 
-// testing / profiling aid: fp32 batches of at least `min_batch` samples hand their finest levels (those with at least
-// `min_tiles` 128-KiB tiles, as many levels as fit one tile per CU) to the owner-computes backward kernel; everything
-// else takes the global-atomic kernel.  Defaults 16384 / 8; min_batch 0xffffffff disables the owner-computes kernel.
-int enerf_debug_grid_bwd_tiled(uint32_t min_batch, uint32_t min_tiles) {
-    g_tiled_min_batch = min_batch;
-    g_tiled_min_tiles = min_tiles ? min_tiles : 1u;
+// testing / profiling aid: fp32 batches of at least `min_batch` samples send the levels spanning at least `min_tiles`
+// 128-KiB tiles through the binned (record list + LDS tile) backward path; everything else takes the global-atomic
+// kernel.  Defaults 16384 / 8; min_batch 0xffffffff disables the binned path.
+int enerf_debug_grid_bwd_binned(uint32_t min_batch, uint32_t min_tiles) {
+    g_binned_min_batch = min_batch;
+    g_binned_min_tiles = min_tiles ? min_tiles : 1u;
     return 0;
 }
 

@@ -199,10 +199,10 @@ int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
 
 /* profiling aid: restrict grid_encode_forward/backward to the levels whose bit is set (default all) */
 int enerf_debug_grid_level_mask(uint32_t mask);
-/* Testing / profiling aid: fp32 grid_encode_backward batches of at least `min_batch` samples hand their finest levels
- * (those with at least `min_tiles` 128-KiB tiles, as many levels as fit one tile per CU) to the owner-computes kernel
- * (LDS-resident tiles, no global atomics); everything else takes the global-atomic kernel.  Defaults 16384 / 8. */
-int enerf_debug_grid_bwd_tiled(uint32_t min_batch, uint32_t min_tiles);
+/* Testing / profiling aid: fp32 grid_encode_backward batches of at least `min_batch` samples send the levels spanning
+ * at least `min_tiles` 128-KiB tiles through the binned path (per-tile record lists summed in LDS, no global float
+ * atomics); everything else takes the global-atomic kernel.  Defaults 16384 / 8. */
+int enerf_debug_grid_bwd_binned(uint32_t min_batch, uint32_t min_tiles);
 
 /* ------------------------------------------------------------------ measurement hooks (not in the reference)
  * When enabled, every launch of the selected kernel family is bracketed by hipEvents on its own stream so that

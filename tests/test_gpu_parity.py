@@ -270,10 +270,10 @@ def test_grid_encode_forward_backward_small(D, C, gridtype):
 
 
 @pytest.mark.parametrize("D,C,gridtype", [(3, 2, 0), (3, 1, 0), (3, 4, 1), (2, 2, 0), (3, 8, 0)])
-def test_grid_backward_owner_computes_kernel(D, C, gridtype):
-    """The LDS-tiled (owner-computes) backward, forced on a small table so that every branch runs: several tiles per
-    level, split batches on the coarse levels, ray-ordered samples (in-wave run aggregation), all three gradient
-    layouts, accumulation into a non-zero gradient buffer."""
+def test_grid_backward_binned_path(D, C, gridtype):
+    """The binned backward (record lists per table tile, summed in LDS), forced on a small table so that every branch
+    runs: several tiles per level, replica lists on the coarse levels, ray-ordered samples (in-wave run aggregation),
+    all three gradient layouts, accumulation into a non-zero gradient buffer."""
     from enerf_amd import _lib
     from enerf_amd.backends import _gridencoder as ge
     offsets, pls = O.grid_offsets(input_dim=D, num_levels=10, level_dim=C, base_resolution=4, log2_hashmap_size=16,
@@ -301,17 +301,18 @@ def test_grid_backward_owner_computes_kernel(D, C, gridtype):
                 gp = np.zeros((L, Bp, C), np.float32); gp[:, :B] = g
                 gg = cu(gp)
             res = []
-            for min_batch in (0, 0xffffffff):                     # owner-computes kernel, global-atomic kernel
-                lib.enerf_debug_grid_bwd_tiled(min_batch, 1)
+            # binned path with one list per tile / with replica lists on the small levels; global-atomic kernel
+            for min_batch, min_tiles in ((0, 1), (0, 8), (0xffffffff, 8)):
+                lib.enerf_debug_grid_bwd_binned(min_batch, min_tiles)
                 gemb = torch.full(emb.shape, 0.5, device=DEV)
                 ge.grid_encode_backward(gg, cu(x), cu(emb), cu(offsets), gemb, B, D, C, L, S, Hb, False, dummy, dummy,
                                         gridtype, layout=layout)
                 res.append(gemb.cpu().numpy() - 0.5)
             scale = np.abs(ge_ref).max()
-            np.testing.assert_allclose(res[0], ge_ref, rtol=1e-4, atol=2e-5 * scale)
-            np.testing.assert_allclose(res[1], ge_ref, rtol=1e-4, atol=2e-5 * scale)
+            for r in res:
+                np.testing.assert_allclose(r, ge_ref, rtol=1e-4, atol=2e-5 * scale)
     finally:
-        lib.enerf_debug_grid_bwd_tiled(16384, 8)
+        lib.enerf_debug_grid_bwd_binned(16384, 8)
 
 
 def test_grid_encode_half_table():

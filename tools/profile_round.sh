@@ -15,7 +15,7 @@ find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_kernel
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$C; timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$C -o c -- $BENCH --render-frames 0 > $OUT/bench_under_$C.log 2>&1
 done
-PTS=$(tail -1 $OUT/bench_under_FETCH_SIZE.log | python -c "import json,sys; print(json.loads(sys.stdin.readline())['roofline']['points_per_launch'])" 2>/dev/null)
+PTS=$(grep '^{"metric"' $OUT/bench_under_FETCH_SIZE.log | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.readline())['roofline']['points_per_launch'])" 2>/dev/null)
 python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_bench.json --meta "command=bench.py --no-cpu-baseline --render-frames 0" --meta "grid_fwd_points_per_launch=$PTS" \
   $(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv")
 
