@@ -39,6 +39,7 @@ SIGNATURES = {
     "enerf_mlp32_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     "enerf_mlp32_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp],
     "enerf_debug_grid_level_mask": [_u32],
+    "enerf_debug_mlp32_wgrad_blocks": [_u32],
     "enerf_debug_grid_bwd_binned": [_u32, _u32],
     "enerf_adam_step": [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u32, _int, _vp],
     "enerf_allocate_splitk": [_sz],

@@ -375,19 +375,35 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ d
     for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
 }
 
-__global__ void __launch_bounds__(256) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                                        float* __restrict__ gw) {
-    // 64 weights per workgroup; the 4 waves each sum a quarter of the partial blocks (fixed order), then combine
-    __shared__ float acc[4][64];
+__global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
+                                                         float* __restrict__ gw) {
+    // 64 weights per workgroup; each of the 16 waves sums every 16th partial block with four independent chains
+    // (fixed order), then the waves' sums are combined in a fixed order: deterministic.
+    __shared__ float acc[16][64];
     const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t part = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (i < NW)
-        for (uint32_t b = part; b < nblocks; b += 4) s += partial[(size_t)b * NW + i];
-    acc[part][threadIdx.x & 63] = s;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (i < NW) {
+        uint32_t b = part;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += partial[(size_t)b * NW + i];
+            s1 += partial[(size_t)(b + 16) * NW + i];
+            s2 += partial[(size_t)(b + 32) * NW + i];
+            s3 += partial[(size_t)(b + 48) * NW + i];
+        }
+        for (; b < nblocks; b += 16) s0 += partial[(size_t)b * NW + i];
+    }
+    acc[part][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (part == 0 && i < NW) gw[i] += (acc[0][threadIdx.x] + acc[1][threadIdx.x]) + (acc[2][threadIdx.x] + acc[3][threadIdx.x]);
+    if (part == 0 && i < NW) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += acc[w][threadIdx.x];
+        gw[i] += t;
+    }
 }
+
+uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 256 otherwise (measured optimum)
 
 uint32_t pgrid(uint32_t B, uint32_t cap) {
     const uint32_t blocks = div_up(div_up(B, 32), 4);
@@ -397,6 +413,12 @@ uint32_t pgrid(uint32_t B, uint32_t cap) {
 }  // namespace
 
 extern "C" {
+
+// tuning aid: number of workgroups (= partial sums) of the weight-gradient kernel
+int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks) {
+    g_wgrad_blocks = blocks;
+    return 0;
+}
 
 // Fused fp32 MLP: X -> (64 x num_hidden, ReLU/none) -> Y [B,out_dim], out_dim <= 32, no bias.  B is ragged; with
 // Bp = B rounded up to 32: X is [B,32] row-major (x_layout 0) or [16,Bp,2] level-major (x_layout 1);
@@ -450,7 +472,8 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
     const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
     const size_t lds = sizeof(float) * NW;
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
-    const uint32_t grid = pgrid(B, 1024), wgrid = pgrid(B, 256);
+    const uint32_t grid = pgrid(B, 1024);
+    const uint32_t wgrid = pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 256u));
     float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NW);
     if (!partial) return ENERF_E_NOMEM;
 #define MLP32_BA(NHV, KPOV, XLV) \
@@ -473,7 +496,7 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
 #undef MLP32_BWD
 #undef MLP32_BWD2
 #undef MLP32_BA
-    k_mlp32_reduce_w<<<div_up(NW, 64), 256, 0, s>>>(partial, wgrid, NW, dW);
+    k_mlp32_reduce_w<<<div_up(NW, 64), 1024, 0, s>>>(partial, wgrid, NW, dW);
     ENERF_LAUNCH_CHECK("mlp32_backward");
     return 0;
 }

@@ -47,7 +47,7 @@ def pad32(n):
 
 class _FusedMLP32(Function):
     @staticmethod
-    def forward(ctx, x, activation, x_layout, batch, *weights):
+    def forward(ctx, x, activation, x_layout, batch, train, *weights):
         in_dim = weights[0].shape[1]
         num_hidden = len(weights) - 1
         out_dim = weights[-1].shape[0]
@@ -69,9 +69,8 @@ class _FusedMLP32(Function):
         if in_dim != 32:
             w0 = torch.nn.functional.pad(w0, (0, 32 - in_dim))
         blob = torch.cat([w0.reshape(-1)] + [w.reshape(-1) for w in weights[1:]]).contiguous()
-        # hidden activations are only written out when a backward pass can follow (under no_grad every
-        # needs_input_grad entry is False)
-        train = any(ctx.needs_input_grad)
+        # `train` (decided by the caller, where grad mode is still visible): hidden activations are only written out
+        # when a backward pass can follow
         fb = torch.empty(num_hidden, Bp, 64, dtype=torch.float32, device=dev) if train else None
         y = torch.empty(B0, out_dim, dtype=torch.float32, device=dev)
         if B0 > 0:
@@ -117,10 +116,11 @@ class _FusedMLP32(Function):
         gx = None
         if need_dx:       # row-major: columns >= in_dim carry zero weight -> zero gradient
             gx = dx if x_layout == 1 else dx[:, :x_cols]
-        return (gx, None, None, None) + tuple(grads)
+        return (gx, None, None, None, None) + tuple(grads)
 
 
 def fused_mlp(x, weights, activation="relu", x_layout=0, batch=None):
     """x [B, in<=32] fp32 CUDA (or [16, pad32(batch), 2] with x_layout=1); weights = list of [out, in] matrices
     (hidden width 64, last out <= 32).  Returns [B, out]."""
-    return _FusedMLP32.apply(x, 0 if activation == "relu" else 6, x_layout, batch, *weights)
+    train = torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights))
+    return _FusedMLP32.apply(x, 0 if activation == "relu" else 6, x_layout, batch, train, *weights)

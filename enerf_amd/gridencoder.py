@@ -16,6 +16,12 @@ from .backends import _gridencoder as _backend
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 
+# The backward kernels *add* into the gradient buffer they are given.  When the embedding table is a leaf parameter
+# whose .grad already exists (zeroed by the optimizer), they add straight into it and autograd gets None for that
+# input: this removes a 52 MB zero-fill and a 156 MB grad += pass from every step.  Only taken with the HIP backend
+# (layout support) and when nothing hooks the parameter's gradient; set to False for the plain autograd behaviour.
+ACCUMULATE_INTO_PARAM_GRAD = True
+
 
 def _supports_layout():
     try:
@@ -79,7 +85,10 @@ class _grid_encode(Function):
         calc_grad_inputs = ctx.calc_grad_inputs
 
         grad = grad.to(embeddings.dtype)
-        grad_embeddings = torch.zeros_like(embeddings)
+        direct_param = (ACCUMULATE_INTO_PARAM_GRAD and ctx.direct and embeddings.is_leaf and embeddings.grad is not None
+                        and embeddings.grad.dtype == embeddings.dtype and embeddings.grad.is_contiguous()
+                        and embeddings.grad.shape == embeddings.shape and not embeddings._backward_hooks)
+        grad_embeddings = embeddings.grad if direct_param else torch.zeros_like(embeddings)
         if calc_grad_inputs:
             grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
         else:
@@ -95,6 +104,8 @@ class _grid_encode(Function):
             _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
                                           calc_grad_inputs, dy_dx, grad_inputs, gridtype)
 
+        if direct_param:
+            grad_embeddings = None
         if calc_grad_inputs:
             return grad_inputs.to(inputs.dtype), grad_embeddings, None, None, None, None, None, None
         return None, grad_embeddings, None, None, None, None, None, None

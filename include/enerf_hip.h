@@ -192,6 +192,10 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
                          uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
                          uint32_t x_layout, enerf_stream_t stream);
 
+/* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
+ * default (768 for one hidden layer, 256 otherwise). */
+int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
+
 /* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
  * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */
 int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,

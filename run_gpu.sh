@@ -1,6 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/smoke.log 2>&1
-tail -4 gpurun_out/pytest_gpu.log; tail -1 gpurun_out/smoke.log
+for wb in 256 384 512 768 1024; do echo "wgrad blocks $wb"; python tools/bench_mlp32.py --wgrad-blocks $wb 2>&1 | grep inference | cut -c1-140; done
