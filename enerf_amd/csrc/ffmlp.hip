@@ -24,7 +24,7 @@ using namespace enerf_ffmlp;
 namespace {
 
 // ================================================================== forward / inference
-template <typename E, int IN_KB, int NL, bool TRAIN>
+template <typename E, int IN_KB, int NL, bool TRAIN, int ACT>
 __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, const E* __restrict__ W, E* __restrict__ fb,
                                                    E* __restrict__ Y, uint32_t B, uint32_t act, uint32_t out_act) {
     using x8 = typename V<E>::x8;
@@ -104,8 +104,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int ob = 0; ob < 2; ob++) {
-                apply_act(acc[t][ob], act);
-                tile_to_frags<E>(acc[t][ob], hb[t][ob]);
+                act_to_frags<E, ACT>(acc[t][ob], act, hb[t][ob]);
                 if (TRAIN) store_tile<E>(fb + s[t] * HID, ob, h, hb[t][ob]);
             }
 #pragma unroll
@@ -124,8 +123,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
                 x8 nb[2][2];
 #pragma unroll
                 for (int ob = 0; ob < 2; ob++) {
-                    apply_act(acc[t][ob], act);
-                    tile_to_frags<E>(acc[t][ob], nb[ob]);
+                    act_to_frags<E, ACT>(acc[t][ob], act, nb[ob]);
                     if (TRAIN) store_tile<E>(fb + ((size_t)l * B + s[t]) * HID, ob, h, nb[ob]);
                 }
 #pragma unroll
@@ -157,7 +155,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
 }
 
 // ================================================================== backward: activation gradients (dgrad chain)
-template <typename E, int IN_KB, int NL>
+template <typename E, int IN_KB, int NL, int ACT>
 __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY, const E* __restrict__ W,
                                                        const E* __restrict__ fb, E* __restrict__ bb,
                                                        E* __restrict__ dX, uint32_t B, uint32_t act) {
@@ -208,7 +206,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY,
             f32x16 a = mma(woT[ib], dyb, (f32x16)(0.0f));
             float fw[16];
             load_tile_f32<E>(fb + ((size_t)(NL - 1) * B + s) * HID, ib, h, fw);
-            apply_act_bwd(a, fw, act);
+            act_bwd_t<ACT>(a, fw, act);
             tile_to_frags<E>(a, gb[ib]);
             store_tile<E>(bb + s * HID, ib, h, gb[ib]);
         }
@@ -223,7 +221,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY,
                 for (int blk = 0; blk < 4; blk++) a = mma(whT[l - 1][ib][blk], gb[blk >> 1][blk & 1], a);
                 float fw[16];
                 load_tile_f32<E>(fb + ((size_t)(l - 1) * B + s) * HID, ib, h, fw);
-                apply_act_bwd(a, fw, act);
+                act_bwd_t<ACT>(a, fw, act);
                 tile_to_frags<E>(a, ng[ib]);
                 store_tile<E>(bb + ((size_t)jj * B + s) * HID, ib, h, ng[ib]);
             }
@@ -280,8 +278,9 @@ template <typename E, bool TRAIN>
 int run_fwd(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t num_layers, uint32_t act,
             uint32_t out_act, void* buffer, void* outputs, hipStream_t s) {
     const uint32_t grid = persistent_grid_fwd(B);
-    FFMLP_DISPATCH(E, (k_ffmlp_fwd<E, KB, NL, TRAIN><<<grid, 256, 0, s>>>((const E*)inputs, (const E*)weights, (E*)buffer,
-                                                                            (E*)outputs, B, act, out_act)));
+    FFMLP_DISPATCH_ACT(E, (k_ffmlp_fwd<E, KB, NL, TRAIN, ACT><<<grid, 256, 0, s>>>((const E*)inputs, (const E*)weights,
+                                                                                     (E*)buffer, (E*)outputs, B, act,
+                                                                                     out_act)));
     return 0;
 }
 
@@ -290,9 +289,9 @@ int run_bwd(const void* grad, const void* inputs, const void* weights, const voi
             uint32_t num_layers, uint32_t act, bool calc_grad_inputs, void* bb, void* grad_inputs, void* grad_weights,
             int dtype, hipStream_t s) {
     const uint32_t grid = persistent_grid(B);
-    FFMLP_DISPATCH(E, (k_ffmlp_bwd_act<E, KB, NL><<<grid, 256, 0, s>>>((const E*)grad, (const E*)weights, (const E*)fb,
-                                                                        (E*)bb, calc_grad_inputs ? (E*)grad_inputs : nullptr,
-                                                                        B, act)));
+    FFMLP_DISPATCH_ACT(E, (k_ffmlp_bwd_act<E, KB, NL, ACT><<<grid, 256, 0, s>>>(
+                              (const E*)grad, (const E*)weights, (const E*)fb, (E*)bb,
+                              calc_grad_inputs ? (E*)grad_inputs : nullptr, B, act)));
     return ffmlp_wgrad_launch(dtype, grad, inputs, fb, bb, B, input_dim, num_layers, grad_weights, s);
 }
 

@@ -139,6 +139,54 @@ __device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::
         for (int e = 0; e < 8; e++) out[kbb][e] = (E)acc[8 * kbb + e];
 }
 
+// activation + conversion of a hidden layer's D tile.  ReLU commutes with the (sign-symmetric, monotone) rounding to
+// 16 bits, so it is applied to the packed result: a signed 16-bit max with 0 on the bit patterns (negative values,
+// -0.0 and negative NaNs are negative integers -> +0.0), one v_pk_max_i16 per two elements instead of one v_max per
+// element before the conversion.
+// ACT: 0 = ReLU, 1 = none, 2 = any other activation (runtime code `a`, out-of-line).  The hidden activation is a
+// kernel template parameter: a runtime switch per tile puts a control-flow diamond (and its register copies) around
+// every one of the dozen tiles a wavefront processes per iteration.
+template <typename E, int ACT>
+__device__ __forceinline__ void act_to_frags(f32x16& acc, uint32_t a, typename V<E>::x8 (&out)[2]) {
+    if (ACT == 1) {
+        tile_to_frags<E>(acc, out);
+    } else if (ACT == 0) {
+        // convert pairs (one v_cvt_pk per two elements), clamp the packed pair, assemble the 16-byte fragment
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef E e16x2 __attribute__((ext_vector_type(2)));
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int kbb = 0; kbb < 2; kbb++) {
+            i32x4 r;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const f32x2 f = {acc[8 * kbb + 2 * p], acc[8 * kbb + 2 * p + 1]};
+                s16x2 v = __builtin_bit_cast(s16x2, __builtin_convertvector(f, e16x2));
+                v = __builtin_elementwise_max(v, (s16x2)(0));
+                r[p] = __builtin_bit_cast(int, v);
+            }
+            out[kbb] = __builtin_bit_cast(typename V<E>::x8, r);
+        }
+    } else {
+        acc = apply_act_generic(acc, a);
+        tile_to_frags<E>(acc, out);
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void act_bwd_t(f32x16& g, const float (&fw)[16], uint32_t a) {
+    if (ACT == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) g[q] = fw[q] > 0.0f ? g[q] : 0.0f;
+    } else if (ACT == 2) {
+        f32x16 f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) f[q] = fw[q];
+        g = apply_act_bwd_generic(g, f, a);
+    }
+}
+__host__ __device__ inline int act_class(uint32_t a) { return a == 0 ? 0 : (a == 6 ? 1 : 2); }
+
 // store / load one [32 samples][32 neurons] D-tile-shaped block of a row-major [B,64] 16-bit buffer:
 // lane (j, h) owns neurons 32*ib + 8*g + 4*h + r  (g = 0..3, r = 0..3)  <->  4 consecutive elements per g
 template <typename E>
@@ -170,6 +218,13 @@ __device__ __forceinline__ void stage_weights(E* wl, const E* __restrict__ w, ui
     for (uint32_t i = threadIdx.x; i < n / 8; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
+
+#define FFMLP_DISPATCH_ACT(E, CALL)                                                 \
+    switch (act_class(act)) {                                                       \
+        case 0: { constexpr int ACT = 0; FFMLP_DISPATCH(E, CALL); } break;          \
+        case 1: { constexpr int ACT = 1; FFMLP_DISPATCH(E, CALL); } break;          \
+        default: { constexpr int ACT = 2; FFMLP_DISPATCH(E, CALL); } break;         \
+    }
 
 #define FFMLP_DISPATCH(E, CALL)                                                     \
     switch (input_dim * 10 + num_layers) {                                          \

@@ -1,2 +1,3 @@
 #!/bin/bash
-for wb in 256 384 512 768 1024; do echo "wgrad blocks $wb"; python tools/bench_mlp32.py --wgrad-blocks $wb 2>&1 | grep inference | cut -c1-140; done
+timeout 600 python tools/bench_ffmlp.py 2>&1 | grep -E "inference" | cut -c1-200
+timeout 600 python -m pytest tests/test_gpu_ffmlp.py -m gpu -x -q 2>&1 | tail -2
