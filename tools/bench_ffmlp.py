@@ -25,9 +25,13 @@ def timeit(fn, n=20, warm=3):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=0, help="only this batch size (default: 307200 and 2097152)")
+    a = ap.parse_args()
     dev = "cuda"
     for dtype in (torch.bfloat16, torch.float16):
-        for B in (307200, 2 * 1024 * 1024):
+        for B in ((a.batch,) if a.batch else (307200, 2 * 1024 * 1024)):
             for name, k in (("sigma", 2), ("color", 3)):
                 nW = 64 * (32 + 64 * (k - 1) + 16)
                 W = (torch.rand(nW, device=dev) - 0.5).to(dtype)
@@ -50,9 +54,8 @@ def main():
                       f"{by_inf/t_inf/1e6:6.0f} GB/s) | train fwd {t_fwd*1e3:7.1f} us ({by_fwd/t_fwd/1e6:6.0f} GB/s) | "
                       f"bwd {t_bwd*1e3:7.1f} us ({3*flops/t_bwd/1e9:6.1f} TFLOP/s useful)")
     # fused fp32 MLP
-    import ctypes
     lib = L.lib()
-    for B in (131072, 2 * 1024 * 1024):
+    for B in ((a.batch,) if a.batch else (131072, 2 * 1024 * 1024)):
         for name, nh, od in (("sigma32", 1, 16), ("color32", 2, 3)):
             nW = 64 * 32 + (nh - 1) * 4096 + od * 64
             W = torch.rand(nW, device=dev) - 0.5
@@ -61,7 +64,7 @@ def main():
             fb = torch.empty(nh, B, 64, device=dev)
             s = L.stream_handle()
             t = timeit(lambda: lib.enerf_mlp32_forward(x.data_ptr(), W.data_ptr(), B, 32, od, nh, 0, 6, fb.data_ptr(),
-                                                       y.data_ptr(), s))
+                                                       y.data_ptr(), 0, s))
             flops = 2.0 * B * (32 * 64 + (nh - 1) * 4096 + 64 * 32)
             print(f"fp32 B={B:8d} {name}: train fwd {t*1e3:7.1f} us ({flops/t/1e9:6.1f} TFLOP/s of 157 peak)")
 

@@ -25,6 +25,6 @@ done
 python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_kernels.json --by-grid --meta "command=tools/bench_kernels.py" \
   $(find /tmp/k_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/k_WRITE_SIZE -name "*counter_collection.csv")
 
-rm -rf /tmp/p_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma -o c -- python $R/tools/bench_ffmlp.py > $OUT/ffmlp_under_mfma.log 2>&1
-python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_mfma_ffmlp.json --by-grid --meta "command=tools/bench_ffmlp.py" $(find /tmp/p_mfma -name "*counter_collection.csv")
+rm -rf /tmp/p_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma -o c -- python $R/tools/bench_ffmlp.py --batch 2097152 > $OUT/ffmlp_under_mfma.log 2>&1
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_mfma_ffmlp.json --by-grid --meta "command=tools/bench_ffmlp.py --batch 2097152" $(find /tmp/p_mfma -name "*counter_collection.csv")
 ls -la $OUT
