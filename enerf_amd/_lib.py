@@ -27,17 +27,19 @@ SIGNATURES = {
     "enerf_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_compact_rays": [_u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int,
-                                  _int, _vp],
+                                  _int, _f32, _f32, _vp],
     "enerf_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp,
-                                   _u32, _int, _int, _vp],
+                                   _u32, _int, _int, _f32, _f32, _vp],
     "enerf_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _int, _vp, _int, _vp],
     "enerf_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _int, _vp],
     "enerf_ffmlp_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _int, _vp],
     "enerf_ffmlp_inference": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _int, _vp],
     "enerf_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp,
                              _int, _vp],
-    "enerf_mlp32_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
-    "enerf_mlp32_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp],
+    "enerf_mlp32_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp],
+    "enerf_mlp32_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _vp,
+                             _u32, _vp],
+    "enerf_sh_encode_forward_strided": [_vp, _vp, _u32, _u32, _u32, _vp],
     "enerf_debug_grid_level_mask": [_u32],
     "enerf_debug_mlp32_wgrad_blocks": [_u32],
     "enerf_debug_grid_bwd_binned": [_u32, _u32],
@@ -47,6 +49,7 @@ SIGNATURES = {
     "enerf_prof_enable": [_int],
     "enerf_prof_reset": [],
     "enerf_prof_read": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],
+    "enerf_adam_step_multi": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp],
     "enerf_abi_version": [],
 }
 
@@ -84,8 +87,18 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
+_raw_stream = None
+
+
 def stream_handle():
+    """hipStream_t of torch's current stream on the current device (the raw-handle query is ~20x cheaper than
+    building a torch.cuda.Stream object, and this runs before every kernel launch)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -109,8 +122,7 @@ def check_contiguous(t, name):
 
 
 def check_floating(t, name):
-    import torch
-    if t.dtype not in (torch.float32, torch.float16, torch.float64):
+    if not t.dtype.is_floating_point:
         raise RuntimeError(f"{name} must be a floating tensor")
 
 

@@ -1,5 +1,6 @@
 """`_gridencoder`: grid_encode_forward / grid_encode_backward with the reference's pybind signature
-(gridencoder/src/bindings.cpp:5-8), plus keyword-only `layout` (0 = [L,B,C] as the reference, 1 = [B,L*C])."""
+(gridencoder/src/bindings.cpp:5-8), plus keyword-only `layout` (0 = [L,B,C] as the reference, 1 = [B,L*C],
+2 = [L,Bp,C] with Bp = B rounded up to 32) and `affine=(add, mul)`: the kernels read inputs as (x + add) * mul."""
 from .. import _lib as L
 
 # points processed per entry point since the last reset (bench.py: algorithmic bytes = 1164 B/point)
@@ -17,7 +18,7 @@ def _chk(t, name, floating=True):
 
 
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H, calc_grad_inputs, dy_dx, gridtype,
-                        *, layout=0):
+                        *, layout=0, affine=(0.0, 1.0)):
     import torch
     if inputs.dtype != torch.float32:
         raise RuntimeError("inputs must be a float32 tensor (gridencoder.cu:437 reads inputs as float*)")
@@ -29,12 +30,12 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H,
     L.check(L.lib().enerf_grid_encode_forward(_chk(inputs, "inputs"), _chk(embeddings, "embeddings"),
                                               _chk(offsets, "offsets", False), _chk(outputs, "outputs"), int(B),
                                               int(D), int(C), int(L_), float(S), int(H), int(bool(calc_grad_inputs)),
-                                              _chk(dy_dx, "dy_dx"), int(gridtype), dt, int(layout),
-                                              L.stream_handle()), "grid_encode_forward")
+                                              _chk(dy_dx, "dy_dx"), int(gridtype), dt, int(layout), affine[0],
+                                              affine[1], L.stream_handle()), "grid_encode_forward")
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L_, S, H, calc_grad_inputs,
-                         dy_dx, grad_inputs, gridtype, *, layout=0):
+                         dy_dx, grad_inputs, gridtype, *, layout=0, affine=(0.0, 1.0)):
     import torch
     if inputs.dtype != torch.float32:
         raise RuntimeError("inputs must be a float32 tensor")
@@ -50,5 +51,6 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                                                _chk(grad_embeddings, "grad_embeddings"), int(B), int(D), int(C),
                                                int(L_), float(S), int(H), int(bool(calc_grad_inputs)),
                                                _chk(dy_dx, "dy_dx"), _chk(grad_inputs, "grad_inputs"),
-                                               int(gridtype), dt, int(layout), L.stream_handle()),
+                                               int(gridtype), dt, int(layout), affine[0], affine[1],
+                                               L.stream_handle()),
             "grid_encode_backward")

@@ -40,6 +40,9 @@ struct LevelTab {
     float scale[kMaxLevels];
     uint32_t resolution[kMaxLevels];
     uint32_t level_mask;   // profiling aid (enerf_debug_grid_level_mask): levels whose bit is clear are skipped
+    float in_add, in_mul;  // inputs are read as (x + in_add) * in_mul: (0, 1) = as given; (bound, 1/(2 bound)) folds
+                           // the wrapper's normalisation (grid.py:150) into the kernels, rounded exactly as torch's
+                           // two elementwise kernels round it
 };
 
 uint32_t g_level_mask = 0xffffffffu;
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        in[d] = inputs[(size_t)b * D + d];
+        in[d] = (inputs[(size_t)b * D + d] + tab.in_add) * tab.in_mul;
         oob |= (in[d] < 0 || in[d] > 1);
     }
     Feat<T, C>* out = reinterpret_cast<Feat<T, C>*>(outputs) +
@@ -413,10 +416,10 @@ __device__ __forceinline__ void scatter_add(__half* row, float w, const float (&
 template <typename T, int D, int C>
 __device__ __forceinline__ bool load_sample(uint32_t b, bool valid, const T* __restrict__ grad,
                                             const float* __restrict__ inputs, uint32_t level, uint32_t B, uint32_t L,
-                                            int grad_layout, float (&in)[D], float (&g)[C]) {
+                                            int grad_layout, float in_add, float in_mul, float (&in)[D], float (&g)[C]) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        in[d] = valid ? inputs[(size_t)b * D + d] : 0.0f;
+        in[d] = valid ? (inputs[(size_t)b * D + d] + in_add) * in_mul : 0.0f;
         valid = valid && !(in[d] < 0 || in[d] > 1);   // out-of-range points contribute nothing
     }
     if (valid) {
@@ -532,7 +535,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
 
     float in[D], g[C], pos[D], v[(1 << D) * C];
     uint32_t pos_grid[D];
-    const bool valid = load_sample<T, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, in, g);
+    const bool valid = load_sample<T, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, tab.in_add, tab.in_mul, in, g);
     cell_of<D>(in, tab.scale[level], pos_grid, pos);
     corner_contrib<D, C>(pos, g, v);
     if (!aggregate_runs<D, C>(valid, lane, pos_grid, v)) return;
@@ -589,7 +592,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd_bin(const float* __re
 
     float in[D], g[C], pos[D], v[(1 << D) * C];
     uint32_t pos_grid[D], cr[1 << D], bin[1 << D], rank[1 << D];
-    const bool valid = load_sample<float, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, in, g);
+    const bool valid = load_sample<float, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, tab.in_add, tab.in_mul, in, g);
     cell_of<D>(in, tab.scale[level], pos_grid, pos);
     corner_contrib<D, C>(pos, g, v);
     const bool head = aggregate_runs<D, C>(valid, lane, pos_grid, v);
@@ -777,7 +780,9 @@ uint32_t* bin_cursors() {
     return g_bin_cursors;
 }
 
-int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H) {
+int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H, float in_add, float in_mul) {
+    tab.in_add = in_add;
+    tab.in_mul = in_mul;
     if (L == 0 || L > kMaxLevels) return -1;
     for (uint32_t l = 0; l < L; l++) {
         // gridencoder.cu:124-126: fp32 exp2f, fp32 multiply/subtract, ceil
@@ -873,10 +878,11 @@ int enerf_debug_grid_bwd_binned(uint32_t min_batch, uint32_t min_tiles) {
 
 int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
-                              void* dy_dx, uint32_t gridtype, int dtype, int out_layout, enerf_stream_t stream) {
+                              void* dy_dx, uint32_t gridtype, int dtype, int out_layout, float in_add, float in_mul,
+                              enerf_stream_t stream) {
     if (B == 0) return 0;
     LevelTab tab;
-    if (fill_level_tab(tab, L, S, H)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
+    if (fill_level_tab(tab, L, S, H, in_add, in_mul)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
     if (out_layout < 0 || out_layout > 2) ENERF_BADARG("GridEncoding: out_layout must be 0, 1 or 2, got %d", out_layout);
     hipStream_t s = (hipStream_t)stream;
@@ -900,11 +906,11 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
 int enerf_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int dtype,
-                               int grad_layout, enerf_stream_t stream) {
+                               int grad_layout, float in_add, float in_mul, enerf_stream_t stream) {
     (void)embeddings;
     if (B == 0) return 0;
     LevelTab tab;
-    if (fill_level_tab(tab, L, S, H)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
+    if (fill_level_tab(tab, L, S, H, in_add, in_mul)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
     if (grad_layout < 0 || grad_layout > 2) ENERF_BADARG("GridEncoding: grad_layout must be 0, 1 or 2, got %d", grad_layout);
     hipStream_t s = (hipStream_t)stream;

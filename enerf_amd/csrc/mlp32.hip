@@ -36,6 +36,34 @@ __device__ __forceinline__ f32x16 mma(float a, float b, f32x16 c) {
 __device__ __forceinline__ int nrow(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 __device__ __forceinline__ float act_fwd(float x, uint32_t a) { return a == 0 ? (x > 0 ? x : 0.0f) : x; }
+// output activation: relu (0), sigmoid (3, torch's 1 / (1 + exp(-x))), none (6)
+__device__ __forceinline__ float out_act_fwd(float x, uint32_t a) {
+    return a == 0 ? (x > 0 ? x : 0.0f) : (a == 3 ? 1.0f / (1.0f + expf(-x)) : x);
+}
+
+// Where the backward kernels take dL/dY from.  Plain: dY[s * stride + o].  Optional fusions of the caller's epilogue:
+//   y_sig != NULL : the forward applied a sigmoid; dY is the gradient of the sigmoid's output and y_sig its value:
+//                   dL/dY = (dY * (1 - y)) * y                                     (torch sigmoid_backward)
+//   dsigma != NULL: output column 0 went through trunc_exp (activation.py:5-17); its gradient is
+//                   dsigma[s] * exp(clamp(h0[s * h0_stride], -15, 15)) instead of dY[.., 0]
+struct DySource {
+    const float* dY;
+    uint32_t stride;
+    const float* y_sig;
+    uint32_t y_sig_stride;
+    const float* dsigma;
+    const float* h0;
+    uint32_t h0_stride;
+};
+__device__ __forceinline__ float load_dy(const DySource& d, size_t s, uint32_t o) {
+    if (d.dsigma && o == 0) return d.dsigma[s] * expf(fminf(fmaxf(d.h0[s * d.h0_stride], -15.0f), 15.0f));
+    float g = d.dY[s * d.stride + o];
+    if (d.y_sig) {
+        const float y = d.y_sig[s * d.y_sig_stride + o];
+        g = (g * (1.0f - y)) * y;
+    }
+    return g;
+}
 __device__ __forceinline__ float act_bwd(float g, float fwd, uint32_t a) { return a == 0 ? (fwd > 0 ? g : 0.0f) : g; }
 
 // blob: [W0 64 x 32 | Wh (NH-1) x 64 x 64 | Wout out_dim x 64], row-major W[out][in]
@@ -75,7 +103,8 @@ __device__ __forceinline__ int kmap(int p, int h) {
 template <int NH, bool TRAIN, int XL>
 __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                    float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
-                                                   uint32_t out_dim, uint32_t act, uint32_t out_act) {
+                                                   uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
+                                                   float* __restrict__ y0_exp) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     stage(wl, W, blob_size(NH, out_dim));
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
@@ -164,7 +193,8 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t r = (uint32_t)nrow(q, h);
-                if (r < out_dim) Y[s * out_dim + r] = act_fwd(o[q], out_act);
+                if (r < out_dim) Y[s * y_stride + r] = out_act_fwd(o[q], out_act);
+                if (r == 0 && y0_exp) y0_exp[s] = expf(o[q]);      // trunc_exp forward of output column 0
             }
         }
     }
@@ -173,7 +203,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
 // ================================================================== backward: activation gradients
 // KPO = number of contraction pairs covering the output dimension (out_dim <= 2 * KPO): pair p = (p, KPO + p)
 template <int NH, int KPO, int XL>
-__global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__ dY, const float* __restrict__ W,
+__global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, const float* __restrict__ W,
                                                        const float* __restrict__ fb, float* __restrict__ bb,
                                                        float* __restrict__ dX, uint32_t B, uint32_t out_dim,
                                                        uint32_t act) {
@@ -215,7 +245,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
 #pragma unroll
         for (int p = 0; p < KPO; p++) {
             const uint32_t o = (uint32_t)(p + KPO * h);
-            dy[p] = (valid && o < out_dim) ? dY[s * out_dim + o] : 0.0f;
+            dy[p] = (valid && o < out_dim) ? load_dy(dys, s, o) : 0.0f;
         }
         f32x16 g[2];
 #pragma unroll
@@ -282,7 +312,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(const float* __restrict__
 // floats: the 32 lanes of a half-wave then read 32 distinct banks) and takes the B operand from there.
 constexpr int XT_LD = 66;
 template <int NH, int XL>
-__global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ dY, const float* __restrict__ X,
+__global__ void __launch_bounds__(256) k_mlp32_bwd_w(DySource dys, const float* __restrict__ X,
                                                      const float* __restrict__ fb, const float* __restrict__ bb,
                                                      float* __restrict__ partial, uint32_t B, uint32_t out_dim) {
     extern __shared__ __attribute__((aligned(16))) float red[];
@@ -343,7 +373,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_w(const float* __restrict__ d
             }
             // output layer
             const float* in = fb + ((size_t)(NH - 1) * Bp + s) * HID;
-            const float dyv = ((uint32_t)j < out_dim && s < B) ? dY[s * out_dim + j] : 0.0f;
+            const float dyv = ((uint32_t)j < out_dim && s < B) ? load_dy(dys, s, (uint32_t)j) : 0.0f;
             awo[0] = mma(dyv, in[j], awo[0]);
             awo[1] = mma(dyv, in[32 + j], awo[1]);
         }
@@ -425,19 +455,23 @@ int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks) {
 // weights: [W0 64x32 | Wh (num_hidden-1) x 64x64 | Wout out_dim x 64]; fb [num_hidden,Bp,64] or NULL (inference).
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
-                        uint32_t x_layout, enerf_stream_t stream) {
+                        uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream) {
     if (B == 0) return 0;
     if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32 (pad the input), got %u", in_dim);
     if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
     if (activation != 0 && activation != 6) ENERF_BADARG("mlp32: activation must be relu (0) or none (6)");
     if (x_layout > 1) ENERF_BADARG("mlp32: x_layout must be 0 (row-major) or 1 (level-major), got %u", x_layout);
+    if (output_activation != 0 && output_activation != 3 && output_activation != 6)
+        ENERF_BADARG("mlp32: output activation must be relu (0), sigmoid (3) or none (6)");
+    if (y_stride == 0) y_stride = out_dim;
+    if (y_stride < out_dim) ENERF_BADARG("mlp32: y_stride %u < out_dim %u", y_stride, out_dim);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_FWD, s);
     const uint32_t grid = pgrid(B, 1024);
     const size_t lds = sizeof(float) * (HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID);
 #define MLP32_FWD2(NHV, TR, XLV) \
-    k_mlp32_fwd<NHV, TR, XLV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation)
+    k_mlp32_fwd<NHV, TR, XLV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation, y_stride, y0_exp)
 #define MLP32_FWD(NHV)                                        \
     do {                                                      \
         if (fb) {                                             \
@@ -461,12 +495,22 @@ int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_
 // [16,Bp,2] (x_layout 1, pad rows written as zeros); dW (fp32 blob) is ACCUMULATED into (+=).
 int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const float* fb, uint32_t B, uint32_t in_dim,
                          uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
-                         uint32_t x_layout, enerf_stream_t stream) {
+                         uint32_t x_layout, uint32_t dy_stride, const float* y_sigmoid, uint32_t y_sigmoid_stride,
+                         const float* dsigma, const float* h0, uint32_t h0_stride, enerf_stream_t stream) {
     if (B == 0) return 0;
     if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32, got %u", in_dim);
     if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
     if (x_layout > 1) ENERF_BADARG("mlp32: x_layout must be 0 (row-major) or 1 (level-major), got %u", x_layout);
+    if ((dsigma == nullptr) != (h0 == nullptr)) ENERF_BADARG("mlp32: dsigma and h0 go together");
+    DySource dys;
+    dys.dY = dY;
+    dys.stride = dy_stride ? dy_stride : out_dim;
+    dys.y_sig = y_sigmoid;
+    dys.y_sig_stride = y_sigmoid_stride ? y_sigmoid_stride : out_dim;
+    dys.dsigma = dsigma;
+    dys.h0 = h0;
+    dys.h0_stride = h0_stride ? h0_stride : 1u;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_BWD, s);
     const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
@@ -477,13 +521,13 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
     float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NW);
     if (!partial) return ENERF_E_NOMEM;
 #define MLP32_BA(NHV, KPOV, XLV) \
-    k_mlp32_bwd_act<NHV, KPOV, XLV><<<grid, 256, lds, s>>>(dY, W, fb, bb, dX, B, out_dim, activation)
+    k_mlp32_bwd_act<NHV, KPOV, XLV><<<grid, 256, lds, s>>>(dys, W, fb, bb, dX, B, out_dim, activation)
 #define MLP32_BWD2(NHV, XLV)                                                                      \
     do {                                                                                          \
         if (out_dim <= 4) MLP32_BA(NHV, 2, XLV);                                                  \
         else if (out_dim <= 16) MLP32_BA(NHV, 8, XLV);                                            \
         else MLP32_BA(NHV, 16, XLV);                                                              \
-        k_mlp32_bwd_w<NHV, XLV><<<wgrid, 256, lds_w, s>>>(dY, X, fb, bb, partial, B, out_dim);    \
+        k_mlp32_bwd_w<NHV, XLV><<<wgrid, 256, lds_w, s>>>(dys, X, fb, bb, partial, B, out_dim);   \
     } while (0)
 #define MLP32_BWD(NHV)                          \
     do {                                        \

@@ -46,9 +46,93 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, float* __re
     }
 }
 
+// All parameters of a model in one launch: the table travels as a kernel argument (no device-side descriptor to keep
+// in sync); workgroup b works on tensor t with first_block[t] <= b < first_block[t + 1].
+constexpr int kMaxAdamTensors = 16;
+struct AdamTable {
+    float* p[kMaxAdamTensors];
+    float* g[kMaxAdamTensors];
+    float* m[kMaxAdamTensors];
+    float* v[kMaxAdamTensors];
+    unsigned long long n[kMaxAdamTensors];
+    float step_size[kMaxAdamTensors];
+    float inv_bc2_sqrt[kMaxAdamTensors];
+    uint32_t first_block[kMaxAdamTensors + 1];
+    uint32_t count;
+};
+
+__global__ void __launch_bounds__(256) k_adam_multi(AdamTable tab, float b1, float b2, float eps, int zero_grad) {
+    uint32_t t = 0;
+    while (t + 1 < tab.count && blockIdx.x >= tab.first_block[t + 1]) t++;
+    float* __restrict__ p = tab.p[t];
+    float* __restrict__ g = tab.g[t];
+    float* __restrict__ m = tab.m[t];
+    float* __restrict__ v = tab.v[t];
+    const size_t n = tab.n[t];
+    const float step_size = tab.step_size[t], inv_bc2_sqrt = tab.inv_bc2_sqrt[t];
+    const uint32_t nblk = tab.first_block[t + 1] - tab.first_block[t];
+    const uint32_t blk = blockIdx.x - tab.first_block[t];
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)nblk * blockDim.x;
+    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        adam1(P.x, G.x, M.x, V.x, b1, b2, eps, step_size, inv_bc2_sqrt);
+        adam1(P.y, G.y, M.y, V.y, b1, b2, eps, step_size, inv_bc2_sqrt);
+        adam1(P.z, G.z, M.z, V.z, b1, b2, eps, step_size, inv_bc2_sqrt);
+        adam1(P.w, G.w, M.w, V.w, b1, b2, eps, step_size, inv_bc2_sqrt);
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const size_t tl = n4 * 4 + (size_t)blk * blockDim.x + threadIdx.x;
+    if (tl < n) {
+        float P = p[tl], M = m[tl], V = v[tl];
+        adam1(P, g[tl], M, V, b1, b2, eps, step_size, inv_bc2_sqrt);
+        p[tl] = P; m[tl] = M; v[tl] = V;
+        if (zero_grad) g[tl] = 0.0f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// The same update for up to 16 parameters in one launch (per-tensor lr and step count; shared betas / eps).
+int enerf_adam_step_multi(uint32_t count, float* const* p, float* const* g, float* const* m, float* const* v,
+                          const size_t* n, const float* lr, const uint32_t* step, float beta1, float beta2, float eps,
+                          int zero_grad, enerf_stream_t stream) {
+    if (count == 0) return 0;
+    if (count > (uint32_t)kMaxAdamTensors) ENERF_BADARG("adam_step_multi: at most %d tensors per call, got %u", kMaxAdamTensors, count);
+    AdamTable tab;
+    uint32_t blocks = 0;
+    for (uint32_t t = 0; t < count; t++) {
+        if ((((uintptr_t)p[t] | (uintptr_t)g[t] | (uintptr_t)m[t] | (uintptr_t)v[t]) & 15) != 0)
+            ENERF_BADARG("adam_step_multi: p/g/m/v must be 16-byte aligned");
+        if (step[t] == 0) ENERF_BADARG("adam_step_multi: step counts from 1");
+        if (n[t] == 0) ENERF_BADARG("adam_step_multi: empty tensor");
+        tab.p[t] = p[t]; tab.g[t] = g[t]; tab.m[t] = m[t]; tab.v[t] = v[t];
+        tab.n[t] = n[t];
+        const double bc1 = 1.0 - pow((double)beta1, (double)step[t]);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step[t]);
+        tab.step_size[t] = (float)((double)lr[t] / bc1);
+        tab.inv_bc2_sqrt[t] = (float)(1.0 / sqrt(bc2));
+        const size_t n4 = n[t] / 4 ? n[t] / 4 : 1;
+        uint32_t b = (uint32_t)((n4 + 255) / 256);
+        if (b > 2048u) b = 2048u;
+        tab.first_block[t] = blocks;
+        blocks += b;
+    }
+    tab.first_block[count] = blocks;
+    tab.count = count;
+    k_adam_multi<<<blocks, 256, 0, (hipStream_t)stream>>>(tab, beta1, beta2, eps, zero_grad);
+    ENERF_LAUNCH_CHECK("adam_step_multi");
+    return 0;
+}
+
 
 // One Adam update of a contiguous fp32 parameter: `step` is the 1-based step count used for bias correction.
 // p, g, m, v must be 16-byte aligned.  zero_grad != 0 also clears g in the same pass.

@@ -27,7 +27,7 @@ __device__ __forceinline__ void st_f(__half* p, float v) { *p = __float2half(v);
 
 template <typename T, int DEG, bool JAC>
 __global__ void __launch_bounds__(256) k_sh_fwd(const T* __restrict__ inputs, T* __restrict__ outputs, uint32_t B,
-                                                T* __restrict__ dy_dx, ShNorm nrm) {
+                                                T* __restrict__ dy_dx, ShNorm nrm, uint32_t out_stride) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     constexpr int C2 = DEG * DEG;
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) k_sh_fwd(const T* __restrict__ inputs, T*
         }
     }
 
-    T* out = outputs + (size_t)b * C2;
+    T* out = outputs + (size_t)b * out_stride;
     if constexpr (sizeof(T) == 4 && (C2 % 4) == 0) {
 #pragma unroll
         for (int i = 0; i < C2; i += 4)
@@ -143,26 +143,28 @@ void fill_norm(ShNorm& nrm) {
 }
 
 template <typename T, int DEG>
-void launch_sh(const T* in, T* out, uint32_t B, bool jac, T* dy_dx, const ShNorm& nrm, hipStream_t s) {
+void launch_sh(const T* in, T* out, uint32_t B, bool jac, T* dy_dx, const ShNorm& nrm, uint32_t out_stride,
+               hipStream_t s) {
+    const uint32_t stride = out_stride ? out_stride : (uint32_t)(DEG * DEG);
     if (jac)
-        k_sh_fwd<T, DEG, true><<<div_up(B, 256), 256, 0, s>>>(in, out, B, dy_dx, nrm);
+        k_sh_fwd<T, DEG, true><<<div_up(B, 256), 256, 0, s>>>(in, out, B, dy_dx, nrm, stride);
     else
-        k_sh_fwd<T, DEG, false><<<div_up(B, 256), 256, 0, s>>>(in, out, B, dy_dx, nrm);
+        k_sh_fwd<T, DEG, false><<<div_up(B, 256), 256, 0, s>>>(in, out, B, dy_dx, nrm, stride);
 }
 
 template <typename T>
-int dispatch_sh(const T* in, T* out, uint32_t B, uint32_t C, bool jac, T* dy_dx, hipStream_t s) {
+int dispatch_sh(const T* in, T* out, uint32_t B, uint32_t C, bool jac, T* dy_dx, uint32_t out_stride, hipStream_t s) {
     ShNorm nrm;
     fill_norm(nrm);
     switch (C) {
-        case 1: launch_sh<T, 1>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 2: launch_sh<T, 2>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 3: launch_sh<T, 3>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 4: launch_sh<T, 4>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 5: launch_sh<T, 5>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 6: launch_sh<T, 6>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 7: launch_sh<T, 7>(in, out, B, jac, dy_dx, nrm, s); break;
-        case 8: launch_sh<T, 8>(in, out, B, jac, dy_dx, nrm, s); break;
+        case 1: launch_sh<T, 1>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 2: launch_sh<T, 2>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 3: launch_sh<T, 3>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 4: launch_sh<T, 4>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 5: launch_sh<T, 5>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 6: launch_sh<T, 6>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 7: launch_sh<T, 7>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
+        case 8: launch_sh<T, 8>(in, out, B, jac, dy_dx, nrm, out_stride, s); break;
         default: ENERF_BADARG("SH encoder only supports degree in [1, 8], got %u", C);
     }
     return 0;
@@ -179,11 +181,24 @@ int enerf_sh_encode_forward(const void* inputs, void* outputs, uint32_t B, uint3
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_SH_FWD, s);
     int rc;
-    if (dtype == ENERF_F32) rc = dispatch_sh<float>((const float*)inputs, (float*)outputs, B, C, calc_grad_inputs != 0, (float*)dy_dx, s);
-    else if (dtype == ENERF_F16) rc = dispatch_sh<__half>((const __half*)inputs, (__half*)outputs, B, C, calc_grad_inputs != 0, (__half*)dy_dx, s);
+    if (dtype == ENERF_F32) rc = dispatch_sh<float>((const float*)inputs, (float*)outputs, B, C, calc_grad_inputs != 0, (float*)dy_dx, 0, s);
+    else if (dtype == ENERF_F16) rc = dispatch_sh<__half>((const __half*)inputs, (__half*)outputs, B, C, calc_grad_inputs != 0, (__half*)dy_dx, 0, s);
     else ENERF_BADARG("SH encoder: dtype must be f32 or f16");
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("sh_encode_forward");
+    return 0;
+}
+
+// extension: fp32 forward without Jacobian into rows of `out_stride` floats (e.g. columns 16..31 of a [B,32] buffer)
+int enerf_sh_encode_forward_strided(const float* inputs, float* outputs, uint32_t B, uint32_t C, uint32_t out_stride,
+                                    enerf_stream_t stream) {
+    if (B == 0) return 0;
+    if (out_stride < C * C) ENERF_BADARG("SH encoder: out_stride %u < degree^2", out_stride);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_SH_FWD, s);
+    const int rc = dispatch_sh<float>(inputs, outputs, B, C, false, nullptr, out_stride, s);
+    if (rc) return rc;
+    ENERF_LAUNCH_CHECK("sh_encode_forward_strided");
     return 0;
 }
 

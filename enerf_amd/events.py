@@ -123,7 +123,9 @@ def train_step_events(model, data, opt, criterion=None):
     images = data["images"]
     B = images.shape[0]
     dev = data["rays_evs_o1"].device
-    bg = torch.rand((B, 1, opt.out_dim_color)).to(dev)
+    # the reference draws this on the host and copies it over (nerf/utils.py:497); a pageable host->device copy
+    # drains the stream every step, so the same U[0,1) draw is made on the device
+    bg = torch.rand((B, 1, opt.out_dim_color), device=dev)
     kw = dict(opt.render_kwargs)
     kw.setdefault("out_dim_color", opt.out_dim_color)
     out1 = model.render(data["rays_evs_o1"], data["rays_evs_d1"], staged=False, bg_color=bg, perturb=True, **kw)

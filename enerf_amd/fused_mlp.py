@@ -76,7 +76,7 @@ class _FusedMLP32(Function):
         if B0 > 0:
             L.check(L.lib().enerf_mlp32_forward(xp.data_ptr(), blob.data_ptr(), B0, 32, out_dim, num_hidden,
                                                 activation, 6, fb.data_ptr() if fb is not None else None,
-                                                y.data_ptr(), x_layout, L.stream_handle()), "mlp32_forward")
+                                                y.data_ptr(), x_layout, 0, None, L.stream_handle()), "mlp32_forward")
         if train:
             ctx.save_for_backward(xp, blob, fb)
             ctx.meta = (B0, in_dim, out_dim, num_hidden, activation, [tuple(w.shape) for w in weights],
@@ -100,7 +100,7 @@ class _FusedMLP32(Function):
             L.check(L.lib().enerf_mlp32_backward(g.data_ptr(), xp.data_ptr(), blob.data_ptr(), fb.data_ptr(), B0, 32,
                                                  out_dim, num_hidden, activation, bb.data_ptr(),
                                                  dx.data_ptr() if dx is not None else None, dw.data_ptr(), x_layout,
-                                                 L.stream_handle()), "mlp32_backward")
+                                                 0, None, 0, None, None, 0, L.stream_handle()), "mlp32_backward")
         elif dx is not None:
             dx.zero_()
         grads, off = [], 0

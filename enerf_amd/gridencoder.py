@@ -23,11 +23,21 @@ _gridtype_to_id = {"hash": 0, "tiled": 1}
 ACCUMULATE_INTO_PARAM_GRAD = True
 
 
+_layout_support = {}
+
+
 def _supports_layout():
-    try:
-        return "layout" in inspect.signature(_backend.grid_encode_forward).parameters
-    except (TypeError, ValueError):
-        return False
+    """Does the active backend's grid_encode_forward take `layout=`?  (cached per backend function: tests swap the
+    module-level `_backend` for the CPU oracle's)"""
+    fn = _backend.grid_encode_forward
+    r = _layout_support.get(fn)
+    if r is None:
+        try:
+            r = "layout" in inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            r = False
+        _layout_support[fn] = r
+    return r
 
 
 class _grid_encode(Function):

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused_mlp
+from . import fused_mlp, fused_network
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .gridencoder import GridEncoder, _supports_layout
@@ -88,6 +88,8 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d):
         """x [N,3] in [-bound,bound], d [N,3] -> sigma [N], color [N,out_dim_color]   (network.py:104-132)"""
+        if fused_network.supported(self, x, d):
+            return fused_network.forward(self, x, d)
         h = self._sigma_mlp(x)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]

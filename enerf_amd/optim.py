@@ -1,7 +1,8 @@
-"""`FusedAdam`: torch.optim.Adam semantics (no weight decay, no amsgrad) with one fused HIP pass per parameter
+"""`FusedAdam`: torch.optim.Adam semantics (no weight decay, no amsgrad) with one fused HIP launch for all parameters
 (csrc/optim.hip).  Drop-in for `torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)` of the
 reference (main_nerf.py:211); param_groups / lr schedulers / state_dict work as for any torch optimizer.
 Parameters that are not CUDA fp32 fall back to the same update written in torch ops."""
+import ctypes
 import math
 
 import torch
@@ -19,6 +20,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        batches = {}          # (beta1, beta2, eps) -> parameters the fused kernel takes, all in one launch
         for group in self.param_groups:
             b1, b2 = group["betas"]
             lr, eps = float(group["lr"]), float(group["eps"])
@@ -33,14 +35,23 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 g = p.grad
                 if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() \
-                        and g.dtype == torch.float32:
-                    L.check(L.lib().enerf_adam_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                                    st["exp_avg_sq"].data_ptr(), p.numel(), lr, b1, b2, eps,
-                                                    st["step"], 0, L.stream_handle()), "adam_step")
+                        and g.dtype == torch.float32 and p.numel() > 0:
+                    batches.setdefault((b1, b2, eps), []).append((p, g, st, lr))
                 else:
                     m, v, t = st["exp_avg"], st["exp_avg_sq"], st["step"]
                     m.lerp_(g, 1 - b1)
                     v.mul_(b2).addcmul_(g, g, value=1 - b2)
                     denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
                     p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+        for (b1, b2, eps), items in batches.items():
+            for k in range(0, len(items), 16):
+                chunk = items[k:k + 16]
+                n = len(chunk)
+                vp, sz, fl, u32 = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_float * n, ctypes.c_uint32 * n
+                L.check(L.lib().enerf_adam_step_multi(
+                    n, vp(*[p.data_ptr() for p, _, _, _ in chunk]), vp(*[g.data_ptr() for _, g, _, _ in chunk]),
+                    vp(*[st["exp_avg"].data_ptr() for _, _, st, _ in chunk]),
+                    vp(*[st["exp_avg_sq"].data_ptr() for _, _, st, _ in chunk]),
+                    sz(*[p.numel() for p, _, _, _ in chunk]), fl(*[lr for _, _, _, lr in chunk]),
+                    u32(*[st["step"] for _, _, st, _ in chunk]), b1, b2, eps, 0, L.stream_handle()), "adam_step_multi")
         return loss

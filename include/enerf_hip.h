@@ -119,13 +119,16 @@ int enerf_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* ray
  * embeddings / outputs / dy_dx / grad share `dtype` (ENERF_F32 or ENERF_F16).
  * out_layout 0 = the reference's [L,B,C]; 1 = [B,L*C] written directly (saves the permute copy of
  * gridencoder/grid.py:52,70 -- used by enerf_amd's own wrapper, not by the reference's); 2 = [L,Bp,C] with
- * Bp = B rounded up to a multiple of 32 and the pad rows zero-filled (the level-major input of enerf_mlp32_*). */
+ * Bp = B rounded up to a multiple of 32 and the pad rows zero-filled (the level-major input of enerf_mlp32_*).
+ * in_add / in_mul: the kernels read every input coordinate as (x + in_add) * in_mul -- (0, 1) for inputs already in
+ * [0,1] as the reference passes them, (bound, 1/(2*bound)) to fold the wrapper's normalisation (grid.py:150) in.
+ * NOTE with a non-identity transform dy_dx / grad_inputs are with respect to the transformed coordinates. */
 
 /* grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype) */
 int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                               int calc_grad_inputs, void* dy_dx, uint32_t gridtype, int dtype, int out_layout,
-                              enerf_stream_t stream);
+                              float in_add, float in_mul, enerf_stream_t stream);
 
 /* grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs,
  *                      dy_dx, grad_inputs, gridtype); grad_embeddings must be zero-filled (grid.py:72);
@@ -133,7 +136,8 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
 int enerf_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs,
-                               uint32_t gridtype, int dtype, int grad_layout, enerf_stream_t stream);
+                               uint32_t gridtype, int dtype, int grad_layout, float in_add, float in_mul,
+                               enerf_stream_t stream);
 
 /* ------------------------------------------------------------------ shencoder
  * shencoder/src/shencoder.cu:402-441; `dtype` ENERF_F32 or ENERF_F16 for every tensor. */
@@ -141,6 +145,11 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
 /* sh_encode_forward(inputs, outputs, B, D, C, calc_grad_inputs, dy_dx);  D must be 3, 1 <= C <= 8 */
 int enerf_sh_encode_forward(const void* inputs, void* outputs, uint32_t B, uint32_t D, uint32_t C,
                             int calc_grad_inputs, void* dy_dx, int dtype, enerf_stream_t stream);
+
+/* extension: fp32 forward, no Jacobian, rows of `outputs` out_stride floats apart (e.g. a 16-column slice of a
+ * [B,32] buffer; 16-byte aligned rows when degree^2 % 4 == 0) */
+int enerf_sh_encode_forward_strided(const float* inputs, float* outputs, uint32_t B, uint32_t C, uint32_t out_stride,
+                                    enerf_stream_t stream);
 
 /* sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs); accumulates into grad_inputs */
 int enerf_sh_encode_backward(const void* grad, const void* inputs, uint32_t B, uint32_t D, uint32_t C,
@@ -182,15 +191,24 @@ int enerf_free_splitk(void);
  * Y [B,out_dim <= 32], no bias; W = [W0 64x32 | Wh (num_hidden-1)x64x64 | Wout out_dim x 64], each W[out][in].
  * B is ragged; Bp = B rounded up to a multiple of 32.  x_layout 0: X is [B,32] row-major; x_layout 1: X is the
  * level-major [16,Bp,2] tensor enerf_grid_encode_forward writes with out_layout 2 (column k = 2*level + c).
- * fb [num_hidden,Bp,64] receives the post-activation hidden states (NULL = inference). */
+ * fb [num_hidden,Bp,64] receives the post-activation hidden states (NULL = inference).
+ * activation: relu (0) / none (6); output_activation additionally sigmoid (3).  Rows of Y are y_stride floats apart
+ * (0 = out_dim), so the result can land in a slice of a wider buffer; y0_exp (optional, [B]) receives
+ * exp(Y[:,0]) -- the trunc_exp forward of the density column (activation.py:5-17). */
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
-                        uint32_t x_layout, enerf_stream_t stream);
-/* dY [B,out_dim]; bb [num_hidden,Bp,64] is scratch (written); dX NULL or laid out like X (x_layout 1: pad rows are
- * written as zeros, ready for enerf_grid_encode_backward with grad_layout 2); dW (fp32 blob) is accumulated (+=). */
+                        uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream);
+/* dY [B,out_dim] with rows dy_stride floats apart (0 = out_dim); bb [num_hidden,Bp,64] is scratch (written); dX NULL
+ * or laid out like X (x_layout 1: pad rows are written as zeros, ready for enerf_grid_encode_backward with
+ * grad_layout 2); dW (fp32 blob) is accumulated (+=).  Optional fused epilogue gradients:
+ *   y_sigmoid (rows y_sigmoid_stride apart): the forward's sigmoid output; dY is then the gradient of the sigmoid's
+ *     output and (dY * (1 - y)) * y is back-propagated;
+ *   dsigma [B] + h0 (rows h0_stride apart): the gradient of output column 0 is dsigma * exp(clamp(h0, -15, 15))
+ *     (trunc_exp backward) instead of dY[:,0]. */
 int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const float* fb, uint32_t B, uint32_t in_dim,
                          uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb, float* dX, float* dW,
-                         uint32_t x_layout, enerf_stream_t stream);
+                         uint32_t x_layout, uint32_t dy_stride, const float* y_sigmoid, uint32_t y_sigmoid_stride,
+                         const float* dsigma, const float* h0, uint32_t h0_stride, enerf_stream_t stream);
 
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 256 otherwise). */
@@ -200,6 +218,11 @@ int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
  * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */
 int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                     uint32_t step, int zero_grad, enerf_stream_t stream);
+/* The same update for up to 16 parameters in one launch: arrays of `count` device pointers / sizes / learning rates /
+ * step counts (host memory), shared betas and eps. */
+int enerf_adam_step_multi(uint32_t count, float* const* p, float* const* g, float* const* m, float* const* v,
+                          const size_t* n, const float* lr, const uint32_t* step, float beta1, float beta2, float eps,
+                          int zero_grad, enerf_stream_t stream);
 
 /* profiling aid: restrict grid_encode_forward/backward to the levels whose bit is set (default all) */
 int enerf_debug_grid_level_mask(uint32_t mask);

@@ -1,5 +1,8 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r01; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/p_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma -o c -- python $R/tools/bench_ffmlp.py --batch 2097152 > $OUT/ffmlp_under_mfma.log 2>&1
-python $R/tools/pmc_summary.py $OUT/r01_pmc_mfma_ffmlp.json --by-grid --meta "command=tools/bench_ffmlp.py --batch 2097152" $(find /tmp/p_mfma -name "*counter_collection.csv")
-cd $R; python tools/bench_ffmlp.py > gpurun_out/ffmlp.log 2>&1; tail -5 gpurun_out/ffmlp.log
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -3 gpurun_out/pytest_gpu.log | cut -c1-250
+for i in 1 2; do timeout 600 python bench.py --no-cpu-baseline --render-frames 0 2>&1 | tail -1 | cut -c1-160; done
+timeout 600 python bench.py --no-cpu-baseline --render-frames 0 --mode events 2>&1 | tail -1 | cut -c1-160
+python tools/cpu_profile_step.py 2>&1 | grep enqueue

@@ -99,9 +99,57 @@ def test_level_major_encoder_into_fused_mlp(B):
         assert float((a - b).abs().max()) <= (2e-5 + 1e-3 * n_kink) * float(b.abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("N", [1, 4096, 70001])
+def test_fused_network_node_matches_unfused_route(monkeypatch, N):
+    """enerf_amd.fused_network (one autograd node for grid -> sigma MLP -> trunc_exp / SH -> colour MLP -> sigmoid)
+    against the op-by-op route of network.py, which itself is pinned against the nn.Linear loop below."""
+    from enerf_amd import fused_network as fn
+    from enerf_amd.network import NeRFNetwork
+    torch.manual_seed(1)
+    m = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(DEV)
+    m.encoder.embeddings.data.uniform_(-1, 1)
+    x = torch.rand(N, 3, device=DEV) * 6 - 3
+    x[0] = torch.tensor([3.0, -3.0, 0.5])                      # on the boundary
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=DEV), dim=-1)
+    gs, gc = torch.randn(N, device=DEV), torch.randn(N, 3, device=DEV)
+
+    def run(enabled):
+        monkeypatch.setattr(fn, "ENABLED", enabled)
+        m.zero_grad()
+        s, c = m(x, d)
+        ((s * gs).sum() + (c * gc).sum()).backward()
+        return s.detach(), c.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    calls = []
+    orig = fn.forward
+    monkeypatch.setattr(fn, "forward", lambda *a: (calls.append(1), orig(*a))[1])
+    s1, c1, g1 = run(True)
+    assert len(calls) == 1
+    s0, c0, g0 = run(False)
+    assert len(calls) == 1
+    assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-6)).max()) < 2e-5
+    assert float((c1 - c0).abs().max()) < 2e-6
+    for n in g0:
+        tol = 5e-4 if N > 10000 else 5e-5          # a ReLU kink flipped by the summation order moves one sample's terms
+        assert float((g1[n] - g0[n]).abs().max()) <= tol * float(g0[n].abs().max()) + 1e-9, n
+    # accumulation straight into an existing .grad gives the same embedding gradient
+    m.zero_grad()
+    m.encoder.embeddings.grad = torch.zeros_like(m.encoder.embeddings)
+    monkeypatch.setattr(fn, "ENABLED", True)
+    s, c = m(x, d)
+    ((s * gs).sum() + (c * gc).sum()).backward()
+    ref = g1["encoder.embeddings"]
+    assert float((m.encoder.embeddings.grad - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9
+    with torch.no_grad():
+        s2, c2 = m(x, d)
+    assert torch.equal(s2, s1) and torch.equal(c2, c1)
+
+
 def test_network_uses_fused_path_and_matches_linear_loop(monkeypatch):
     from enerf_amd import fused_mlp as fm
+    from enerf_amd import fused_network as fn
     from enerf_amd.network import NeRFNetwork
+    monkeypatch.setattr(fn, "ENABLED", False)
     torch.manual_seed(0)
     m = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
     m.encoder.embeddings.data.uniform_(-1, 1)

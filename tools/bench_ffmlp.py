@@ -64,7 +64,7 @@ def main():
             fb = torch.empty(nh, B, 64, device=dev)
             s = L.stream_handle()
             t = timeit(lambda: lib.enerf_mlp32_forward(x.data_ptr(), W.data_ptr(), B, 32, od, nh, 0, 6, fb.data_ptr(),
-                                                       y.data_ptr(), 0, s))
+                                                       y.data_ptr(), 0, 0, None, s))
             flops = 2.0 * B * (32 * 64 + (nh - 1) * 4096 + 64 * 32)
             print(f"fp32 B={B:8d} {name}: train fwd {t*1e3:7.1f} us ({flops/t/1e9:6.1f} TFLOP/s of 157 peak)")
 

@@ -45,10 +45,10 @@ def main():
         dY = torch.randn(B, out, device=dev)
         dX = torch.empty_like(X)
         dW = torch.zeros(nw, device=dev)
-        t_inf = timeit(lambda: lib.enerf_mlp32_forward(X.data_ptr(), W.data_ptr(), B, 32, out, nh, 0, 6, None, Y.data_ptr(), xl, s))
-        t_fwd = timeit(lambda: lib.enerf_mlp32_forward(X.data_ptr(), W.data_ptr(), B, 32, out, nh, 0, 6, fb.data_ptr(), Y.data_ptr(), xl, s))
+        t_inf = timeit(lambda: lib.enerf_mlp32_forward(X.data_ptr(), W.data_ptr(), B, 32, out, nh, 0, 6, None, Y.data_ptr(), xl, 0, None, s))
+        t_fwd = timeit(lambda: lib.enerf_mlp32_forward(X.data_ptr(), W.data_ptr(), B, 32, out, nh, 0, 6, fb.data_ptr(), Y.data_ptr(), xl, 0, None, s))
         t_bwd = timeit(lambda: lib.enerf_mlp32_backward(dY.data_ptr(), X.data_ptr(), W.data_ptr(), fb.data_ptr(), B, 32, out, nh, 0,
-                                                        bb.data_ptr(), dX.data_ptr(), dW.data_ptr(), xl, s))
+                                                        bb.data_ptr(), dX.data_ptr(), dW.data_ptr(), xl, 0, None, 0, None, None, 0, s))
         macs = 32 * 64 + (nh - 1) * 64 * 64 + 64 * out
         print(f"{name:34s} B={B}: inference {t_inf:6.1f} us | train fwd {t_fwd:6.1f} us | bwd (act+w+reduce) {t_bwd:6.1f} us"
               f" | fwd {2 * macs * B / t_fwd / 1e6:6.1f} TFLOP/s, bwd {4 * macs * B / t_bwd / 1e6:6.1f} TFLOP/s")

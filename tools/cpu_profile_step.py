@@ -1,0 +1,38 @@
+"""Where does the host time of a training step go?  cProfile over N steps (development aid)."""
+import cProfile
+import os
+import pstats
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from enerf_amd.network import NeRFNetwork  # noqa: E402
+from enerf_amd.trainer import TrainHarness  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(dev)
+h = TrainHarness(model, occupancy="synthetic", world=1)
+batches = bench.build_batches(8, 4096, dev, 0, 3)
+for i in range(40):
+    h.step_rgb(*batches[i % 8])
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for i in range(48):
+    h.step_rgb(*batches[i % 8])
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"enqueue {1e3 * (t1 - t0) / 48:.3f} ms/step, drained after {1e3 * (t2 - t0) / 48:.3f} ms/step")
+pr = cProfile.Profile()
+pr.enable()
+for i in range(48):
+    h.step_rgb(*batches[i % 8])
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(60)
