@@ -242,9 +242,22 @@ __device__ __forceinline__ uint32_t march_one_ray(const RayCtx& c, float t0, flo
 // empty lanes jump through a precomputed per-lane "next" index.  The emitted samples, their count and their
 // positions are bit-identical to the one-thread-per-ray loop above; the work per ray is spread over 64 lanes
 // instead of one latency-bound thread.
-template <bool WRITE>
+// Chunk log (count pass -> write pass): the chunks of a ray that emitted anything, as (first lattice point, emit mask).
+// Everything the write pass stores -- positions, dt, real delta-t -- is a function of those two and of the ray, so it
+// replays the log instead of marching again: no bitfield reads, no serial control-flow replay.
+struct ChunkEntry {
+    float base;
+    uint32_t pad;
+    unsigned long long emit;
+};
+constexpr uint32_t kLogCap = 64;                 // entries per ray; a ray that needs more is re-marched by the write pass
+constexpr uint32_t kLogOverflow = 0xffffffffu;
+
+template <bool WRITE, bool LOG = false>
 __device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, float far, uint32_t limit, float* xyzs,
-                                                  float* dirs, float* deltas) {
+                                                  float* dirs, float* deltas, ChunkEntry* log = nullptr,
+                                                  uint32_t* nlog = nullptr) {
+    uint32_t logged = 0;
     const int lane = lane_id();
     const float dt = c.dt_min;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes strictly below mine
@@ -319,10 +332,52 @@ __device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, flo
             }
             last_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_next), top));
             count += nemit;
+            if (LOG) {
+                if (logged < kLogCap && lane == 0) {
+                    log[logged].base = base;
+                    log[logged].emit = emit;
+                }
+                logged++;
+            }
         }
         base = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_next), nvalid - 1));
     }
+    if (LOG && lane == 0) *nlog = logged <= kLogCap ? logged : kLogOverflow;
     return count;
+}
+
+// Write pass of the wave-per-ray marcher: replay a ray's chunk log.
+__device__ __forceinline__ void lattice_replay(const RayCtx& c, float t0, const ChunkEntry* log, uint32_t nlog,
+                                               float* xyzs, float* dirs, float* deltas) {
+    const int lane = lane_id();
+    const float dt = c.dt_min;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    float last_t = t0;
+    uint32_t count = 0;
+    for (uint32_t e = 0; e < nlog; e++) {
+        const float base = log[e].base;
+        const unsigned long long emit = log[e].emit;
+        const float delta = (base + dt) - base;
+        const float delta2 = ((base + delta) + dt) - (base + delta);
+        const bool progression = base >= 2.0f * dt && delta2 == delta;
+        const float ti = progression ? fmaf((float)lane, delta, base) : base;
+        const float t_next = ti + dt;
+        const unsigned long long before = emit & below;
+        const int prev = before ? 63 - __builtin_clzll(before) : 0;
+        const float prev_next = __shfl(t_next, prev, 64);
+        if ((emit >> lane) & 1ull) {
+            const size_t k = (size_t)count + (uint32_t)__popcll(before);
+            xyzs[k * 3] = clampf_(fmaf(ti, c.dx, c.ox), -c.bound, c.bound);
+            xyzs[k * 3 + 1] = clampf_(fmaf(ti, c.dy, c.oy), -c.bound, c.bound);
+            xyzs[k * 3 + 2] = clampf_(fmaf(ti, c.dz, c.oz), -c.bound, c.bound);
+            dirs[k * 3] = c.dx; dirs[k * 3 + 1] = c.dy; dirs[k * 3 + 2] = c.dz;
+            deltas[k * 2] = clampf_(ti * c.dt_gamma, c.dt_min, c.dt_max);
+            deltas[k * 2 + 1] = t_next - (before ? prev_next : last_t);
+        }
+        const int top = 63 - __builtin_clzll(emit);
+        last_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_next), top));
+        count += (uint32_t)__popcll(emit);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__ rays_o,
@@ -330,14 +385,16 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
                                                        const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
                                                        uint32_t N, uint32_t C, uint32_t H,
                                                        const float* __restrict__ nears, const float* __restrict__ fars,
-                                                       int32_t* rays, uint32_t perturb) {
+                                                       int32_t* rays, uint32_t perturb, ChunkEntry* __restrict__ log,
+                                                       uint32_t* __restrict__ nlog) {
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (n >= N) return;
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
     float t0 = nears[n];
     if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
-    const uint32_t cnt = lattice_march<false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr);
+    const uint32_t cnt = lattice_march<false, true>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                    log + (size_t)n * kLogCap, nlog + n);
     if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
 }
 
@@ -347,7 +404,9 @@ __global__ void __launch_bounds__(256) k_march_write_w(const float* __restrict__
                                                        uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                                        const float* __restrict__ nears, const float* __restrict__ fars,
                                                        float* xyzs, float* dirs, float* deltas,
-                                                       const int32_t* __restrict__ rays, uint32_t perturb) {
+                                                       const int32_t* __restrict__ rays, uint32_t perturb,
+                                                       const ChunkEntry* __restrict__ log,
+                                                       const uint32_t* __restrict__ nlog) {
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (n >= N) return;
     const uint32_t point_index = (uint32_t)rays[(size_t)n * 3 + 1];
@@ -358,8 +417,13 @@ __global__ void __launch_bounds__(256) k_march_write_w(const float* __restrict__
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
     float t0 = nears[n];
     if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
-    (void)lattice_march<true>(c, t0, fars[n], num_steps, xyzs + (size_t)point_index * 3,
-                              dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
+    const uint32_t entries = __builtin_amdgcn_readfirstlane(nlog[n]);
+    if (entries != kLogOverflow)
+        lattice_replay(c, t0, log + (size_t)n * kLogCap, entries, xyzs + (size_t)point_index * 3,
+                       dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
+    else
+        (void)lattice_march<true>(c, t0, fars[n], num_steps, xyzs + (size_t)point_index * 3,
+                                  dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
 }
 
 __global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -725,11 +789,17 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     if (dt_gamma == 0.0f) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
+        // the count pass logs every emitting chunk; the write pass replays the log
+        const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
+        if (!ws) return ENERF_E_NOMEM;
+        ChunkEntry* log = (ChunkEntry*)ws;
+        uint32_t* nlog = (uint32_t*)(ws + log_bytes);
         k_march_count_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays,
-                                                     perturb);
+                                                     perturb, log, nlog);
         k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
         k_march_write_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars,
-                                                     xyzs, dirs, deltas, rays, perturb);
+                                                     xyzs, dirs, deltas, rays, perturb, log, nlog);
     } else {
         k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
                                                    fars, rays, perturb);

@@ -18,8 +18,8 @@ void set_error(const char* fmt, ...) {
 
 // ---- workspaces -----------------------------------------------------------
 static std::mutex g_ws_mu;
-static void* g_ws_ptr[WS_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-static size_t g_ws_bytes[WS_SLOTS] = {0, 0, 0, 0};
+static void* g_ws_ptr[WS_SLOTS] = {};
+static size_t g_ws_bytes[WS_SLOTS] = {};
 
 void* workspace(int slot, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
