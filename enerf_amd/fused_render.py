@@ -1,0 +1,97 @@
+"""One autograd node for a whole training render on the MI355X fp32 path (the `self.training` branch of
+NeRFRenderer.run_cuda, nerf/renderer.py:318-353 of the reference):
+
+    near_far_from_aabb -> march_rays_train -> network (fused_network) -> composite_rays_train
+    -> image + (1 - weights_sum) * bg_color,  depth normalised to [0,1]
+
+Every kernel is the library's; what the node removes is the autograd / dispatcher traffic between them (four Function
+nodes, a dozen elementwise launches), which is what bounds a 4096-ray step once the kernels are fast.  Values are those
+of the op-by-op route; `tests/test_gpu_training.py` compares the two.
+"""
+import torch
+from torch.autograd import Function
+
+from . import fused_network as fnet
+from . import raymarching as _rm
+from .backends import _raymarching as _rb
+
+ENABLED = True
+
+
+def supported(model, rays_o, rays_d, bg_color, dt_gamma):
+    if not (ENABLED and fnet.ENABLED and model.training and model.cuda_ray and model.bg_radius <= 0
+            and rays_o.is_cuda and rays_o.dtype == torch.float32 and rays_d.dtype == torch.float32
+            and not torch.is_autocast_enabled() and not rays_o.requires_grad and not rays_d.requires_grad
+            and _rm._DEVICE == "cuda" and torch.is_grad_enabled()):
+        return False
+    if isinstance(bg_color, torch.Tensor) and bg_color.requires_grad:
+        return False
+    probe = rays_o.view(-1, 3)
+    return fnet.supported(model, probe, probe)
+
+
+class _FusedRenderTrain(Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, model, bg_color, counter, mean_count, perturb, force_all_rays, dt_gamma,
+                max_steps, embeddings, ws0, ws1, wc0, wc1, wc2):
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        nears = torch.empty(N, dtype=torch.float32, device=dev)
+        fars = torch.empty(N, dtype=torch.float32, device=dev)
+        _rb.near_far_from_aabb(rays_o, rays_d, model.aabb_train, N, model.min_near, nears, fars)
+
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            M = mean_count + (128 - mean_count % 128)            # raymarching.py:186-189 (align = 128)
+        xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        _rb.march_rays_train(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
+                             model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
+        if force_all_rays or mean_count <= 0:
+            m = int(counter[0].item())
+            m += 128 - m % 128
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+            M = m
+
+        train = any(p.requires_grad for p in (embeddings, ws0, ws1, wc0, wc1, wc2))
+        sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), train, embeddings, model.encoder.offsets,
+                                           ws0, ws1, wc0, wc1, wc2)
+        scale = float(model.density_scale)
+        sigmas = sigma if scale == 1.0 else sigma * scale
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        _rb.composite_rays_train_forward(sigmas, rgb, deltas, rays, M, N, weights_sum, depth, image)
+        out_image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        out_depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        if train:
+            ctx.sv = sv
+            ctx.rest = (sigmas, rgb, deltas, rays, weights_sum, image, bg_color, M, N, scale)
+        ctx.mark_non_differentiable(out_depth)
+        return out_depth, out_image
+
+    @staticmethod
+    def backward(ctx, _g_depth, g_image):
+        sigmas, rgb, deltas, rays, weights_sum, image, bg_color, M, N, scale = ctx.rest
+        g_image = g_image.reshape(N, 3).float().contiguous()
+        # out_image = image + (1 - weights_sum)[:, None] * bg  ->  d/d(weights_sum) = -(g . bg)
+        g_ws = -(g_image * bg_color).sum(-1) if isinstance(bg_color, torch.Tensor) else -(g_image.sum(-1) * bg_color)
+        g_ws = g_ws.reshape(N).contiguous()
+        g_sigmas = torch.zeros_like(sigmas)
+        g_rgbs = torch.zeros_like(rgb)
+        _rb.composite_rays_train_backward(g_ws, g_image, sigmas, rgb, deltas, rays, weights_sum, image, M, N, g_sigmas,
+                                          g_rgbs)
+        g = fnet.nerf_backward(ctx.sv, g_sigmas, g_rgbs, sigma_scale=scale)
+        return (None,) * 10 + g
+
+
+def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
+    """-> depth [N], image [N,3] (+ the step counter bookkeeping of run_cuda)."""
+    counter = model.step_counter[model.local_step % 16]
+    counter.zero_()
+    model.local_step += 1
+    params = fnet.network_params(model)
+    return _FusedRenderTrain.apply(rays_o, rays_d, model, bg_color, counter, int(model.mean_count), bool(perturb),
+                                   bool(force_all_rays), float(dt_gamma), int(max_steps), *params)

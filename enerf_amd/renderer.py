@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import raymarching
+from . import fused_render, raymarching
 
 
 def _meshgrid_ij(*args):
@@ -179,6 +179,16 @@ class NeRFRenderer(nn.Module):
         rays_d = rays_d.contiguous().view(-1, 3)
         N = rays_o.shape[0]
         device = rays_o.device
+
+        if self.training and bg_color is not None and fused_render.supported(self, rays_o, rays_d, bg_color, dt_gamma):
+            depth, image = fused_render.render_train(self, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma,
+                                                     max_steps)
+            return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3)}
+        if self.training and bg_color is None and self.bg_radius <= 0 \
+                and fused_render.supported(self, rays_o, rays_d, 1, dt_gamma):
+            depth, image = fused_render.render_train(self, rays_o, rays_d, 1, perturb, force_all_rays, dt_gamma,
+                                                     max_steps)
+            return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3)}
 
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d,
                                                      self.aabb_train if self.training else self.aabb_infer,
