@@ -206,7 +206,7 @@ template <int NH, int KPO, int XL>
 __global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, const float* __restrict__ W,
                                                        const float* __restrict__ fb, float* __restrict__ bb,
                                                        float* __restrict__ dX, uint32_t B, uint32_t out_dim,
-                                                       uint32_t act) {
+                                                       uint32_t act, float* __restrict__ dy_eff) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     stage(wl, W, blob_size(NH, out_dim));
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, const float
         for (int p = 0; p < KPO; p++) {
             const uint32_t o = (uint32_t)(p + KPO * h);
             dy[p] = (valid && o < out_dim) ? load_dy(dys, s, o) : 0.0f;
+            // with a fused epilogue gradient, leave the effective dL/dY behind for the weight-gradient kernel
+            if (dy_eff && valid && o < out_dim) dy_eff[s * out_dim + o] = dy[p];
         }
         f32x16 g[2];
 #pragma unroll
@@ -518,16 +520,29 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
     const uint32_t grid = pgrid(B, 1024);
     const uint32_t wgrid = pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 256u));
-    float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NW);
+    // fused epilogue gradients are evaluated once, by the dgrad kernel, which leaves the effective dL/dY in the
+    // workspace for the weight-gradient kernel (whose inner loop is load-bound)
+    const bool fused_dy = y_sigmoid != nullptr || dsigma != nullptr || dys.stride != out_dim;
+    const size_t part_bytes = sizeof(float) * (size_t)wgrid * NW;
+    float* partial = (float*)workspace(WS_FFMLP, part_bytes + (fused_dy ? sizeof(float) * (size_t)B * out_dim : 0));
     if (!partial) return ENERF_E_NOMEM;
+    float* dy_eff = fused_dy ? partial + (size_t)wgrid * NW : nullptr;
+    DySource dys_w = dys;
+    if (fused_dy) {
+        dys_w.dY = dy_eff;
+        dys_w.stride = out_dim;
+        dys_w.y_sig = nullptr;
+        dys_w.dsigma = nullptr;
+        dys_w.h0 = nullptr;
+    }
 #define MLP32_BA(NHV, KPOV, XLV) \
-    k_mlp32_bwd_act<NHV, KPOV, XLV><<<grid, 256, lds, s>>>(dys, W, fb, bb, dX, B, out_dim, activation)
+    k_mlp32_bwd_act<NHV, KPOV, XLV><<<grid, 256, lds, s>>>(dys, W, fb, bb, dX, B, out_dim, activation, dy_eff)
 #define MLP32_BWD2(NHV, XLV)                                                                      \
     do {                                                                                          \
         if (out_dim <= 4) MLP32_BA(NHV, 2, XLV);                                                  \
         else if (out_dim <= 16) MLP32_BA(NHV, 8, XLV);                                            \
         else MLP32_BA(NHV, 16, XLV);                                                              \
-        k_mlp32_bwd_w<NHV, XLV><<<wgrid, 256, lds_w, s>>>(dys, X, fb, bb, partial, B, out_dim);   \
+        k_mlp32_bwd_w<NHV, XLV><<<wgrid, 256, lds_w, s>>>(dys_w, X, fb, bb, partial, B, out_dim); \
     } while (0)
 #define MLP32_BWD(NHV)                          \
     do {                                        \
