@@ -49,6 +49,52 @@ def test_training_reduces_loss(net):
     assert model.mean_count > 0 and model.iter_density == math.ceil(160 / 16)
 
 
+@pytest.mark.parametrize("bg", ["none", "scalar", "tensor"])
+@pytest.mark.parametrize("mean_count", [-1, 40000])
+def test_fused_render_node_matches_op_by_op_route(monkeypatch, bg, mean_count):
+    """enerf_amd.fused_render (one autograd node for near_far -> march -> network -> composite -> background blend)
+    against run_cuda's op-by-op training branch: same sample counters, image, depth and parameter gradients; with
+    the sample budget unknown (mean_count <= 0, first 16 steps) and fixed (later steps, with overflow drop rule)."""
+    from enerf_amd import fused_network, fused_render, scene
+    from enerf_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    model.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    scene.install_occupancy(model)
+    model.train()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    (ro, rd), _ = scene.training_batch(0, 3000, DEV, generator=g)
+    gi = torch.randn(3000, 3, device=DEV)
+    bg_color = {"none": None, "scalar": 0.25, "tensor": torch.rand(1, 1, 3, device=DEV)}[bg]
+    calls = []
+    orig = fused_render.render_train
+    monkeypatch.setattr(fused_render, "render_train", lambda *a: (calls.append(1), orig(*a))[1])
+
+    def run(fused):
+        monkeypatch.setattr(fused_render, "ENABLED", fused)
+        monkeypatch.setattr(fused_network, "ENABLED", fused)
+        model.zero_grad()
+        model.local_step = 0
+        model.step_counter.zero_()
+        model.mean_count = mean_count
+        out = model.render(ro.view(1, -1, 3) if bg == "tensor" else ro, rd.view(1, -1, 3) if bg == "tensor" else rd,
+                           staged=False, bg_color=bg_color, perturb=True)
+        (out["image"].reshape(-1, 3) * gi).sum().backward()
+        return (out["image"].detach().reshape(-1, 3), out["depth"].detach().reshape(-1), model.step_counter[0].clone(),
+                {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    im1, dp1, c1, g1 = run(True)
+    assert len(calls) == 1
+    im0, dp0, c0, g0 = run(False)
+    assert len(calls) == 1
+    assert torch.equal(c1, c0)                                   # samples / rays counted: bit-exact
+    assert float((im1 - im0).abs().max()) < 2e-5
+    assert float((dp1 - dp0).abs().max()) < 2e-5
+    assert set(g1) == set(g0)
+    for n in g0:
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-9, n
+
+
 def test_step_is_deterministic_in_integer_state():
     from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
