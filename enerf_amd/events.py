@@ -59,10 +59,18 @@ def get_event_rays(xs, ys, c2w_before, c2w_at, intrinsics):
     }
 
 
+_luma_factors = {}
+
+
 def rgb_to_luma(rgb, esim=True):
-    """[..., 3] -> [..., 1]; BT.601 weights for esim, BT.709 otherwise."""
-    w = (0.299, 0.587, 0.114) if esim else (0.2126, 0.7152, 0.0722)
-    factors = torch.tensor(w, dtype=torch.float32, device=rgb.device)
+    """[..., 3] -> [..., 1]; BT.601 weights for esim, BT.709 otherwise.  (utils/event_utils.py:23-33 builds the
+    weight tensor on every call; here it is built once per device -- on a GPU that construction is a synchronous
+    host-to-device copy in the middle of the step.)"""
+    key = (rgb.device, bool(esim))
+    factors = _luma_factors.get(key)
+    if factors is None:
+        w = (0.299, 0.587, 0.114) if esim else (0.2126, 0.7152, 0.0722)
+        factors = _luma_factors[key] = torch.tensor(w, dtype=torch.float32, device=rgb.device)
     return torch.sum(rgb * factors[None, :], axis=-1)[..., None]
 
 

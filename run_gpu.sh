@@ -1,4 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_training.py -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-tail -12 gpurun_out/pytest_gpu.log | cut -c1-300
+python tools/cpu_profile_events.py 2>&1 | grep enqueue
+for i in 1 2; do timeout 600 python bench.py --no-cpu-baseline --render-frames 0 --mode events 2>&1 | tail -1 | cut -c1-160; done
