@@ -289,6 +289,25 @@ def gold_misc():
     save("ref_misc", x=x, trunc_exp=y, trunc_exp_grad=x.grad, p=p, freq=f(p))
 
 
+def gold_state_dict_schema():
+    """state_dict layout (key -> shape, dtype) of the reference's two network classes with cuda_ray on, at the bounds
+    of the BASELINE configs: what a reference `.pth` checkpoint's 'model' entry looks like (nerf/utils.py
+    save_checkpoint stores model.state_dict() plus mean_count / mean_density when cuda_ray)."""
+    import json
+    schema = {}
+    for mod, name in (("nerf.network", "network"), ("nerf.network_ff", "network_ff")):
+        cls = __import__(mod, fromlist=["NeRFNetwork"]).NeRFNetwork
+        for bound in (1, 2, 3):
+            kw = dict(encoding="hashgrid", bound=bound, cuda_ray=True)
+            if name == "network":
+                kw["out_dim_color"] = 3
+            model = cls(**kw)
+            schema[f"{name}_bound{bound}"] = {k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, "ref_state_dict_schema.json"), "w") as f:
+        json.dump(schema, f, indent=1, sort_keys=True)
+    print("  wrote ref_state_dict_schema.json", {k: len(v) for k, v in schema.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -299,7 +318,7 @@ def main():
     ref_import.install()
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
-            gold_composite_vs_run, gold_events, gold_misc]
+            gold_composite_vs_run, gold_events, gold_misc, gold_state_dict_schema]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

@@ -205,3 +205,40 @@ def test_trunc_exp_and_freq_encoder():
     f = FreqEncoder(input_dim=3, max_freq_log2=5, N_freqs=6)
     assert f.output_dim == 39
     assert_close(f(t(g["p"])), g["freq"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ checkpoint compatibility
+@pytest.mark.parametrize("which", ["network", "network_ff"])
+@pytest.mark.parametrize("bound", [1, 2, 3])
+def test_state_dict_layout_matches_reference(which, bound):
+    """tests/golden/ref_state_dict_schema.json was minted from the reference's own classes (oracle/make_golden.py):
+    key -> (shape, dtype) of model.state_dict() with cuda_ray on.  This repo's mirrors must produce the identical
+    layout, so a reference `.pth` ('model' entry, nerf/utils.py save_checkpoint) loads with strict=True and a
+    checkpoint written here loads into the reference."""
+    import json
+    import os
+    if which == "network":
+        from enerf_amd.network import NeRFNetwork
+        model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3)
+    else:
+        from enerf_amd.network_ff import NeRFNetwork
+        model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_state_dict_schema.json")) as f:
+        schema = json.load(f)[f"{which}_bound{bound}"]
+    mine = {k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}
+    assert mine == schema
+    # a reference-format checkpoint (random contents of the reference's shapes / dtypes) loads strictly
+    g = torch.Generator().manual_seed(bound)
+    ckpt = {}
+    for k, (shape, dtype) in schema.items():
+        dt = getattr(torch, dtype.split(".")[1])
+        if k == "encoder.offsets":
+            ckpt[k] = model.state_dict()[k].clone()
+        elif dt.is_floating_point:
+            ckpt[k] = torch.rand(shape, generator=g).to(dt)
+        else:
+            ckpt[k] = torch.randint(0, 100, shape, generator=g).to(dt)
+    missing, unexpected = model.load_state_dict(ckpt, strict=True)
+    assert not missing and not unexpected
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ckpt[k]), k
