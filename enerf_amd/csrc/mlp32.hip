@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, const float
 // floats: the 32 lanes of a half-wave then read 32 distinct banks) and takes the B operand from there.
 constexpr int XT_LD = 66;
 template <int NH, int XL>
-__global__ void __launch_bounds__(256) k_mlp32_bwd_w(DySource dys, const float* __restrict__ X,
+__global__ void __launch_bounds__(256, 2) k_mlp32_bwd_w(DySource dys, const float* __restrict__ X,
                                                      const float* __restrict__ fb, const float* __restrict__ bb,
                                                      float* __restrict__ partial, uint32_t B, uint32_t out_dim) {
     extern __shared__ __attribute__((aligned(16))) float red[];
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict
     }
 }
 
-uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 256 otherwise (measured optimum)
+uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
 uint32_t pgrid(uint32_t B, uint32_t cap) {
     const uint32_t blocks = div_up(div_up(B, 32), 4);
@@ -519,7 +519,7 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
     const size_t lds = sizeof(float) * NW;
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
     const uint32_t grid = pgrid(B, 1024);
-    const uint32_t wgrid = pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 256u));
+    const uint32_t wgrid = pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 512u));
     // fused epilogue gradients are evaluated once, by the dgrad kernel, which leaves the effective dL/dY in the
     // workspace for the weight-gradient kernel (whose inner loop is load-bound)
     const bool fused_dy = y_sigmoid != nullptr || dsigma != nullptr || dys.stride != out_dim;

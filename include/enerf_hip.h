@@ -211,7 +211,7 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
                          const float* dsigma, const float* h0, uint32_t h0_stride, enerf_stream_t stream);
 
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
- * default (768 for one hidden layer, 256 otherwise). */
+ * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
 
 /* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
