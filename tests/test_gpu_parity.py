@@ -123,6 +123,69 @@ def test_march_rays_train_overflow_drop_rule(rm, scenes):
     assert got[4][0] == tot
 
 
+def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm):
+    """Every cell occupied: rays emit a sample at every lattice point until max_steps (1024) -- the maximum the path
+    can produce per ray, and more emitting 64-point chunks than the count pass's per-ray log holds for the longest
+    rays (the write pass then re-marches those rays).  Bit-exact against the oracle, perturbed and not."""
+    bound = 2
+    C = 1 + math.ceil(math.log2(bound))
+    bits = np.full(C * H ** 3 // 8, 0xff, np.uint8)
+    o, d, aabb = _rays(96, 33, bound)
+    o[:8] = np.array([-1.9, -1.9, -1.9], np.float32) + np.linspace(0, 0.05, 8, dtype=np.float32)[:, None]
+    d[:8] = np.array([1, 1, 1], np.float32) / np.sqrt(3, dtype=np.float32)          # along the diagonal: > 1024 points
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    for perturb in (0, 1):
+        M = 96 * 1024
+        ref = O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, M, nears, fars, perturb)
+        got = _gpu_march_train(rm, o, d, bits, bound, 0.0, C, M, nears, fars, perturb)
+        assert ref[3][:8, 2].max() == 1024                     # saturated at max_steps
+        for a, b, name in zip(got, ref, ("xyzs", "dirs", "deltas", "rays", "counter")):
+            assert np.array_equal(a, b), name
+    # max_steps = 8192 with every other cell occupied (even x): the diagonal rays emit ~3600 samples from ~110
+    # chunks, more than the 64 the log holds -> re-march fallback of the write pass
+    bits = np.full(C * H ** 3 // 8, 0x55, np.uint8)
+    M = 96 * 8192
+    ref = O.march_rays_train(o, d, bits, bound, 0.0, 8192, C, H, M, nears, fars, 1)
+    got = _gpu_march_train(rm, o, d, bits, bound, 0.0, C, M, nears, fars, 1, max_steps=8192)
+    assert ref[3][:8, 2].max() > 3000
+    for a, b, name in zip(got, ref, ("xyzs", "dirs", "deltas", "rays", "counter")):
+        assert np.array_equal(a, b), name
+
+
+def test_empty_inputs_are_noops():
+    """N == 0 / B == 0 / n_alive == 0 through every entry point: status 0, nothing read or written."""
+    from enerf_amd import _lib
+    lib = _lib.lib()
+    s = _lib.stream_handle()
+    z = None
+    assert lib.enerf_near_far_from_aabb(z, z, z, 0, 0.2, z, z, s) == 0
+    assert lib.enerf_polar_from_ray(z, z, 1.0, 0, z, s) == 0
+    assert lib.enerf_morton3D(z, 0, z, s) == 0
+    assert lib.enerf_morton3D_invert(z, 0, z, s) == 0
+    assert lib.enerf_packbits(z, 0, 0.01, z, s) == 0
+    assert lib.enerf_march_rays_train(z, z, z, 1.0, 0.0, 1024, 0, 1, 128, 0, z, z, z, z, z, z, z, 0, s) == 0
+    assert lib.enerf_composite_rays_train_forward(z, z, z, z, 0, 0, z, z, z, s) == 0
+    assert lib.enerf_composite_rays_train_backward(z, z, z, z, z, z, z, z, 0, 0, z, z, s) == 0
+    assert lib.enerf_march_rays(0, 8, z, z, z, z, 1.0, 0.0, 1024, 1, 128, z, z, z, z, z, z, 0, s) == 0
+    assert lib.enerf_composite_rays(0, 8, z, z, z, z, z, z, z, z, s) == 0
+    assert lib.enerf_compact_rays(0, z, z, z, z, z, s) == 0
+    assert lib.enerf_grid_encode_forward(z, z, z, z, 0, 3, 2, 16, 0.5, 16, 0, z, 0, 0, 0, 0.0, 1.0, s) == 0
+    assert lib.enerf_grid_encode_backward(z, z, z, z, z, 0, 3, 2, 16, 0.5, 16, 0, z, z, 0, 0, 0, 0.0, 1.0, s) == 0
+    assert lib.enerf_sh_encode_forward(z, z, 0, 3, 4, 0, z, 0, s) == 0
+    assert lib.enerf_sh_encode_backward(z, z, 0, 3, 4, z, z, 0, s) == 0
+    assert lib.enerf_ffmlp_forward(z, z, 0, 32, 16, 64, 2, 0, 6, z, z, 2, s) == 0
+    assert lib.enerf_ffmlp_inference(z, z, 0, 32, 16, 64, 2, 0, 6, z, z, 2, s) == 0
+    assert lib.enerf_ffmlp_backward(z, z, z, z, 0, 32, 16, 64, 2, 0, 6, 1, z, z, z, 2, s) == 0
+    assert lib.enerf_mlp32_forward(z, z, 0, 32, 16, 1, 0, 6, z, z, 0, 0, z, s) == 0
+    assert lib.enerf_mlp32_backward(z, z, z, z, 0, 32, 16, 1, 0, z, z, z, 0, 0, z, 0, z, z, 0, s) == 0
+    torch.cuda.synchronize()
+    # and through the host-side mirrors
+    from enerf_amd.network import NeRFNetwork
+    m = NeRFNetwork(encoding="hashgrid", bound=1, cuda_ray=True, out_dim_color=3).to(DEV)
+    sg, c = m(torch.empty(0, 3, device=DEV), torch.empty(0, 3, device=DEV))
+    assert sg.shape == (0,) and c.shape == (0, 3)
+
+
 # ------------------------------------------------------------------ composite_rays_train: 1e-4 rel
 @pytest.mark.parametrize("bound,N", [(1, 200), (3, 4096)])
 def test_composite_rays_train_fwd_bwd(rm, scenes, bound, N):
