@@ -42,6 +42,7 @@ SIGNATURES = {
     "enerf_sh_encode_forward_strided": [_vp, _vp, _u32, _u32, _u32, _vp],
     "enerf_debug_grid_level_mask": [_u32],
     "enerf_debug_mlp32_wgrad_blocks": [_u32],
+    "enerf_debug_mlp32_fused_backward": [_int],
     "enerf_debug_grid_bwd_binned": [_u32, _u32],
     "enerf_adam_step": [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u32, _int, _vp],
     "enerf_allocate_splitk": [_sz],

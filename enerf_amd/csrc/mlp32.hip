@@ -407,6 +407,234 @@ __global__ void __launch_bounds__(256, 2) k_mlp32_bwd_w(DySource dys, const floa
     for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
 }
 
+// ================================================================== backward: dgrad + wgrad in one kernel
+// The dgrad chain holds every operand of the weight gradients in registers already -- the activation gradients it
+// computes and the forward activations it loads -- only in the "lane = sample" orientation, while
+// dW[o][i] = sum_s G[o][s] In[i][s] contracts over samples.  Each 32x32 tile is therefore passed through LDS once
+// (written from the accumulator layout as T[row][sample], row stride 33: both the writes and the operand reads
+// T[lane][2p + h] are bank-conflict free) and consumed as A / B operands right there: the backward_buffer never
+// exists in HBM (140 MB of traffic per 138 K samples for the colour net) and the activations are read once.
+// One workgroup per CU (the tiles of 4 waves + the weights take ~110 KiB of LDS); per-workgroup partial sums are
+// reduced by k_mlp32_reduce_w as before.  NH <= 2.
+constexpr int T_LD = 33;
+constexpr int T_SZ = 32 * T_LD;
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+__device__ __forceinline__ void tile_to_lds(float* t, int j, int h, const f32x16& v) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) t[nrow(q, h) * T_LD + j] = v[q];
+}
+
+template <int NH, int KPO, int XL>
+__global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const float* __restrict__ X,
+                                                         const float* __restrict__ W, const float* __restrict__ fb,
+                                                         float* __restrict__ dX, float* __restrict__ partial, uint32_t B,
+                                                         uint32_t out_dim, uint32_t act) {
+    constexpr uint32_t NW_MAX = HID * IN + (NH - 1) * HID * HID + 32 * HID;
+    constexpr uint32_t PER_WAVE = 5 * T_SZ + (XL == 1 ? 16 * XT_LD : 0);
+    __shared__ __attribute__((aligned(16))) float lds[NW_MAX + 4 * PER_WAVE];
+    float* wl = lds;                                   // weights during set-up, block-level dW sums at the end
+    const uint32_t NW = blob_size(NH, out_dim);
+    stage(wl, W, NW);
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    const int wid = threadIdx.x >> 6;
+    const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
+    const uint32_t Bp = (B + 31u) & ~31u;
+    float* wv = lds + NW_MAX + wid * PER_WAVE;
+    float* ga[2] = {wv, wv + T_SZ};                    // activation gradients of the current layer (A operands)
+    float* ft[2] = {wv + 2 * T_SZ, wv + 3 * T_SZ};     // forward activations feeding it (B operands)
+    float* dyt = wv + 4 * T_SZ;                        // dL/dY tile
+    float* xt = wv + 5 * T_SZ;                         // level-major X tile (XL == 1)
+
+    float woT[2][KPO], whT[NH > 1 ? NH - 1 : 1][2][2][16], wiT[2][16];
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+        for (int p = 0; p < KPO; p++) {
+            const uint32_t o = (uint32_t)(p + KPO * h);
+            woT[ib][p] = o < out_dim ? wout[o * HID + 32 * ib + j] : 0.0f;
+        }
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    whT[l][ib][ob][q] = wl[HID * IN + l * HID * HID + (32 * ob + nrow(q, h)) * HID + 32 * ib + j];
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) wiT[ob][q] = wl[(32 * ob + nrow(q, h)) * IN + j];
+    __syncthreads();                                   // every wave has its fragments: wl may be reused
+    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) wl[i] = 0.0f;
+
+    f32x16 aw0[2], awh[NH > 1 ? NH - 1 : 1][2][2], awo[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        aw0[a] = (f32x16)(0.0f);
+        awo[a] = (f32x16)(0.0f);
+#pragma unroll
+        for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) awh[l][a][b] = (f32x16)(0.0f);
+    }
+
+    const uint32_t ntiles = Bp / 32;
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const size_t s0 = (size_t)tile * 32;
+        const size_t s = s0 + j;
+        const bool valid = s < B;
+        // ---- output layer
+        float dy[KPO];
+#pragma unroll
+        for (int p = 0; p < KPO; p++) {
+            const uint32_t o = (uint32_t)(p + KPO * h);
+            dy[p] = (valid && o < out_dim) ? load_dy(dys, s, o) : 0.0f;
+        }
+        // every forward-activation tile of this sample tile is requested up front: with one wave per SIMD the
+        // loads of the deeper layers travel while the output layer computes
+        f32x16 g[2], fwl[NH][2];
+#pragma unroll
+        for (int l = NH - 1; l >= 0; l--)
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) load_tile(fb + ((size_t)l * Bp + s) * HID, ib, h, fwl[l][ib]);
+        f32x16(&fw)[2] = fwl[NH - 1];
+        wave_lds_fence();
+#pragma unroll
+        for (int p = 0; p < KPO; p++) dyt[(p + KPO * h) * T_LD + j] = dy[p];
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+            g[ib] = (f32x16)(0.0f);
+#pragma unroll
+            for (int p = 0; p < KPO; p++) g[ib] = mma(woT[ib][p], dy[p], g[ib]);
+            tile_to_lds(ft[ib], j, h, fw[ib]);
+#pragma unroll
+            for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(g[ib][q], fw[ib][q], act);
+        }
+        wave_lds_fence();
+        // dWout[o][i] += dY[o][s] * fb_last[i][s]
+#pragma unroll 4
+        for (int p = 0; p < 16; p++) {
+            const float a = (uint32_t)j < 2u * KPO ? dyt[j * T_LD + 2 * p + h] : 0.0f;
+            awo[0] = mma(a, ft[0][j * T_LD + 2 * p + h], awo[0]);
+            awo[1] = mma(a, ft[1][j * T_LD + 2 * p + h], awo[1]);
+        }
+        wave_lds_fence();
+        tile_to_lds(ga[0], j, h, g[0]);
+        tile_to_lds(ga[1], j, h, g[1]);
+        // ---- hidden layers
+#pragma unroll
+        for (int jj = 1; jj < NH; jj++) {
+            const int l = NH - jj;
+            f32x16 n[2];
+            f32x16(&fw)[2] = fwl[l - 1];
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                n[ib] = (f32x16)(0.0f);
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) n[ib] = mma(whT[l - 1][ib][ob][q], g[ob][q], n[ib]);
+            }
+            wave_lds_fence();
+            tile_to_lds(ft[0], j, h, fw[0]);
+            tile_to_lds(ft[1], j, h, fw[1]);
+            wave_lds_fence();
+            // dWh[l-1][o][i] += G_l[o][s] * fb[l-1][i][s]
+#pragma unroll 4
+            for (int p = 0; p < 16; p++) {
+                const float a0 = ga[0][j * T_LD + 2 * p + h], a1 = ga[1][j * T_LD + 2 * p + h];
+                const float b0 = ft[0][j * T_LD + 2 * p + h], b1 = ft[1][j * T_LD + 2 * p + h];
+                awh[l - 1][0][0] = mma(a0, b0, awh[l - 1][0][0]);
+                awh[l - 1][0][1] = mma(a0, b1, awh[l - 1][0][1]);
+                awh[l - 1][1][0] = mma(a1, b0, awh[l - 1][1][0]);
+                awh[l - 1][1][1] = mma(a1, b1, awh[l - 1][1][1]);
+            }
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(n[ib][q], fw[ib][q], act);
+            wave_lds_fence();
+            tile_to_lds(ga[0], j, h, g[0]);
+            tile_to_lds(ga[1], j, h, g[1]);
+        }
+        // ---- input layer
+        if (XL == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int f = t * 256 + lane * 4, lv = f >> 6, off = f & 63;
+                const float4 v = *reinterpret_cast<const float4*>(X + ((size_t)lv * Bp + s0) * 2 + off);
+                *reinterpret_cast<float2*>(xt + lv * XT_LD + off) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(xt + lv * XT_LD + off + 2) = make_float2(v.z, v.w);
+            }
+        }
+        if (dX) {
+            f32x16 d = (f32x16)(0.0f);
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) d = mma(wiT[ob][q], g[ob][q], d);
+            if (XL == 0) {
+                if (valid) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) =
+                            make_float4(d[4 * gq], d[4 * gq + 1], d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const size_t lv = (size_t)(4 * gq + 2 * h);
+                    *reinterpret_cast<float2*>(dX + (lv * Bp + s) * 2) = make_float2(d[4 * gq], d[4 * gq + 1]);
+                    *reinterpret_cast<float2*>(dX + ((lv + 1) * Bp + s) * 2) = make_float2(d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            }
+        }
+        wave_lds_fence();
+        // dW0[o][i] += G_0[o][s] * X[s][i]
+#pragma unroll 4
+        for (int p = 0; p < 16; p++) {
+            const size_t sx = s0 + 2 * p + h;
+            float xin;
+            if (XL == 0) xin = sx < B ? X[sx * IN + j] : 0.0f;
+            else xin = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
+            aw0[0] = mma(ga[0][j * T_LD + 2 * p + h], xin, aw0[0]);
+            aw0[1] = mma(ga[1][j * T_LD + 2 * p + h], xin, aw0[1]);
+        }
+    }
+
+    // block-level sums in a fixed wave order (deterministic), then one partial per workgroup
+    float* red = wl;
+    auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t o = (uint32_t)(32 * ob + nrow(q, h));
+            if (o < nrows) red[base + o * ld + 32 * nb + j] += a[q];
+        }
+    };
+    __syncthreads();
+    for (int turn = 0; turn < 4; turn++) {
+        if (wid == turn) {
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID);
+#pragma unroll
+            for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID);
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim);
+        }
+        __syncthreads();
+    }
+    float* dst = partial + (size_t)blockIdx.x * NW;
+    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
+}
+
 __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
                                                          float* __restrict__ gw) {
     // 64 weights per workgroup; each of the 16 waves sums every 16th partial block with four independent chains
@@ -435,6 +663,7 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict
     }
 }
 
+bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
 uint32_t pgrid(uint32_t B, uint32_t cap) {
@@ -445,6 +674,12 @@ uint32_t pgrid(uint32_t B, uint32_t cap) {
 }  // namespace
 
 extern "C" {
+
+// testing aid: 1 (default) = fused dgrad + wgrad kernel for num_hidden <= 2, 0 = separate dgrad / wgrad kernels
+int enerf_debug_mlp32_fused_backward(int on) {
+    g_fused_bwd = on != 0;
+    return 0;
+}
 
 // tuning aid: number of workgroups (= partial sums) of the weight-gradient kernel
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks) {
@@ -518,11 +753,13 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
     const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
     const size_t lds = sizeof(float) * NW;
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
+    const bool fused = g_fused_bwd && num_hidden <= 2;
     const uint32_t grid = pgrid(B, 1024);
-    const uint32_t wgrid = pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 512u));
+    const uint32_t wgrid = fused ? pgrid(B, 256)
+                                 : pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 512u));
     // fused epilogue gradients are evaluated once, by the dgrad kernel, which leaves the effective dL/dY in the
     // workspace for the weight-gradient kernel (whose inner loop is load-bound)
-    const bool fused_dy = y_sigmoid != nullptr || dsigma != nullptr || dys.stride != out_dim;
+    const bool fused_dy = !fused && (y_sigmoid != nullptr || dsigma != nullptr || dys.stride != out_dim);
     const size_t part_bytes = sizeof(float) * (size_t)wgrid * NW;
     float* partial = (float*)workspace(WS_FFMLP, part_bytes + (fused_dy ? sizeof(float) * (size_t)B * out_dim : 0));
     if (!partial) return ENERF_E_NOMEM;
@@ -549,9 +786,23 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
         if (x_layout == 0) MLP32_BWD2(NHV, 0);  \
         else MLP32_BWD2(NHV, 1);                \
     } while (0)
-    if (num_hidden == 1) MLP32_BWD(1);
+#define MLP32_BF(NHV, KPOV, XLV) \
+    k_mlp32_bwd_fused<NHV, KPOV, XLV><<<wgrid, 256, 0, s>>>(dys, X, W, fb, dX, partial, B, out_dim, activation)
+#define MLP32_BF2(NHV, XLV)                      \
+    do {                                         \
+        if (out_dim <= 4) MLP32_BF(NHV, 2, XLV); \
+        else if (out_dim <= 16) MLP32_BF(NHV, 8, XLV); \
+        else MLP32_BF(NHV, 16, XLV);             \
+    } while (0)
+    if (fused) {
+        (void)bb;
+        if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }
+        else { if (x_layout == 0) MLP32_BF2(2, 0); else MLP32_BF2(2, 1); }
+    } else if (num_hidden == 1) MLP32_BWD(1);
     else if (num_hidden == 2) MLP32_BWD(2);
     else MLP32_BWD(3);
+#undef MLP32_BF2
+#undef MLP32_BF
 #undef MLP32_BWD
 #undef MLP32_BWD2
 #undef MLP32_BA

@@ -210,6 +210,9 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
                          uint32_t x_layout, uint32_t dy_stride, const float* y_sigmoid, uint32_t y_sigmoid_stride,
                          const float* dsigma, const float* h0, uint32_t h0_stride, enerf_stream_t stream);
 
+/* Testing aid: 1 (default) lets enerf_mlp32_backward use its fused dgrad + wgrad kernel (num_hidden <= 2; `bb` is then
+ * not written), 0 forces the separate dgrad / wgrad kernels. */
+int enerf_debug_mlp32_fused_backward(int on);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
