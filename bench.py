@@ -45,6 +45,10 @@ def parse():
                     help="samples per inference iteration relative to the reference schedule (image is identical)")
     ap.add_argument("--net", choices=["linear", "ff"], default="linear",
                     help="linear = nerf/network.py (BASELINE configs[1-3]); ff = nerf/network_ff.py FFMLP bf16 (configs[4])")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
+                         "timing behind `roofline` only sees the launches that stay eager)")
+    ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
@@ -165,7 +169,7 @@ def main():
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
     model.infer_batch_mult = args.render_batch_mult
-    harness = TrainHarness(model, occupancy="synthetic", world=world)
+    harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs)
     parallel.broadcast_state(model)
     batches = build_batches(8, args.rays, device, rank, args.bound)
     ev_opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
@@ -193,7 +197,9 @@ def main():
     samples_acc = torch.zeros((), dtype=torch.int64, device=device)
     gb.STATS.update(fwd_points=0, fwd_calls=0, bwd_points=0, bwd_calls=0)
     _lib.prof.reset()
-    _lib.prof.enable(True)
+    # live hipEvent timing of the roofline kernel (and its backward) over the timed region; the other kernel families
+    # are in profiles/ (rocprofv3) -- timing all of them costs ~25 event records per step, 5 % of a 1 ms step
+    _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):

@@ -51,6 +51,7 @@ SIGNATURES = {
     "enerf_prof_reset": [],
     "enerf_prof_read": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],
     "enerf_adam_step_multi": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp],
+    "enerf_prof_enable_mask": [_u32],
     "enerf_abi_version": [],
 }
 
@@ -144,8 +145,16 @@ class prof:
                "ffmlp_fwd": 6, "ffmlp_bwd": 7, "march_infer": 8, "composite_infer": 9}
 
     @staticmethod
-    def enable(on=True):
-        lib().enerf_prof_enable(1 if on else 0)
+    def enable(on=True, only=None):
+        """Time every kernel family (on=True), none (False), or just the named ones (only=("grid_fwd", ...)): each
+        timed call puts two event records on the stream, which is not free at ~60 launches per millisecond."""
+        if on and only is not None:
+            mask = 0
+            for name in only:
+                mask |= 1 << prof.KERNELS[name]
+            lib().enerf_prof_enable_mask(mask)
+        else:
+            lib().enerf_prof_enable(1 if on else 0)
 
     @staticmethod
     def reset():

@@ -45,12 +45,12 @@ struct EvPair {
     hipEvent_t a, b;
 };
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
+static uint32_t g_prof_mask = 0;     // bit k: time kernel family k
 static std::vector<EvPair> g_prof_ev[ENERF_K_COUNT];
 static const size_t kMaxPairs = 1 << 16;
 
 ProfScope::ProfScope(int kernel_id, hipStream_t stream) : id(kernel_id), s(stream), slot(nullptr) {
-    if (!g_prof_on) return;
+    if (!((g_prof_mask >> id) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_ev[id].size() >= kMaxPairs) return;
     EvPair p;
@@ -80,7 +80,13 @@ int enerf_abi_version(void) { return 1; }
 
 int enerf_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
-    enerf::g_prof_on = on != 0;
+    enerf::g_prof_mask = on ? 0xffffffffu : 0u;
+    return 0;
+}
+
+int enerf_prof_enable_mask(uint32_t mask) {
+    std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
+    enerf::g_prof_mask = mask;
     return 0;
 }
 

@@ -89,9 +89,16 @@ class _FusedRenderTrain(Function):
 
 def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
     """-> depth [N], image [N,3] (+ the step counter bookkeeping of run_cuda)."""
-    counter = model.step_counter[model.local_step % 16]
+    # graph replay needs the counter at a fixed address; the harness copies it into the step_counter ring afterwards
+    counter = getattr(model, "graph_counter", None)
+    if counter is None:
+        counter = model.step_counter[model.local_step % 16]
+        model.local_step += 1
     counter.zero_()
-    model.local_step += 1
     params = fnet.network_params(model)
-    return _FusedRenderTrain.apply(rays_o, rays_d, model, bg_color, counter, int(model.mean_count), bool(perturb),
+    mean_count = int(model.mean_count)
+    quantum = int(getattr(model, "sample_budget_quantum", 0))
+    if quantum > 0 and mean_count > 0:
+        mean_count = (mean_count + quantum - 1) // quantum * quantum       # fewer distinct shapes (never fewer slots)
+    return _FusedRenderTrain.apply(rays_o, rays_d, model, bg_color, counter, mean_count, bool(perturb),
                                    bool(force_all_rays), float(dt_gamma), int(max_steps), *params)

@@ -7,6 +7,12 @@ Trainer.train_one_epoch do per iteration in the reference (main_nerf.py:211-214,
 `occupancy="synthetic"` keeps marching against the analytic scene's bitfield: update_extra_state() still runs (its cost
 is part of the step) but the synthetic grid is restored afterwards, so sample counts stay reproducible with
 random-init weights.
+
+`use_graphs=True` (fused fp32 HIP path only): once the sample budget is known (after the first 16 steps) the
+render -> loss -> backward part of an RGB step is captured into a HIP graph per (ray count, sample budget) and replayed;
+update_extra_state, the gradient all-reduce and the optimizer stay outside.  The sample budget is rounded up to a
+multiple of 8192 samples so that the 16-step windows share graphs (a larger budget never drops a ray the reference's
+budget would keep).  A 4096-ray step is otherwise bounded by the host's launch rate, not by the kernels.
 """
 import torch
 
@@ -16,7 +22,7 @@ from .parallel import GradAverager
 
 
 class TrainHarness:
-    def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16):
+    def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16, use_graphs=False):
         self.model = model
         adam = FusedAdam if next(model.parameters()).is_cuda else torch.optim.Adam
         self.opt = adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
@@ -27,6 +33,10 @@ class TrainHarness:
         self._syn = None
         if model.cuda_ray and occupancy == "synthetic":
             self._syn = scene.install_occupancy(model)
+        self.use_graphs = bool(use_graphs)
+        self._graphs = {}
+        if self.use_graphs:
+            model.sample_budget_quantum = 8192
 
     def maybe_update_extra_state(self):
         m = self.model
@@ -36,11 +46,78 @@ class TrainHarness:
                 m.density_grid.copy_(self._syn[0])
                 m.density_bitfield.copy_(self._syn[1])
 
+    # ------------------------------------------------------------------ HIP-graph replay of render + loss + backward
+    def _graph_key(self, tag, rays_o):
+        m = self.model
+        q = m.sample_budget_quantum
+        return (tag, tuple(rays_o.shape), (int(m.mean_count) + q - 1) // q * q)
+
+    def _capture(self, inputs, loss_fn):
+        """Capture loss_fn(static inputs) + backward; returns the replay state."""
+        from . import _lib
+        m = self.model
+        _lib.prof.enable(False)                       # hipEvent timing hooks cannot live inside a captured graph
+        if getattr(m, "graph_counter", None) is None:
+            m.graph_counter = torch.zeros(2, dtype=torch.int32, device=inputs[0].device)
+        st = {"in": [t.clone() for t in inputs]}
+        params = [p for p in m.parameters() if p.requires_grad]
+
+        def fwd_bwd():
+            loss = loss_fn(*st["in"])
+            loss.backward()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                        # warm-up on the capture stream: workspaces reach their size
+                self.opt.zero_grad(set_to_none=True)
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        self.opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st["loss"] = fwd_bwd().detach()
+        st["graph"] = g
+        st["grads"] = [(p, p.grad) for p in params]
+        return st
+
+    def _replay(self, st, inputs, renders):
+        m = self.model
+        for dst, src in zip(st["in"], inputs):
+            dst.copy_(src)
+        st["graph"].replay()
+        for p, g in st["grads"]:
+            p.grad = g
+        # every render of the step used the same fixed-address counter; the ring gets the last render's counts
+        for _ in range(renders):
+            m.step_counter[m.local_step % 16].copy_(m.graph_counter)
+            m.local_step += 1
+        if self.avg is not None:
+            self.avg()
+        self.opt.step()
+        return st["loss"].detach()
+
+    def _graphable(self, rays_o, rays_d):
+        from . import fused_render
+        return (self.use_graphs and self.model.mean_count > 0
+                and fused_render.supported(self.model, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3),
+                                           1, 0))
+
     def step_rgb(self, rays_o, rays_d, target, **render_kw):
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
         self.model.train()
         self.maybe_update_extra_state()
         self.global_step += 1
+        if self._graphable(rays_o, rays_d):
+            m = self.model
+            key = self._graph_key("rgb", rays_o)
+            if key not in self._graphs:
+                self._graphs[key] = self._capture(
+                    (rays_o, rays_d, target),
+                    lambda ro, rd, tg: torch.nn.functional.mse_loss(
+                        m.render(ro, rd, staged=False, bg_color=None, perturb=True, **render_kw)["image"], tg))
+            return self._replay(self._graphs[key], (rays_o, rays_d, target), 1)
         self.opt.zero_grad(set_to_none=True)
         out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=True, **render_kw)
         loss = torch.nn.functional.mse_loss(out["image"], target)
@@ -48,7 +125,7 @@ class TrainHarness:
         if self.avg is not None:
             self.avg()
         self.opt.step()
-        return loss
+        return loss.detach()
 
     def step_events(self, data, opt):
         """One event training step: two renders sharing one backward (nerf/utils.py:482-573)."""
@@ -56,10 +133,18 @@ class TrainHarness:
         self.model.train()
         self.maybe_update_extra_state()
         self.global_step += 1
+        if opt.event_only and self._graphable(data["rays_evs_o1"], data["rays_evs_d1"]):
+            names = ("images", "rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols")
+            key = self._graph_key("events", data["rays_evs_o1"])
+            inputs = tuple(data[n] for n in names)
+            if key not in self._graphs:
+                self._graphs[key] = self._capture(
+                    inputs, lambda *ts: train_step_events(self.model, dict(zip(names, ts)), opt)[0])
+            return self._replay(self._graphs[key], inputs, 2)
         self.opt.zero_grad(set_to_none=True)
         loss, _ = train_step_events(self.model, data, opt)
         loss.backward()
         if self.avg is not None:
             self.avg()
         self.opt.step()
-        return loss
+        return loss.detach()

@@ -250,6 +250,8 @@ int enerf_debug_grid_bwd_binned(uint32_t min_batch, uint32_t min_tiles);
 #define ENERF_K_COUNT 10
 
 int enerf_prof_enable(int on);
+/* bit k of `mask` enables timing of kernel family k only (each timed call costs two event records on the stream) */
+int enerf_prof_enable_mask(uint32_t mask);
 int enerf_prof_reset(void);
 /* Synchronises the recorded events; returns total milliseconds and launch count for `kernel_id`. [host ptrs] */
 int enerf_prof_read(int kernel_id, double* total_ms, uint64_t* launches);

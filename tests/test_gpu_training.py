@@ -95,6 +95,26 @@ def test_fused_render_node_matches_op_by_op_route(monkeypatch, bg, mean_count):
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-9, n
 
 
+def test_graph_replay_matches_eager_steps():
+    """TrainHarness(use_graphs=True): render + loss + backward replayed as a HIP graph once the sample budget is known.
+    Same budgets, same inputs -> the loss trajectory and the sample counters are those of the eager harness."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 2048, 2)
+    runs = []
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        model.sample_budget_quantum = 8192                    # the graph harness rounds the budget up; match it
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", use_graphs=graphs)
+        losses = [h.step_rgb(*data[i % len(data)]).clone() for i in range(40)]
+        runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu(), len(h._graphs)))
+    (l0, c0, n0), (l1, c1, n1) = runs
+    assert n0 == 0 and n1 >= 1
+    assert torch.equal(c0, c1)
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
+
+
 def test_step_is_deterministic_in_integer_state():
     from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
