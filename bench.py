@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
                          "timing behind `roofline` only sees the launches that stay eager)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="N > 1: do not march the next batch underneath the gradient all-reduce")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256)
@@ -170,6 +172,7 @@ def main():
     model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
     model.infer_batch_mult = args.render_batch_mult
     harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs)
+    harness.prefetch = not args.no_prefetch
     parallel.broadcast_state(model)
     batches = build_batches(8, args.rays, device, rank, args.bound)
     ev_opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
@@ -177,7 +180,8 @@ def main():
     def one_step(i):
         ro, rd, target = batches[i % len(batches)]
         if args.mode == "rgb":
-            return harness.step_rgb(ro, rd, target)
+            nxt = batches[(i + 1) % len(batches)]
+            return harness.step_rgb(ro, rd, target, next_rays=(nxt[0], nxt[1]) if world > 1 else None)
         ro2, rd2, _ = batches[(i + 1) % len(batches)]
         pols = torch.sign(target[..., 0] - 0.5)
         data = {"images": target, "rays_evs_o1": ro, "rays_evs_d1": rd, "rays_evs_o2": ro2, "rays_evs_d2": rd2,
@@ -204,9 +208,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         one_step(i)
-        samples_acc += model.step_counter[(model.local_step - 1) % 16, 0].to(torch.int64)
+        # slot of the render(s) this step consumed (a prefetched march of the next step may already own the newest one)
+        slot = getattr(model, "rendered_counter_slot", None)
+        slot = (model.local_step - 1) % 16 if slot is None else slot
+        samples_acc += model.step_counter[slot, 0].to(torch.int64)
         if args.mode == "events":
-            samples_acc += model.step_counter[(model.local_step - 2) % 16, 0].to(torch.int64)
+            samples_acc += model.step_counter[(slot - 1) % 16, 0].to(torch.int64)
     sync()
     t1 = time.perf_counter()
     _lib.prof.enable(False)

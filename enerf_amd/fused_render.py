@@ -30,30 +30,42 @@ def supported(model, rays_o, rays_d, bg_color, dt_gamma):
     return fnet.supported(model, probe, probe)
 
 
+def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps):
+    """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
+    Returns the sample buffers; a data-parallel harness runs it for the NEXT batch while the gradient all-reduce of
+    the current step is in flight (TrainHarness.prefetch_march)."""
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    nears = torch.empty(N, dtype=torch.float32, device=dev)
+    fars = torch.empty(N, dtype=torch.float32, device=dev)
+    _rb.near_far_from_aabb(rays_o, rays_d, model.aabb_train, N, model.min_near, nears, fars)
+    M = N * max_steps
+    if not force_all_rays and mean_count > 0:
+        M = mean_count + (128 - mean_count % 128)            # raymarching.py:186-189 (align = 128)
+    xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+    dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+    deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    _rb.march_rays_train(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
+                         model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
+    if force_all_rays or mean_count <= 0:
+        m = int(counter[0].item())
+        m += 128 - m % 128
+        xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        M = m
+    return dict(nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas, rays=rays, M=M)
+
+
 class _FusedRenderTrain(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, model, bg_color, counter, mean_count, perturb, force_all_rays, dt_gamma,
-                max_steps, embeddings, ws0, ws1, wc0, wc1, wc2):
+                max_steps, pre, embeddings, ws0, ws1, wc0, wc1, wc2):
         N = rays_o.shape[0]
         dev = rays_o.device
-        nears = torch.empty(N, dtype=torch.float32, device=dev)
-        fars = torch.empty(N, dtype=torch.float32, device=dev)
-        _rb.near_far_from_aabb(rays_o, rays_d, model.aabb_train, N, model.min_near, nears, fars)
-
-        M = N * max_steps
-        if not force_all_rays and mean_count > 0:
-            M = mean_count + (128 - mean_count % 128)            # raymarching.py:186-189 (align = 128)
-        xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-        dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-        deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
-        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
-        _rb.march_rays_train(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
-                             model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
-        if force_all_rays or mean_count <= 0:
-            m = int(counter[0].item())
-            m += 128 - m % 128
-            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
-            M = m
+        if pre is None:
+            pre = march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps)
+        nears, fars, xyzs, dirs, deltas, rays, M = (pre[k] for k in ("nears", "fars", "xyzs", "dirs", "deltas", "rays",
+                                                                     "M"))
 
         train = any(p.requires_grad for p in (embeddings, ws0, ws1, wc0, wc1, wc2))
         sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), train, embeddings, model.encoder.offsets,
@@ -84,21 +96,55 @@ class _FusedRenderTrain(Function):
         _rb.composite_rays_train_backward(g_ws, g_image, sigmas, rgb, deltas, rays, weights_sum, image, M, N, g_sigmas,
                                           g_rgbs)
         g = fnet.nerf_backward(ctx.sv, g_sigmas, g_rgbs, sigma_scale=scale)
-        return (None,) * 10 + g
+        return (None,) * 11 + g
 
 
-def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
-    """-> depth [N], image [N,3] (+ the step counter bookkeeping of run_cuda)."""
-    # graph replay needs the counter at a fixed address; the harness copies it into the step_counter ring afterwards
-    counter = getattr(model, "graph_counter", None)
-    if counter is None:
-        counter = model.step_counter[model.local_step % 16]
-        model.local_step += 1
-    counter.zero_()
-    params = fnet.network_params(model)
+def _budget(model):
     mean_count = int(model.mean_count)
     quantum = int(getattr(model, "sample_budget_quantum", 0))
     if quantum > 0 and mean_count > 0:
         mean_count = (mean_count + quantum - 1) // quantum * quantum       # fewer distinct shapes (never fewer slots)
-    return _FusedRenderTrain.apply(rays_o, rays_d, model, bg_color, counter, mean_count, bool(perturb),
-                                   bool(force_all_rays), float(dt_gamma), int(max_steps), *params)
+    return mean_count
+
+
+def _next_counter(model):
+    # graph replay needs the counter at a fixed address; the harness copies it into the step_counter ring afterwards
+    counter = getattr(model, "graph_counter", None)
+    if counter is None:
+        model.last_counter_slot = model.local_step % 16
+        counter = model.step_counter[model.last_counter_slot]
+        model.local_step += 1
+    counter.zero_()
+    return counter
+
+
+def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024):
+    """Run the parameter-independent stage of the NEXT training render now (e.g. under a gradient all-reduce).  The
+    result is picked up by the next render_train call on the same ray tensors; anything that changes what the stage
+    reads (update_extra_state: bitfield, sample budget) must not happen in between -- the caller's responsibility."""
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
+    pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False, float(dt_gamma),
+                      int(max_steps))
+    pre["slot"] = getattr(model, "last_counter_slot", None)
+    model._premarched = (key, pre)
+
+
+def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
+    """-> depth [N], image [N,3] (+ the step counter bookkeeping of run_cuda)."""
+    pre = None
+    stash = getattr(model, "_premarched", None)
+    if stash is not None:
+        model._premarched = None
+        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
+        if stash[0] == key and not force_all_rays:
+            pre = stash[1]
+            model.rendered_counter_slot = pre["slot"]
+    counter = None
+    if pre is None:
+        counter = _next_counter(model)
+        model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
+    params = fnet.network_params(model)
+    return _FusedRenderTrain.apply(rays_o, rays_d, model, bg_color, counter, _budget(model), bool(perturb),
+                                   bool(force_all_rays), float(dt_gamma), int(max_steps), pre, *params)

@@ -45,17 +45,22 @@ class GradAverager:
         self.big = [p for p in self.params if p.numel() >= big_threshold]
         self.small = [p for p in self.params if p.numel() < big_threshold]
         self._flat = None
+        self._works = []
+        self._avg_in_op = False
 
-    def __call__(self):
+    def start(self):
+        """Launch the two collectives (async).  Work queued on the current stream afterwards overlaps with them."""
+        self._works = []
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
-        world = dist.get_world_size()
-        works = []
+        # RCCL averages in the collective; gloo (CPU tests) only sums
+        self._avg_in_op = dist.get_backend() == "nccl"
+        op = dist.ReduceOp.AVG if self._avg_in_op else dist.ReduceOp.SUM
         for p in self.big:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
-        small = [p for p in self.small]
+            self._works.append(dist.all_reduce(p.grad, op=op, async_op=True))
+        small = self.small
         if small:
             n = sum(p.numel() for p in small)
             if self._flat is None or self._flat.numel() != n or self._flat.device != small[0].device:
@@ -68,20 +73,33 @@ class GradAverager:
                 else:
                     self._flat[off:off + k].copy_(p.grad.reshape(-1))
                 off += k
-            works.append(dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
+            self._works.append(dist.all_reduce(self._flat, op=op, async_op=True))
+
+    def finish(self):
+        """Wait for the collectives and leave the averaged gradients in p.grad."""
+        if not self._works:
+            return
+        for w in self._works:
             w.wait()
-        inv = 1.0 / world
-        for p in self.big:
-            p.grad.mul_(inv)
-        if small:
+        self._works = []
+        inv = 1.0 / dist.get_world_size()
+        if not self._avg_in_op:
+            for p in self.big:
+                p.grad.mul_(inv)
+        if self.small:
             off = 0
-            for p in small:
+            for p in self.small:
                 k = p.numel()
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
-                p.grad.copy_(self._flat[off:off + k].view_as(p)).mul_(inv)
+                p.grad.copy_(self._flat[off:off + k].view_as(p))
+                if not self._avg_in_op:
+                    p.grad.mul_(inv)
                 off += k
+
+    def __call__(self):
+        self.start()
+        self.finish()
 
 
 def broadcast_state(model, src=0):

@@ -33,6 +33,7 @@ class TrainHarness:
         self._syn = None
         if model.cuda_ray and occupancy == "synthetic":
             self._syn = scene.install_occupancy(model)
+        self.prefetch = True          # data parallel: march the next batch underneath the gradient all-reduce
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         if self.use_graphs:
@@ -104,7 +105,24 @@ class TrainHarness:
                 and fused_render.supported(self.model, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3),
                                            1, 0))
 
-    def step_rgb(self, rays_o, rays_d, target, **render_kw):
+    def _reduce_grads(self, next_rays=None):
+        """Average gradients across ranks.  With `next_rays` = (rays_o, rays_d) of the following step, the part of that
+        step's render that does not read the parameters (near_far + march_rays_train, ~20 % of a step) is issued right
+        after the collectives and runs underneath them; skipped whenever the next step starts with
+        update_extra_state (new bitfield / sample budget) or the sample budget is not known yet."""
+        if self.avg is None:
+            return
+        self.avg.start()
+        m = self.model
+        if (next_rays is not None and self.prefetch and m.cuda_ray and m.mean_count > 0
+                and self.global_step % self.update_interval != 0):
+            from . import fused_render
+            ro, rd = next_rays
+            if fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1, 0):
+                fused_render.prefetch_march(m, ro, rd, perturb=True)
+        self.avg.finish()
+
+    def step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
         self.model.train()
         self.maybe_update_extra_state()
@@ -122,8 +140,7 @@ class TrainHarness:
         out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=True, **render_kw)
         loss = torch.nn.functional.mse_loss(out["image"], target)
         loss.backward()
-        if self.avg is not None:
-            self.avg()
+        self._reduce_grads(next_rays)
         self.opt.step()
         return loss.detach()
 

@@ -115,6 +115,36 @@ def test_graph_replay_matches_eager_steps():
     assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
 
 
+def test_prefetched_march_gives_the_same_steps():
+    """Data-parallel harness: the parameter-independent stage of the NEXT render (near_far + march) is issued right after
+    the gradient collectives are launched.  With a stand-in averager (single process) the prefetching harness must
+    reproduce the plain one: same sample counters, same loss trajectory, across update_extra_state boundaries."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+
+    class NoComm:
+        def start(self): pass
+        def finish(self): pass
+
+    data = _batches(4, 2048, 2)
+    runs = []
+    for prefetch in (False, True):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.avg = NoComm()
+        h.prefetch = prefetch
+        losses, slots = [], []
+        for i in range(52):
+            nxt = data[(i + 1) % len(data)]
+            losses.append(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1])).clone())
+            slots.append(int(model.step_counter[model.rendered_counter_slot, 0]))
+        runs.append((torch.stack(losses).cpu(), slots, model.mean_count))
+    (l0, s0, m0), (l1, s1, m1) = runs
+    assert s0 == s1 and m0 == m1
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
+
+
 def test_step_is_deterministic_in_integer_state():
     from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
