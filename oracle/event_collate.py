@@ -1,0 +1,73 @@
+"""CPU restatement (plain Python loops / numpy, TEST INFRASTRUCTURE ONLY) of the reference's event-pair preparation:
+
+  group_events       nerf/provider.py:1147-1199   dict of pixel -> event list in first-occurrence order, > 1 event per
+                                                  pixel, flattened; xy_numEvs_Idx, idx_no_successor, num_successor_evs
+  collate_pairs      nerf/provider.py:1367-1410   the per-step Python loop (successor filter, random window end,
+                                                  polarity sum) -- with the uniform draws passed in instead of taken
+                                                  from numpy's global generator
+
+Parity status: "unpinned" against a run of the reference itself -- EventNeRFDataset needs its dataset files on disk to
+be constructed; these functions are a line-by-line transcription, checked against an independent brute-force
+definition in tests/test_event_sampler.py.
+"""
+import numpy as np
+
+
+def group_events(events):
+    events_in = np.asarray(events, dtype=np.float32)
+    events_in = np.asarray(sorted(events_in, key=lambda x: x[2]))                 # provider.py:1152
+    evs_dict_xy = {}
+    for ev in events_in:                                                          # :1156-1161
+        key_xy = (ev[0], ev[1])
+        if key_xy in evs_dict_xy:
+            evs_dict_xy[key_xy].append(ev.tolist())
+        else:
+            evs_dict_xy[key_xy] = [ev.tolist()]
+    evs_dict_xy = dict((k, v) for k, v in evs_dict_xy.items() if len(v) > 1)       # :1163
+    xys = list(evs_dict_xy.keys())
+    num_evs_at_xy = np.asarray([len(evs_dict_xy[xy]) for xy in xys])              # :1168
+    xy_numEvs_Idx = np.concatenate((num_evs_at_xy[:, None],
+                                    np.append(0, np.cumsum(num_evs_at_xy)[:-1])[:, None]), axis=1)   # :1171
+    cum = np.cumsum(num_evs_at_xy)
+    num_evs = int(cum[-1])
+    idx_no_successor = cum - 1                                                    # :1178
+    num_successor_evs = np.zeros(num_evs).astype(np.int64)                        # :1181-1186
+    j = 0
+    for i in range(num_evs):
+        if i >= cum[j]:
+            j += 1
+        num_successor_evs[i] = cum[j] - i - 1
+    flat = []
+    for xy in xys:                                                                # :1190-1197
+        for ev in evs_dict_xy[xy]:
+            flat.append(ev)
+    return {"events": np.asarray(flat, dtype=np.float32), "xy_numEvs_Idx": xy_numEvs_Idx,
+            "idx_no_successor": idx_no_successor, "num_successor_evs": num_successor_evs}
+
+
+def collate_pairs(g, eidx, u_end, acc_max_num_evs=0):
+    """provider.py:1369-1398 with eidx (the randint draw) and u_end in [0,1) (mapped onto randint's range) given."""
+    no_succ = set(int(v) for v in g["idx_no_successor"])
+    eidx = np.asarray([e - 1 if int(e) in no_succ else e for e in eidx])          # :1371
+    eidx_end, sum_pols = [], []
+    for k, ev_id_start in enumerate(eidx):
+        num_successors = g["num_successor_evs"][ev_id_start]
+        if acc_max_num_evs:
+            num_successors = np.minimum(num_successors, acc_max_num_evs + 1)
+        # np.random.randint(ev_id_start + 1, ev_id_start + 1 + num_successors)
+        ev_id_end = ev_id_start + 1 + min(int(np.floor(u_end[k] * num_successors)), int(num_successors) - 1)
+        ps = g["events"][(ev_id_start + 1):(ev_id_end + 1), 3]
+        sum_pols.append(ps.sum())
+        eidx_end.append(ev_id_end)
+    xs = g["events"][eidx, 0]
+    ys = g["events"][eidx, 1]
+    return eidx, np.asarray(eidx_end), np.asarray(sum_pols, dtype=np.float32), xs, ys
+
+
+def collate_single(g, u_xy, choice):
+    """provider.py:1400-1405 (accumulate_evs off) with the per-pixel uniforms and the np.random.choice result given."""
+    num_evs_xy = g["xy_numEvs_Idx"][:, 0]
+    eidx = (u_xy * num_evs_xy - 1).astype(int) + g["xy_numEvs_Idx"][:, 1]
+    eidx = eidx[choice]
+    pols = g["events"][eidx + 1, 3]
+    return eidx, eidx + 1, pols, g["events"][eidx, 0], g["events"][eidx, 1]

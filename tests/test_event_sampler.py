@@ -1,0 +1,111 @@
+"""Event-pair sampling (enerf_amd/event_sampler.py) against the loop restatement of the reference
+(oracle/event_collate.py) and against a brute-force definition, on CPU; on the GPU against the CPU result."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import event_collate as EC
+
+
+def _events(n, w, h, seed):
+    rng = np.random.default_rng(seed)
+    xs = rng.integers(0, w, n)
+    ys = rng.integers(0, h, n)
+    ts = rng.permutation(n * 3)[:n].astype(np.float64) * 1000.0           # distinct timestamps, shuffled order
+    ps = rng.choice([-1.0, 1.0], n)
+    return np.stack([xs, ys, ts, ps], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,w,h", [(400, 6, 5), (5000, 40, 30), (64, 64, 64)])
+def test_tables_match_reference_loops(n, w, h):
+    from enerf_amd.event_sampler import build_event_tables
+    ev = _events(n, w, h, n)
+    if n == 64:
+        ev[:8, :2] = ev[0, :2]                                             # make sure some pixel has > 1 event
+    g = EC.group_events(ev)
+    t = build_event_tables(torch.from_numpy(ev))
+    assert np.array_equal(t["events"].numpy(), g["events"])
+    assert np.array_equal(t["num_at_xy"].numpy(), g["xy_numEvs_Idx"][:, 0])
+    assert np.array_equal(t["first_at_xy"].numpy(), g["xy_numEvs_Idx"][:, 1])
+    assert np.array_equal(t["no_successor"].nonzero().flatten().numpy(), g["idx_no_successor"])
+    assert np.array_equal(t["num_successor"].numpy(), g["num_successor_evs"])
+    # brute force: successors = later events at the same pixel in the flattened list
+    e = g["events"]
+    for i in range(0, len(e), max(1, len(e) // 50)):
+        same = (e[i + 1:, 0] == e[i, 0]) & (e[i + 1:, 1] == e[i, 1])
+        assert int(same.sum()) == int(t["num_successor"][i])
+        assert np.all(e[i + 1:][same][:, 2] > e[i, 2])
+
+
+@pytest.mark.parametrize("acc_max", [0, 3])
+def test_accumulated_pairs_match_reference_loop(acc_max):
+    from enerf_amd.event_sampler import build_event_tables, sample_event_pairs
+    ev = _events(6000, 32, 24, 7)
+    g = EC.group_events(ev)
+    t = build_event_tables(torch.from_numpy(ev))
+    N, M = len(g["events"]), 2048
+    rng = np.random.default_rng(8)
+    eidx = rng.integers(0, N, M)
+    u = rng.random(M)
+    rs, re_, rp, rx, ry = EC.collate_pairs(g, eidx, u, acc_max)
+    s, e, p, xs, ys = sample_event_pairs(t, M, True, acc_max, draws={"start": torch.from_numpy(eidx),
+                                                                      "u_end": torch.from_numpy(u)})
+    assert np.array_equal(s.numpy(), rs) and np.array_equal(e.numpy(), re_)
+    assert np.array_equal(p[0].numpy(), rp)                               # sums of +-1: exact
+    assert np.array_equal(xs[0].numpy(), rx) and np.array_equal(ys[0].numpy(), ry)
+    ee = g["events"]
+    assert np.all(ee[rs, 0] == ee[re_, 0]) and np.all(ee[rs, 1] == ee[re_, 1]) and np.all(ee[rs, 2] < ee[re_, 2])
+    if acc_max:
+        assert int((e - s).max()) <= acc_max + 1
+
+
+def test_single_successor_pairs_match_reference():
+    from enerf_amd.event_sampler import build_event_tables, sample_event_pairs
+    ev = _events(3000, 20, 20, 9)
+    g = EC.group_events(ev)
+    t = build_event_tables(torch.from_numpy(ev))
+    P = len(g["xy_numEvs_Idx"])
+    rng = np.random.default_rng(10)
+    u = rng.random(P)
+    choice = rng.integers(0, P, 512)
+    rs, re_, rp, rx, ry = EC.collate_single(g, u, choice)
+    s, e, p, xs, ys = sample_event_pairs(t, 512, False, draws={"u_xy": torch.from_numpy(u),
+                                                                "choice": torch.from_numpy(choice)})
+    assert np.array_equal(s.numpy(), rs) and np.array_equal(e.numpy(), re_) and np.array_equal(p[0].numpy(), rp)
+    assert np.array_equal(xs[0].numpy(), rx) and np.array_equal(ys[0].numpy(), ry)
+
+
+def test_batch_has_the_reference_data_dict_entries():
+    from enerf_amd.event_sampler import build_event_tables, event_pair_batch
+    ev = _events(2000, 16, 12, 11)
+    t = build_event_tables(torch.from_numpy(ev))
+    N = t["events"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    poses = torch.eye(4)[:3].repeat(N, 1, 1) + 0.01 * torch.randn(N, 3, 4, generator=g)
+    out = event_pair_batch(t, poses, (10.0, 10.0, 8.0, 6.0), 256, True, 4, generator=g)
+    assert set(out) == {"rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols"}
+    assert out["rays_evs_o1"].shape == (1, 256, 3) and out["rays_evs_d2"].shape == (1, 256, 3)
+    assert out["pols"].shape == (1, 256) and float(out["pols"].abs().max()) <= 5
+    assert torch.allclose(out["rays_evs_d1"].norm(dim=-1), (out["rays_evs_d1"] * 0 + 1).sum(-1) / 3, atol=0.2)
+
+
+@pytest.mark.gpu
+def test_device_tables_and_pairs_match_cpu():
+    from enerf_amd.event_sampler import build_event_tables, sample_event_pairs
+    ev = torch.from_numpy(_events(200000, 346, 260, 12))
+    tc = build_event_tables(ev)
+    tg = build_event_tables(ev.cuda())
+    for k in tc:
+        assert torch.equal(tc[k], tg[k].cpu()), k
+    N = tc["events"].shape[0]
+    g = torch.Generator().manual_seed(5)
+    draws = {"start": torch.randint(0, N, (4096,), generator=g), "u_end": torch.rand(4096, generator=g, dtype=torch.float64)}
+    a = sample_event_pairs(tc, 4096, True, 8, draws=draws)
+    b = sample_event_pairs(tg, 4096, True, 8, draws=draws)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y.cpu())
+    # free-running generator on the device: pairs are valid (same pixel, later time, window bound)
+    s, e, p, xs, ys = sample_event_pairs(tg, 4096, True, 8, generator=torch.Generator(device="cuda").manual_seed(1))
+    evg = tg["events"]
+    assert bool((evg[s, 0] == evg[e, 0]).all()) and bool((evg[s, 1] == evg[e, 1]).all())
+    assert bool((evg[s, 2] < evg[e, 2]).all()) and int((e - s).max()) <= 9 and int((e - s).min()) >= 1
