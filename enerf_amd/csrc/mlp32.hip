@@ -8,9 +8,11 @@
 // native surface; enerf_amd/network.py routes its MLPs here (enerf_amd/fused_mlp.py), state_dict unchanged.
 //
 // Orientation as in ffmlp.hip: D[neuron][sample].  With one fp32 per lane per operand the D tile of one layer is the
-// B operand of the next layer *as is* (MFMA q of input block ib consumes accumulator register q); the weight-gradient
-// kernel reads its operands straight from the row-major [B,64] buffers (a wavefront reads two 128-byte row segments
-// per MFMA), no transposes anywhere.
+// B operand of the next layer *as is* (MFMA q of input block ib consumes accumulator register q).  The backward of a
+// net with up to two hidden layers is ONE kernel (k_mlp32_bwd_fused): the dgrad chain passes each activation /
+// gradient tile through LDS once and consumes it as a weight-gradient operand on the spot, so no backward buffer is
+// written.  Deeper nets use the separate dgrad (k_mlp32_bwd_act) and weight-gradient (k_mlp32_bwd_w) kernels; the
+// latter reads its operands straight from the row-major [B,64] buffers (two 128-byte row segments per MFMA).
 //
 // Batches are ragged: B is the number of valid samples, every scratch buffer (fb, bb) and the level-major input has
 // Bp = B rounded up to 32 rows, and samples >= B carry zeros through every kernel, so callers never pad or copy.

@@ -203,9 +203,9 @@ __global__ void __launch_bounds__(256) k_packbits(const float* __restrict__ grid
 
 // ------------------------------------------------------------------ march_rays_train
 // Pass structure (replaces the reference's count -> 2 global atomics -> write in one thread):
-//   k_march_count : num_steps[n]  (written to rays[n][2])
+//   k_march_count : num_steps[n]  (written to rays[n][2]); the wave-per-ray variant also logs its emitting chunks
 //   k_march_scan  : single workgroup exclusive scan -> rays[n] = (n, base + excl, num_steps); counter update
-//   k_march_write : re-march and emit samples at the scanned offset
+//   k_march_write : emit samples at the scanned offset (wave-per-ray: replay of the chunk log; thread-per-ray: re-march)
 // so offsets are those of sequential execution and reproducible run to run.
 template <bool WRITE>
 __device__ __forceinline__ uint32_t march_one_ray(const RayCtx& c, float t0, float far, uint32_t limit, float* xyzs,

@@ -3,7 +3,8 @@ module (same constructor arguments, attribute / parameter / buffer names and ini
 
 MI355X-side difference, invisible to callers: when the backend advertises `layout=` support (the HIP backend does),
 the kernel writes the [B, L*C] result directly and reads the [B, L*C] gradient directly, so the two full
-permute+copy passes of grid.py:52 and grid.py:70 disappear.
+permute+copy passes of grid.py:52 and grid.py:70 disappear.  `GridEncoder.forward_level_major` additionally exposes
+the kernel-native [L, Bp, C] tensor for consumers that can read it in place (enerf_amd.fused_mlp / fused_network).
 """
 import inspect
 
