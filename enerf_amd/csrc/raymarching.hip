@@ -123,6 +123,66 @@ __device__ __forceinline__ bool eval_step(const RayCtx& c, float t, float& x, fl
     return occ;
 }
 
+// Fixed-step (dt_gamma == 0), power-of-two H <= kTabH form of eval_cell for the wave-per-ray marchers: the same values
+// bit for bit, from far fewer instructions.
+//   * dt == dt_min and the level bound from it are constants of the ray (RayFixed).
+//   * 1 / mip_bound: 2^-level exactly below the clamp, the ray constant 1 / bound at it.
+//   * 0.5 * (double)f * (double)H == f * (0.5f * H) exactly when H is a power of two (both scalings are exact).
+//   * the voxel-face coordinate (n + 0.5 + 0.5 sign) / (H - 1) * 2 - 1 only takes the H + 1 values n' = n or n + 1:
+//     a table in LDS (face_tab, built per workgroup with the reference's own float expression) replaces three IEEE
+//     divisions per lattice point; expand_tab does the same for the Morton bit spreading.
+constexpr uint32_t kTabH = 256;
+struct MarchTabs {
+    const float* face;        // [H + 1]
+    const uint32_t* expand;   // [H]
+};
+struct RayFixed {
+    int ld;                   // level bound from dt_min
+    float rbound;             // 1 / bound
+    float half_h;             // 0.5f * H
+    int sx, sy, sz;           // 1 where the direction component is positive (copysign semantics), else 0
+};
+__device__ __forceinline__ bool march_fast_ok(uint32_t H) { return H <= kTabH && (H & (H - 1u)) == 0u; }
+__device__ __forceinline__ void build_march_tabs(float* face, uint32_t* expand, uint32_t H) {
+    const float hm1 = (float)(H - 1);
+    for (uint32_t k = threadIdx.x; k <= H; k += blockDim.x) face[k] = fmaf((float)k / hm1, 2.0f, -1.0f);
+    for (uint32_t k = threadIdx.x; k < H; k += blockDim.x) expand[k] = expand_bits(k);
+    __syncthreads();
+}
+__device__ __forceinline__ void ray_fixed_init(RayFixed& f, const RayCtx& c) {
+    f.ld = mip_exponent((float)((double)(c.dt_min * (float)c.H) * 0.5), c.C);
+    f.rbound = 1 / c.bound;
+    f.half_h = 0.5f * (float)c.H;
+    f.sx = signf_(c.dx) > 0 ? 1 : 0;
+    f.sy = signf_(c.dy) > 0 ? 1 : 0;
+    f.sz = signf_(c.dz) > 0 ? 1 : 0;
+}
+__device__ __forceinline__ bool eval_cell_fixed(const RayCtx& c, const RayFixed& f, const MarchTabs& tb, float t, float& x,
+                                                float& y, float& z, float& tt) {
+    const float bound = c.bound;
+    const uint32_t H = c.H;
+    x = clampf_(fmaf(t, c.dx, c.ox), -bound, bound);
+    y = clampf_(fmaf(t, c.dy, c.oy), -bound, bound);
+    z = clampf_(fmaf(t, c.dz, c.oz), -bound, bound);
+    const int lp = mip_exponent(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), c.C);
+    const int level = lp > f.ld ? lp : f.ld;
+    const float pw = (float)(1 << level);
+    const bool clamped = pw > bound;                                  // mip_bound = min(2^level, bound)
+    const float mip_bound = clamped ? bound : pw;
+    const float mip_rbound = clamped ? f.rbound : __int_as_float((127 - level) << 23);   // 2^-level
+    const float hm1 = (float)(H - 1);
+    const int nx = (int)clampf_(fmaf(x, mip_rbound, 1.0f) * f.half_h, 0.0f, hm1);
+    const int ny = (int)clampf_(fmaf(y, mip_rbound, 1.0f) * f.half_h, 0.0f, hm1);
+    const int nz = (int)clampf_(fmaf(z, mip_rbound, 1.0f) * f.half_h, 0.0f, hm1);
+    const uint32_t index = (uint32_t)level * H * H * H + (tb.expand[nx] | (tb.expand[ny] << 1) | (tb.expand[nz] << 2));
+    const bool occ = (c.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    const float tx = fmaf(tb.face[nx + f.sx], mip_bound, -x) * c.rdx;
+    const float ty = fmaf(tb.face[ny + f.sy], mip_bound, -y) * c.rdy;
+    const float tz = fmaf(tb.face[nz + f.sz], mip_bound, -z) * c.rdz;
+    tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    return occ;
+}
+
 // ------------------------------------------------------------------ small per-element kernels
 __global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                   const float* __restrict__ aabb, uint32_t N, float min_near,
@@ -253,11 +313,13 @@ struct ChunkEntry {
 constexpr uint32_t kLogCap = 64;                 // entries per ray; a ray that needs more is re-marched by the write pass
 constexpr uint32_t kLogOverflow = 0xffffffffu;
 
-template <bool WRITE, bool LOG = false>
+template <bool WRITE, bool LOG = false, bool FAST = false>
 __device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, float far, uint32_t limit, float* xyzs,
                                                   float* dirs, float* deltas, ChunkEntry* log = nullptr,
-                                                  uint32_t* nlog = nullptr) {
+                                                  uint32_t* nlog = nullptr, const MarchTabs* tabs = nullptr) {
     uint32_t logged = 0;
+    RayFixed rf;
+    if (FAST) ray_fixed_init(rf, c);
     const int lane = lane_id();
     const float dt = c.dt_min;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes strictly below mine
@@ -280,12 +342,20 @@ __device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, flo
         const unsigned long long vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
 
         float x, y, z, dts, tt;
-        const bool occ = eval_cell(c, ti, x, y, z, dts, tt);
+        bool occ;
+        if (FAST) {
+            occ = eval_cell_fixed(c, rf, *tabs, ti, x, y, z, tt);
+            dts = dt;
+        } else {
+            occ = eval_cell(c, ti, x, y, z, dts, tt);
+        }
         const float t_next = ti + dt;                                           // the true next lattice value
-        // per-lane jump target for an empty cell: first lattice index j > lane with !(t_j < tt)
+        // per-lane jump target for an empty cell: first lattice index j > lane with !(t_j < tt).  The first guess
+        // may be off (FAST: reciprocal instead of a division); the two loops below make it exact either way.
         int nxt = lane + 1;
         if (progression && ti < tt) {
-            int j = lane + (int)fminf(fmaxf(ceilf((tt - ti) / delta), 1.0f), 64.0f);
+            const float steps = FAST ? (tt - ti) * __builtin_amdgcn_rcpf(delta) : (tt - ti) / delta;
+            int j = lane + (int)fminf(fmaxf(ceilf(steps), 1.0f), 64.0f);
             while (j - 1 > lane && !(fmaf((float)(j - 1), delta, base) < tt)) j--;
             while (j < 64 && fmaf((float)j, delta, base) < tt) j++;
             nxt = j;
@@ -387,14 +457,21 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
                                                        const float* __restrict__ nears, const float* __restrict__ fars,
                                                        int32_t* rays, uint32_t perturb, ChunkEntry* __restrict__ log,
                                                        uint32_t* __restrict__ nlog) {
+    __shared__ float s_face[kTabH + 1];
+    __shared__ uint32_t s_expand[kTabH];
+    const bool fast = march_fast_ok(H);
+    if (fast) build_march_tabs(s_face, s_expand, H);
+    const MarchTabs tabs = {s_face, s_expand};
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (n >= N) return;
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
     float t0 = nears[n];
     if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
-    const uint32_t cnt = lattice_march<false, true>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                    log + (size_t)n * kLogCap, nlog + n);
+    const uint32_t cnt = fast ? lattice_march<false, true, true>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                                 log + (size_t)n * kLogCap, nlog + n, &tabs)
+                              : lattice_march<false, true, false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                                  log + (size_t)n * kLogCap, nlog + n);
     if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
 }
 
@@ -623,6 +700,11 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
                                                       float bound, uint32_t max_steps, uint32_t C, uint32_t H,
                                                       const uint8_t* __restrict__ grid, const float* __restrict__ fars,
                                                       float* xyzs, float* dirs, float* deltas, uint32_t perturb) {
+    __shared__ float s_face[kTabH + 1];
+    __shared__ uint32_t s_expand[kTabH];
+    const bool fast = march_fast_ok(H);
+    if (fast) build_march_tabs(s_face, s_expand, H);
+    const MarchTabs tabs = {s_face, s_expand};
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (n >= n_alive) return;
     const int index = rays_alive[n];
@@ -631,7 +713,11 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
     ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, 0.0f, max_steps, C, H);
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
     const size_t base = (size_t)n * n_step;
-    (void)lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+    if (fast)
+        (void)lattice_march<true, false, true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+                                               deltas + base * 2, nullptr, nullptr, &tabs);
+    else
+        (void)lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
 }
 
 __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step,
