@@ -416,6 +416,159 @@ __device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, flo
     return count;
 }
 
+// The same marcher for the fixed-step, table-friendly case (FAST above), restructured around what actually bounds it.
+// Counters on the plain version: 2.2 scalar instructions per vector instruction and 40 % of the wave cycles waiting --
+// a wave spends its time in (a) the latency of the occupancy-byte load each chunk starts with and (b) the serial
+// replay, one scalar round trip (readlane, compare, branch) per voxel crossed.  Hence:
+//   * software pipelining: the lattice does not depend on occupancy, so the next chunk's geometry is computed and its
+//     occupancy bytes are requested BEFORE the current chunk is replayed;
+//   * pointer doubling: every lane learns in 6 shuffle rounds where the chain of empty-voxel jumps starting at it ends
+//     (first occupied lane reached, or the lane whose jump leaves the chunk), so the scalar replay takes one step per
+//     occupied run instead of one per voxel.
+// Same visited set, same emitted samples, bit for bit.
+struct ChunkGeo {
+    float base, delta, ti, x, y, z, tt, t_next;
+    int nvalid, nxt;
+    unsigned long long vmask;
+    uint32_t bit, byte;
+};
+__device__ __forceinline__ ChunkGeo chunk_geometry(const RayCtx& c, const RayFixed& f, const MarchTabs& tb, float base,
+                                                   float far, int lane) {
+    ChunkGeo g;
+    const float dt = c.dt_min;
+    g.base = base;
+    g.delta = (base + dt) - base;
+    const float delta2 = ((base + g.delta) + dt) - (base + g.delta);
+    int e;
+    (void)frexpf(base, &e);
+    const float bin_top = ldexpf(1.0f, e);                                  // base in [bin_top/2, bin_top)
+    const bool progression = base >= 2.0f * dt && delta2 == g.delta;
+    g.ti = progression ? fmaf((float)lane, g.delta, base) : base;           // exact within the binade
+    const bool ok = lane == 0 || (progression && g.ti < bin_top);
+    const unsigned long long okm = __ballot(ok && g.ti < far);
+    g.nvalid = okm == ~0ull ? 64 : __builtin_ctzll(~okm);                   // leading run of usable lanes (>= 1)
+    g.vmask = g.nvalid == 64 ? ~0ull : ((1ull << g.nvalid) - 1ull);
+    g.t_next = g.ti + dt;
+
+    // eval_cell_fixed, with the occupancy byte only requested here
+    const float bound = c.bound;
+    const uint32_t H = c.H;
+    g.x = clampf_(fmaf(g.ti, c.dx, c.ox), -bound, bound);
+    g.y = clampf_(fmaf(g.ti, c.dy, c.oy), -bound, bound);
+    g.z = clampf_(fmaf(g.ti, c.dz, c.oz), -bound, bound);
+    const int lp = mip_exponent(fmaxf(fabsf(g.x), fmaxf(fabsf(g.y), fabsf(g.z))), c.C);
+    const int level = lp > f.ld ? lp : f.ld;
+    const float pw = (float)(1 << level);
+    const bool clamped = pw > bound;
+    const float mip_bound = clamped ? bound : pw;
+    const float mip_rbound = clamped ? f.rbound : __int_as_float((127 - level) << 23);
+    const float hm1 = (float)(H - 1);
+    const int nx = (int)clampf_(fmaf(g.x, mip_rbound, 1.0f) * f.half_h, 0.0f, hm1);
+    const int ny = (int)clampf_(fmaf(g.y, mip_rbound, 1.0f) * f.half_h, 0.0f, hm1);
+    const int nz = (int)clampf_(fmaf(g.z, mip_rbound, 1.0f) * f.half_h, 0.0f, hm1);
+    const uint32_t index = (uint32_t)level * H * H * H + (tb.expand[nx] | (tb.expand[ny] << 1) | (tb.expand[nz] << 2));
+    g.bit = index & 7u;
+    g.byte = c.grid[index >> 3];
+    const float tx = fmaf(tb.face[nx + f.sx], mip_bound, -g.x) * c.rdx;
+    const float ty = fmaf(tb.face[ny + f.sy], mip_bound, -g.y) * c.rdy;
+    const float tz = fmaf(tb.face[nz + f.sz], mip_bound, -g.z) * c.rdz;
+    g.tt = g.ti + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    // jump target of an empty cell: first lattice index j > lane with !(t_j < tt) (the loops make any guess exact)
+    g.nxt = lane + 1;
+    if (progression && g.ti < g.tt) {
+        int j = lane + (int)fminf(fmaxf(ceilf((g.tt - g.ti) * __builtin_amdgcn_rcpf(g.delta)), 1.0f), 64.0f);
+        while (j - 1 > lane && !(fmaf((float)(j - 1), g.delta, base) < g.tt)) j--;
+        while (j < 64 && fmaf((float)j, g.delta, base) < g.tt) j++;
+        g.nxt = j;
+    }
+    return g;
+}
+
+template <bool WRITE, bool LOG>
+__device__ __forceinline__ uint32_t lattice_march_fast(const RayCtx& c, const MarchTabs& tabs, float t0, float far,
+                                                       uint32_t limit, float* xyzs, float* dirs, float* deltas,
+                                                       ChunkEntry* log, uint32_t* nlog) {
+    RayFixed rf;
+    ray_fixed_init(rf, c);
+    const int lane = lane_id();
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    float tt_pending = -__builtin_huge_valf();
+    float last_t = t0;
+    uint32_t count = 0, logged = 0;
+    if (t0 < far && limit > 0) {
+        ChunkGeo A = chunk_geometry(c, rf, tabs, t0, far, lane);
+        while (true) {
+            const float base_next = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.t_next), A.nvalid - 1));
+            const bool have_next = base_next < far;
+            ChunkGeo Bn = A;
+            if (have_next) Bn = chunk_geometry(c, rf, tabs, base_next, far, lane);     // its loads fly during the replay
+
+            const bool occ = ((A.byte >> A.bit) & 1u) != 0;
+            const unsigned long long occm = __ballot(occ) & A.vmask;
+            // pointer doubling over the empty lanes: ps = (lane reached << 8) | lane whose jump got there
+            int ps = (occ || lane >= A.nvalid) ? ((lane << 8) | lane) : (((A.nxt < 64 ? A.nxt : 64) << 8) | lane);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const int P = ps >> 8;
+                const int q = __shfl(ps, P < 64 ? P : 63, 64);
+                if (P < A.nvalid && (q >> 8) != P) ps = q;       // landed on an empty lane inside the chunk: keep going
+            }
+            const unsigned long long reach = __ballot(!(A.ti < tt_pending)) & A.vmask;
+            int cur = reach ? __builtin_ctzll(reach) : A.nvalid;
+            if (cur < A.nvalid) tt_pending = -__builtin_huge_valf();
+            unsigned long long emit = 0ull;
+            uint32_t room = limit - count;
+            while (cur < A.nvalid && room > 0) {
+                if ((occm >> cur) & 1ull) {
+                    const unsigned long long rest = ~(occm >> cur);
+                    uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : (uint32_t)(64 - cur);
+                    if (run > room) run = room;
+                    emit |= (run == 64 ? ~0ull : ((1ull << run) - 1ull)) << cur;
+                    cur += (int)run;
+                    room -= run;
+                } else {
+                    const int e = __builtin_amdgcn_readlane(ps, cur);
+                    if ((e >> 8) >= A.nvalid) {
+                        tt_pending = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.tt), e & 0xff));
+                        cur = A.nvalid;
+                    } else {
+                        cur = e >> 8;
+                    }
+                }
+            }
+            const uint32_t nemit = (uint32_t)__popcll(emit);
+            if (nemit) {
+                const int top = 63 - __builtin_clzll(emit);
+                if (WRITE) {
+                    const unsigned long long before = emit & below;
+                    const int prev = before ? 63 - __builtin_clzll(before) : 0;
+                    const float prev_next = __shfl(A.t_next, prev, 64);
+                    if ((emit >> lane) & 1ull) {
+                        const size_t k = (size_t)count + (uint32_t)__popcll(before);
+                        xyzs[k * 3] = A.x; xyzs[k * 3 + 1] = A.y; xyzs[k * 3 + 2] = A.z;
+                        dirs[k * 3] = c.dx; dirs[k * 3 + 1] = c.dy; dirs[k * 3 + 2] = c.dz;
+                        deltas[k * 2] = c.dt_min;
+                        deltas[k * 2 + 1] = A.t_next - (before ? prev_next : last_t);
+                    }
+                }
+                last_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.t_next), top));
+                count += nemit;
+                if (LOG) {
+                    if (logged < kLogCap && lane == 0) {
+                        log[logged].base = A.base;
+                        log[logged].emit = emit;
+                    }
+                    logged++;
+                }
+            }
+            if (!have_next || count >= limit) break;
+            A = Bn;
+        }
+    }
+    if (LOG && lane == 0) *nlog = logged <= kLogCap ? logged : kLogOverflow;
+    return count;
+}
+
 // Write pass of the wave-per-ray marcher: replay a ray's chunk log.
 __device__ __forceinline__ void lattice_replay(const RayCtx& c, float t0, const ChunkEntry* log, uint32_t nlog,
                                                float* xyzs, float* dirs, float* deltas) {
@@ -468,8 +621,8 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
     float t0 = nears[n];
     if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
-    const uint32_t cnt = fast ? lattice_march<false, true, true>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                                 log + (size_t)n * kLogCap, nlog + n, &tabs)
+    const uint32_t cnt = fast ? lattice_march_fast<false, true>(c, tabs, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                                log + (size_t)n * kLogCap, nlog + n)
                               : lattice_march<false, true, false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
                                                                   log + (size_t)n * kLogCap, nlog + n);
     if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
@@ -714,8 +867,8 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
     const size_t base = (size_t)n * n_step;
     if (fast)
-        (void)lattice_march<true, false, true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
-                                               deltas + base * 2, nullptr, nullptr, &tabs);
+        (void)lattice_march_fast<true, false>(c, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+                                              deltas + base * 2, nullptr, nullptr);
     else
         (void)lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
 }
