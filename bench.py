@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
                          "timing behind `roofline` only sees the launches that stay eager)")
+    ap.add_argument("--graph-leg-steps", type=int, default=48,
+                    help="extra steps timed with HIP-graph replay after the main (eager) timed region; 0 = skip")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="N > 1: do not march the next batch underneath the gradient all-reduce")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
@@ -194,6 +196,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # warm-up runs with the same timing hooks as the timed region, so their events exist before the clock starts
+    _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
     for i in range(args.warmup):
         one_step(i)
     sync()
@@ -243,6 +247,26 @@ def main():
             roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / \
                 (kernels["grid_bwd"]["avg_ms"] * 1e-3) / 1e9
 
+    # ---- graph-replay leg (not part of `value`; single GPU, fp32 fused path): the same steps with render + loss +
+    # backward replayed as a HIP graph.  Reported beside the eager number because the per-kernel hipEvent timing that
+    # `roofline` needs cannot see launches inside a replayed graph.
+    graph_replay = None
+    if world == 1 and not args.graphs and args.net == "linear" and args.graph_leg_steps > 0:
+        harness.use_graphs = True
+        model.sample_budget_quantum = 8192
+        for i in range(args.warmup + args.steps, args.warmup + args.steps + 24):
+            one_step(i)
+        sync()
+        tg0 = time.perf_counter()
+        for i in range(args.graph_leg_steps):
+            one_step(i)
+        sync()
+        tg = (time.perf_counter() - tg0) / args.graph_leg_steps
+        harness.use_graphs = False
+        graph_replay = {"ms_per_step": tg * 1e3,
+                        "rays_per_sec": args.rays * (2 if args.mode == "events" else 1) / tg,
+                        "steps": args.graph_leg_steps, "graphs_captured": len(harness._graphs)}
+
     # ---- render leg (not part of `value`): full 640x480 frame through the inference loop
     render = None
     if args.render_frames > 0:
@@ -291,6 +315,7 @@ def main():
             "train_ray_samples_per_sec": total_samples / elapsed,
             "samples_per_step_per_gpu": total_samples / args.steps / world,
             "render": render,
+            "graph_replay": graph_replay,
             "kernels": kernels,
             "roofline": roofline,
             "cpu_baseline": cpu,

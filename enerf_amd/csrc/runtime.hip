@@ -46,29 +46,33 @@ struct EvPair {
 };
 static std::mutex g_prof_mu;
 static uint32_t g_prof_mask = 0;     // bit k: time kernel family k
-static std::vector<EvPair> g_prof_ev[ENERF_K_COUNT];
+static std::vector<EvPair> g_prof_ev[ENERF_K_COUNT];      // created once, reused after enerf_prof_reset
+static size_t g_prof_used[ENERF_K_COUNT] = {};
 static const size_t kMaxPairs = 1 << 16;
 
 ProfScope::ProfScope(int kernel_id, hipStream_t stream) : id(kernel_id), s(stream), slot(nullptr) {
     if (!((g_prof_mask >> id) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof_ev[id].size() >= kMaxPairs) return;
-    EvPair p;
-    if (hipEventCreate(&p.a) != hipSuccess) return;
-    if (hipEventCreate(&p.b) != hipSuccess) {
-        (void)hipEventDestroy(p.a);
-        return;
+    if (g_prof_used[id] >= kMaxPairs) return;
+    if (g_prof_used[id] == g_prof_ev[id].size()) {
+        EvPair p;
+        if (hipEventCreate(&p.a) != hipSuccess) return;
+        if (hipEventCreate(&p.b) != hipSuccess) {
+            (void)hipEventDestroy(p.a);
+            return;
+        }
+        g_prof_ev[id].push_back(p);
     }
-    (void)hipEventRecord(p.a, s);
-    g_prof_ev[id].push_back(p);
-    slot = (void*)(uintptr_t)g_prof_ev[id].size();  // 1-based index
+    (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].a, s);
+    g_prof_used[id]++;
+    slot = (void*)(uintptr_t)g_prof_used[id];  // 1-based index
 }
 
 ProfScope::~ProfScope() {
     if (!slot) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     size_t i = (size_t)(uintptr_t)slot - 1;
-    if (i < g_prof_ev[id].size()) (void)hipEventRecord(g_prof_ev[id][i].b, s);
+    if (i < g_prof_used[id]) (void)hipEventRecord(g_prof_ev[id][i].b, s);
 }
 
 }  // namespace enerf
@@ -92,13 +96,7 @@ int enerf_prof_enable_mask(uint32_t mask) {
 
 int enerf_prof_reset(void) {
     std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
-    for (int k = 0; k < ENERF_K_COUNT; k++) {
-        for (auto& p : enerf::g_prof_ev[k]) {
-            (void)hipEventDestroy(p.a);
-            (void)hipEventDestroy(p.b);
-        }
-        enerf::g_prof_ev[k].clear();
-    }
+    for (int k = 0; k < ENERF_K_COUNT; k++) enerf::g_prof_used[k] = 0;     // the events themselves are kept for reuse
     return 0;
 }
 
@@ -107,7 +105,8 @@ int enerf_prof_read(int kernel_id, double* total_ms, uint64_t* launches) {
     std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
     double tot = 0;
     uint64_t n = 0;
-    for (auto& p : enerf::g_prof_ev[kernel_id]) {
+    for (size_t i = 0; i < enerf::g_prof_used[kernel_id]; i++) {
+        auto& p = enerf::g_prof_ev[kernel_id][i];
         if (hipEventSynchronize(p.b) != hipSuccess) continue;
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {

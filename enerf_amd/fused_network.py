@@ -34,20 +34,18 @@ from .fused_mlp import pad32
 ENABLED = True
 
 
-def supported(net, x, d):
+_arch_ok = {}      # id(net) -> (weak check key, bool): the architecture part of `supported` does not change per call
+
+
+def _architecture_supported(net):
     from .gridencoder import GridEncoder
     from .shencoder import SHEncoder
     enc, encd = getattr(net, "encoder", None), getattr(net, "encoder_dir", None)
     if not (isinstance(getattr(net, "sigma_net", None), torch.nn.ModuleList)
             and isinstance(getattr(net, "color_net", None), torch.nn.ModuleList)):
         return False
-    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and d.dtype == torch.float32 and x.dim() == 2
-            and d.dim() == 2 and not torch.is_autocast_enabled() and not getattr(net, "disable_view_direction", True)):
-        return False
-    if x.requires_grad or d.requires_grad:
-        return False
     if not (isinstance(enc, GridEncoder) and enc.num_levels == 16 and enc.level_dim == 2 and enc.input_dim == 3
-            and enc.embeddings.dtype == torch.float32 and _ge._supports_layout()):
+            and enc.embeddings.dtype == torch.float32):
         return False
     if not (isinstance(encd, SHEncoder) and encd.degree == 4):
         return False
@@ -55,6 +53,20 @@ def supported(net, x, d):
     return (len(s) == 2 and tuple(s[0].weight.shape) == (64, 32) and tuple(s[1].weight.shape) == (16, 64)
             and len(c) == 3 and tuple(c[0].weight.shape) == (64, 31) and tuple(c[1].weight.shape) == (64, 64)
             and c[2].weight.shape[1] == 64 and c[2].weight.shape[0] <= 32)
+
+
+def supported(net, x, d):
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and d.dtype == torch.float32 and x.dim() == 2
+            and d.dim() == 2 and not torch.is_autocast_enabled() and not getattr(net, "disable_view_direction", True)):
+        return False
+    if x.requires_grad or d.requires_grad:
+        return False
+    key = (id(net.encoder.embeddings) if hasattr(net, "encoder") and hasattr(net.encoder, "embeddings") else 0,
+           net.encoder.embeddings.dtype if hasattr(net, "encoder") and hasattr(net.encoder, "embeddings") else None)
+    hit = _arch_ok.get(id(net))
+    if hit is None or hit[0] != key:
+        hit = _arch_ok[id(net)] = (key, _architecture_supported(net))
+    return hit[1] and _ge._supports_layout()
 
 
 def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2):

@@ -20,6 +20,13 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.step_now()
+        return loss
+
+    @torch.no_grad()
+    def step_now(self):
+        """The update itself.  `step()` is wrapped by torch.optim.Optimizer with profiler / hook plumbing that costs
+        ~40 us per call; a training loop that needs neither can call this directly."""
         batches = {}          # (beta1, beta2, eps) -> parameters the fused kernel takes, all in one launch
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -54,4 +61,3 @@ class FusedAdam(torch.optim.Optimizer):
                     vp(*[st["exp_avg_sq"].data_ptr() for _, _, st, _ in chunk]),
                     sz(*[p.numel() for p, _, _, _ in chunk]), fl(*[lr for _, _, _, lr in chunk]),
                     u32(*[st["step"] for _, _, st, _ in chunk]), b1, b2, eps, 0, L.stream_handle()), "adam_step_multi")
-        return loss

@@ -35,4 +35,4 @@ for i in range(48):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(60)
+st.sort_stats("tottime").print_stats(45)
