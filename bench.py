@@ -48,12 +48,16 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
                          "timing behind `roofline` only sees the launches that stay eager)")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="do not pin this rank to a block of 8 host cores (unpinned, the launch thread migrates over the "
+                         "box's 256 cores and the host-bound step time jitters by 10-15 %)")
     ap.add_argument("--graph-leg-steps", type=int, default=48,
                     help="extra steps timed with HIP-graph replay after the main (eager) timed region; 0 = skip")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="N > 1: do not march the next batch underneath the gradient all-reduce")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
     # development aids: exercise the N > 1 code path on a single-GPU box (gloo all-reduce, every rank on one device)
@@ -148,6 +152,9 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
     from enerf_amd import parallel, _lib
     from enerf_amd.backends import _gridencoder as gb, _raymarching as rb
     import torch.distributed as dist
@@ -160,6 +167,13 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    # one process per GPU, pinned to its own block of host cores (launch thread + autograd thread + HIP runtime threads)
+    full_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if full_affinity is not None and not args.no_pin and len(full_affinity) >= 16:
+        cores = sorted(full_affinity)
+        k = 8
+        start = (k * (1 + local_rank)) % (len(cores) - k + 1)
+        os.sched_setaffinity(0, cores[start:start + k])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -291,7 +305,15 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+        # in a fresh, unpinned process: this one's thread pools were created under the 8-core pin
+        import subprocess
+        env = dict(os.environ)
+        env.pop("HIP_VISIBLE_DEVICES", None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-rays",
+                            str(args.cpu_rays), "--cpu-budget-s", str(args.cpu_budget_s), "--bound", str(args.bound)],
+                           capture_output=True, text=True, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        cpu = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]}
 
     if rank == 0:
         out = {

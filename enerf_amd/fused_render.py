@@ -148,3 +148,43 @@ def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_ga
     params = fnet.network_params(model)
     return _FusedRenderTrain.apply(rays_o, rays_d, model, bg_color, counter, _budget(model), bool(perturb),
                                    bool(force_all_rays), float(dt_gamma), int(max_steps), pre, *params)
+
+
+class _ManualCtx:
+    """Stand-in for the autograd context when the node is driven by hand (TrainHarness's MSE step)."""
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+def render_train_manual(model, rays_o, rays_d, bg_color, perturb=True, dt_gamma=0, max_steps=1024):
+    """Forward of the fused training render WITHOUT autograd: returns (depth, image, ctx); feed d(loss)/d(image) to
+    render_train_manual_backward(ctx, g_image) for the parameter gradients.  For loops whose loss gradient is known in
+    closed form (MSE): skips the autograd engine round trip, its AccumulateGrad nodes and the loss's backward kernels."""
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    pre = None
+    stash = getattr(model, "_premarched", None)
+    if stash is not None:
+        model._premarched = None
+        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
+        if stash[0] == key:
+            pre = stash[1]
+            model.rendered_counter_slot = pre["slot"]
+    counter = None
+    if pre is None:
+        counter = _next_counter(model)
+        model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
+    ctx = _ManualCtx()
+    with torch.no_grad():
+        depth, image = _FusedRenderTrain.forward(ctx, rays_o, rays_d, model, bg_color, counter, _budget(model),
+                                                 bool(perturb), False, float(dt_gamma), int(max_steps), pre,
+                                                 *fnet.network_params(model))
+    return depth, image, ctx
+
+
+def render_train_manual_backward(ctx, g_image):
+    """-> gradients of fused_network.network_params(model), in that order (the first is None when the embedding
+    gradient was added straight into the parameter's .grad)."""
+    with torch.no_grad():
+        return _FusedRenderTrain.backward(ctx, None, g_image)[11:]

@@ -34,6 +34,7 @@ class TrainHarness:
         if model.cuda_ray and occupancy == "synthetic":
             self._syn = scene.install_occupancy(model)
         self.prefetch = True          # data parallel: march the next batch underneath the gradient all-reduce
+        self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self.use_graphs = bool(use_graphs)

@@ -95,6 +95,25 @@ def test_fused_render_node_matches_op_by_op_route(monkeypatch, bg, mean_count):
         assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-9, n
 
 
+def test_manual_mse_step_matches_autograd_step():
+    """TrainHarness.manual_mse: the RGB step drives the fused render node by hand with the closed-form MSE gradient.
+    Same loss trajectory and counters as the autograd-driven step."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 2048, 2)
+    runs = []
+    for manual in (False, True):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.manual_mse = manual
+        losses = [h.step_rgb(*data[i % len(data)]).clone() for i in range(40)]
+        runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu()))
+    (l0, c0), (l1, c1) = runs
+    assert torch.equal(c0, c1)
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
+
+
 def test_graph_replay_matches_eager_steps():
     """TrainHarness(use_graphs=True): render + loss + backward replayed as a HIP graph once the sample budget is known.
     Same budgets, same inputs -> the loss trajectory and the sample counters are those of the eager harness."""
