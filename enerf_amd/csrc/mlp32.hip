@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t r = (uint32_t)nrow(q, h);
-                if (r < out_dim) Y[s * y_stride + r] = out_act_fwd(o[q], out_act);
+                if (Y && r < out_dim) Y[s * y_stride + r] = out_act_fwd(o[q], out_act);
                 if (r == 0 && y0_exp) y0_exp[s] = expf(o[q]);      // trunc_exp forward of output column 0
             }
         }

@@ -187,3 +187,26 @@ def forward(net, x, d):
     params = network_params(net)
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     return _FusedNeRF.apply(x, d, network_cfg(net), train, params[0], net.encoder.offsets, *params[1:])
+
+
+def density_sigma(net, x):
+    """sigma [N] only (no geo_feat, no autograd): what update_extra_state needs from density() for its 2 M cell
+    samples per cascade -- the sigma MLP writes exp(column 0) and nothing else."""
+    enc = net.encoder
+    x = x.contiguous()
+    B = x.shape[0]
+    dev = x.device
+    sigma = torch.empty(B, dtype=torch.float32, device=dev)
+    if B == 0:
+        return sigma
+    Bp = pad32(B)
+    S = float(np.log2(enc.per_level_scale))
+    affine = (float(net.bound), float(np.float32(1.0) / np.float32(2 * net.bound)))
+    feats = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
+    _gb.grid_encode_forward(x, enc.embeddings.detach().contiguous(), enc.offsets, feats, B, 3, 2, 16, S,
+                            enc.base_resolution, False, feats, enc.gridtype_id, layout=2, affine=affine)
+    ws0, ws1 = net.sigma_net[0].weight, net.sigma_net[1].weight
+    blob = torch.cat([ws0.detach().reshape(-1), ws1.detach().reshape(-1)])
+    L.check(L.lib().enerf_mlp32_forward(feats.data_ptr(), blob.data_ptr(), B, 32, 16, 1, 0, 6, None, None, 1, 0,
+                                        sigma.data_ptr(), L.stream_handle()), "mlp32_forward(sigma only)")
+    return sigma

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import fused_render, raymarching
+from . import fused_network, fused_render, raymarching
 
 
 def _meshgrid_ij(*args):
@@ -358,7 +358,10 @@ class NeRFRenderer(nn.Module):
         half_grid_size = bound / self.grid_size
         cas_xyzs = xyzs * (bound - half_grid_size)
         cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-        sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
+        if cas_xyzs.dim() == 2 and fused_network.supported(self, cas_xyzs, cas_xyzs):
+            sigmas = fused_network.density_sigma(self, cas_xyzs)       # sigma only: no geo_feat written
+        else:
+            sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
         sigmas *= self.density_scale * 0.003383
         return sigmas
 

@@ -194,7 +194,8 @@ int enerf_free_splitk(void);
  * fb [num_hidden,Bp,64] receives the post-activation hidden states (NULL = inference).
  * activation: relu (0) / none (6); output_activation additionally sigmoid (3).  Rows of Y are y_stride floats apart
  * (0 = out_dim), so the result can land in a slice of a wider buffer; y0_exp (optional, [B]) receives
- * exp(Y[:,0]) -- the trunc_exp forward of the density column (activation.py:5-17). */
+ * exp(Y[:,0]) -- the trunc_exp forward of the density column (activation.py:5-17); Y may be NULL when only y0_exp is
+ * wanted (density-grid updates). */
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
                         uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream);

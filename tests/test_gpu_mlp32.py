@@ -194,3 +194,19 @@ def test_fused_adam_matches_torch_adam():
         oa.step(); ob.step(); sa.step(); sb.step()
         for a, b in zip(pa, pb):
             assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
+
+
+def test_density_sigma_only_path_matches_density():
+    """fused_network.density_sigma (update_extra_state's evaluator: sigma MLP writes exp(column 0) only) vs
+    NeRFNetwork.density on the same points."""
+    from enerf_amd import fused_network as fn
+    from enerf_amd.network import NeRFNetwork
+    torch.manual_seed(2)
+    m = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    m.encoder.embeddings.data.uniform_(-1, 1)
+    x = torch.rand(50001, 3, device=DEV) * 4 - 2
+    with torch.no_grad():
+        ref = m.density(x)["sigma"]
+        got = fn.density_sigma(m, x)
+    assert got.shape == ref.shape
+    assert float(((got - ref).abs() / ref.abs().clamp(min=1e-6)).max()) < 2e-5
