@@ -20,7 +20,13 @@ SIGNATURES = {
     "enerf_packbits": [_vp, _u32, _f32, _vp, _vp],
     "enerf_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _u32, _vp],
+    "enerf_march_rays_train_ex": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _u32, _u32, _vp],
     "enerf_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "enerf_composite_rays_train_forward_blend": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _f32, _vp,
+                                                 _vp],
+    "enerf_composite_rays_train_backward_mse": [_vp, _vp, _f32, _vp, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _u32, _u32, _vp, _vp, _vp],
     "enerf_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "enerf_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                          _vp, _u32, _vp],

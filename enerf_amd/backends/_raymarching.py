@@ -68,6 +68,52 @@ def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, 
             "march_rays_train")
 
 
+def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                        rays, counter, perturb, zero_unwritten):
+    """march_rays_train into possibly uninitialised xyzs / dirs / deltas (include/enerf_hip.h)."""
+    L.check(L.lib().enerf_march_rays_train_ex(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
+                                              float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
+                                              int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
+                                              _f32(dirs, "dirs"), _f32(deltas, "deltas"), _i32(rays, "rays"),
+                                              _i32(counter, "counter"), int(perturb), int(bool(zero_unwritten)),
+                                              L.stream_handle()), "march_rays_train_ex")
+
+
+def _background(bg_color, N):
+    """-> (pointer, stride, scalar) of the C ABI's background triple."""
+    import torch
+    if isinstance(bg_color, torch.Tensor):
+        if bg_color.numel() == 1:
+            return None, 0, float(bg_color)
+        bg = _f32(bg_color, "bg_color")
+        if bg_color.numel() == 3:
+            return bg, 0, 0.0
+        if bg_color.numel() == 3 * N:
+            return bg, 3, 0.0
+        raise ValueError(f"bg_color: expected 1, 3 or {3 * N} elements, got {bg_color.numel()}")
+    return None, 0, float(bg_color)
+
+
+def composite_rays_train_forward_blend(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image, bg_color,
+                                       out_image):
+    bg, stride, scalar = _background(bg_color, N)
+    L.check(L.lib().enerf_composite_rays_train_forward_blend(
+        _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"), _f32(deltas, "deltas"), _i32(rays, "rays"), int(M), int(N),
+        _f32(weights_sum, "weights_sum"), None if depth is None else _f32(depth, "depth"), _f32(image, "image"), bg,
+        stride, scalar, _f32(out_image, "out_image"), L.stream_handle()), "composite_rays_train_forward_blend")
+
+
+def composite_rays_train_backward_mse(out_image, target, grad_scale, bg_color, counter, sigmas, rgbs, deltas, rays,
+                                      weights_sum, image, M, N, grad_sigmas, grad_rgbs):
+    bg, stride, scalar = _background(bg_color, N)
+    L.check(L.lib().enerf_composite_rays_train_backward_mse(
+        _f32(out_image, "out_image"), _f32(target, "target"), float(grad_scale), bg, stride, scalar,
+        _i32(counter, "counter"), _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"), _f32(deltas, "deltas"),
+        _i32(rays, "rays"), _f32(weights_sum, "weights_sum"), _f32(image, "image"), int(M), int(N),
+        _f32(grad_sigmas, "grad_sigmas"), _f32(grad_rgbs, "grad_rgbs"), L.stream_handle()),
+        "composite_rays_train_backward_mse")
+
+
 def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image):
     L.check(L.lib().enerf_composite_rays_train_forward(_f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"),
                                                        _f32(deltas, "deltas"), _i32(rays, "rays"), int(M), int(N),

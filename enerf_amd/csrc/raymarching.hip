@@ -628,6 +628,13 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
     if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
 }
 
+// rows [lo, hi) of the three sample buffers <- 0 (thread `tid` of `nthreads`)
+__device__ __forceinline__ void zero_rows(float* xyzs, float* dirs, float* deltas, uint32_t lo, uint32_t hi,
+                                          uint32_t tid, uint32_t nthreads) {
+    for (size_t i = (size_t)lo * 3 + tid; i < (size_t)hi * 3; i += nthreads) { xyzs[i] = 0.0f; dirs[i] = 0.0f; }
+    for (size_t i = (size_t)lo * 2 + tid; i < (size_t)hi * 2; i += nthreads) deltas[i] = 0.0f;
+}
+
 __global__ void __launch_bounds__(256) k_march_write_w(const float* __restrict__ rays_o,
                                                        const float* __restrict__ rays_d,
                                                        const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
@@ -636,13 +643,25 @@ __global__ void __launch_bounds__(256) k_march_write_w(const float* __restrict__
                                                        float* xyzs, float* dirs, float* deltas,
                                                        const int32_t* __restrict__ rays, uint32_t perturb,
                                                        const ChunkEntry* __restrict__ log,
-                                                       const uint32_t* __restrict__ nlog) {
+                                                       const uint32_t* __restrict__ nlog,
+                                                       const int32_t* __restrict__ counter, uint32_t ray_blocks) {
+    if (blockIdx.x >= ray_blocks) {
+        // zero_unwritten: rows past the last reserved sample (the caller handed over uninitialised buffers)
+        const uint32_t used = min((uint32_t)counter[0], M);
+        zero_rows(xyzs, dirs, deltas, used, M, (blockIdx.x - ray_blocks) * blockDim.x + threadIdx.x,
+                  (gridDim.x - ray_blocks) * blockDim.x);
+        return;
+    }
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (n >= N) return;
     const uint32_t point_index = (uint32_t)rays[(size_t)n * 3 + 1];
     const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
     if (num_steps == 0) return;
-    if (point_index + num_steps >= M) return;
+    if (point_index + num_steps >= M) {
+        // dropped for lack of room: its reservation, clipped to the buffer, is the other region nobody writes
+        if (counter && point_index < M) zero_rows(xyzs, dirs, deltas, point_index, M, lane_id(), 64);
+        return;
+    }
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
     float t0 = nears[n];
@@ -753,11 +772,23 @@ __device__ __forceinline__ void comp_chunk(bool active, float sigma, float dl0, 
     k.d = wave_bcast(d_i, 63);
 }
 
+// background colour of the blend `image + (1 - weights_sum) * bg`: a scalar (color == nullptr), one RGB (stride 0) or one
+// RGB per ray (stride 3)
+struct Background {
+    const float* color;
+    uint32_t stride;
+    float scalar;
+    __device__ __forceinline__ float at(uint32_t ray, int ch) const {
+        return color ? color[(size_t)ray * stride + ch] : scalar;
+    }
+};
+
 __global__ void __launch_bounds__(256) k_composite_train_fwd(const float* __restrict__ sigmas,
                                                              const float* __restrict__ rgbs,
                                                              const float* __restrict__ deltas,
                                                              const int32_t* __restrict__ rays, uint32_t M, uint32_t N,
-                                                             float* weights_sum, float* depth, float* image) {
+                                                             float* weights_sum, float* depth, float* image,
+                                                             Background bg, float* out_image) {
     const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= N) return;
     const int lane = lane_id();
@@ -765,8 +796,14 @@ __global__ void __launch_bounds__(256) k_composite_train_fwd(const float* __rest
     const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
     if (num_steps == 0 || offset + num_steps >= M) {
         if (lane == 0) {
-            weights_sum[index] = 0; depth[index] = 0;
+            weights_sum[index] = 0;
+            if (depth) depth[index] = 0;
             image[(size_t)index * 3] = 0; image[(size_t)index * 3 + 1] = 0; image[(size_t)index * 3 + 2] = 0;
+            if (out_image) {
+                out_image[(size_t)index * 3] = bg.at(index, 0);
+                out_image[(size_t)index * 3 + 1] = bg.at(index, 1);
+                out_image[(size_t)index * 3 + 2] = bg.at(index, 2);
+            }
         }
         return;
     }
@@ -782,25 +819,69 @@ __global__ void __launch_bounds__(256) k_composite_train_fwd(const float* __rest
         comp_chunk(active, sigma, dl.x, dl.y, c0, c1, c2, lane, k, w, T_post, r_i, g_i, b_i, ws_i);
     }
     if (lane == 0) {
-        weights_sum[index] = k.ws; depth[index] = k.d;
+        weights_sum[index] = k.ws;
+        if (depth) depth[index] = k.d;
         image[(size_t)index * 3] = k.r; image[(size_t)index * 3 + 1] = k.g; image[(size_t)index * 3 + 2] = k.b;
+        if (out_image) {
+            // image + (1 - weights_sum) * bg_color, in torch's operation order (nerf/renderer.py:352)
+            const float rest = 1.0f - k.ws;
+            // (separately rounded multiply and add: bit-identical to the elementwise route, no fma contraction)
+            out_image[(size_t)index * 3] = __fadd_rn(k.r, __fmul_rn(rest, bg.at(index, 0)));
+            out_image[(size_t)index * 3 + 1] = __fadd_rn(k.g, __fmul_rn(rest, bg.at(index, 1)));
+            out_image[(size_t)index * 3 + 2] = __fadd_rn(k.b, __fmul_rn(rest, bg.at(index, 2)));
+        }
     }
 }
 
+// the fused form of the backward: gradient of an MSE loss on the blended image, computed in place of reading it
+struct MseTail {
+    const float* out_image;
+    const float* target;
+    float scale;
+    Background bg;
+    const int32_t* counter;
+};
+
+template <bool MSE>
 __global__ void __launch_bounds__(256) k_composite_train_bwd(
     const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
     const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
     const int32_t* __restrict__ rays, const float* __restrict__ weights_sum, const float* __restrict__ image,
-    uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs) {
+    uint32_t M, uint32_t N, float* grad_sigmas, float* grad_rgbs, MseTail mse, uint32_t ray_blocks) {
+    if (MSE && blockIdx.x >= ray_blocks) {
+        // rows past the last reserved sample get zero gradients (the caller handed over uninitialised buffers)
+        const uint32_t used = min((uint32_t)mse.counter[0], M);
+        const uint32_t tid = (blockIdx.x - ray_blocks) * blockDim.x + threadIdx.x;
+        const uint32_t nth = (gridDim.x - ray_blocks) * blockDim.x;
+        for (size_t i = (size_t)used + tid; i < (size_t)M; i += nth) grad_sigmas[i] = 0.0f;
+        for (size_t i = (size_t)used * 3 + tid; i < (size_t)M * 3; i += nth) grad_rgbs[i] = 0.0f;
+        return;
+    }
     const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= N) return;
     const int lane = lane_id();
     const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1];
     const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
-    if (num_steps == 0 || offset + num_steps >= M) return;
-    const float gws = grad_weights_sum[index];
-    const float gi0 = grad_image[(size_t)index * 3], gi1 = grad_image[(size_t)index * 3 + 1],
-                gi2 = grad_image[(size_t)index * 3 + 2];
+    if (num_steps == 0 || offset + num_steps >= M) {
+        if (MSE && num_steps != 0 && offset < M) {          // a dropped ray's reservation, clipped to the buffer
+            for (size_t i = (size_t)offset + lane; i < (size_t)M; i += 64) grad_sigmas[i] = 0.0f;
+            for (size_t i = (size_t)offset * 3 + lane; i < (size_t)M * 3; i += 64) grad_rgbs[i] = 0.0f;
+        }
+        return;
+    }
+    float gws, gi0, gi1, gi2;
+    if (MSE) {
+        // loss = mean((out_image - target)^2): d/d(out_image) = (out_image - target) * scale, scale = 2 / (3 N) * upstream;
+        // out_image = image + (1 - weights_sum) * bg  ->  d/d(weights_sum) = -(g . bg)
+        gi0 = (mse.out_image[(size_t)index * 3] - mse.target[(size_t)index * 3]) * mse.scale;
+        gi1 = (mse.out_image[(size_t)index * 3 + 1] - mse.target[(size_t)index * 3 + 1]) * mse.scale;
+        gi2 = (mse.out_image[(size_t)index * 3 + 2] - mse.target[(size_t)index * 3 + 2]) * mse.scale;
+        gws = -(gi0 * mse.bg.at(index, 0) + gi1 * mse.bg.at(index, 1) + gi2 * mse.bg.at(index, 2));
+    } else {
+        gws = grad_weights_sum[index];
+        gi0 = grad_image[(size_t)index * 3]; gi1 = grad_image[(size_t)index * 3 + 1];
+        gi2 = grad_image[(size_t)index * 3 + 2];
+    }
     const float r_final = image[(size_t)index * 3], g_final = image[(size_t)index * 3 + 1],
                 b_final = image[(size_t)index * 3 + 2];
     const float ws_final = weights_sum[index];
@@ -1022,7 +1103,23 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                            const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
                            int32_t* counter, uint32_t perturb, enerf_stream_t stream) {
-    if (N == 0) return 0;
+    return enerf_march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs,
+                                     dirs, deltas, rays, counter, perturb, 0, stream);
+}
+
+int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                              const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                              int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
+                              enerf_stream_t stream) {
+    if (N == 0) {
+        if (zero_unwritten && M) {
+            (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, (hipStream_t)stream);
+            (void)hipMemsetAsync(dirs, 0, (size_t)M * 12, (hipStream_t)stream);
+            (void)hipMemsetAsync(deltas, 0, (size_t)M * 8, (hipStream_t)stream);
+        }
+        return 0;
+    }
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays_train: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
@@ -1037,9 +1134,16 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
         k_march_count_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays,
                                                      perturb, log, nlog);
         k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
-        k_march_write_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars,
-                                                     xyzs, dirs, deltas, rays, perturb, log, nlog);
+        const uint32_t ray_blocks = div_up(N, 4);
+        k_march_write_w<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
+            rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, perturb, log, nlog,
+            zero_unwritten ? counter : nullptr, ray_blocks);
     } else {
+        if (zero_unwritten) {
+            (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, s);
+            (void)hipMemsetAsync(dirs, 0, (size_t)M * 12, s);
+            (void)hipMemsetAsync(deltas, 0, (size_t)M * 8, s);
+        }
         k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
                                                    fars, rays, perturb);
         k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
@@ -1056,8 +1160,24 @@ int enerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, c
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_COMPOSITE_FWD, s);
-    k_composite_train_fwd<<<div_up(N, 4), 256, 0, s>>>(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image);
+    k_composite_train_fwd<<<div_up(N, 4), 256, 0, s>>>(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image,
+                                                       Background{nullptr, 0, 0.0f}, nullptr);
     ENERF_LAUNCH_CHECK("composite_rays_train_forward");
+    return 0;
+}
+
+int enerf_composite_rays_train_forward_blend(const float* sigmas, const float* rgbs, const float* deltas,
+                                             const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
+                                             float* depth, float* image, const float* bg_color, uint32_t bg_stride,
+                                             float bg_scalar, float* out_image, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    if (!out_image) ENERF_BADARG("composite_rays_train_forward_blend: out_image is required");
+    if (bg_color && bg_stride != 0 && bg_stride != 3) ENERF_BADARG("composite_rays_train_forward_blend: bg_stride %u", bg_stride);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_COMPOSITE_FWD, s);
+    k_composite_train_fwd<<<div_up(N, 4), 256, 0, s>>>(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image,
+                                                       Background{bg_color, bg_stride, bg_scalar}, out_image);
+    ENERF_LAUNCH_CHECK("composite_rays_train_forward_blend");
     return 0;
 }
 
@@ -1068,9 +1188,35 @@ int enerf_composite_rays_train_backward(const float* grad_weights_sum, const flo
     if (N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_COMPOSITE_BWD, s);
-    k_composite_train_bwd<<<div_up(N, 4), 256, 0, s>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
-                                                       weights_sum, image, M, N, grad_sigmas, grad_rgbs);
+    k_composite_train_bwd<false><<<div_up(N, 4), 256, 0, s>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays,
+                                                              weights_sum, image, M, N, grad_sigmas, grad_rgbs,
+                                                              MseTail{}, div_up(N, 4));
     ENERF_LAUNCH_CHECK("composite_rays_train_backward");
+    return 0;
+}
+
+int enerf_composite_rays_train_backward_mse(const float* out_image, const float* target, float grad_scale,
+                                            const float* bg_color, uint32_t bg_stride, float bg_scalar,
+                                            const int32_t* counter, const float* sigmas, const float* rgbs,
+                                            const float* deltas, const int32_t* rays, const float* weights_sum,
+                                            const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
+                                            float* grad_rgbs, enerf_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (M) {
+            (void)hipMemsetAsync(grad_sigmas, 0, (size_t)M * 4, s);
+            (void)hipMemsetAsync(grad_rgbs, 0, (size_t)M * 12, s);
+        }
+        return 0;
+    }
+    if (!counter) ENERF_BADARG("composite_rays_train_backward_mse: counter is required");
+    if (bg_color && bg_stride != 0 && bg_stride != 3) ENERF_BADARG("composite_rays_train_backward_mse: bg_stride %u", bg_stride);
+    ProfScope prof(ENERF_K_COMPOSITE_BWD, s);
+    const uint32_t ray_blocks = div_up(N, 4);
+    k_composite_train_bwd<true><<<ray_blocks + 64, 256, 0, s>>>(
+        nullptr, nullptr, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs,
+        MseTail{out_image, target, grad_scale, Background{bg_color, bg_stride, bg_scalar}, counter}, ray_blocks);
+    ENERF_LAUNCH_CHECK("composite_rays_train_backward_mse");
     return 0;
 }
 

@@ -69,6 +69,16 @@ def supported(net, x, d):
     return hit[1] and _ge._supports_layout()
 
 
+_ZERO_COLUMN = {}
+
+
+def _zero_column(dev):
+    z = _ZERO_COLUMN.get(dev)
+    if z is None:
+        z = _ZERO_COLUMN[dev] = torch.zeros(64, 1, dtype=torch.float32, device=dev)
+    return z
+
+
 def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2):
     """The kernel sequence itself (no autograd): returns sigma [B], rgb [B,out], and -- when `train` -- the tensors
     nerf_backward needs."""
@@ -101,7 +111,7 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2)
     L.check(lib.enerf_sh_encode_forward_strided(d.data_ptr(), h32.data_ptr() + 64, B, 4, 32, stream),
             "sh_encode_forward_strided")
     # colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16]
-    blob_c = torch.cat([wc0.new_zeros(64, 1), wc0[:, 16:], wc0[:, :16]], dim=1).reshape(-1)
+    blob_c = torch.cat([_zero_column(dev), wc0[:, 16:], wc0[:, :16]], dim=1).reshape(-1)
     blob_c = torch.cat([blob_c, wc1.reshape(-1), wc2.reshape(-1)])
     fb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev) if train else None
     L.check(lib.enerf_mlp32_forward(h32.data_ptr(), blob_c.data_ptr(), B, 32, out_c, 2, 0, 3,
@@ -129,13 +139,13 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0):
         g_sigma = g_sigma * sigma_scale
     bb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev)
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
-    dw_c = torch.zeros_like(blob_c)
+    dw = torch.zeros(blob_s.numel() + blob_c.numel(), dtype=torch.float32, device=dev)     # one fill for both blobs
+    dw_s, dw_c = dw[:blob_s.numel()], dw[blob_s.numel():]
     L.check(lib.enerf_mlp32_backward(g_rgb.data_ptr(), sv["h32"].data_ptr(), blob_c.data_ptr(), sv["fb_c"].data_ptr(),
                                      B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), dw_c.data_ptr(), 0, 0,
                                      sv["rgb"].data_ptr(), out_c, None, None, 0, stream), "mlp32_backward(color)")
     bb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev)
     dfeat = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
-    dw_s = torch.zeros_like(blob_s)
     L.check(lib.enerf_mlp32_backward(dx32.data_ptr(), sv["feats"].data_ptr(), blob_s.data_ptr(),
                                      sv["fb_s"].data_ptr(), B, 32, 16, 1, 0, bb_s.data_ptr(), dfeat.data_ptr(),
                                      dw_s.data_ptr(), 1, 32, None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32,

@@ -42,18 +42,26 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     M = N * max_steps
     if not force_all_rays and mean_count > 0:
         M = mean_count + (128 - mean_count % 128)            # raymarching.py:186-189 (align = 128)
-    xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-    dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-    deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
-    _rb.march_rays_train(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
-                         model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
     if force_all_rays or mean_count <= 0:
+        xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
+        deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+        _rb.march_rays_train(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
+                             model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
         m = int(counter[0].item())
         m += 128 - m % 128
         xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
         M = m
-    return dict(nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas, rays=rays, M=M)
+    else:
+        # budgeted buffers: the write pass zero-fills the rows no ray writes, so no torch.zeros passes over them
+        xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+        _rb.march_rays_train_ex(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+                                model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                                perturb, True)
+    return dict(nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas, rays=rays, M=M, counter=counter)
 
 
 class _FusedRenderTrain(Function):
@@ -75,8 +83,10 @@ class _FusedRenderTrain(Function):
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        _rb.composite_rays_train_forward(sigmas, rgb, deltas, rays, M, N, weights_sum, depth, image)
-        out_image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        out_image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        # composite + `image + (1 - weights_sum).unsqueeze(-1) * bg_color` in one launch
+        _rb.composite_rays_train_forward_blend(sigmas, rgb, deltas, rays, M, N, weights_sum, depth, image, bg_color,
+                                               out_image)
         out_depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         if train:
             ctx.sv = sv
@@ -133,14 +143,11 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
 
 def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
     """-> depth [N], image [N,3] (+ the step counter bookkeeping of run_cuda)."""
-    pre = None
-    stash = getattr(model, "_premarched", None)
-    if stash is not None:
-        model._premarched = None
-        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
-        if stash[0] == key and not force_all_rays:
-            pre = stash[1]
-            model.rendered_counter_slot = pre["slot"]
+    pre = _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps)
+    if force_all_rays:
+        pre = None
+    if pre is not None:
+        model.rendered_counter_slot = pre["slot"]
     counter = None
     if pre is None:
         counter = _next_counter(model)
@@ -150,41 +157,52 @@ def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_ga
                                    bool(force_all_rays), float(dt_gamma), int(max_steps), pre, *params)
 
 
-class _ManualCtx:
-    """Stand-in for the autograd context when the node is driven by hand (TrainHarness's MSE step)."""
+def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
+    stash = getattr(model, "_premarched", None)
+    if stash is None:
+        return None
+    model._premarched = None
+    key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
+    return stash[1] if stash[0] == key else None
 
-    def mark_non_differentiable(self, *a):
-        pass
 
+def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0):
+    """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
+    -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
+    embedding gradient was added straight into the parameter's .grad).
 
-def render_train_manual(model, rays_o, rays_d, bg_color, perturb=True, dt_gamma=0, max_steps=1024):
-    """Forward of the fused training render WITHOUT autograd: returns (depth, image, ctx); feed d(loss)/d(image) to
-    render_train_manual_backward(ctx, g_image) for the parameter gradients.  For loops whose loss gradient is known in
-    closed form (MSE): skips the autograd engine round trip, its AccumulateGrad nodes and the loss's backward kernels."""
+    For loops whose loss is the reference's default (nerf/utils.py:628, MSE): the loss gradient and the blend's
+    d/d(weights_sum) are formed inside the composite backward kernel, which also zero-fills what it does not write;
+    depth is not computed.  What is skipped relative to render_train + autograd: the engine round trip, its
+    AccumulateGrad nodes, ~18 elementwise / fill launches."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
-    pre = None
-    stash = getattr(model, "_premarched", None)
-    if stash is not None:
-        model._premarched = None
-        key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
-        if stash[0] == key:
-            pre = stash[1]
+    target = target.contiguous().view(-1, 3)
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    with torch.no_grad():
+        pre = _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps)
+        if pre is not None:
             model.rendered_counter_slot = pre["slot"]
-    counter = None
-    if pre is None:
-        counter = _next_counter(model)
-        model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
-    ctx = _ManualCtx()
-    with torch.no_grad():
-        depth, image = _FusedRenderTrain.forward(ctx, rays_o, rays_d, model, bg_color, counter, _budget(model),
-                                                 bool(perturb), False, float(dt_gamma), int(max_steps), pre,
-                                                 *fnet.network_params(model))
-    return depth, image, ctx
-
-
-def render_train_manual_backward(ctx, g_image):
-    """-> gradients of fused_network.network_params(model), in that order (the first is None when the embedding
-    gradient was added straight into the parameter's .grad)."""
-    with torch.no_grad():
-        return _FusedRenderTrain.backward(ctx, None, g_image)[11:]
+        else:
+            counter = _next_counter(model)
+            model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
+            pre = march_stage(model, rays_o, rays_d, counter, _budget(model), bool(perturb), False, float(dt_gamma),
+                              int(max_steps))
+        xyzs, dirs, deltas, rays, M = (pre[k] for k in ("xyzs", "dirs", "deltas", "rays", "M"))
+        sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), True, model.encoder.embeddings,
+                                           model.encoder.offsets, *fnet.network_params(model)[1:])
+        scale = float(model.density_scale)
+        sigmas = sigma if scale == 1.0 else sigma * scale
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        out_image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        _rb.composite_rays_train_forward_blend(sigmas, rgb, deltas, rays, M, N, weights_sum, None, image, bg_color,
+                                               out_image)
+        g_sigmas = torch.empty_like(sigmas)
+        g_rgbs = torch.empty_like(rgb)
+        _rb.composite_rays_train_backward_mse(out_image, target, 2.0 * float(upstream) / (3 * N), bg_color,
+                                              pre["counter"], sigmas, rgb, deltas, rays, weights_sum, image, M, N,
+                                              g_sigmas, g_rgbs)
+        grads = fnet.nerf_backward(sv, g_sigmas, g_rgbs, sigma_scale=scale)
+    return out_image, grads

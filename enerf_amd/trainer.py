@@ -56,8 +56,9 @@ class TrainHarness:
         q = m.sample_budget_quantum
         return (tag, tuple(rays_o.shape), (int(m.mean_count) + q - 1) // q * q)
 
-    def _capture(self, inputs, loss_fn):
-        """Capture loss_fn(static inputs) + backward; returns the replay state."""
+    def _capture(self, inputs, loss_fn, fwd_bwd_fn=None):
+        """Capture loss_fn(static inputs) + backward -- or fwd_bwd_fn(static inputs), which leaves the gradients in
+        p.grad itself and returns the loss; returns the replay state."""
         from . import _lib
         m = self.model
         _lib.prof.enable(False)                       # hipEvent timing hooks cannot live inside a captured graph
@@ -67,6 +68,8 @@ class TrainHarness:
         params = [p for p in m.parameters() if p.requires_grad]
 
         def fwd_bwd():
+            if fwd_bwd_fn is not None:
+                return fwd_bwd_fn(*st["in"])
             loss = loss_fn(*st["in"])
             loss.backward()
             return loss
@@ -125,6 +128,35 @@ class TrainHarness:
                 fused_render.prefetch_march(m, ro, rd, perturb=True)
         self.avg.finish()
 
+    def _manual_ok(self, rays_o, rays_d, target, render_kw):
+        from . import fused_render
+        m = self.model
+        return (self.manual_mse and m.cuda_ray and m.mean_count > 0 and target.dtype == torch.float32
+                and not set(render_kw) - {"dt_gamma", "max_steps"}
+                and fused_render.supported(m, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3), 1,
+                                           render_kw.get("dt_gamma", 0)))
+
+    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024):
+        """Render + MSE + backward with the loss gradient in closed form (fused_render.train_step_mse): same kernels
+        for the render and its backward, no autograd graph, no loss-backward / blend / depth / fill launches.
+        Leaves the gradients in p.grad, returns the loss."""
+        from . import fused_network, fused_render
+        m = self.model
+        for p in self._params:                      # nothing accumulates across steps (zero_grad(set_to_none=True))
+            p.grad = None
+        image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps)
+        for p, g in zip(fused_network.network_params(m), grads):
+            if g is not None:
+                p.grad = g.view_as(p)
+        with torch.no_grad():
+            return torch.nn.functional.mse_loss(image, target.view(-1, 3))
+
+    def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
+        loss = self._manual_fwd_bwd(rays_o, rays_d, target, **render_kw)
+        self._reduce_grads(next_rays)
+        self._opt_step()
+        return loss
+
     def step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
         if not self.model.training:                 # Module.train() walks every submodule: 40 us of a 900 us step
@@ -135,11 +167,15 @@ class TrainHarness:
             m = self.model
             key = self._graph_key("rgb", rays_o)
             if key not in self._graphs:
+                manual = self._manual_ok(rays_o, rays_d, target, render_kw)
                 self._graphs[key] = self._capture(
                     (rays_o, rays_d, target),
                     lambda ro, rd, tg: torch.nn.functional.mse_loss(
-                        m.render(ro, rd, staged=False, bg_color=None, perturb=True, **render_kw)["image"], tg))
+                        m.render(ro, rd, staged=False, bg_color=None, perturb=True, **render_kw)["image"], tg),
+                    (lambda ro, rd, tg: self._manual_fwd_bwd(ro, rd, tg, **render_kw)) if manual else None)
             return self._replay(self._graphs[key], (rays_o, rays_d, target), 1)
+        if self._manual_ok(rays_o, rays_d, target, render_kw):
+            return self._step_rgb_manual(rays_o, rays_d, target, next_rays, **render_kw)
         self.opt.zero_grad(set_to_none=True)
         out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=True, **render_kw)
         loss = torch.nn.functional.mse_loss(out["image"], target)

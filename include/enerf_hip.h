@@ -83,6 +83,16 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
                            const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                            int32_t* rays, int32_t* counter, uint32_t perturb, enerf_stream_t stream);
 
+/* Extension of march_rays_train for callers that hand over UNINITIALISED sample buffers (zero_unwritten != 0): every
+ * row no ray writes -- past the last reservation, and a dropped ray's reservation clipped to M -- is zero-filled by the
+ * write pass itself, so the three torch.zeros of raymarching.py:205-207 become torch.empty.  zero_unwritten == 0 is
+ * exactly enerf_march_rays_train. */
+int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                              const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                              int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
+                              enerf_stream_t stream);
+
 /* raymarching.cu:581-589  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
 int enerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                        const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
@@ -95,6 +105,26 @@ int enerf_composite_rays_train_backward(const float* grad_weights_sum, const flo
                                         const float* rgbs, const float* deltas, const int32_t* rays,
                                         const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                         float* grad_sigmas, float* grad_rgbs, enerf_stream_t stream);
+
+/* composite_rays_train_forward + the background blend that follows it in the renderer (nerf/renderer.py:352
+ * `image = image + (1 - weights_sum).unsqueeze(-1) * bg_color`), one launch: out_image[N,3] receives the blend, `image`
+ * still receives the unblended colour (the backward needs it).  bg_color: NULL -> the scalar bg_scalar; else [3]
+ * (bg_stride 0) or [N,3] (bg_stride 3).  depth may be NULL (a training step that does not use it). */
+int enerf_composite_rays_train_forward_blend(const float* sigmas, const float* rgbs, const float* deltas,
+                                             const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
+                                             float* depth, float* image, const float* bg_color, uint32_t bg_stride,
+                                             float bg_scalar, float* out_image, enerf_stream_t stream);
+
+/* composite_rays_train_backward for loss = mean((out_image - target)^2) * upstream (nerf/utils.py:628 with the default
+ * MSE criterion): grad_image = (out_image - target) * grad_scale with grad_scale = 2 / (3 N) * upstream, and
+ * grad_weights_sum = -(grad_image . bg), both formed in the kernel.  grad_sigmas / grad_rgbs may be UNINITIALISED: rows no
+ * ray covers are zero-filled here (counter = the march's counter, counter[0] = samples reserved). */
+int enerf_composite_rays_train_backward_mse(const float* out_image, const float* target, float grad_scale,
+                                            const float* bg_color, uint32_t bg_stride, float bg_scalar,
+                                            const int32_t* counter, const float* sigmas, const float* rgbs,
+                                            const float* deltas, const int32_t* rays, const float* weights_sum,
+                                            const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
+                                            float* grad_rgbs, enerf_stream_t stream);
 
 /* raymarching.cu:807-813  march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
  *                                    max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, perturb) */

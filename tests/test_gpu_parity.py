@@ -123,6 +123,32 @@ def test_march_rays_train_overflow_drop_rule(rm, scenes):
     assert got[4][0] == tot
 
 
+@pytest.mark.parametrize("overflow", [False, True])
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
+def test_march_rays_train_ex_zero_fills_unwritten_rows(rm, scenes, overflow, dt_gamma):
+    """march_rays_train_ex(zero_unwritten=1) on NaN-filled buffers == march_rays_train on zero-filled ones, bit for bit:
+    the budget tail and a dropped ray's clipped reservation are the rows no ray writes."""
+    bound = 2
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(700, 23, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    tot = int(O.march_rays_train(o, d, bits, bound, dt_gamma, 1024, C, H, 700 * 1024, nears, fars, 1)[4][0])
+    M = tot // 2 if overflow else tot + 3000
+    M += 128 - M % 128
+    ref = _gpu_march_train(rm, o, d, bits, bound, dt_gamma, C, M, nears, fars, 1)
+    N = len(o)
+    xyzs = torch.full((M, 3), float("nan"), device=DEV); dirs = torch.full((M, 3), float("nan"), device=DEV)
+    deltas = torch.full((M, 2), float("nan"), device=DEV)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    rm.march_rays_train_ex(cu(o), cu(d), cu(bits), bound, dt_gamma, 1024, N, C, H, M, cu(nears), cu(fars), xyzs, dirs,
+                           deltas, rays, counter, 1, True)
+    got = [x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)]
+    for a, b, name in zip(got, ref, ("xyzs", "dirs", "deltas", "rays", "counter")):
+        assert np.array_equal(a, b), name
+    assert (got[4][0] > M) == overflow
+
+
 def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm):
     """Every cell occupied: rays emit a sample at every lattice point until max_steps (1024) -- the maximum the path
     can produce per ray, and more emitting 64-point chunks than the count pass's per-ray log holds for the longest
@@ -227,6 +253,52 @@ def test_composite_rays_train_dropped_and_empty_rays(rm):
     rm.composite_rays_train_forward(cu(sig), cu(rgb), cu(dl), cu(rays), M, 4, a, b, c)
     assert_close(a, ws, rtol=1e-5, atol=1e-7); assert_close(c, image, rtol=1e-5, atol=1e-7)
     assert ws[1] == 0 and ws[0] == 0 and ws[2] > 0       # ray index 1 overflows (10+54 >= 64), index 0 is empty
+
+
+@pytest.mark.parametrize("bg_kind,overflow", [("scalar", True), ("rgb", False), ("per_ray", True), ("scalar", False)])
+def test_composite_blend_forward_and_mse_backward(rm, scenes, bg_kind, overflow):
+    """The fused forms (include/enerf_hip.h: ..._forward_blend / ..._backward_mse) against the plain kernels plus the
+    elementwise steps they absorb: image + (1 - ws) * bg;  grad_image = (out - target) * scale,  grad_ws = -(g . bg);
+    zero gradients wherever no ray reaches, on NaN-filled outputs.  Includes an empty and a dropped ray."""
+    bound, N = 2, 1500
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(N, 41, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    tot = int(O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, N * 1024, nears, fars, 1)[4][0])
+    M = int(tot * 0.9) if overflow else tot + 2000            # overflow: the last rays are dropped
+    M += 128 - M % 128
+    xyzs, dirs, deltas, rays, counter = O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, M, nears, fars, 1)
+    assert (counter[0] > M) == overflow and (rays[:, 2] == 0).any()
+    rng = np.random.default_rng(8)
+    sig = cu((rng.random(M) * 25).astype(np.float32)); rgb = cu(rng.random((M, 3)).astype(np.float32))
+    dl = cu(deltas[:M]); rays_t = cu(rays); cnt = cu(counter)
+    bg = {"scalar": 0.75, "rgb": cu(rng.random(3).astype(np.float32)),
+          "per_ray": cu(rng.random((N, 3)).astype(np.float32))}[bg_kind]
+    ws0 = torch.empty(N, device=DEV); dp0 = torch.empty(N, device=DEV); im0 = torch.empty(N, 3, device=DEV)
+    rm.composite_rays_train_forward(sig, rgb, dl, rays_t, M, N, ws0, dp0, im0)
+    for depth in (torch.empty(N, device=DEV), None):
+        ws1 = torch.empty(N, device=DEV); im1 = torch.empty(N, 3, device=DEV); out = torch.empty(N, 3, device=DEV)
+        rm.composite_rays_train_forward_blend(sig, rgb, dl, rays_t, M, N, ws1, depth, im1, bg, out)
+        assert torch.equal(ws1, ws0) and torch.equal(im1, im0)
+        if depth is not None:
+            assert torch.equal(depth, dp0)
+        assert torch.equal(out, im0 + (1 - ws0).unsqueeze(-1) * bg)
+    target = cu(rng.random((N, 3)).astype(np.float32))
+    scale = 2.0 / (3 * N) * 1.7
+    g_im = (out - target) * scale
+    g_ws = -(g_im * bg).sum(-1)
+    gs0 = torch.zeros(M, device=DEV); gc0 = torch.zeros(M, 3, device=DEV)
+    rm.composite_rays_train_backward(g_ws.contiguous(), g_im.contiguous(), sig, rgb, dl, rays_t, ws0, im0, M, N, gs0, gc0)
+    gs1 = torch.full((M,), float("nan"), device=DEV); gc1 = torch.full((M, 3), float("nan"), device=DEV)
+    rm.composite_rays_train_backward_mse(out, target, scale, bg, cnt, sig, rgb, dl, rays_t, ws0, im0, M, N, gs1, gc1)
+    assert torch.isfinite(gs1).all() and torch.isfinite(gc1).all()
+    assert float((gc1 - gc0).abs().max()) <= 1e-6 * float(gc0.abs().max())
+    assert float((gs1 - gs0).abs().max()) <= 2e-5 * float(gs0.abs().max())
+    covered = torch.zeros(M, dtype=torch.bool, device=DEV)
+    for i, off, n in rays.tolist():
+        if n and off + n < M:
+            covered[off:off + n] = True
+    assert not gs1[~covered].any() and not gc1[~covered].any() and (~covered).sum() > (0 if overflow else 2000)
 
 
 # ------------------------------------------------------------------ inference trio
