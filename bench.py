@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--graph-leg-steps", type=int, default=48,
                     help="extra steps timed with HIP-graph replay after the main (eager) timed region; 0 = skip")
     ap.add_argument("--no-prefetch", action="store_true",
-                    help="N > 1: do not march the next batch underneath the gradient all-reduce")
+                    help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
@@ -197,7 +197,7 @@ def main():
         ro, rd, target = batches[i % len(batches)]
         if args.mode == "rgb":
             nxt = batches[(i + 1) % len(batches)]
-            return harness.step_rgb(ro, rd, target, next_rays=(nxt[0], nxt[1]) if world > 1 else None)
+            return harness.step_rgb(ro, rd, target, next_rays=(nxt[0], nxt[1]))
         ro2, rd2, _ = batches[(i + 1) % len(batches)]
         pols = torch.sign(target[..., 0] - 0.5)
         data = {"images": target, "rays_evs_o1": ro, "rays_evs_d1": rd, "rays_evs_o2": ro2, "rays_evs_d2": rd2,

@@ -1,0 +1,341 @@
+// density_update.hip -- the device side of NeRFRenderer.update_extra_state (nerf/renderer.py:472-560 of the reference):
+// which cells of the cascaded occupancy grid get re-evaluated, and what happens to their densities afterwards.  The
+// density network itself (hash grid + sigma MLP) runs between the two entry points, on the buffers they exchange.
+//
+//   enerf_density_grid_cells   full sweep : every cell of every cascade, x fastest (renderer.py:484-512)
+//                              partial    : per cascade N uniformly drawn cells + N draws (with replacement) from the
+//                                           cells with density > 0 (renderer.py:514-527), emitted in Morton order
+//                              -> Morton indices + jittered query positions of all cascades in one batch
+//   enerf_density_grid_update  tmp_grid[cas, indices] = sigma * scale; EMA max with decay where both are valid;
+//                              mean of clamp(grid, 0); packbits against min(mean, density_thresh); step-counter sum
+//                              (renderer.py:541-558) -- the mean never visits the host before the bitfield is packed
+//
+// What the reference does with ~40 torch ops per cascade, three host synchronisations (nonzero, two .item()) and 1 M-point
+// scattered gathers is here ~10 launches, one read-back of 16 bytes, and coherent gathers: the sampled cells are sorted
+// (23-bit radix sort of (cascade, Morton index) keys) so neighbouring query points share hash-grid rows.  The sampling
+// is the same in distribution, not in its random numbers (torch's Philox stream is not reproduced): parity unpinned.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+using namespace enerf;
+
+namespace {
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t compact_bits(uint32_t x) {
+    x = x & 0x49249249;
+    x = (x | (x >> 2)) & 0xc30c30c3;
+    x = (x | (x >> 4)) & 0x0f00f00f;
+    x = (x | (x >> 8)) & 0xff0000ff;
+    x = (x | (x >> 16)) & 0x0000ffff;
+    return x;
+}
+
+// counter-based generator: four independent 32-bit words per (seed, counter) -- splitmix64 finaliser, two rounds
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+struct Rand4 {
+    uint32_t w[4];
+};
+__device__ __forceinline__ Rand4 rand4(uint64_t seed, uint64_t counter) {
+    const uint64_t a = mix64(seed + 0x9e3779b97f4a7c15ULL * (2 * counter + 1));
+    const uint64_t b = mix64(a + 0x9e3779b97f4a7c15ULL * (2 * counter + 2) + seed);
+    return Rand4{{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)}};
+}
+__device__ __forceinline__ float unit_float(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }   // [0, 1)
+
+struct Cascades {
+    float span[8];      // bound_c - half_grid_size
+    float half[8];      // half_grid_size = bound_c / H
+};
+
+// query position of cell (x, y, z) of cascade `cas`: 2 * c / (H - 1) - 1, scaled to the cascade, jittered inside the cell
+__device__ __forceinline__ void cell_position(const Cascades& cs, uint32_t cas, uint32_t H, uint32_t x, uint32_t y,
+                                              uint32_t z, const Rand4& r, float* out) {
+    const float inv = 1.0f / (float)(H - 1);
+    const float span = cs.span[cas], half = cs.half[cas];
+    out[0] = (2.0f * (float)x * inv - 1.0f) * span + (unit_float(r.w[0]) * 2.0f - 1.0f) * half;
+    out[1] = (2.0f * (float)y * inv - 1.0f) * span + (unit_float(r.w[1]) * 2.0f - 1.0f) * half;
+    out[2] = (2.0f * (float)z * inv - 1.0f) * span + (unit_float(r.w[2]) * 2.0f - 1.0f) * half;
+}
+
+// ---- full sweep: thread per (cascade, cell), x fastest so that consecutive query points are x-neighbours
+__global__ void __launch_bounds__(256) k_cells_full(Cascades cs, uint32_t C, uint32_t H, uint32_t logH, uint64_t seed,
+                                                    int32_t* __restrict__ indices, float* __restrict__ xyzs) {
+    const uint32_t H3 = H * H * H;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= C * H3) return;
+    const uint32_t cas = p / H3, cell = p - cas * H3;
+    const uint32_t x = cell & (H - 1), y = (cell >> logH) & (H - 1), z = cell >> (2 * logH);
+    indices[p] = (int32_t)morton3(x, y, z);
+    cell_position(cs, cas, H, x, y, z, rand4(seed, p), xyzs + (size_t)p * 3);
+}
+
+// ---- partial update, step 1: the cells with density > 0, compacted per cascade in index order
+constexpr uint32_t kOccBlock = 4096;     // cells per workgroup (256 threads x 16)
+
+__global__ void __launch_bounds__(256) k_occ_count(const float* __restrict__ grid, uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    const float* g = grid + (size_t)blockIdx.x * kOccBlock + threadIdx.x * 16;
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 v = reinterpret_cast<const float4*>(g)[q];
+        c += (v.x > 0.0f) + (v.y > 0.0f) + (v.z > 0.0f) + (v.w > 0.0f);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one workgroup per cascade: exclusive scan of its block counts (in place), total -> cas_counts[cas]
+__global__ void __launch_bounds__(1024) k_occ_scan(uint32_t* __restrict__ block_counts, uint32_t blocks_per_cas,
+                                                   uint32_t* __restrict__ cas_counts) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    uint32_t* bc = block_counts + (size_t)blockIdx.x * blocks_per_cas;
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < blocks_per_cas; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < blocks_per_cas ? bc[i] : 0u;
+        const uint32_t incl = wave_incl_scan_add_u32(v, lane);
+        if (lane == 63) wtot[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += wtot[w];
+        const uint32_t carry = carry_s;
+        if (i < blocks_per_cas) bc[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cas_counts[blockIdx.x] = carry_s;
+}
+
+__global__ void __launch_bounds__(256) k_occ_compact(const float* __restrict__ grid,
+                                                     const uint32_t* __restrict__ block_offsets, uint32_t blocks_per_cas,
+                                                     uint32_t H3, uint32_t* __restrict__ list) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t cas = blockIdx.x / blocks_per_cas;
+    const uint32_t cell0 = (blockIdx.x - cas * blocks_per_cas) * kOccBlock + threadIdx.x * 16;
+    const float* g = grid + (size_t)cas * H3 + cell0;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 v = reinterpret_cast<const float4*>(g)[q];
+        mask |= (uint32_t)(v.x > 0.0f) << (4 * q) | (uint32_t)(v.y > 0.0f) << (4 * q + 1) |
+                (uint32_t)(v.z > 0.0f) << (4 * q + 2) | (uint32_t)(v.w > 0.0f) << (4 * q + 3);
+    }
+    const uint32_t c = (uint32_t)__popc(mask);
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_add_u32(c, lane);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    uint32_t off = block_offsets[blockIdx.x] + incl - c;
+    for (int w = 0; w < wid; w++) off += wsum[w];
+    uint32_t* out = list + (size_t)cas * H3 + off;
+    while (mask) {
+        const int b = __builtin_ctz(mask);
+        mask &= mask - 1;
+        *out++ = cell0 + (uint32_t)b;
+    }
+}
+
+// ---- partial update, step 2: (cascade << bits | Morton index) keys of the cells to evaluate
+__global__ void __launch_bounds__(256) k_select_keys(uint32_t C, uint32_t N, uint32_t bits, uint32_t H3, uint64_t seed,
+                                                     const uint32_t* __restrict__ cas_counts,
+                                                     const uint32_t* __restrict__ list, uint32_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 2 * N) return;
+    const uint32_t cas = i / (2 * N), j = i - cas * 2 * N;
+    const Rand4 r = rand4(seed ^ 0x5bd1e995u, i);
+    uint32_t idx = r.w[0] & (H3 - 1);                               // uniform cell (H^3 is a power of two)
+    const uint32_t cnt = cas_counts[cas];
+    if (j >= N && cnt) idx = list[(size_t)cas * H3 + (uint32_t)(((uint64_t)r.w[1] * cnt) >> 32)];   // occupied cell
+    keys[i] = cas << bits | idx;
+}
+
+// ---- partial update, step 3 (after the sort): keys -> Morton indices + jittered positions
+__global__ void __launch_bounds__(256) k_cells_from_keys(Cascades cs, uint32_t P, uint32_t H, uint32_t bits,
+                                                         uint64_t seed, const uint32_t* __restrict__ keys,
+                                                         int32_t* __restrict__ indices, float* __restrict__ xyzs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t key = keys[p];
+    const uint32_t idx = key & ((1u << bits) - 1), cas = key >> bits;
+    indices[p] = (int32_t)idx;
+    cell_position(cs, cas, H, compact_bits(idx), compact_bits(idx >> 1), compact_bits(idx >> 2), rand4(seed, p),
+                  xyzs + (size_t)p * 3);
+}
+
+// ---- update: scatter, EMA + mean, packbits
+__global__ void __launch_bounds__(256) k_tmp_scatter(const int32_t* __restrict__ indices, const float* __restrict__ sigmas,
+                                                     uint32_t n_per_cas, uint32_t P, uint32_t H3, float scale,
+                                                     float* __restrict__ tmp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t cas = p / n_per_cas;
+    tmp[(size_t)cas * H3 + (uint32_t)indices[p]] = sigmas[p] * scale;       // duplicates: some writer wins, as in torch
+}
+
+__device__ __forceinline__ float ema1(float g, float t, float decay, float& acc) {
+    if (g >= 0.0f && t >= 0.0f) g = fmaxf(g * decay, t);          // `tmp` untouched = NaN bit pattern: never >= 0
+    acc += fmaxf(g, 0.0f);
+    return g;
+}
+
+__global__ void __launch_bounds__(256) k_ema_mean(float* __restrict__ grid, const float* __restrict__ tmp, uint32_t total4,
+                                                  float decay, double* __restrict__ sum) {
+    __shared__ float wsum[4];
+    float acc = 0.0f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        float4 g = reinterpret_cast<float4*>(grid)[i];
+        const float4 t = reinterpret_cast<const float4*>(tmp)[i];
+        g.x = ema1(g.x, t.x, decay, acc); g.y = ema1(g.y, t.y, decay, acc);
+        g.z = ema1(g.z, t.z, decay, acc); g.w = ema1(g.w, t.w, decay, acc);
+        reinterpret_cast<float4*>(grid)[i] = g;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, (double)((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])));
+}
+
+__global__ void __launch_bounds__(256) k_packbits_mean(const float* __restrict__ grid, uint32_t nbytes,
+                                                       const double* __restrict__ sum, double inv_total,
+                                                       float density_thresh, uint8_t* __restrict__ bitfield,
+                                                       const int32_t* __restrict__ step_counter, uint32_t total_step,
+                                                       double* __restrict__ stats) {
+    const float mean = (float)(*sum * inv_total);
+    const float thresh = fminf(mean, density_thresh);
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) {
+        stats[0] = (double)mean;
+        long long c = 0;
+        for (uint32_t s = 0; s < total_step; s++) c += step_counter[s * 2];
+        stats[1] = (double)c;
+    }
+    if (n >= nbytes) return;
+    const float4 a = reinterpret_cast<const float4*>(grid)[(size_t)n * 2];
+    const float4 b = reinterpret_cast<const float4*>(grid)[(size_t)n * 2 + 1];
+    uint32_t bits = 0;
+    bits |= a.x > thresh ? 1u : 0u;  bits |= a.y > thresh ? 2u : 0u;
+    bits |= a.z > thresh ? 4u : 0u;  bits |= a.w > thresh ? 8u : 0u;
+    bits |= b.x > thresh ? 16u : 0u; bits |= b.y > thresh ? 32u : 0u;
+    bits |= b.z > thresh ? 64u : 0u; bits |= b.w > thresh ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+bool grid_shape_ok(uint32_t C, uint32_t H) { return C >= 1 && C <= 8 && H >= 16 && H <= 512 && (H & (H - 1)) == 0; }
+
+Cascades make_cascades(uint32_t C, uint32_t H, float bound) {
+    Cascades cs;
+    for (uint32_t c = 0; c < 8; c++) {
+        // renderer.py:498-501  bound = min(2 ** cas, self.bound); half_grid_size = bound / self.grid_size
+        const double b = fmin((double)(1u << c), (double)bound);
+        const double half = b / (double)H;
+        cs.span[c] = c < C ? (float)(b - half) : 0.0f;
+        cs.half[c] = c < C ? (float)half : 0.0f;
+    }
+    return cs;
+}
+
+uint32_t log2u(uint32_t v) {
+    uint32_t l = 0;
+    while ((1u << l) < v) l++;
+    return l;
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, float bound, uint32_t n_uniform,
+                             uint64_t seed, int32_t* indices, float* xyzs, enerf_stream_t stream) {
+    if (!grid_shape_ok(C, H)) ENERF_BADARG("density_grid_cells: C=%u H=%u (need 1..8 cascades, H a power of two in 16..512)", C, H);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t logH = log2u(H), bits = 3 * logH;
+    const uint32_t H3 = 1u << bits;
+    const Cascades cs = make_cascades(C, H, bound);
+    if (!density_grid) {
+        const uint32_t P = C * H3;
+        k_cells_full<<<div_up(P, 256), 256, 0, s>>>(cs, C, H, logH, seed, indices, xyzs);
+        ENERF_LAUNCH_CHECK("density_grid_cells(full)");
+        return 0;
+    }
+    if (n_uniform == 0) return 0;
+    if ((uint64_t)C * 2 * n_uniform > 0x7fffffffULL) ENERF_BADARG("density_grid_cells: too many samples");
+    const uint32_t P = C * 2 * n_uniform;
+    const uint32_t blocks_per_cas = H3 / kOccBlock, nblocks = C * blocks_per_cas;
+    const int end_bit = (int)(bits + log2u(C));
+    size_t sort_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0,
+                                          end_bit, s) != hipSuccess)
+        ENERF_BADARG("density_grid_cells: radix sort sizing failed");
+    const size_t o_counts = 0, o_cas = o_counts + align256((size_t)nblocks * 4), o_list = o_cas + 256,
+                 o_keys = o_list + align256((size_t)C * H3 * 4), o_sorted = o_keys + align256((size_t)P * 4),
+                 o_sort = o_sorted + align256((size_t)P * 4), total = o_sort + align256(sort_bytes);
+    char* ws = (char*)workspace(WS_DENSITY, total);
+    if (!ws) return ENERF_E_NOMEM;
+    uint32_t* block_counts = (uint32_t*)(ws + o_counts);
+    uint32_t* cas_counts = (uint32_t*)(ws + o_cas);
+    uint32_t* list = (uint32_t*)(ws + o_list);
+    uint32_t* keys = (uint32_t*)(ws + o_keys);
+    uint32_t* sorted = (uint32_t*)(ws + o_sorted);
+    k_occ_count<<<nblocks, 256, 0, s>>>(density_grid, block_counts);
+    k_occ_scan<<<C, 1024, 0, s>>>(block_counts, blocks_per_cas, cas_counts);
+    k_occ_compact<<<nblocks, 256, 0, s>>>(density_grid, block_counts, blocks_per_cas, H3, list);
+    k_select_keys<<<div_up(P, 256), 256, 0, s>>>(C, n_uniform, bits, H3, seed, cas_counts, list, keys);
+    if (hipcub::DeviceRadixSort::SortKeys(ws + o_sort, sort_bytes, keys, sorted, (int)P, 0, end_bit, s) != hipSuccess)
+        ENERF_BADARG("density_grid_cells: radix sort failed");
+    k_cells_from_keys<<<div_up(P, 256), 256, 0, s>>>(cs, P, H, bits, seed, sorted, indices, xyzs);
+    ENERF_LAUNCH_CHECK("density_grid_cells(partial)");
+    return 0;
+}
+
+int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint32_t n_per_cascade, uint32_t C, uint32_t H,
+                              float sigma_scale, float decay, float density_thresh, float* density_grid,
+                              uint8_t* bitfield, const int32_t* step_counter, uint32_t total_step, double* stats,
+                              enerf_stream_t stream) {
+    if (!grid_shape_ok(C, H)) ENERF_BADARG("density_grid_update: C=%u H=%u", C, H);
+    if (total_step > 16) ENERF_BADARG("density_grid_update: total_step %u > 16", total_step);
+    if (!stats) ENERF_BADARG("density_grid_update: stats is required");
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t H3 = H * H * H;
+    const size_t cells = (size_t)C * H3;
+    char* ws = (char*)workspace(WS_DENSITY, 256 + cells * 4);
+    if (!ws) return ENERF_E_NOMEM;
+    double* sum = (double*)ws;
+    float* tmp = (float*)(ws + 256);
+    int e = check_hip(hipMemsetAsync(sum, 0, 8, s), "density_grid_update: memset");
+    if (!e) e = check_hip(hipMemsetAsync(tmp, 0xFF, cells * 4, s), "density_grid_update: memset");   // NaN: "not evaluated"
+    if (e) return e;
+    const uint32_t P = n_per_cascade * C;
+    if (P) k_tmp_scatter<<<div_up(P, 256), 256, 0, s>>>(indices, sigmas, n_per_cascade, P, H3, sigma_scale, tmp);
+    k_ema_mean<<<2048, 256, 0, s>>>(density_grid, tmp, (uint32_t)(cells / 4), decay, sum);
+    const uint32_t nbytes = (uint32_t)(cells / 8);
+    k_packbits_mean<<<div_up(nbytes, 256), 256, 0, s>>>(density_grid, nbytes, sum, 1.0 / (double)cells, density_thresh,
+                                                        bitfield, step_counter, total_step, stats);
+    ENERF_LAUNCH_CHECK("density_grid_update");
+    return 0;
+}
+
+}  // extern "C"

@@ -128,15 +128,28 @@ def _next_counter(model):
     return counter
 
 
-def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024):
+def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None):
     """Run the parameter-independent stage of the NEXT training render now (e.g. under a gradient all-reduce).  The
     result is picked up by the next render_train call on the same ray tensors; anything that changes what the stage
-    reads (update_extra_state: bitfield, sample budget) must not happen in between -- the caller's responsibility."""
+    reads (update_extra_state: bitfield, sample budget) must not happen in between -- the caller's responsibility.
+
+    With `stream` the stage is issued on that HIP stream, ordered after everything queued so far on the current one
+    (so it never overlaps a march of the current stream: the marcher's chunk-log workspace is shared), and runs
+    concurrently with what the current stream does next -- the marcher is latency / VALU bound and hides under the
+    MFMA- and HBM-bound backward kernels.  The consumer waits on the stage's event."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
-    pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False, float(dt_gamma),
-                      int(max_steps))
+    if stream is None:
+        pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
+                          float(dt_gamma), int(max_steps))
+    else:
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
+                              float(dt_gamma), int(max_steps))
+            pre["ready"] = torch.cuda.Event()
+            pre["ready"].record(stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)
     model._premarched = (key, pre)
 
@@ -163,10 +176,21 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
         return None
     model._premarched = None
     key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
-    return stash[1] if stash[0] == key else None
+    if stash[0] != key:
+        return None
+    pre = stash[1]
+    ready = pre.pop("ready", None)
+    if ready is not None:                       # marched on a side stream: order this stream after it, and tell the
+        cur = torch.cuda.current_stream()       # caching allocator that the buffers now live here as well
+        cur.wait_event(ready)
+        for t in pre.values():
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+    return pre
 
 
-def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0):
+def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,
+                   after_forward=None):
     """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
     -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
     embedding gradient was added straight into the parameter's .grad).
@@ -174,7 +198,7 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
     For loops whose loss is the reference's default (nerf/utils.py:628, MSE): the loss gradient and the blend's
     d/d(weights_sum) are formed inside the composite backward kernel, which also zero-fills what it does not write;
     depth is not computed.  What is skipped relative to render_train + autograd: the engine round trip, its
-    AccumulateGrad nodes, ~18 elementwise / fill launches."""
+    AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     target = target.contiguous().view(-1, 3)
@@ -199,6 +223,8 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
         out_image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         _rb.composite_rays_train_forward_blend(sigmas, rgb, deltas, rays, M, N, weights_sum, None, image, bg_color,
                                                out_image)
+        if after_forward is not None:
+            after_forward()                     # e.g. prefetch_march of the next batch on a side stream
         g_sigmas = torch.empty_like(sigmas)
         g_rgbs = torch.empty_like(rgb)
         _rb.composite_rays_train_backward_mse(out_image, target, 2.0 * float(upstream) / (3 * N), bg_color,

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import fused_network, fused_render, raymarching
+from . import density_update, fused_network, fused_render, raymarching
 
 
 def _meshgrid_ij(*args):
@@ -305,6 +305,8 @@ class NeRFRenderer(nn.Module):
     def update_extra_state(self, decay=0.95, S=128):
         if not self.cuda_ray:
             return
+        if density_update.supported(self):
+            return density_update.update(self, decay)        # device-side selection / EMA / packbits, one read-back
         dev = self.density_grid.device
         tmp_grid = -torch.ones_like(self.density_grid)
 

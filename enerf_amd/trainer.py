@@ -37,6 +37,7 @@ class TrainHarness:
         self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
+        self._side = None             # HIP stream of the next batch's march (created on first use)
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         if self.use_graphs:
@@ -136,7 +137,22 @@ class TrainHarness:
                 and fused_render.supported(m, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3), 1,
                                            render_kw.get("dt_gamma", 0)))
 
-    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024):
+    def _side_prefetch(self, next_rays):
+        """-> a callable that marches the next batch on the side stream (see fused_render.prefetch_march), or None when
+        the next step starts with update_extra_state (new bitfield / budget) or nothing is known about it."""
+        m = self.model
+        if (next_rays is None or not self.prefetch or getattr(m, "graph_counter", None) is not None
+                or self.global_step % self.update_interval == 0):
+            return None
+        from . import fused_render
+        ro, rd = next_rays
+        if not fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1, 0):
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return lambda: fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side)
+
+    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None):
         """Render + MSE + backward with the loss gradient in closed form (fused_render.train_step_mse): same kernels
         for the render and its backward, no autograd graph, no loss-backward / blend / depth / fill launches.
         Leaves the gradients in p.grad, returns the loss."""
@@ -144,7 +160,8 @@ class TrainHarness:
         m = self.model
         for p in self._params:                      # nothing accumulates across steps (zero_grad(set_to_none=True))
             p.grad = None
-        image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps)
+        image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps,
+                                                   after_forward=after_forward)
         for p, g in zip(fused_network.network_params(m), grads):
             if g is not None:
                 p.grad = g.view_as(p)
@@ -152,8 +169,9 @@ class TrainHarness:
             return torch.nn.functional.mse_loss(image, target.view(-1, 3))
 
     def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
-        loss = self._manual_fwd_bwd(rays_o, rays_d, target, **render_kw)
-        self._reduce_grads(next_rays)
+        side = self._side_prefetch(next_rays) if not render_kw else None
+        loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=side, **render_kw)
+        self._reduce_grads(None if side is not None else next_rays)
         self._opt_step()
         return loss
 

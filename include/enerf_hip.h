@@ -72,6 +72,33 @@ int enerf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, e
 /* raymarching.cu:294-302  packbits(grid, N, density_thresh, bitfield); N = number of output bytes */
 int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, enerf_stream_t stream);
 
+/* ---- density-grid maintenance: the device side of NeRFRenderer.update_extra_state (nerf/renderer.py:472-560) --------
+ * The reference builds the candidate cells and applies the results with ~40 torch ops per cascade and three host
+ * synchronisations; these two entry points are that logic around the density network evaluation, which stays with the
+ * caller (hash grid + sigma MLP on `xyzs`, giving `sigmas`).  H must be a power of two (the Morton layout), 1 <= C <= 8.
+ *
+ * enerf_density_grid_cells: Morton indices (int32, per cascade) and jittered query positions [P,3] of the cells to evaluate,
+ * cascades concatenated.
+ *   density_grid == NULL : full sweep (renderer.py:484-512), P = C * H^3, cells in x-fastest order.
+ *   density_grid != NULL : partial update (renderer.py:514-538), P = C * 2 * n_uniform: per cascade n_uniform uniformly
+ *                          drawn cells and n_uniform draws with replacement from the cells with density > 0 (all uniform
+ *                          when none is), emitted sorted by Morton index.
+ * Positions: (2 * coord / (H - 1) - 1) * (bound_c - half) + U(-half, half), bound_c = min(2^cas, bound), half =
+ * bound_c / H.  Random numbers come from a counter-based generator keyed by `seed` (same distribution as the reference's
+ * torch.randint / rand_like calls, not the same stream). */
+int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, float bound, uint32_t n_uniform,
+                             uint64_t seed, int32_t* indices, float* xyzs, enerf_stream_t stream);
+
+/* enerf_density_grid_update (renderer.py:541-558): tmp_grid = -1; tmp_grid[cas, indices] = sigmas * sigma_scale (n_per_cascade
+ * entries per cascade); where density_grid >= 0 and tmp_grid >= 0: density_grid = max(density_grid * decay, tmp_grid);
+ * mean = mean(clamp(density_grid, 0)); bitfield = packbits(density_grid, min(mean, density_thresh)).
+ * stats (device, 2 doubles) receives {mean, sum of step_counter[0:total_step][0]} -- the one read-back of the update
+ * (mean_density, mean_count).  step_counter: int32 [16,2] (may be NULL when total_step == 0). */
+int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint32_t n_per_cascade, uint32_t C, uint32_t H,
+                              float sigma_scale, float decay, float density_thresh, float* density_grid,
+                              uint8_t* bitfield, const int32_t* step_counter, uint32_t total_step, double* stats,
+                              enerf_stream_t stream);
+
 /* raymarching.cu:482-490  march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
  *                                          nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
  * xyzs/dirs/deltas must be zero-filled by the caller (raymarching.py:205-207).

@@ -1,0 +1,52 @@
+"""CPU restatement (numpy, TEST INFRASTRUCTURE ONLY) of the deterministic parts of NeRFRenderer.update_extra_state
+(nerf/renderer.py:472-560 of the reference):
+
+  cell_centres       :496-503, :528-533   xyzs = 2 * coords / (grid_size - 1) - 1, scaled by (bound_c - half_grid_size);
+                                          the jitter added on top is uniform in [-half_grid_size, half_grid_size]
+  apply_update       :538-553             tmp_grid scatter, EMA max with decay, mean of clamp(grid, 0), packbits against
+                                          min(mean, density_thresh)
+  mean_count         :555-558             int(sum(step_counter[:total_step, 0]) / total_step)
+
+Parity status: "unpinned" against a run of the reference itself -- update_extra_state lives inside NeRFRenderer and needs
+the reference's CUDA raymarching extension (morton3D, packbits) to execute; these functions transcribe its tensor
+expressions.  Which cells are drawn (torch.randint / rand_like) is random in the reference and only checked in
+distribution by the tests.
+"""
+import numpy as np
+
+from . import oracle as O
+
+
+def cascade_geometry(cas, bound, grid_size):
+    b = min(2 ** cas, bound)                                  # :498
+    half = b / grid_size                                      # :499
+    return b - half, half
+
+
+def cell_centres(indices, cas, bound, grid_size):
+    """Unjittered query positions of Morton cells `indices` of cascade `cas` -> [n,3] float32."""
+    coords = O.morton3D_invert(np.asarray(indices, np.int32)).astype(np.float32)
+    xyzs = np.float32(2) * coords / np.float32(grid_size - 1) - np.float32(1)      # :496
+    span, _ = cascade_geometry(cas, bound, grid_size)
+    return (xyzs * np.float32(span)).astype(np.float32)                            # :501
+
+
+def apply_update(density_grid, indices, sigmas, sigma_scale, decay, density_thresh):
+    """density_grid [C,H^3] f32, indices [C,n] (unique per cascade, or the last writer wins), sigmas [C,n]
+    -> (new grid, mean, bitfield)."""
+    grid = np.array(density_grid, np.float32, copy=True)
+    tmp = -np.ones_like(grid)                                                      # :480
+    for cas in range(grid.shape[0]):
+        tmp[cas, np.asarray(indices[cas], np.int64)] = np.asarray(sigmas[cas], np.float32) * np.float32(sigma_scale)
+    valid = (grid >= 0) & (tmp >= 0)                                               # :541
+    grid[valid] = np.maximum(grid[valid] * np.float32(decay), tmp[valid])          # :542
+    mean = float(np.mean(np.clip(grid, 0, None), dtype=np.float64))                # :543
+    thresh = min(mean, density_thresh)                                             # :547
+    return grid, mean, O.packbits(grid.reshape(-1), np.float32(thresh))            # :548
+
+
+def mean_count(step_counter, local_step):
+    total_step = min(16, local_step)                                               # :555
+    if total_step <= 0:
+        return None
+    return int(int(np.asarray(step_counter)[:total_step, 0].sum()) / total_step)   # :557

@@ -144,12 +144,19 @@ def test_graph_replay_matches_eager_steps():
     assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
 
 
-def test_prefetched_march_gives_the_same_steps():
-    """Data-parallel harness: the parameter-independent stage of the NEXT render (near_far + march) is issued right after
-    the gradient collectives are launched.  With a stand-in averager (single process) the prefetching harness must
-    reproduce the plain one: same sample counters, same loss trajectory, across update_extra_state boundaries."""
+@pytest.mark.parametrize("manual", [True, False])
+def test_prefetched_march_gives_the_same_steps(monkeypatch, manual):
+    """The parameter-independent stage of the NEXT render (near_far + march) is issued early: on a side stream once the
+    forward is queued (closed-form MSE step), or right after the gradient collectives are launched (autograd step, with
+    a stand-in averager here).  Either way the prefetching harness must reproduce the plain one: same sample counters,
+    same loss trajectory, across update_extra_state boundaries."""
+    from enerf_amd import fused_render
     from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
+    streams = []
+    orig = fused_render.prefetch_march
+    monkeypatch.setattr(fused_render, "prefetch_march",
+                        lambda *a, **k: (streams.append(k.get("stream")), orig(*a, **k))[1])
 
     class NoComm:
         def start(self): pass
@@ -163,6 +170,7 @@ def test_prefetched_march_gives_the_same_steps():
         h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
         h.avg = NoComm()
         h.prefetch = prefetch
+        h.manual_mse = manual
         losses, slots = [], []
         for i in range(52):
             nxt = data[(i + 1) % len(data)]
@@ -170,6 +178,7 @@ def test_prefetched_march_gives_the_same_steps():
             slots.append(int(model.step_counter[model.rendered_counter_slot, 0]))
         runs.append((torch.stack(losses).cpu(), slots, model.mean_count))
     (l0, s0, m0), (l1, s1, m1) = runs
+    assert len(streams) >= 30 and all((st is not None) == manual for st in streams)
     assert s0 == s1 and m0 == m1
     assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
 
