@@ -78,6 +78,20 @@ __device__ __forceinline__ void stage(float* wl, const float* __restrict__ w, ui
     __syncthreads();
 }
 
+// Forward kernel staging: each matrix row is rotated by its row index (element (r, c) of a K-wide matrix sits at
+// r * K + (c + r) % K).  The forward's register set-up reads one column per instruction, rows across lanes -- a
+// 32-way bank conflict in the plain layout, conflict-free in the rotated one.
+__device__ __forceinline__ uint32_t rot(uint32_t r, uint32_t c, uint32_t K) { return r * K + ((c + r) & (K - 1)); }
+__device__ __forceinline__ void stage_rot(float* wl, const float* __restrict__ w, int NH, uint32_t out_dim) {
+    const uint32_t n0 = HID * IN, n = blob_size(NH, out_dim);
+    for (uint32_t i = threadIdx.x; i < n0; i += blockDim.x) wl[rot(i / IN, i % IN, IN)] = w[i];
+    for (uint32_t i = n0 + threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t l = i - n0;
+        wl[n0 + rot(l / HID, l % HID, HID)] = w[i];     // rows of all 64-wide matrices, numbered through
+    }
+    __syncthreads();
+}
+
 // store / load a D-tile-shaped [32 samples][32 neurons] block of a row-major [B,64] fp32 buffer (16 B per g)
 __device__ __forceinline__ void store_tile(float* rowptr, int ib, int h, const f32x16& v) {
 #pragma unroll
@@ -102,13 +116,16 @@ __device__ __forceinline__ int kmap(int p, int h) {
 }
 
 // ================================================================== forward
-template <int NH, bool TRAIN, int XL>
+// SIG: only exp(output 0) is wanted (Y == NULL, y0_exp set: the density-grid update) -- the output layer is then one
+// 64-term dot product per sample on the VALU (each half-wave holds 32 of the 64 hidden activations of its sample)
+// instead of a 32-row MFMA tile of which 31 rows would be thrown away.
+template <int NH, bool TRAIN, int XL, bool SIG = false>
 __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                    float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
                                                    uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
                                                    float* __restrict__ y0_exp) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    stage(wl, W, blob_size(NH, out_dim));
+    stage_rot(wl, W, NH, out_dim);
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
 
@@ -116,7 +133,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
 #pragma unroll
     for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-        for (int p = 0; p < 16; p++) w0[ob][p] = wl[(32 * ob + j) * IN + kmap<XL>(p, h)];
+        for (int p = 0; p < 16; p++) w0[ob][p] = wl[rot(32 * ob + j, kmap<XL>(p, h), IN)];
 #pragma unroll
     for (int l = 0; l < NH - 1; l++)
 #pragma unroll
@@ -125,13 +142,16 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             for (int ib = 0; ib < 2; ib++)
 #pragma unroll
                 for (int q = 0; q < 16; q++)
-                    wh[l][ob][ib][q] = wl[HID * IN + l * HID * HID + (32 * ob + j) * HID + 32 * ib + nrow(q, h)];
+                    wh[l][ob][ib][q] = wl[HID * IN + rot(l * HID + 32 * ob + j, 32 * ib + nrow(q, h), HID)];
     {
-        const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
+        const float* w64 = wl + HID * IN;                 // the 64-wide matrices; Wout's rows follow the hidden ones
+        const uint32_t r0 = (NH - 1) * HID;
 #pragma unroll
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) wo[ib][q] = (uint32_t)j < out_dim ? wout[j * HID + 32 * ib + nrow(q, h)] : 0.0f;
+            for (int q = 0; q < 16; q++)
+                wo[ib][q] = SIG ? w64[rot(r0, 32 * ib + nrow(q, h), HID)]
+                                : ((uint32_t)j < out_dim ? w64[rot(r0 + j, 32 * ib + nrow(q, h), HID)] : 0.0f);
     }
 
     const uint32_t ntiles = Bp / 32;
@@ -185,6 +205,18 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             }
             a[0] = n[0];
             a[1] = n[1];
+        }
+        if (SIG) {
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                p0 = fmaf(wo[0][q], a[0][q], p0);
+                p1 = fmaf(wo[1][q], a[1][q], p1);
+            }
+            float p = p0 + p1;
+            p += __shfl_xor(p, 32, 64);
+            if (valid && h == 0) y0_exp[s] = expf(p);
+            continue;
         }
         f32x16 o = (f32x16)(0.0f);
 #pragma unroll
@@ -668,6 +700,9 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict
 bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
+uint32_t g_fwd_blocks = 0;          // 0: default cap of the forward grid
+uint32_t g_bwd_blocks = 0;          // 0: default cap of the fused backward grid
+
 uint32_t pgrid(uint32_t B, uint32_t cap) {
     const uint32_t blocks = div_up(div_up(B, 32), 4);
     return blocks < cap ? blocks : cap;
@@ -680,6 +715,13 @@ extern "C" {
 // testing aid: 1 (default) = fused dgrad + wgrad kernel for num_hidden <= 2, 0 = separate dgrad / wgrad kernels
 int enerf_debug_mlp32_fused_backward(int on) {
     g_fused_bwd = on != 0;
+    return 0;
+}
+
+// tuning aids: workgroup caps of the forward / fused backward grids (0 = defaults)
+int enerf_debug_mlp32_grid_caps(uint32_t fwd_blocks, uint32_t bwd_blocks) {
+    g_fwd_blocks = fwd_blocks;
+    g_bwd_blocks = bwd_blocks;
     return 0;
 }
 
@@ -707,7 +749,9 @@ int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_
     if (y_stride < out_dim) ENERF_BADARG("mlp32: y_stride %u < out_dim %u", y_stride, out_dim);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_FWD, s);
-    const uint32_t grid = pgrid(B, 1024);
+    // two workgroups per CU are resident (the weights sit in ~130-210 registers): one round of them, each wave
+    // setting up once, beats four short-lived ones per CU (measured at the 138 k-sample training batch)
+    const uint32_t grid = pgrid(B, g_fwd_blocks ? g_fwd_blocks : 512);
     const size_t lds = sizeof(float) * (HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID);
 #define MLP32_FWD2(NHV, TR, XLV) \
     k_mlp32_fwd<NHV, TR, XLV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation, y_stride, y0_exp)
@@ -721,7 +765,10 @@ int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_
             else MLP32_FWD2(NHV, false, 1);                   \
         }                                                     \
     } while (0)
-    if (num_hidden == 1) MLP32_FWD(1);
+    if (num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1)
+        k_mlp32_fwd<1, false, 1, true><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation,
+                                                              y_stride, y0_exp);
+    else if (num_hidden == 1) MLP32_FWD(1);
     else if (num_hidden == 2) MLP32_FWD(2);
     else MLP32_FWD(3);
 #undef MLP32_FWD
@@ -757,7 +804,7 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
     const bool fused = g_fused_bwd && num_hidden <= 2;
     const uint32_t grid = pgrid(B, 1024);
-    const uint32_t wgrid = fused ? pgrid(B, 256)
+    const uint32_t wgrid = fused ? pgrid(B, g_bwd_blocks ? g_bwd_blocks : 256)
                                  : pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 512u));
     // fused epilogue gradients are evaluated once, by the dgrad kernel, which leaves the effective dL/dY in the
     // workspace for the weight-gradient kernel (whose inner loop is load-bound)

@@ -274,6 +274,8 @@ int enerf_debug_mlp32_fused_backward(int on);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
+/* tuning aid: workgroup caps of the mlp32 forward and fused-backward grids (0 = built-in defaults) */
+int enerf_debug_mlp32_grid_caps(uint32_t fwd_blocks, uint32_t bwd_blocks);
 
 /* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
  * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */

@@ -30,9 +30,12 @@ def main():
     ap.add_argument("--B", type=int, default=137856 - 5)
     ap.add_argument("--wgrad-blocks", type=int, default=0)
     ap.add_argument("--unfused-backward", action="store_true")
+    ap.add_argument("--fwd-blocks", type=int, default=0)
+    ap.add_argument("--bwd-blocks", type=int, default=0)
     a = ap.parse_args()
     if a.unfused_backward:
         L.lib().enerf_debug_mlp32_fused_backward(0)
+    L.lib().enerf_debug_mlp32_grid_caps(a.fwd_blocks, a.bwd_blocks)
     if a.wgrad_blocks:
         L.lib().enerf_debug_mlp32_wgrad_blocks(a.wgrad_blocks)
     B, Bp, dev = a.B, pad32(a.B), "cuda"
