@@ -697,6 +697,30 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict
     }
 }
 
+// The two weight blobs of the fused NeRF network (enerf_amd/fused_network.py) from the five nn.Linear weights, one launch:
+//   [ws0 64x32 | ws1 16x64 | W0c 64x32 | wc1 64x64 | wc2 out_c x 64]
+// W0c = the colour net's first layer re-ordered for the [raw density | geo_feat 15 | SH 16] input rows the sigma net
+// and the SH encoder write: column 0 <- 0, columns 1..15 <- wc0[:, 16..30], columns 16..31 <- wc0[:, 0..15].
+// `zero` (optional, same length) is cleared in the same pass: the dW accumulator of the backward.
+__global__ void __launch_bounds__(256) k_pack_nerf_weights(const float* __restrict__ ws0, const float* __restrict__ ws1,
+                                                           const float* __restrict__ wc0, const float* __restrict__ wc1,
+                                                           const float* __restrict__ wc2, uint32_t out_c,
+                                                           float* __restrict__ blob, float* __restrict__ zero) {
+    const uint32_t n = 2048 + 1024 + 2048 + 4096 + 64 * out_c;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v;
+        if (i < 2048) v = ws0[i];
+        else if (i < 3072) v = ws1[i - 2048];
+        else if (i < 5120) {
+            const uint32_t r = (i - 3072) >> 5, c = (i - 3072) & 31;
+            v = c == 0 ? 0.0f : wc0[r * 31 + (c < 16 ? 15 + c : c - 16)];
+        } else if (i < 9216) v = wc1[i - 5120];
+        else v = wc2[i - 9216];
+        blob[i] = v;
+        if (zero) zero[i] = 0.0f;
+    }
+}
+
 bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
@@ -728,6 +752,14 @@ int enerf_debug_mlp32_grid_caps(uint32_t fwd_blocks, uint32_t bwd_blocks) {
 // tuning aid: number of workgroups (= partial sums) of the weight-gradient kernel
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks) {
     g_wgrad_blocks = blocks;
+    return 0;
+}
+
+int enerf_nerf_pack_weights(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
+                            uint32_t out_c, float* blob, float* zero, enerf_stream_t stream) {
+    if (out_c == 0 || out_c > 32) ENERF_BADARG("nerf_pack_weights: out_c must be in [1, 32], got %u", out_c);
+    k_pack_nerf_weights<<<16, 256, 0, (hipStream_t)stream>>>(ws0, ws1, wc0, wc1, wc2, out_c, blob, zero);
+    ENERF_LAUNCH_CHECK("nerf_pack_weights");
     return 0;
 }
 

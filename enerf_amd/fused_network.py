@@ -69,16 +69,6 @@ def supported(net, x, d):
     return hit[1] and _ge._supports_layout()
 
 
-_ZERO_COLUMN = {}
-
-
-def _zero_column(dev):
-    z = _ZERO_COLUMN.get(dev)
-    if z is None:
-        z = _ZERO_COLUMN[dev] = torch.zeros(64, 1, dtype=torch.float32, device=dev)
-    return z
-
-
 def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2):
     """The kernel sequence itself (no autograd): returns sigma [B], rgb [B,out], and -- when `train` -- the tensors
     nerf_backward needs."""
@@ -103,23 +93,27 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2)
                             layout=2, affine=affine)
     stream = L.stream_handle()
     h32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
-    blob_s = torch.cat([ws0.reshape(-1), ws1.reshape(-1)])
+    # both weight blobs (and, when training, the zeroed dW accumulator of the backward) in one launch
+    blob = torch.empty(3072 + 6144 + 64 * out_c, dtype=torch.float32, device=dev)
+    dw = torch.empty_like(blob) if train else None
+    L.check(lib.enerf_nerf_pack_weights(ws0.data_ptr(), ws1.data_ptr(), wc0.data_ptr(), wc1.data_ptr(), wc2.data_ptr(),
+                                        out_c, blob.data_ptr(), dw.data_ptr() if train else None, stream),
+            "nerf_pack_weights")
+    blob_s, blob_c = blob[:3072], blob[3072:]
     fb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev) if train else None
     L.check(lib.enerf_mlp32_forward(feats.data_ptr(), blob_s.data_ptr(), B, 32, 16, 1, 0, 6,
                                     fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
                                     stream), "mlp32_forward(sigma)")
     L.check(lib.enerf_sh_encode_forward_strided(d.data_ptr(), h32.data_ptr() + 64, B, 4, 32, stream),
             "sh_encode_forward_strided")
-    # colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16]
-    blob_c = torch.cat([_zero_column(dev), wc0[:, 16:], wc0[:, :16]], dim=1).reshape(-1)
-    blob_c = torch.cat([blob_c, wc1.reshape(-1), wc2.reshape(-1)])
+    # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
     fb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev) if train else None
     L.check(lib.enerf_mlp32_forward(h32.data_ptr(), blob_c.data_ptr(), B, 32, out_c, 2, 0, 3,
                                     fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, stream),
             "mlp32_forward(color)")
     saved = None
     if train:
-        saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, blob_s=blob_s,
+        saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, blob_s=blob_s, dw=dw,
                      blob_c=blob_c, rgb=rgb, B=B, S=S, H=base_resolution, gridtype=gridtype, affine=affine,
                      out_c=out_c, param=embeddings)
     return sigma, rgb, saved
@@ -139,7 +133,9 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0):
         g_sigma = g_sigma * sigma_scale
     bb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev)
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
-    dw = torch.zeros(blob_s.numel() + blob_c.numel(), dtype=torch.float32, device=dev)     # one fill for both blobs
+    dw = sv.pop("dw", None)                         # zeroed by the forward's pack launch; a second backward refills
+    if dw is None:
+        dw = torch.zeros(blob_s.numel() + blob_c.numel(), dtype=torch.float32, device=dev)
     dw_s, dw_c = dw[:blob_s.numel()], dw[blob_s.numel():]
     L.check(lib.enerf_mlp32_backward(g_rgb.data_ptr(), sv["h32"].data_ptr(), blob_c.data_ptr(), sv["fb_c"].data_ptr(),
                                      B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), dw_c.data_ptr(), 0, 0,

@@ -253,6 +253,14 @@ int enerf_free_splitk(void);
  * (0 = out_dim), so the result can land in a slice of a wider buffer; y0_exp (optional, [B]) receives
  * exp(Y[:,0]) -- the trunc_exp forward of the density column (activation.py:5-17); Y may be NULL when only y0_exp is
  * wanted (density-grid updates). */
+/* Weight blobs of the fused fp32 NeRF network (nerf/network.py:60-105: sigma_net 32-64-16, color_net 31-64-64-out_c,
+ * both bias-free) from the five nn.Linear weights in one launch:
+ *   blob = [ws0 64x32 | ws1 16x64 | W0c 64x32 | wc1 64x64 | wc2 out_c x 64]   (3072 + 6144 + 64*out_c floats)
+ * W0c re-orders color_net[0].weight [64,31] (inputs: SH 16 | geo_feat 15) for the [raw density | geo_feat | SH] rows the
+ * kernels exchange: column 0 = 0.  `zero` (optional, same length) is cleared in the same pass. */
+int enerf_nerf_pack_weights(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
+                            uint32_t out_c, float* blob, float* zero, enerf_stream_t stream);
+
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
                         uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream);
