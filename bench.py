@@ -229,9 +229,9 @@ def main():
         # slot of the render(s) this step consumed (a prefetched march of the next step may already own the newest one)
         slot = getattr(model, "rendered_counter_slot", None)
         slot = (model.local_step - 1) % 16 if slot is None else slot
-        samples_acc += model.step_counter[slot, 0].to(torch.int64)
+        samples_acc.add_(model.step_counter[slot, 0])              # bookkeeping: one tiny launch per render
         if args.mode == "events":
-            samples_acc += model.step_counter[(slot - 1) % 16, 0].to(torch.int64)
+            samples_acc.add_(model.step_counter[(slot - 1) % 16, 0])
     sync()
     t1 = time.perf_counter()
     _lib.prof.enable(False)

@@ -26,7 +26,7 @@ SIGNATURES = {
     "enerf_composite_rays_train_forward_blend": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _f32, _vp,
                                                  _vp],
     "enerf_composite_rays_train_backward_mse": [_vp, _vp, _f32, _vp, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                                _u32, _u32, _vp, _vp, _vp],
+                                                _u32, _u32, _vp, _vp, _vp, _vp],
     "enerf_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "enerf_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                          _vp, _u32, _vp],

@@ -840,10 +840,12 @@ struct MseTail {
     float scale;
     Background bg;
     const int32_t* counter;
+    float* loss;            // optional: += loss_scale * sum((out_image - target)^2) over the rays (one atomic per workgroup)
+    float loss_scale;
 };
 
 template <bool MSE>
-__global__ void __launch_bounds__(256) k_composite_train_bwd(
+__global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
     const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
     const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
     const int32_t* __restrict__ rays, const float* __restrict__ weights_sum, const float* __restrict__ image,
@@ -858,6 +860,25 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd(
         return;
     }
     const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (MSE && mse.loss) {
+        // the loss value itself, for whoever logs it: every ray contributes, marched or not
+        __shared__ float s_err[16];
+        float e = 0.0f;
+        if (n < N && lane_id() < 3) {
+            const uint32_t ray = (uint32_t)rays[(size_t)n * 3];
+            const float d = mse.out_image[(size_t)ray * 3 + lane_id()] - mse.target[(size_t)ray * 3 + lane_id()];
+            e = d * d;
+        }
+        e += __shfl_down(e, 2, 64);
+        e += __shfl_down(e, 1, 64);
+        if (lane_id() == 0) s_err[threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += s_err[w];
+            atomicAdd(mse.loss, t * mse.loss_scale);      // same-address atomics cost ~12 ns each: 16 rays share one
+        }
+    }
     if (n >= N) return;
     const int lane = lane_id();
     const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1];
@@ -1200,7 +1221,7 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
                                             const int32_t* counter, const float* sigmas, const float* rgbs,
                                             const float* deltas, const int32_t* rays, const float* weights_sum,
                                             const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
-                                            float* grad_rgbs, enerf_stream_t stream) {
+                                            float* grad_rgbs, float* loss, enerf_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
         if (M) {
@@ -1212,10 +1233,12 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
     if (!counter) ENERF_BADARG("composite_rays_train_backward_mse: counter is required");
     if (bg_color && bg_stride != 0 && bg_stride != 3) ENERF_BADARG("composite_rays_train_backward_mse: bg_stride %u", bg_stride);
     ProfScope prof(ENERF_K_COMPOSITE_BWD, s);
-    const uint32_t ray_blocks = div_up(N, 4);
-    k_composite_train_bwd<true><<<ray_blocks + 64, 256, 0, s>>>(
+    const uint32_t ray_blocks = div_up(N, 16);
+    k_composite_train_bwd<true><<<ray_blocks + 16, 1024, 0, s>>>(
         nullptr, nullptr, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs,
-        MseTail{out_image, target, grad_scale, Background{bg_color, bg_stride, bg_scalar}, counter}, ray_blocks);
+        MseTail{out_image, target, grad_scale, Background{bg_color, bg_stride, bg_scalar}, counter, loss,
+                1.0f / (3.0f * (float)N)},
+        ray_blocks);
     ENERF_LAUNCH_CHECK("composite_rays_train_backward_mse");
     return 0;
 }

@@ -38,6 +38,8 @@ class TrainHarness:
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self._side = None             # HIP stream of the next batch's march (created on first use)
+        self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
+        self._loss_ring_clean = False
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         if self.use_graphs:
@@ -160,11 +162,21 @@ class TrainHarness:
         m = self.model
         for p in self._params:                      # nothing accumulates across steps (zero_grad(set_to_none=True))
             p.grad = None
+        loss = None
+        if not self.use_graphs:                     # (a captured graph would always accumulate into the same slot)
+            # loss values land in a ring of device scalars, cleared once per lap: no loss kernels, no per-step fill
+            slot = self.global_step % self._loss_ring.numel()
+            if slot == 0 or not self._loss_ring_clean:
+                self._loss_ring.zero_()
+                self._loss_ring_clean = True
+            loss = self._loss_ring[slot]
         image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps,
-                                                   after_forward=after_forward)
+                                                   after_forward=after_forward, loss_out=loss)
         for p, g in zip(fused_network.network_params(m), grads):
             if g is not None:
                 p.grad = g.view_as(p)
+        if loss is not None:
+            return loss             # a view into the ring: overwritten one lap (64 steps) later -- clone to keep it
         with torch.no_grad():
             return torch.nn.functional.mse_loss(image, target.view(-1, 3))
 

@@ -145,13 +145,15 @@ int enerf_composite_rays_train_forward_blend(const float* sigmas, const float* r
 /* composite_rays_train_backward for loss = mean((out_image - target)^2) * upstream (nerf/utils.py:628 with the default
  * MSE criterion): grad_image = (out_image - target) * grad_scale with grad_scale = 2 / (3 N) * upstream, and
  * grad_weights_sum = -(grad_image . bg), both formed in the kernel.  grad_sigmas / grad_rgbs may be UNINITIALISED: rows no
- * ray covers are zero-filled here (counter = the march's counter, counter[0] = samples reserved). */
+ * ray covers are zero-filled here (counter = the march's counter, counter[0] = samples reserved).
+ * loss (optional, device scalar): mean((out_image - target)^2) is ADDED to it (one float atomic per workgroup, so the
+ * value is reproducible to rounding only) -- the caller zeroes it; the gradients do not depend on it. */
 int enerf_composite_rays_train_backward_mse(const float* out_image, const float* target, float grad_scale,
                                             const float* bg_color, uint32_t bg_stride, float bg_scalar,
                                             const int32_t* counter, const float* sigmas, const float* rgbs,
                                             const float* deltas, const int32_t* rays, const float* weights_sum,
                                             const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
-                                            float* grad_rgbs, enerf_stream_t stream);
+                                            float* grad_rgbs, float* loss, enerf_stream_t stream);
 
 /* raymarching.cu:807-813  march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
  *                                    max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, perturb) */

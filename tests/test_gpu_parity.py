@@ -290,7 +290,10 @@ def test_composite_blend_forward_and_mse_backward(rm, scenes, bg_kind, overflow)
     gs0 = torch.zeros(M, device=DEV); gc0 = torch.zeros(M, 3, device=DEV)
     rm.composite_rays_train_backward(g_ws.contiguous(), g_im.contiguous(), sig, rgb, dl, rays_t, ws0, im0, M, N, gs0, gc0)
     gs1 = torch.full((M,), float("nan"), device=DEV); gc1 = torch.full((M, 3), float("nan"), device=DEV)
-    rm.composite_rays_train_backward_mse(out, target, scale, bg, cnt, sig, rgb, dl, rays_t, ws0, im0, M, N, gs1, gc1)
+    loss = torch.full((1,), 2.0, device=DEV)
+    rm.composite_rays_train_backward_mse(out, target, scale, bg, cnt, sig, rgb, dl, rays_t, ws0, im0, M, N, gs1, gc1, loss)
+    want = 2.0 + float(torch.nn.functional.mse_loss(out, target))             # the loss value is ADDED to the scalar
+    assert abs(float(loss) - want) < 1e-5 * want
     assert torch.isfinite(gs1).all() and torch.isfinite(gc1).all()
     assert float((gc1 - gc0).abs().max()) <= 1e-6 * float(gc0.abs().max())
     assert float((gs1 - gs0).abs().max()) <= 2e-5 * float(gs0.abs().max())
