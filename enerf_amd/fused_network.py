@@ -119,10 +119,19 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2)
     return sigma, rgb, saved
 
 
-def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0):
+def unpack_weight_grads(dw, out_c):
+    """The five MLP weight gradients as laid out by the parameters, from the flat dW accumulator
+    [ws0 | ws1 | W0c | wc1 | wc2] of the backward (views, except wc0 whose columns are put back in order)."""
+    g0 = dw[3072:5120].view(64, 32)
+    return (dw[:2048].view(64, 32), dw[2048:3072].view(16, 64), torch.cat([g0[:, 16:], g0[:, 1:16]], dim=1),
+            dw[5120:9216].view(64, 64), dw[9216:].view(out_c, 64))
+
+
+def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False):
     """Gradients of (embeddings, ws0, ws1, wc0, wc1, wc2) given d(sigma) [B] and d(rgb) [B,out] (contiguous fp32).
     `sigma_scale` multiplies d(sigma) on the fly (the renderer's density_scale).  The embedding gradient is None when
-    it was added straight into the parameter's .grad."""
+    it was added straight into the parameter's .grad.  raw=True: -> (embedding gradient, flat dW accumulator) -- what a
+    data-parallel caller all-reduces (two buffers) before unpack_weight_grads."""
     B, out_c = sv["B"], sv["out_c"]
     Bp = pad32(B)
     dev = sv["x"].device
@@ -153,10 +162,9 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0):
     g_emb = param.grad if direct else torch.zeros_like(emb)
     _gb.grid_encode_backward(dfeat, sv["x"], emb, sv["offsets"], g_emb, B, 3, 2, 16, sv["S"], sv["H"], False, dfeat,
                              dfeat, sv["gridtype"], layout=2, affine=sv["affine"])
-    g0 = dw_c[:2048].view(64, 32)
-    return (None if direct else g_emb, dw_s[:2048].view(64, 32), dw_s[2048:].view(16, 64),
-            torch.cat([g0[:, 16:], g0[:, 1:16]], dim=1), dw_c[2048:2048 + 4096].view(64, 64),
-            dw_c[2048 + 4096:].view(out_c, 64))
+    if raw:
+        return (None if direct else g_emb, dw)
+    return (None if direct else g_emb,) + unpack_weight_grads(dw, out_c)
 
 
 class _FusedNeRF(Function):

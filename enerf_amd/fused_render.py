@@ -190,7 +190,7 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
 
 
 def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,
-                   after_forward=None, loss_out=None):
+                   after_forward=None, loss_out=None, raw=False):
     """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
     -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
     embedding gradient was added straight into the parameter's .grad).
@@ -199,7 +199,8 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
     d/d(weights_sum) are formed inside the composite backward kernel, which also zero-fills what it does not write;
     depth is not computed.  What is skipped relative to render_train + autograd: the engine round trip, its
     AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued;
-    `loss_out` (a zeroed device scalar) receives the loss value from the backward kernel itself."""
+    `loss_out` (a zeroed device scalar) receives the loss value from the backward kernel itself; raw=True returns the
+    gradients as (embedding gradient, flat MLP dW accumulator) -- see fused_network.nerf_backward."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     target = target.contiguous().view(-1, 3)
@@ -231,5 +232,5 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
         _rb.composite_rays_train_backward_mse(out_image, target, 2.0 * float(upstream) / (3 * N), bg_color,
                                               pre["counter"], sigmas, rgb, deltas, rays, weights_sum, image, M, N,
                                               g_sigmas, g_rgbs, loss_out)
-        grads = fnet.nerf_backward(sv, g_sigmas, g_rgbs, sigma_scale=scale)
+        grads = fnet.nerf_backward(sv, g_sigmas, g_rgbs, sigma_scale=scale, raw=raw)
     return out_image, grads

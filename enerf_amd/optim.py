@@ -24,25 +24,40 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
-    def step_now(self):
+    def step_now(self, only=None, ranges=None):
         """The update itself.  `step()` is wrapped by torch.optim.Optimizer with profiler / hook plumbing that costs
-        ~40 us per call; a training loop that needs neither can call this directly."""
+        ~40 us per call; a training loop that needs neither can call this directly.
+
+        only   : restrict the update to these parameters (a data-parallel loop updates each bucket as soon as its
+                 all-reduce has landed).  Every parameter must be stepped exactly once per optimisation step.
+        ranges : {parameter: (lo, hi)} -- update only elements [lo, hi) of that (fused-path) parameter; the step
+                 count advances on the range starting at 0."""
         batches = {}          # (beta1, beta2, eps) -> parameters the fused kernel takes, all in one launch
+        only = None if only is None else {id(p) for p in only}
         for group in self.param_groups:
             b1, b2 = group["betas"]
             lr, eps = float(group["lr"]), float(group["eps"])
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only is not None and id(p) not in only):
                     continue
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                lo, hi = (0, p.numel()) if ranges is None or p not in ranges else ranges[p]
+                if lo == 0:
+                    st["step"] += 1
                 g = p.grad
                 if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() \
                         and g.dtype == torch.float32 and p.numel() > 0:
+                    if (lo, hi) != (0, p.numel()):
+                        if lo % 4 or hi <= lo:
+                            raise ValueError("FusedAdam ranges must start on a multiple of 4 elements")
+                        batches.setdefault((b1, b2, eps), []).append((p.view(-1)[lo:hi], g.view(-1)[lo:hi], dict(
+                            step=st["step"], exp_avg=st["exp_avg"].view(-1)[lo:hi],
+                            exp_avg_sq=st["exp_avg_sq"].view(-1)[lo:hi]), lr))
+                        continue
                     batches.setdefault((b1, b2, eps), []).append((p, g, st, lr))
                 else:
                     m, v, t = st["exp_avg"], st["exp_avg_sq"], st["step"]

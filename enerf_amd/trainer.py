@@ -38,6 +38,8 @@ class TrainHarness:
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self._side = None             # HIP stream of the next batch's march (created on first use)
+        self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
+        self._raw_grads = None
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
         self._loss_ring_clean = False
         self.use_graphs = bool(use_graphs)
@@ -154,7 +156,7 @@ class TrainHarness:
             self._side = torch.cuda.Stream()
         return lambda: fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side)
 
-    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None):
+    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None, raw=False):
         """Render + MSE + backward with the loss gradient in closed form (fused_render.train_step_mse): same kernels
         for the render and its backward, no autograd graph, no loss-backward / blend / depth / fill launches.
         Leaves the gradients in p.grad, returns the loss."""
@@ -171,18 +173,60 @@ class TrainHarness:
                 self._loss_ring_clean = True
             loss = self._loss_ring[slot]
         image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps,
-                                                   after_forward=after_forward, loss_out=loss)
-        for p, g in zip(fused_network.network_params(m), grads):
-            if g is not None:
-                p.grad = g.view_as(p)
+                                                   after_forward=after_forward, loss_out=loss, raw=raw)
+        if raw:
+            self._raw_grads = grads                 # (embedding gradient, flat dW): _finish_distributed takes over
+        else:
+            for p, g in zip(fused_network.network_params(m), grads):
+                if g is not None:
+                    p.grad = g.view_as(p)
         if loss is not None:
             return loss             # a view into the ring: overwritten one lap (64 steps) later -- clone to keep it
         with torch.no_grad():
             return torch.nn.functional.mse_loss(image, target.view(-1, 3))
 
+    def _finish_distributed(self):
+        """Data-parallel tail of the closed-form step: the hash-table gradient is all-reduced in `comm_chunks` pieces
+        and Adam runs on each piece as it lands (the optimizer pass over the table hides under the remaining
+        collectives); the MLP gradients travel as the backward's one flat dW buffer."""
+        import torch.distributed as dist
+        from . import fused_network
+        m = self.model
+        g_emb, dw = self._raw_grads
+        self._raw_grads = None
+        emb = m.encoder.embeddings
+        emb.grad = g_emb
+        nccl = dist.get_backend() == "nccl"                 # RCCL averages in the collective; gloo only sums
+        op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        inv = 1.0 / dist.get_world_size()
+        flat = g_emb.view(-1)
+        n = flat.numel()
+        step = -(-n // self.comm_chunks)
+        step += (-step) % 4                                  # FusedAdam ranges start on multiples of 4 elements
+        bounds = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+        works = [dist.all_reduce(flat[lo:hi], op=op, async_op=True) for lo, hi in bounds]
+        w_dw = dist.all_reduce(dw, op=op, async_op=True)
+        for (lo, hi), w in zip(bounds, works):
+            w.wait()
+            if not nccl:
+                flat[lo:hi].mul_(inv)
+            self.opt.step_now(only=[emb], ranges={emb: (lo, hi)})
+        w_dw.wait()
+        if not nccl:
+            dw.mul_(inv)
+        small = fused_network.network_params(m)[1:]
+        for p, g in zip(small, fused_network.unpack_weight_grads(dw, small[-1].shape[0])):
+            p.grad = g.view_as(p)
+        self.opt.step_now(only=small)
+
     def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
         side = self._side_prefetch(next_rays) if not render_kw else None
-        loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=side, **render_kw)
+        chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")
+                   and self.comm_chunks > 0)
+        loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=side, raw=chunked, **render_kw)
+        if chunked:
+            self._finish_distributed()
+            return loss
         self._reduce_grads(None if side is not None else next_rays)
         self._opt_step()
         return loss

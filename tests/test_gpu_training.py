@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _batches(n, n_rays, bound):
+def _batches(n, n_rays, bound, seed=11):
     from enerf_amd import scene
-    g = torch.Generator(device=DEV).manual_seed(11)
+    g = torch.Generator(device=DEV).manual_seed(seed)
     out = []
     for b in range(n):
         (ro, rd), _ = scene.training_batch(b, n_rays, DEV, generator=g)
@@ -224,3 +224,49 @@ def test_render_psnr_vs_cpu_oracle_route(monkeypatch):
     psnr = 10 * math.log10(1.0 / max(mse, 1e-20))
     print(f"PSNR(HIP, CPU oracle) = {psnr:.1f} dB over {inds.numel()} pixels")
     assert psnr >= 70.0
+
+
+def _dp_worker(rank, world, port, chunks, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from enerf_amd.network import NeRFNetwork
+        from enerf_amd.trainer import TrainHarness
+        torch.cuda.set_device(0)
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=world)
+        h.comm_chunks = chunks
+        data = _batches(4, 1024, 2, seed=10 + rank)          # every rank renders its own rays
+        losses = []
+        for i in range(36):
+            nxt = data[(i + 1) % len(data)]
+            losses.append(float(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]))))
+        torch.cuda.synchronize()
+        out[(chunks, rank)] = (losses, {n: p.detach().cpu() for n, p in model.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_chunked_allreduce_adam_pipeline_matches_bucket_path():
+    """Two ranks (gloo, both on this GPU): the closed-form step's data-parallel tail -- hash-table gradient all-reduced in
+    pieces with Adam applied piece by piece, MLP gradients as one flat buffer -- gives the replicas the same weights as
+    the two-bucket GradAverager + one optimizer step, and keeps the replicas identical."""
+    import socket
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for chunks in (0, 4):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_dp_worker, args=(2, port, chunks, out), nprocs=2, join=True)
+    for chunks in (0, 4):
+        p0, p1 = out[(chunks, 0)][1], out[(chunks, 1)][1]
+        for n in p0:
+            assert torch.equal(p0[n], p1[n]), (chunks, n)                       # replicas stay identical
+    la, lb = np.array(out[(0, 0)][0]), np.array(out[(4, 0)][0])
+    assert np.abs(la - lb).max() <= 1e-4 * np.abs(la).max()
+    for n, a in out[(0, 0)][1].items():
+        b = out[(4, 0)][1][n]
+        assert float((a - b).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
