@@ -12,6 +12,10 @@ BENCH="python $R/bench.py --no-cpu-baseline"
 rm -rf /tmp/p_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $BENCH > $OUT/bench_under_stats.log 2>&1
 find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
 
+# live hipEvent timing vs rocprofv3 on the same launches: a run whose timed region is the tail of the process
+rm -rf /tmp/p_agree; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_agree -o a -- $BENCH --render-frames 0 --graph-leg-steps 0 > $OUT/bench_under_trace.log 2>&1
+python $R/tools/agree.py $(find /tmp/p_agree -name "*kernel_trace.csv") $OUT/bench_under_trace.log $OUT/${TAG}_hipevent_vs_rocprof.json
+
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$C; timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$C -o c -- $BENCH --render-frames 0 > $OUT/bench_under_$C.log 2>&1
 done

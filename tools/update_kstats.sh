@@ -24,7 +24,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o s
 find /tmp/ks -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/upd_$MODE.csv \;
 python - <<PY
 import csv
-rows=list(csv.DictReader(open("$R/gpurun_out/upd_$MODE.csv")))
+rows=[r for r in csv.DictReader(open("$R/gpurun_out/upd_$MODE.csv"))
+      if "k_" in r["Name"] or "rocprim" in r["Name"] or "fillBuffer" in r["Name"]]   # the update's own launches
 print("== $MODE (per update)")
 for r in rows[:14]:
     print(f'{r["Name"][:80]:80s} calls {int(r["Calls"])/10:5.1f}  us {float(r["TotalDurationNs"])/1e4:8.1f}')
