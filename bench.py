@@ -198,11 +198,17 @@ def main():
         if args.mode == "rgb":
             nxt = batches[(i + 1) % len(batches)]
             return harness.step_rgb(ro, rd, target, next_rays=(nxt[0], nxt[1]))
+        return harness.step_events(event_data(i), ev_opt, next_data=event_data(i + 1))
+
+    def event_data(i):
+        ro, rd, target = batches[i % len(batches)]
         ro2, rd2, _ = batches[(i + 1) % len(batches)]
-        pols = torch.sign(target[..., 0] - 0.5)
-        data = {"images": target, "rays_evs_o1": ro, "rays_evs_d1": rd, "rays_evs_o2": ro2, "rays_evs_d2": rd2,
-                "pols": pols}
-        return harness.step_events(data, ev_opt)
+        if i % len(batches) not in pols_cache:
+            pols_cache[i % len(batches)] = torch.sign(target[..., 0] - 0.5)
+        return {"images": target, "rays_evs_o1": ro, "rays_evs_d1": rd, "rays_evs_o2": ro2, "rays_evs_d2": rd2,
+                "pols": pols_cache[i % len(batches)]}
+
+    pols_cache = {}
 
     def sync():
         torch.cuda.synchronize()

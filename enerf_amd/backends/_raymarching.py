@@ -107,7 +107,8 @@ def composite_rays_train_backward_mse(out_image, target, grad_scale, bg_color, c
                                       weights_sum, image, M, N, grad_sigmas, grad_rgbs, loss=None):
     bg, stride, scalar = _background(bg_color, N)
     L.check(L.lib().enerf_composite_rays_train_backward_mse(
-        _f32(out_image, "out_image"), _f32(target, "target"), float(grad_scale), bg, stride, scalar,
+        _f32(out_image, "out_image"), None if target is None else _f32(target, "target"), float(grad_scale), bg,
+        stride, scalar,
         _i32(counter, "counter"), _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"), _f32(deltas, "deltas"),
         _i32(rays, "rays"), _f32(weights_sum, "weights_sum"), _f32(image, "image"), int(M), int(N),
         _f32(grad_sigmas, "grad_sigmas"), _f32(grad_rgbs, "grad_rgbs"),

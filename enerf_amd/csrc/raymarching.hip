@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
         return;
     }
     const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (MSE && mse.loss) {
+    if (MSE && mse.loss && mse.target) {
         // the loss value itself, for whoever logs it: every ray contributes, marched or not
         __shared__ float s_err[16];
         float e = 0.0f;
@@ -894,9 +894,15 @@ __global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
     if (MSE) {
         // loss = mean((out_image - target)^2): d/d(out_image) = (out_image - target) * scale, scale = 2 / (3 N) * upstream;
         // out_image = image + (1 - weights_sum) * bg  ->  d/d(weights_sum) = -(g . bg)
-        gi0 = (mse.out_image[(size_t)index * 3] - mse.target[(size_t)index * 3]) * mse.scale;
-        gi1 = (mse.out_image[(size_t)index * 3 + 1] - mse.target[(size_t)index * 3 + 1]) * mse.scale;
-        gi2 = (mse.out_image[(size_t)index * 3 + 2] - mse.target[(size_t)index * 3 + 2]) * mse.scale;
+        // (target == nullptr: out_image already holds d loss / d out_image of some other loss)
+        gi0 = mse.out_image[(size_t)index * 3], gi1 = mse.out_image[(size_t)index * 3 + 1];
+        gi2 = mse.out_image[(size_t)index * 3 + 2];
+        if (mse.target) {
+            gi0 -= mse.target[(size_t)index * 3];
+            gi1 -= mse.target[(size_t)index * 3 + 1];
+            gi2 -= mse.target[(size_t)index * 3 + 2];
+        }
+        gi0 *= mse.scale; gi1 *= mse.scale; gi2 *= mse.scale;
         gws = -(gi0 * mse.bg.at(index, 0) + gi1 * mse.bg.at(index, 1) + gi2 * mse.bg.at(index, 2));
     } else {
         gws = grad_weights_sum[index];

@@ -151,3 +151,37 @@ def train_step_events(model, data, opt, criterion=None):
         crit = criterion if criterion is not None else torch.nn.MSELoss(reduction="none")
         loss = loss + opt.weight_loss_rgb * crit(out["image"], gt).mean()
     return loss, delta
+
+
+def train_step_events_manual(model, data, opt, after_forward=None):
+    """The event-only step with the two renders driven without autograd (fused_render.render_train_raw /
+    backward_raw): only the loss itself -- a few elementwise ops on two [N,3] images -- goes through autograd, and its
+    gradient is handed to the renders' closed backward.  Same values as train_step_events + loss.backward()
+    (nerf/utils.py:482-546); leaves the gradients in p.grad and returns (loss, delta)."""
+    from . import fused_network as fnet
+    from . import fused_render as fr
+    B = data["images"].shape[0]
+    dev = data["rays_evs_o1"].device
+    bg = torch.rand((B, 1, opt.out_dim_color), device=dev)
+    kw = {k: v for k, v in opt.render_kwargs.items() if k in ("dt_gamma", "max_steps")}
+    shape = data["rays_evs_o1"].shape[:-1]
+    img1, ctx1 = fr.render_train_raw(model, data["rays_evs_o1"], data["rays_evs_d1"], bg, True, **kw)
+    img2, ctx2 = fr.render_train_raw(model, data["rays_evs_o2"], data["rays_evs_d2"], bg, True, **kw)
+    if after_forward is not None:
+        after_forward()                                 # e.g. the next step's two marches on a side stream
+    a = img1.view(*shape, 3).requires_grad_(True)
+    b = img2.view(*shape, 3).requires_grad_(True)
+    with torch.enable_grad():
+        loss, delta = event_loss(a, b, data["pols"], opt)
+        g1, g2 = torch.autograd.grad(loss, [a, b])
+    params = fnet.network_params(model)
+    emb = params[0]
+    for p in params:
+        p.grad = None
+    g_emb, dw1 = fr.backward_raw(ctx1, g_image=g1, raw=True)
+    emb.grad = g_emb                                    # the second backward adds straight into it
+    _, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True)
+    dw1 += dw2
+    for p, g in zip(params[1:], fnet.unpack_weight_grads(dw1, params[-1].shape[0])):
+        p.grad = g.view_as(p)
+    return loss.detach(), delta

@@ -151,7 +151,10 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)
-    model._premarched = (key, pre)
+    stash = getattr(model, "_premarched", None)
+    if not isinstance(stash, dict):
+        stash = model._premarched = {}
+    stash[key] = pre                                 # (an event step stashes both of its renders)
 
 
 def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
@@ -172,13 +175,13 @@ def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_ga
 
 def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
     stash = getattr(model, "_premarched", None)
-    if stash is None:
+    if not stash:
         return None
-    model._premarched = None
     key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
-    if stash[0] != key:
+    pre = stash.pop(key, None)
+    if pre is None:
+        stash.clear()                                # marched for rays that are not coming: drop, march afresh
         return None
-    pre = stash[1]
     ready = pre.pop("ready", None)
     if ready is not None:                       # marched on a side stream: order this stream after it, and tell the
         cur = torch.cuda.current_stream()       # caching allocator that the buffers now live here as well
@@ -189,21 +192,11 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
     return pre
 
 
-def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,
-                   after_forward=None, loss_out=None, raw=False):
-    """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
-    -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
-    embedding gradient was added straight into the parameter's .grad).
-
-    For loops whose loss is the reference's default (nerf/utils.py:628, MSE): the loss gradient and the blend's
-    d/d(weights_sum) are formed inside the composite backward kernel, which also zero-fills what it does not write;
-    depth is not computed.  What is skipped relative to render_train + autograd: the engine round trip, its
-    AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued;
-    `loss_out` (a zeroed device scalar) receives the loss value from the backward kernel itself; raw=True returns the
-    gradients as (embedding gradient, flat MLP dW accumulator) -- see fused_network.nerf_backward."""
+def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024):
+    """Forward half of a training render without autograd: -> (image [N,3] blended with bg_color, ctx).  Feed the
+    gradient of whatever loss was computed on `image` to backward_raw(ctx, ...).  No depth."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
-    target = target.contiguous().view(-1, 3)
     N = rays_o.shape[0]
     dev = rays_o.device
     with torch.no_grad():
@@ -223,14 +216,50 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         out_image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        if isinstance(bg_color, torch.Tensor):
+            bg_color = bg_color.detach().to(torch.float32).contiguous()
         _rb.composite_rays_train_forward_blend(sigmas, rgb, deltas, rays, M, N, weights_sum, None, image, bg_color,
                                                out_image)
-        if after_forward is not None:
-            after_forward()                     # e.g. prefetch_march of the next batch on a side stream
-        g_sigmas = torch.empty_like(sigmas)
-        g_rgbs = torch.empty_like(rgb)
-        _rb.composite_rays_train_backward_mse(out_image, target, 2.0 * float(upstream) / (3 * N), bg_color,
-                                              pre["counter"], sigmas, rgb, deltas, rays, weights_sum, image, M, N,
-                                              g_sigmas, g_rgbs, loss_out)
-        grads = fnet.nerf_backward(sv, g_sigmas, g_rgbs, sigma_scale=scale, raw=raw)
-    return out_image, grads
+    ctx = dict(sv=sv, sigmas=sigmas, rgb=rgb, deltas=deltas, rays=rays, weights_sum=weights_sum, image=image,
+               out_image=out_image, bg=bg_color, counter=pre["counter"], M=M, N=N, scale=scale)
+    return out_image, ctx
+
+
+def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, raw=False):
+    """Backward half.  Either g_image = d loss / d image [N,3], or target [N,3] for loss = mean((image - target)^2) *
+    upstream (gradient and, with loss_out, value formed inside the composite backward).  -> the gradients of
+    fused_network.network_params(model) (raw=True: (embedding gradient, flat dW), see fused_network.nerf_backward);
+    the embedding gradient is None when it was added into an existing embeddings.grad."""
+    N, M = ctx["N"], ctx["M"]
+    with torch.no_grad():
+        g_sigmas = torch.empty_like(ctx["sigmas"])
+        g_rgbs = torch.empty_like(ctx["rgb"])
+        if target is not None:
+            _rb.composite_rays_train_backward_mse(ctx["out_image"], target.contiguous().view(-1, 3),
+                                                  2.0 * float(upstream) / (3 * N), ctx["bg"], ctx["counter"],
+                                                  ctx["sigmas"], ctx["rgb"], ctx["deltas"], ctx["rays"],
+                                                  ctx["weights_sum"], ctx["image"], M, N, g_sigmas, g_rgbs, loss_out)
+        else:
+            _rb.composite_rays_train_backward_mse(g_image.detach().to(torch.float32).contiguous().view(-1, 3), None,
+                                                  1.0, ctx["bg"], ctx["counter"], ctx["sigmas"], ctx["rgb"],
+                                                  ctx["deltas"], ctx["rays"], ctx["weights_sum"], ctx["image"], M, N,
+                                                  g_sigmas, g_rgbs, None)
+        return fnet.nerf_backward(ctx["sv"], g_sigmas, g_rgbs, sigma_scale=ctx["scale"], raw=raw)
+
+
+def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,
+                   after_forward=None, loss_out=None, raw=False):
+    """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
+    -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
+    embedding gradient was added straight into the parameter's .grad).
+
+    For loops whose loss is the reference's default (nerf/utils.py:628, MSE): the loss gradient and the blend's
+    d/d(weights_sum) are formed inside the composite backward kernel, which also zero-fills what it does not write;
+    depth is not computed.  What is skipped relative to render_train + autograd: the engine round trip, its
+    AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued;
+    `loss_out` (a zeroed device scalar) receives the loss value from the backward kernel itself; raw=True returns the
+    gradients as (embedding gradient, flat MLP dW accumulator) -- see fused_network.nerf_backward."""
+    out_image, ctx = render_train_raw(model, rays_o, rays_d, bg_color, perturb, dt_gamma, max_steps)
+    if after_forward is not None:
+        after_forward()                         # e.g. prefetch_march of the next batch on a side stream
+    return out_image, backward_raw(ctx, target=target, upstream=upstream, loss_out=loss_out, raw=raw)

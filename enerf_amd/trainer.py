@@ -141,20 +141,25 @@ class TrainHarness:
                 and fused_render.supported(m, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3), 1,
                                            render_kw.get("dt_gamma", 0)))
 
-    def _side_prefetch(self, next_rays):
-        """-> a callable that marches the next batch on the side stream (see fused_render.prefetch_march), or None when
-        the next step starts with update_extra_state (new bitfield / budget) or nothing is known about it."""
+    def _side_prefetch(self, *next_rays):
+        """-> a callable that marches the next step's ray sets (one (rays_o, rays_d) pair per render) on the side
+        stream (see fused_render.prefetch_march), or None when the next step starts with update_extra_state (new
+        bitfield / budget) or nothing is known about it."""
         m = self.model
-        if (next_rays is None or not self.prefetch or getattr(m, "graph_counter", None) is not None
-                or self.global_step % self.update_interval == 0):
+        if (not next_rays or any(r is None for r in next_rays) or not self.prefetch
+                or getattr(m, "graph_counter", None) is not None or self.global_step % self.update_interval == 0):
             return None
         from . import fused_render
-        ro, rd = next_rays
-        if not fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1, 0):
-            return None
+        for ro, rd in next_rays:
+            if not fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1, 0):
+                return None
         if self._side is None:
             self._side = torch.cuda.Stream()
-        return lambda: fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side)
+
+        def issue():
+            for ro, rd in next_rays:
+                fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side)
+        return issue
 
     def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None, raw=False):
         """Render + MSE + backward with the loss gradient in closed form (fused_render.train_step_mse): same kernels
@@ -258,7 +263,7 @@ class TrainHarness:
         self.opt.step()
         return loss.detach()
 
-    def step_events(self, data, opt):
+    def step_events(self, data, opt, next_data=None):
         """One event training step: two renders sharing one backward (nerf/utils.py:482-573)."""
         from .events import train_step_events
         if not self.model.training:
@@ -274,9 +279,28 @@ class TrainHarness:
                     inputs, lambda *ts: train_step_events(self.model, dict(zip(names, ts)), opt)[0])
             return self._replay(self._graphs[key], inputs, 2)
         self.opt.zero_grad(set_to_none=True)
+        if self._events_manual_ok(data, opt):
+            from .events import train_step_events_manual
+            side = None
+            if next_data is not None and not opt.render_kwargs:
+                side = self._side_prefetch((next_data["rays_evs_o1"], next_data["rays_evs_d1"]),
+                                           (next_data["rays_evs_o2"], next_data["rays_evs_d2"]))
+            loss, _ = train_step_events_manual(self.model, data, opt, after_forward=side)
+            self._reduce_grads()
+            self._opt_step()
+            return loss
         loss, _ = train_step_events(self.model, data, opt)
         loss.backward()
         if self.avg is not None:
             self.avg()
         self.opt.step()
         return loss.detach()
+
+    def _events_manual_ok(self, data, opt):
+        from . import fused_render
+        m = self.model
+        ro, rd = data["rays_evs_o1"], data["rays_evs_d1"]
+        return (self.manual_mse and opt.event_only and m.cuda_ray and m.mean_count > 0
+                and not set(opt.render_kwargs) - {"dt_gamma", "max_steps", "out_dim_color"}
+                and fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1,
+                                           opt.render_kwargs.get("dt_gamma", 0)))

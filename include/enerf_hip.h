@@ -146,6 +146,8 @@ int enerf_composite_rays_train_forward_blend(const float* sigmas, const float* r
  * MSE criterion): grad_image = (out_image - target) * grad_scale with grad_scale = 2 / (3 N) * upstream, and
  * grad_weights_sum = -(grad_image . bg), both formed in the kernel.  grad_sigmas / grad_rgbs may be UNINITIALISED: rows no
  * ray covers are zero-filled here (counter = the march's counter, counter[0] = samples reserved).
+ * target == NULL: `out_image` is taken to hold d loss / d out_image of some other loss (times grad_scale), everything
+ * else as above -- the general backward of "composite + background blend" into uninitialised buffers.
  * loss (optional, device scalar): mean((out_image - target)^2) is ADDED to it (one float atomic per workgroup, so the
  * value is reproducible to rounding only) -- the caller zeroes it; the gradients do not depend on it. */
 int enerf_composite_rays_train_backward_mse(const float* out_image, const float* target, float grad_scale,

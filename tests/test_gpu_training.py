@@ -270,3 +270,42 @@ def test_data_parallel_chunked_allreduce_adam_pipeline_matches_bucket_path():
     for n, a in out[(0, 0)][1].items():
         b = out[(4, 0)][1][n]
         assert float((a - b).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
+
+
+def test_event_step_with_closed_render_backward_matches_autograd_step(monkeypatch):
+    """step_events: the two renders run without autograd, the event loss alone goes through it and hands its gradient
+    to the renders' closed backward.  Same loss trajectory, counters and (in the mean) weights as the autograd step."""
+    from enerf_amd import events
+    from enerf_amd.events import EventOptions
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 2048, 2)
+    opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
+    calls = []
+    orig = events.train_step_events_manual
+    monkeypatch.setattr(events, "train_step_events_manual", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    runs = []
+    for manual in (False, True):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.manual_mse = manual
+        losses = []
+        torch.manual_seed(3)                                   # the step draws a random background colour
+        def batch(i):
+            ro, rd, tg = data[i % len(data)]
+            ro2, rd2, _ = data[(i + 1) % len(data)]
+            return {"images": tg.view(1, -1, 3), "rays_evs_o1": ro.view(1, -1, 3), "rays_evs_d1": rd.view(1, -1, 3),
+                    "rays_evs_o2": ro2.view(1, -1, 3), "rays_evs_d2": rd2.view(1, -1, 3),
+                    "pols": torch.sign(tg[..., 0] - 0.5).view(1, -1)}
+
+        for i in range(40):      # the closed-form run also marches the next step's two ray sets early (side stream)
+            losses.append(h.step_events(batch(i), opt, next_data=batch(i + 1) if manual else None).clone())
+        runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
+                     {n: p.detach().clone() for n, p in model.named_parameters()}))
+        assert len(calls) == (40 - 16 if manual else 0)
+    (l0, c0, p0), (l1, c1, p1) = runs
+    assert torch.equal(c0, c1)
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 2e-4
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().mean()) <= 1e-3 * float(p0[n].abs().mean()), n
