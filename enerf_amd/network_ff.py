@@ -7,6 +7,7 @@ stores out_dim_color (3) so `render(staged=True)` also works.
 """
 import torch
 
+from . import fused_network_ff
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .ffmlp import FFMLP
@@ -40,6 +41,8 @@ class NeRFNetwork(NeRFRenderer):
         return torch.cat([d.to(geo_feat.dtype), geo_feat, p], dim=-1)
 
     def forward(self, x, d):
+        if fused_network_ff.supported(self, x, d):
+            return fused_network_ff.forward(self, x, d)           # inference: grid encode + one MFMA kernel
         h = self.sigma_net(self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]

@@ -257,6 +257,17 @@ int enerf_free_splitk(void);
  * (0 = out_dim), so the result can land in a slice of a wider buffer; y0_exp (optional, [B]) receives
  * exp(Y[:,0]) -- the trunc_exp forward of the density column (activation.py:5-17); Y may be NULL when only y0_exp is
  * wanted (density-grid updates). */
+/* The whole network of nerf/network_ff.py (network_ff.py:60-88) as one inference kernel on the matrix cores:
+ *   sigma_net = FFMLP(32 -> 64 -> 64 -> 16), sigma = exp(h[0]), geo_feat = h[1:16];
+ *   color_net = FFMLP([SH(4) 16 | geo_feat 15 | 0] -> 64 -> 64 -> 64 -> 16), rgb = sigmoid(h[0:3]).
+ * feats: the grid encoder's level-major fp32 output [16, Mp, 2], Mp = M rounded up to 32, pad rows zero
+ * (enerf_grid_encode_forward, out_layout 2); dirs [M,3] fp32; w_sigma / w_color: the two FFMLP `weights` parameters as
+ * they are (fp32, [W0 64x32 | Wh 64x64 x (layers-1) | Wout 16x64], 7168 and 11264 floats), converted to `dtype`
+ * (ENERF_BF16 / ENERF_F16) on the way into LDS.  sigma [M], rgb [M,3] fp32, holding the 16-bit-rounded values the
+ * op-by-op route produces (16-bit net outputs; exp / sigmoid in fp32 on the rounded value, rounded again). */
+int enerf_ffnerf_inference(const float* feats, const float* dirs, const float* w_sigma, const float* w_color, uint32_t M,
+                           int dtype, float* sigma, float* rgb, enerf_stream_t stream);
+
 /* Weight blobs of the fused fp32 NeRF network (nerf/network.py:60-105: sigma_net 32-64-16, color_net 31-64-64-out_c,
  * both bias-free) from the five nn.Linear weights in one launch:
  *   blob = [ws0 64x32 | ws1 16x64 | W0c 64x32 | wc1 64x64 | wc2 out_c x 64]   (3072 + 6144 + 64*out_c floats)

@@ -147,3 +147,43 @@ def test_network_ff_render_runs_and_matches_fp32_stack():
     rel = ((sigma - sig_ref).abs() / sig_ref.clamp(min=1e-3))
     assert rel.median() < 0.02 and rel.max() < 0.3
     assert torch.isfinite(rgb).all() and rgb.shape == (3000, 3) and rgb.min() >= 0 and rgb.max() <= 1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n", [1, 4000, 70001])
+def test_fused_ff_network_inference_matches_op_by_op_route(monkeypatch, dtype, n):
+    """nerf/network_ff.py's forward as grid encode + ONE MFMA kernel (csrc/ffnerf.hip) against the op-by-op route
+    (encoder -> FFMLP -> exp ; SH, cat -> FFMLP -> sigmoid): same 16-bit roundings, so the results agree to an ulp of
+    the compute type almost everywhere (a hidden activation that lands on a rounding boundary may flip one)."""
+    from enerf_amd import fused_network_ff
+    from enerf_amd.ffmlp import FFMLP
+    from enerf_amd.network_ff import NeRFNetwork
+    monkeypatch.setattr(FFMLP, "compute_dtype", dtype)
+    torch.manual_seed(0)
+    net = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to("cuda").eval()
+    net.encoder.embeddings.data.uniform_(-1.0, 1.0)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    net.color_net.weights.data.copy_((torch.rand(net.color_net.weights.shape, generator=g, device="cuda") - 0.5) * 0.6)
+    x = (torch.rand(n, 3, generator=g, device="cuda") * 2 - 1) * 2
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g, device="cuda"), dim=-1)
+    calls = []
+    orig = fused_network_ff.forward
+    monkeypatch.setattr(fused_network_ff, "forward", lambda *a: (calls.append(1), orig(*a))[1])
+    with torch.no_grad():
+        s1, c1 = net(x, d)
+        monkeypatch.setattr(fused_network_ff, "ENABLED", False)
+        s0, c0 = net(x, d)
+    assert len(calls) == 1 and s1.dtype == torch.float32 and c1.shape == (n, 3)
+    s0, c0 = s0.float(), c0.float()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    rel = ((s1 - s0).abs() / s0.abs().clamp(min=1e-6))
+    assert float((rel > 2.5 * ulp).float().mean()) < 0.02 and float(rel.max()) < 0.1, float(rel.max())
+    err = (c1 - c0).abs()
+    assert float((err > 2.5 * ulp).float().mean()) < 0.02 and float(err.max()) < 0.05, float(err.max())
+    if n > 1:
+        assert float(s1.std()) > 0 and float(c1.std()) > 0.01      # not a degenerate comparison
+    # a network that may need gradients keeps the autograd route
+    monkeypatch.setattr(fused_network_ff, "ENABLED", True)
+    net.train()
+    net(x[:64], d[:64])
+    assert len(calls) == 1
