@@ -308,6 +308,25 @@ def main():
                   "rays_per_frame": scene.H * scene.W, "ms_per_frame": tr / args.render_frames * 1e3,
                   "march_iterations_per_frame": rb.STATS["infer_calls"] / args.render_frames}
         model.train()
+        if args.net != "ff" and rank == 0:
+            # BASELINE configs[4]: the same frame through the fully-fused (bf16 MFMA) networks of nerf/network_ff.py
+            from enerf_amd.network_ff import NeRFNetwork as FFNet
+            torch.manual_seed(0)
+            ffm = FFNet(encoding="hashgrid", bound=args.bound, cuda_ray=True).to(device).eval()
+            scene.install_occupancy(ffm)
+            ffm.infer_batch_mult = args.render_batch_mult
+            with torch.no_grad():
+                ffm.render(ro, rd, staged=False, bg_color=None, perturb=False)
+                torch.cuda.synchronize()
+                rb.STATS.update(infer_samples=0, infer_calls=0)
+                tr0 = time.perf_counter()
+                for _ in range(args.render_frames):
+                    ffm.render(ro, rd, staged=False, bg_color=None, perturb=False)
+                torch.cuda.synchronize()
+                tr = time.perf_counter() - tr0
+            render["ffmlp_nets"] = {"msamples_per_sec": rb.STATS["infer_samples"] / tr / 1e6,
+                                    "ms_per_frame": tr / args.render_frames * 1e3, "dtype": "bf16"}
+            del ffm
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
