@@ -297,6 +297,8 @@ int enerf_debug_mlp32_fused_backward(int on);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
+/* tuning aid: largest alive-ray count for which enerf_march_rays runs one wavefront per ray (when n_step < 16) */
+int enerf_debug_march_wave_max_rays(uint32_t n);
 /* tuning aid: workgroup caps of the mlp32 forward and fused-backward grids (0 = built-in defaults) */
 int enerf_debug_mlp32_grid_caps(uint32_t fwd_blocks, uint32_t bwd_blocks);
 

@@ -18,12 +18,16 @@ def main():
     ap.add_argument("--bound", type=int, default=2)
     ap.add_argument("--mult", type=int, default=8)
     ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--wave-max-rays", type=int, default=0, help="tuning: wave-per-ray march up to this many rays")
     a = ap.parse_args()
     if a.net == "ff":
         from enerf_amd.network_ff import NeRFNetwork
     else:
         from enerf_amd.network import NeRFNetwork
     dev = "cuda"
+    if a.wave_max_rays:
+        from enerf_amd import _lib
+        _lib.lib().enerf_debug_march_wave_max_rays(a.wave_max_rays)
     torch.manual_seed(0)
     m = NeRFNetwork(encoding="hashgrid", bound=a.bound, cuda_ray=True, out_dim_color=3).to(dev).eval()
     scene.install_occupancy(m)
