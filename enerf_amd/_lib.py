@@ -55,6 +55,7 @@ SIGNATURES = {
     "enerf_debug_mlp32_fused_backward": [_int],
     "enerf_debug_grid_bwd_binned": [_u32, _u32],
     "enerf_density_grid_cells": [_vp, _u32, _u32, _f32, _u32, _c.c_uint64, _vp, _vp, _vp],
+    "enerf_mark_untrained_grid": [_vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _f32, _vp, _vp],
     "enerf_density_grid_update": [_vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _vp, _vp, _vp, _u32, _vp, _vp],
     "enerf_adam_step": [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u32, _int, _vp],
     "enerf_allocate_splitk": [_sz],

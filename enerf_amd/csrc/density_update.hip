@@ -242,6 +242,34 @@ __global__ void __launch_bounds__(256) k_packbits_mean(const float* __restrict__
     bitfield[n] = (uint8_t)bits;
 }
 
+// ---- mark_untrained_grid (nerf/renderer.py:408-469): a cell no training camera sees gets density -1 for good.
+// One thread per (cascade, Morton cell): the cell centre is taken into every camera frame (c2w poses, so
+// cam = (p - t) . R, i.e. R^T (p - t)) and tested against the frustum widened by two half-cells; the loop over the
+// cameras stops at the first one that sees the cell (the reference counts them all and tests count == 0).
+__global__ void __launch_bounds__(256) k_mark_untrained(const float* __restrict__ poses, uint32_t n_poses,
+                                                        uint32_t pose_stride, float tan_x, float tan_y, Cascades cs,
+                                                        uint32_t C, uint32_t H, float* __restrict__ grid) {
+    const uint32_t H3 = H * H * H;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= C * H3) return;
+    const uint32_t cas = p / H3, idx = p - cas * H3;
+    const float inv = 1.0f / (float)(H - 1);
+    const float span = cs.span[cas], margin = cs.half[cas] * 2.0f;
+    const float wx = (2.0f * (float)compact_bits(idx) * inv - 1.0f) * span;
+    const float wy = (2.0f * (float)compact_bits(idx >> 1) * inv - 1.0f) * span;
+    const float wz = (2.0f * (float)compact_bits(idx >> 2) * inv - 1.0f) * span;
+    bool seen = false;
+    for (uint32_t b = 0; b < n_poses && !seen; b++) {
+        const float* m = poses + (size_t)b * pose_stride;          // row-major 4x4 (or 3x4): m[4 * row + col]
+        const float dx = wx - m[3], dy = wy - m[7], dz = wz - m[11];
+        const float cx = dx * m[0] + dy * m[4] + dz * m[8];
+        const float cy = dx * m[1] + dy * m[5] + dz * m[9];
+        const float cz = dx * m[2] + dy * m[6] + dz * m[10];
+        seen = cz > 0.0f && fabsf(cx) < tan_x * cz + margin && fabsf(cy) < tan_y * cz + margin;
+    }
+    if (!seen) grid[p] = -1.0f;
+}
+
 bool grid_shape_ok(uint32_t C, uint32_t H) { return C >= 1 && C <= 8 && H >= 16 && H <= 512 && (H & (H - 1)) == 0; }
 
 Cascades make_cascades(uint32_t C, uint32_t H, float bound) {
@@ -308,6 +336,20 @@ int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, 
         ENERF_BADARG("density_grid_cells: radix sort failed");
     k_cells_from_keys<<<div_up(P, 256), 256, 0, s>>>(cs, P, H, bits, seed, sorted, indices, xyzs);
     ENERF_LAUNCH_CHECK("density_grid_cells(partial)");
+    return 0;
+}
+
+int enerf_mark_untrained_grid(const float* poses, uint32_t n_poses, uint32_t pose_stride, float fx, float fy, float cx,
+                              float cy, uint32_t C, uint32_t H, float bound, float* density_grid,
+                              enerf_stream_t stream) {
+    if (!grid_shape_ok(C, H)) ENERF_BADARG("mark_untrained_grid: C=%u H=%u", C, H);
+    if (pose_stride != 16 && pose_stride != 12) ENERF_BADARG("mark_untrained_grid: poses are [B,4,4] or [B,3,4] fp32");
+    if (fx == 0.0f || fy == 0.0f) ENERF_BADARG("mark_untrained_grid: zero focal length");
+    const uint32_t cells = C * H * H * H;
+    k_mark_untrained<<<div_up(cells, 256), 256, 0, (hipStream_t)stream>>>(poses, n_poses, pose_stride, cx / fx, cy / fy,
+                                                                          make_cascades(C, H, bound), C, H,
+                                                                          density_grid);
+    ENERF_LAUNCH_CHECK("mark_untrained_grid");
     return 0;
 }
 

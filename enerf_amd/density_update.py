@@ -61,3 +61,14 @@ def update(model, decay=0.95):
     if total_step > 0:
         model.mean_count = int(counted / total_step)
     model.local_step = 0
+
+
+@torch.no_grad()
+def mark_untrained(model, poses, intrinsic):
+    """NeRFRenderer.mark_untrained_grid (nerf/renderer.py:408-469) as one launch: cells no camera sees get -1."""
+    poses = torch.as_tensor(poses, dtype=torch.float32).to(model.density_grid.device).contiguous()
+    fx, fy, cx, cy = (float(v) for v in intrinsic)
+    L.check(L.lib().enerf_mark_untrained_grid(poses.data_ptr(), poses.shape[0], poses.shape[1] * poses.shape[2], fx, fy,
+                                              cx, cy, int(model.cascade), int(model.grid_size), float(model.bound),
+                                              model.density_grid.data_ptr(), L.stream_handle()),
+            "mark_untrained_grid")

@@ -266,6 +266,8 @@ class NeRFRenderer(nn.Module):
     def mark_untrained_grid(self, poses, intrinsic, S=64):
         if not self.cuda_ray:
             return
+        if density_update.supported(self):
+            return density_update.mark_untrained(self, poses, intrinsic)       # one launch instead of the 5-level loop
         if isinstance(poses, np.ndarray):
             poses = torch.from_numpy(poses)
         B = poses.shape[0]

@@ -89,6 +89,13 @@ int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t*
 int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, float bound, uint32_t n_uniform,
                              uint64_t seed, int32_t* indices, float* xyzs, enerf_stream_t stream);
 
+/* enerf_mark_untrained_grid (renderer.py:408-469): density_grid[cas, cell] = -1 for every cell whose centre no camera
+ * sees: cam = R^T (centre - t) for each c2w pose ([B,4,4] row-major fp32, pose_stride 16, or [B,3,4], 12); seen when
+ * cam.z > 0 and |cam.x| < cx/fx * cam.z + 2*half_cell and |cam.y| < cy/fy * cam.z + 2*half_cell. */
+int enerf_mark_untrained_grid(const float* poses, uint32_t n_poses, uint32_t pose_stride, float fx, float fy, float cx,
+                              float cy, uint32_t C, uint32_t H, float bound, float* density_grid,
+                              enerf_stream_t stream);
+
 /* enerf_density_grid_update (renderer.py:541-558): tmp_grid = -1; tmp_grid[cas, indices] = sigmas * sigma_scale (n_per_cascade
  * entries per cascade); where density_grid >= 0 and tmp_grid >= 0: density_grid = max(density_grid * decay, tmp_grid);
  * mean = mean(clamp(density_grid, 0)); bitfield = packbits(density_grid, min(mean, density_thresh)).

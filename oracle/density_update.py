@@ -6,6 +6,7 @@
   apply_update       :538-553             tmp_grid scatter, EMA max with decay, mean of clamp(grid, 0), packbits against
                                           min(mean, density_thresh)
   mean_count         :555-558             int(sum(step_counter[:total_step, 0]) / total_step)
+  untrained_cells    :408-469             mark_untrained_grid: cells no camera frustum (widened by two half-cells) sees
 
 Parity status: "unpinned" against a run of the reference itself -- update_extra_state lives inside NeRFRenderer and needs
 the reference's CUDA raymarching extension (morton3D, packbits) to execute; these functions transcribe its tensor
@@ -50,3 +51,23 @@ def mean_count(step_counter, local_step):
     if total_step <= 0:
         return None
     return int(int(np.asarray(step_counter)[:total_step, 0].sum()) / total_step)   # :557
+
+
+def untrained_cells(poses, intrinsic, cascade, bound, grid_size):
+    """-> bool [cascade, H^3] (Morton order): True where mark_untrained_grid writes -1 (:408-469)."""
+    poses = np.asarray(poses, np.float32)
+    fx, fy, cx, cy = intrinsic
+    H3 = grid_size ** 3
+    idx = np.arange(H3, dtype=np.int32)
+    out = np.zeros((cascade, H3), bool)
+    for cas in range(cascade):
+        span, half = cascade_geometry(cas, bound, grid_size)
+        world = cell_centres(idx, cas, bound, grid_size)                                      # :440-446
+        count = np.zeros(H3, np.int64)
+        for pose in poses:
+            cam = (world - pose[:3, 3].astype(np.float32)) @ pose[:3, :3].astype(np.float32)   # :454-455
+            mask = (cam[:, 2] > 0) & (np.abs(cam[:, 0]) < np.float32(cx / fx) * cam[:, 2] + np.float32(half * 2)) \
+                & (np.abs(cam[:, 1]) < np.float32(cy / fy) * cam[:, 2] + np.float32(half * 2))  # :458-461
+            count += mask
+        out[cas] = count == 0                                                                  # :468
+    return out

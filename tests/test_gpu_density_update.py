@@ -183,3 +183,26 @@ def test_update_extra_state_native_vs_torch_route(monkeypatch, partial):
     if partial:
         touched = (g1 != before * 1.0) | (g1 != before)
         assert 0.1 < float((g1 != before).float().mean()) < 0.8      # about half the cells are re-evaluated
+
+
+def test_mark_untrained_grid_native_vs_oracle_and_torch_route(monkeypatch):
+    """One launch per call against the numpy restatement and the reference-shaped 5-level torch loop: cells on a frustum
+    boundary may fall either way (summation order of the 3x3 rotation), everything else must agree."""
+    from enerf_amd import density_update, scene
+    from enerf_amd.network import NeRFNetwork
+    poses = np.stack([scene.pose(i).numpy() for i in range(0, 32, 5)]).astype(np.float32)
+    intrinsic = (320.0, 320.0, 320.0, 240.0)
+    grids = []
+    for native in (True, False):
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        model.density_grid.fill_(0.25)
+        monkeypatch.setattr(density_update, "ENABLED", native)
+        model.mark_untrained_grid(poses, intrinsic)
+        grids.append(model.density_grid.cpu().numpy())
+    want = OD.untrained_cells(poses, intrinsic, 2, 2, 128)
+    for g in grids:
+        assert set(np.unique(g)) == {-1.0, 0.25}
+    frac = want.mean()
+    assert 0.02 < frac < 0.98                                   # the cameras see part of the volume, not all of it
+    assert np.mean((grids[0] == -1) != want) < 2e-4
+    assert np.mean((grids[0] == -1) != (grids[1] == -1)) < 2e-4
