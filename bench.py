@@ -53,6 +53,8 @@ def parse():
                          "box's 256 cores and the host-bound step time jitters by 10-15 %)")
     ap.add_argument("--graph-leg-steps", type=int, default=48,
                     help="extra steps timed with HIP-graph replay after the main (eager) timed region; 0 = skip")
+    ap.add_argument("--comm-bf16", action="store_true",
+                    help="N > 1: all-reduce the hash-table gradient in bf16 (opt-in; fp32 is the default and the headline)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
@@ -189,6 +191,8 @@ def main():
     model.infer_batch_mult = args.render_batch_mult
     harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs)
     harness.prefetch = not args.no_prefetch
+    if args.comm_bf16:
+        harness.comm_dtype = torch.bfloat16
     parallel.broadcast_state(model)
     batches = build_batches(8, args.rays, device, rank, args.bound)
     ev_opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)

@@ -39,6 +39,7 @@ class TrainHarness:
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self._side = None             # HIP stream of the next batch's march (created on first use)
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
+        self.comm_dtype = None        # torch.bfloat16: halve the table gradient's bytes on the wire (changes rounding)
         self._raw_grads = None
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
         self._loss_ring_clean = False
@@ -209,10 +210,16 @@ class TrainHarness:
         step = -(-n // self.comm_chunks)
         step += (-step) % 4                                  # FusedAdam ranges start on multiples of 4 elements
         bounds = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
-        works = [dist.all_reduce(flat[lo:hi], op=op, async_op=True) for lo, hi in bounds]
+        if self.comm_dtype is None:
+            wire = [flat[lo:hi] for lo, hi in bounds]
+        else:                                                # opt-in: the table gradient crosses xGMI in 16 bits
+            wire = [flat[lo:hi].to(self.comm_dtype) for lo, hi in bounds]
+        works = [dist.all_reduce(t, op=op, async_op=True) for t in wire]
         w_dw = dist.all_reduce(dw, op=op, async_op=True)
-        for (lo, hi), w in zip(bounds, works):
+        for (lo, hi), t, w in zip(bounds, wire, works):
             w.wait()
+            if self.comm_dtype is not None:
+                flat[lo:hi].copy_(t)
             if not nccl:
                 flat[lo:hi].mul_(inv)
             self.opt.step_now(only=[emb], ranges={emb: (lo, hi)})

@@ -226,7 +226,7 @@ def test_render_psnr_vs_cpu_oracle_route(monkeypatch):
     assert psnr >= 70.0
 
 
-def _dp_worker(rank, world, port, chunks, out):
+def _dp_worker(rank, world, port, chunks, out, comm_dtype=None):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -239,13 +239,15 @@ def _dp_worker(rank, world, port, chunks, out):
         model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
         h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=world)
         h.comm_chunks = chunks
+        h.comm_dtype = comm_dtype
         data = _batches(4, 1024, 2, seed=10 + rank)          # every rank renders its own rays
         losses = []
         for i in range(36):
             nxt = data[(i + 1) % len(data)]
             losses.append(float(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]))))
         torch.cuda.synchronize()
-        out[(chunks, rank)] = (losses, {n: p.detach().cpu() for n, p in model.named_parameters()})
+        out[(chunks if comm_dtype is None else "bf16", rank)] = (losses, {n: p.detach().cpu()
+                                                                            for n, p in model.named_parameters()})
     finally:
         dist.destroy_process_group()
 
@@ -261,6 +263,13 @@ def test_data_parallel_chunked_allreduce_adam_pipeline_matches_bucket_path():
     for chunks in (0, 4):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         mp.spawn(_dp_worker, args=(2, port, chunks, out), nprocs=2, join=True)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, 4, out, torch.bfloat16), nprocs=2, join=True)
+    # opt-in 16-bit wire format for the table gradient: replicas still identical, same training within bf16 rounding
+    p0, p1 = out[("bf16", 0)][1], out[("bf16", 1)][1]
+    assert all(torch.equal(p0[n], p1[n]) for n in p0)
+    lc = np.array(out[("bf16", 0)][0])
+    assert np.abs(lc - np.array(out[(4, 0)][0])).max() <= 0.05 * np.abs(lc).max()
     for chunks in (0, 4):
         p0, p1 = out[(chunks, 0)][1], out[(chunks, 1)][1]
         for n in p0:
