@@ -933,6 +933,56 @@ __global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
 }
 
 // ------------------------------------------------------------------ inference: march / composite / compact
+// One thread per ray, dt_gamma == 0, with the fast cell evaluator and the empty-voxel skip in closed form.  The
+// reference's `do { t += dt; } while (t < tt);` walks the lattice t, fl(t + dt), ... one addition at a time; inside a
+// binade those points are t + k * delta exactly (see the lattice marcher below for the conditions), so the last point
+// below min(voxel exit, top of the binade) is reached with one fma and only the step that crosses it is a real
+// addition.  Same samples, bit for bit; an empty stretch costs O(binades crossed) instead of O(steps skipped).
+__device__ __forceinline__ float skip_empty(float t, float tt, float dt) {
+    t += dt;                                                  // do { ... } executes at least once
+    while (t < tt) {
+        const float delta = (t + dt) - t;
+        const float delta2 = ((t + delta) + dt) - (t + delta);
+        if (t >= 2.0f * dt && delta2 == delta) {
+            int e;
+            (void)frexpf(t, &e);
+            const float lim = fminf(tt, ldexpf(1.0f, e));     // t < lim: t is below the voxel exit and inside its binade
+            float m = floorf((lim - t) * __builtin_amdgcn_rcpf(delta));
+            while (m > 0.0f && !(fmaf(m, delta, t) < lim)) m -= 1.0f;
+            while (fmaf(m + 1.0f, delta, t) < lim) m += 1.0f;
+            t = fmaf(m, delta, t);                            // last lattice point below lim (exact)
+        }
+        t += dt;
+    }
+    return t;
+}
+template <bool WRITE>
+__device__ __forceinline__ uint32_t march_one_ray_fast(const RayCtx& c, const RayFixed& rf, const MarchTabs& tb, float t0,
+                                                       float far, uint32_t limit, float* xyzs, float* dirs,
+                                                       float* deltas) {
+    const float dt = c.dt_min;
+    float t = t0, last_t = t0;
+    uint32_t step = 0;
+    while (t < far && step < limit) {
+        float x, y, z, tt;
+        if (eval_cell_fixed(c, rf, tb, t, x, y, z, tt)) {
+            t += dt;
+            if (WRITE) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = c.dx; dirs[1] = c.dy; dirs[2] = c.dz;
+                deltas[0] = dt;
+                deltas[1] = t - last_t;
+                last_t = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+            }
+            step++;
+        } else {
+            t = skip_empty(t, tt, dt);
+        }
+    }
+    return step;
+}
+
 __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n_step,
                                                     const int32_t* __restrict__ rays_alive,
                                                     const float* __restrict__ rays_t,
@@ -941,6 +991,10 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     uint32_t H, const uint8_t* __restrict__ grid,
                                                     const float* __restrict__ fars, float* xyzs, float* dirs,
                                                     float* deltas, uint32_t perturb) {
+    __shared__ float s_face[kTabH + 1];
+    __shared__ uint32_t s_expand[kTabH];
+    const bool fast = dt_gamma == 0.0f && march_fast_ok(H);
+    if (fast) build_march_tabs(s_face, s_expand, H);
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const int index = rays_alive[n];
@@ -949,7 +1003,15 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
     const size_t base = (size_t)n * n_step;
-    (void)march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+    if (fast) {
+        RayFixed rf;
+        ray_fixed_init(rf, c);
+        const MarchTabs tabs = {s_face, s_expand};
+        (void)march_one_ray_fast<true>(c, rf, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+                                       deltas + base * 2);
+    } else {
+        (void)march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+    }
 }
 
 // wave-per-ray variant (dt_gamma == 0): same lattice marcher as training; pays off once rays are few or n_step is
