@@ -1313,8 +1313,10 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
 
 // tuning aid: largest ray count for which the inference march uses one wavefront per ray (n_step < 16)
 static uint32_t g_march_wave_max_rays = 65536u;
+static uint32_t g_march_wave_min_steps = 16u;
 int enerf_debug_march_wave_max_rays(uint32_t n) {
-    g_march_wave_max_rays = n;
+    g_march_wave_max_rays = n & 0xffffffu;          // bits 24..31: minimum n_step for the wave marcher (0 = keep)
+    if (n >> 24) g_march_wave_min_steps = n >> 24;
     return 0;
 }
 
@@ -1329,7 +1331,7 @@ int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_aliv
     ProfScope prof(ENERF_K_MARCH_INFER, s);
     // Same samples either way (bit-identical).  One thread per ray wins while there are enough rays to fill the chip with
     // short loops; one wavefront per ray wins when rays are few or each must produce many samples.
-    if (dt_gamma == 0.0f && (n_alive <= g_march_wave_max_rays || n_step >= 16u))
+    if (dt_gamma == 0.0f && (n_alive <= g_march_wave_max_rays || n_step >= g_march_wave_min_steps))
         k_march_rays_w<<<div_up(n_alive, 4), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
                                                           max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
     else
