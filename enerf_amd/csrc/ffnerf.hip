@@ -146,110 +146,160 @@ __global__ void __launch_bounds__(256, 2) k_ffnerf_infer(const float* __restrict
 
     const uint32_t Mp = (M + 31u) & ~31u;
     const uint32_t ntiles = Mp / 32;
+    // T tiles (64 samples) per iteration: two independent MFMA dependency chains per layer, and every hidden-layer
+    // fragment read from LDS feeds T MFMAs
+    constexpr int T = 2;
+    const uint32_t ngroups = div_up(ntiles, (uint32_t)T);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     const float2* f2 = reinterpret_cast<const float2*>(feats);
 
-    // inputs of a tile: features of levels 8*kb + 4*h .. +3 (pad rows of the level-major tensor are zero) + direction
-    TileIn in = {};
-    if (gw < ntiles) in = load_inputs(f2, dirs, gw, j, h, M, Mp);
+    // inputs of a tile: features of levels 8*kb + 4*h .. +3 (pad rows of the level-major tensor are zero) + direction;
+    // a group's second tile may lie past the end: it is computed on the last tile's data and not stored
+    TileIn in[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) in[t] = TileIn{};
+    if (gw < ngroups) {
+#pragma unroll
+        for (int t = 0; t < T; t++) in[t] = load_inputs(f2, dirs, min(gw * T + t, ntiles - 1), j, h, M, Mp);
+    }
 
-    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
-        const size_t s = (size_t)tile * 32 + j;
+    for (uint32_t grp = gw; grp < ngroups; grp += nw) {
+        size_t s[T];
+        bool live[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            s[t] = (size_t)(grp * T + t) * 32 + j;
+            live[t] = s[t] < M && h == 0;
+        }
         // an opaque zero keeps the hidden-layer fragment reads inside the loop (they are loop invariant otherwise)
         uint32_t opaque;
         asm volatile("s_mov_b32 %0, 0" : "=s"(opaque));
         const x8* frh = fr + opaque;
-        x8 xb[2];
+        x8 xb[T][2];
+        float dx[T], dy[T], dz[T];
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++)
+        for (int t = 0; t < T; t++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                xb[kb][2 * q] = (E)in.f[kb][q].x;
-                xb[kb][2 * q + 1] = (E)in.f[kb][q].y;
-            }
-        const float dx = in.dx, dy = in.dy, dz = in.dz;
-        if (tile + nw < ntiles)                                    // next tile's loads fly during this tile's MFMAs
-            in = load_inputs(f2, dirs, tile + nw, j, h, M, Mp);
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    xb[t][kb][2 * q] = (E)in[t].f[kb][q].x;
+                    xb[t][kb][2 * q + 1] = (E)in[t].f[kb][q].y;
+                }
+            dx[t] = in[t].dx; dy[t] = in[t].dy; dz[t] = in[t].dz;
+        }
+        if (grp + nw < ngroups) {                                  // next group's loads fly during this one's MFMAs
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                in[t] = load_inputs(f2, dirs, min((grp + nw) * T + t, ntiles - 1), j, h, M, Mp);
+        }
 
         // ---- sigma net
-        f32x16 acc[2];
-        x8 hb[2][2];
+        f32x16 acc[T][2];
+        x8 hb[T][2][2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                acc[t][ob] = (f32x16)(0.0f);
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) acc[t][ob] = mma(s_w0[ob][kb], xb[t][kb], acc[t][ob]);
+            }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[t][ob], 0, hb[t][ob]);
 #pragma unroll
         for (int ob = 0; ob < 2; ob++) {
-            acc[ob] = (f32x16)(0.0f);
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) acc[ob] = mma(s_w0[ob][kb], xb[kb], acc[ob]);
+            for (int t = 0; t < T; t++) acc[t][ob] = (f32x16)(0.0f);
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) {
+                const x8 w = frh[(F_SWH + 4 * ob + blk) * 64];
+#pragma unroll
+                for (int t = 0; t < T; t++) acc[t][ob] = mma(w, hb[t][blk >> 1][blk & 1], acc[t][ob]);
+            }
         }
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[ob], 0, hb[ob]);
-#pragma unroll
-        for (int ob = 0; ob < 2; ob++) {
-            acc[ob] = (f32x16)(0.0f);
-#pragma unroll
-            for (int blk = 0; blk < 4; blk++)
-                acc[ob] = mma(frh[(F_SWH + 4 * ob + blk) * 64], hb[blk >> 1][blk & 1], acc[ob]);
-        }
-        {
+        for (int t = 0; t < T; t++) {
             x8 nb[2][2];
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[ob], 0, nb[ob]);
+            for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[t][ob], 0, nb[ob]);
 #pragma unroll
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-                for (int kbb = 0; kbb < 2; kbb++) hb[ob][kbb] = nb[ob][kbb];
+                for (int kbb = 0; kbb < 2; kbb++) hb[t][ob][kbb] = nb[ob][kbb];
         }
-        f32x16 so = (f32x16)(0.0f);
+        x8 geo[T][2];
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++) so = mma(s_wo[blk], hb[blk >> 1][blk & 1], so);
-        x8 geo[2];
-        tile_to_frags<E>(so, geo);                  // geo[0]: rows 0..15 = [sigma_raw | geo_feat] in D-tile order
-        if (h == 0 && s < M) sigma[s] = (float)(E)expf((float)geo[0][0]);          // trunc_exp forward
+        for (int t = 0; t < T; t++) {
+            f32x16 so = (f32x16)(0.0f);
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) so = mma(s_wo[blk], hb[t][blk >> 1][blk & 1], so);
+            tile_to_frags<E>(so, geo[t]);           // geo[0]: rows 0..15 = [sigma_raw | geo_feat] in D-tile order
+            if (live[t]) sigma[s[t]] = (float)(E)expf((float)geo[t][0][0]);         // trunc_exp forward
+        }
 
         // ---- colour net
-        float Y[16];
-        sh4(dx, dy, dz, nrm, Y);
-        x8 xsh;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            // lower lane half takes Y[e], upper Y[8 + e]: a bit select (left as `h ? :` the compiler spills Y to
-            // scratch and indexes it by lane)
-            const uint32_t m = 0u - (uint32_t)h;
-            xsh[e] = (E)__uint_as_float((__float_as_uint(Y[e]) & ~m) | (__float_as_uint(Y[8 + e]) & m));
+        for (int t = 0; t < T; t++) {
+            float Y[16];
+            sh4(dx[t], dy[t], dz[t], nrm, Y);
+            x8 xsh;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                // lower lane half takes Y[e], upper Y[8 + e]: a bit select (left as `h ? :` the compiler spills Y to
+                // scratch and indexes it by lane)
+                const uint32_t m = 0u - (uint32_t)h;
+                xsh[e] = (E)__uint_as_float((__float_as_uint(Y[e]) & ~m) | (__float_as_uint(Y[8 + e]) & m));
+            }
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {
+                acc[t][ob] = mma(c_w0[ob][0], xsh, (f32x16)(0.0f));
+                acc[t][ob] = mma(c_w0[ob][1], geo[t][0], acc[t][ob]);
+            }
         }
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++) {
-            acc[ob] = mma(c_w0[ob][0], xsh, (f32x16)(0.0f));
-            acc[ob] = mma(c_w0[ob][1], geo[0], acc[ob]);
-        }
+        for (int t = 0; t < T; t++)
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[ob], 0, hb[ob]);
+            for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[t][ob], 0, hb[t][ob]);
 #pragma unroll
         for (int l = 0; l < 2; l++) {
 #pragma unroll
             for (int ob = 0; ob < 2; ob++) {
-                acc[ob] = (f32x16)(0.0f);
 #pragma unroll
-                for (int blk = 0; blk < 4; blk++)
-                    acc[ob] = mma(frh[(F_CWH + 8 * l + 4 * ob + blk) * 64], hb[blk >> 1][blk & 1], acc[ob]);
+                for (int t = 0; t < T; t++) acc[t][ob] = (f32x16)(0.0f);
+#pragma unroll
+                for (int blk = 0; blk < 4; blk++) {
+                    const x8 w = frh[(F_CWH + 8 * l + 4 * ob + blk) * 64];
+#pragma unroll
+                    for (int t = 0; t < T; t++) acc[t][ob] = mma(w, hb[t][blk >> 1][blk & 1], acc[t][ob]);
+                }
             }
-            x8 nb[2][2];
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[ob], 0, nb[ob]);
+            for (int t = 0; t < T; t++) {
+                x8 nb[2][2];
 #pragma unroll
-            for (int ob = 0; ob < 2; ob++)
+                for (int ob = 0; ob < 2; ob++) act_to_frags<E, 0>(acc[t][ob], 0, nb[ob]);
 #pragma unroll
-                for (int kbb = 0; kbb < 2; kbb++) hb[ob][kbb] = nb[ob][kbb];
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int kbb = 0; kbb < 2; kbb++) hb[t][ob][kbb] = nb[ob][kbb];
+            }
         }
-        f32x16 co = (f32x16)(0.0f);
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++) co = mma(c_wo[blk], hb[blk >> 1][blk & 1], co);
-        if (h == 0 && s < M) {
-            // rows 0, 1, 2 of the output tile sit in elements 0, 1, 2 of the lower lane half
+        for (int t = 0; t < T; t++) {
+            f32x16 co = (f32x16)(0.0f);
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float o = (float)(E)co[c];
-                rgb[s * 3 + c] = (float)(E)(1.0f / (1.0f + expf(-o)));
+            for (int blk = 0; blk < 4; blk++) co = mma(c_wo[blk], hb[t][blk >> 1][blk & 1], co);
+            if (live[t]) {
+                // rows 0, 1, 2 of the output tile sit in elements 0, 1, 2 of the lower lane half
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float o = (float)(E)co[c];
+                    rgb[s[t] * 3 + c] = (float)(E)(1.0f / (1.0f + expf(-o)));
+                }
             }
         }
     }
@@ -280,7 +330,7 @@ int enerf_ffnerf_inference(const float* feats, const float* dirs, const float* w
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_FWD, s);
     const uint32_t tiles = div_up(M, 32);
-    uint32_t blocks = div_up(tiles, 4);
+    uint32_t blocks = div_up(div_up(tiles, 2u), 4);
     if (blocks > 512u) blocks = 512u;
     if (dtype == ENERF_BF16)
         k_ffnerf_infer<__bf16><<<blocks, 256, 0, s>>>(feats, dirs, w_sigma, w_color, M, nrm, sigma, rgb);
