@@ -30,6 +30,8 @@ SIGNATURES = {
     "enerf_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "enerf_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                          _vp, _u32, _vp],
+    "enerf_march_rays_ex": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
+                            _vp, _u32, _u32, _vp],
     "enerf_composite_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_compact_rays": [_u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_grid_encode_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _u32, _int,

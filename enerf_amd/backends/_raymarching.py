@@ -132,6 +132,19 @@ def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, de
         L.stream_handle()), "composite_rays_train_backward")
 
 
+def march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
+                  fars, xyzs, dirs, deltas, perturb):
+    """march_rays into uninitialised buffers: unfilled slots and alignment rows are zeroed by the kernel."""
+    STATS["infer_samples"] += int(n_alive) * int(n_step)
+    STATS["infer_calls"] += 1
+    L.check(L.lib().enerf_march_rays_ex(int(n_alive), int(n_step), _i32(rays_alive, "rays_alive"),
+                                        _f32(rays_t, "rays_t"), _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"),
+                                        float(bound), float(dt_gamma), int(max_steps), int(C), int(H), _u8(grid, "grid"),
+                                        _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
+                                        _f32(dirs, "dirs"), _f32(deltas, "deltas"), int(perturb), int(xyzs.shape[0]),
+                                        L.stream_handle()), "march_rays_ex")
+
+
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
                fars, xyzs, dirs, deltas, perturb):
     STATS["infer_samples"] += int(n_alive) * int(n_step)

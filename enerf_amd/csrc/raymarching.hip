@@ -990,12 +990,14 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
                                                     uint32_t H, const uint8_t* __restrict__ grid,
                                                     const float* __restrict__ fars, float* xyzs, float* dirs,
-                                                    float* deltas, uint32_t perturb) {
+                                                    float* deltas, uint32_t perturb, uint32_t zero_rows_to) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     const bool fast = dt_gamma == 0.0f && march_fast_ok(H);
     if (fast) build_march_tabs(s_face, s_expand, H);
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_rows_to && blockIdx.x == gridDim.x - 1)          // alignment rows past the last ray's slots
+        zero_rows(xyzs, dirs, deltas, n_alive * n_step, zero_rows_to, threadIdx.x, blockDim.x);
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     float t = rays_t[n];
@@ -1003,15 +1005,18 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
     const size_t base = (size_t)n * n_step;
+    uint32_t got;
     if (fast) {
         RayFixed rf;
         ray_fixed_init(rf, c);
         const MarchTabs tabs = {s_face, s_expand};
-        (void)march_one_ray_fast<true>(c, rf, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+        got = march_one_ray_fast<true>(c, rf, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
                                        deltas + base * 2);
     } else {
-        (void)march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+        got = march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
     }
+    if (zero_rows_to && got < n_step)                          // the slots this ray did not fill (delta == 0: end)
+        zero_rows(xyzs, dirs, deltas, (uint32_t)base + got, (uint32_t)base + n_step, 0, 1);
 }
 
 // wave-per-ray variant (dt_gamma == 0): same lattice marcher as training; pays off once rays are few or n_step is
@@ -1022,13 +1027,16 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
                                                       const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                       float bound, uint32_t max_steps, uint32_t C, uint32_t H,
                                                       const uint8_t* __restrict__ grid, const float* __restrict__ fars,
-                                                      float* xyzs, float* dirs, float* deltas, uint32_t perturb) {
+                                                      float* xyzs, float* dirs, float* deltas, uint32_t perturb,
+                                                      uint32_t zero_rows_to) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     const bool fast = march_fast_ok(H);
     if (fast) build_march_tabs(s_face, s_expand, H);
     const MarchTabs tabs = {s_face, s_expand};
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (zero_rows_to && blockIdx.x == gridDim.x - 1)
+        zero_rows(xyzs, dirs, deltas, n_alive * n_step, zero_rows_to, threadIdx.x, blockDim.x);
     if (n >= n_alive) return;
     const int index = rays_alive[n];
     float t = rays_t[n];
@@ -1036,11 +1044,15 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
     ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, 0.0f, max_steps, C, H);
     if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
     const size_t base = (size_t)n * n_step;
+    uint32_t got;
     if (fast)
-        (void)lattice_march_fast<true, false>(c, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+        got = lattice_march_fast<true, false>(c, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
                                               deltas + base * 2, nullptr, nullptr);
     else
-        (void)lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+        got = lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+    got = __builtin_amdgcn_readfirstlane(got);
+    if (zero_rows_to && got < n_step)
+        zero_rows(xyzs, dirs, deltas, (uint32_t)base + got, (uint32_t)base + n_step, lane_id(), 64);
 }
 
 __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32_t n_step,
@@ -1324,8 +1336,26 @@ int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_aliv
                      const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                      uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
                      float* dirs, float* deltas, uint32_t perturb, enerf_stream_t stream) {
+    return enerf_march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                               grid, nears, fars, xyzs, dirs, deltas, perturb, 0, stream);
+}
+
+int enerf_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                        const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                        uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                        float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t zero_rows_to,
+                        enerf_stream_t stream) {
     (void)nears;
-    if (n_alive == 0 || n_step == 0) return 0;
+    if (zero_rows_to && zero_rows_to < n_alive * n_step)
+        ENERF_BADARG("march_rays_ex: zero_rows_to %u < n_alive * n_step", zero_rows_to);
+    if (n_alive == 0 || n_step == 0) {
+        if (zero_rows_to) {
+            (void)hipMemsetAsync(xyzs, 0, (size_t)zero_rows_to * 12, (hipStream_t)stream);
+            (void)hipMemsetAsync(dirs, 0, (size_t)zero_rows_to * 12, (hipStream_t)stream);
+            (void)hipMemsetAsync(deltas, 0, (size_t)zero_rows_to * 8, (hipStream_t)stream);
+        }
+        return 0;
+    }
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_INFER, s);
@@ -1333,11 +1363,12 @@ int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_aliv
     // short loops; one wavefront per ray wins when rays are few or each must produce many samples.
     if (dt_gamma == 0.0f && (n_alive <= g_march_wave_max_rays || n_step >= g_march_wave_min_steps))
         k_march_rays_w<<<div_up(n_alive, 4), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
-                                                          max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb);
+                                                          max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb,
+                                                          zero_rows_to);
     else
         k_march_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
                                                           dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
-                                                          perturb);
+                                                          perturb, zero_rows_to);
     ENERF_LAUNCH_CHECK("march_rays");
     return 0;
 }

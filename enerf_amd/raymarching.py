@@ -193,6 +193,14 @@ class _march_rays(Function):
         if align > 0:
             M += align - (M % align)
         dev = rays_o.device
+        if hasattr(_backend, "march_rays_ex"):
+            # the HIP marcher zero-fills what it does not write: no torch.zeros passes over the sample buffers
+            xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+            dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+            deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+            _backend.march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C,
+                                   H, density_bitfield, near, far, xyzs, dirs, deltas, perturb)
+            return xyzs, dirs, deltas
         xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
         dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
         deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)

@@ -171,6 +171,16 @@ int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_aliv
                      uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                      float* xyzs, float* dirs, float* deltas, uint32_t perturb, enerf_stream_t stream);
 
+/* Extension of march_rays for UNINITIALISED xyzs / dirs / deltas of `zero_rows_to` rows (>= n_alive * n_step; 0 =
+ * plain enerf_march_rays): every slot a ray does not fill and the alignment rows past the last ray are zero-filled by
+ * the march itself (delta == 0 is what ends a ray in composite_rays), so the three torch.zeros of
+ * raymarching.py:318-320 become torch.empty. */
+int enerf_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                        const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                        uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                        float* xyzs, float* dirs, float* deltas, uint32_t perturb, uint32_t zero_rows_to,
+                        enerf_stream_t stream);
+
 /* raymarching.cu:903-909  composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas,
  *                                        weights_sum, depth, image)   -- in place */
 int enerf_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,

@@ -373,6 +373,31 @@ def test_inference_march_perturb_seed_bit_exact(rm, scenes):
     assert np.array_equal(gx.cpu().numpy(), x) and np.array_equal(gl.cpu().numpy(), dl)
 
 
+@pytest.mark.parametrize("n_alive,n_step,dt_gamma", [(3000, 8, 0.0), (70000, 8, 0.0), (900, 40, 0.0), (1500, 6, 1.0 / 256)])
+def test_march_rays_ex_zero_fills_what_it_does_not_write(rm, scenes, n_alive, n_step, dt_gamma):
+    """march_rays_ex on NaN-filled buffers == march_rays on zero-filled ones, bit for bit (thread-per-ray, wave-per-ray
+    and the dt_gamma != 0 marcher): slots a ray does not fill and the alignment rows come out zero."""
+    bound = 2
+    grid, bits, C = scenes[bound]
+    N = max(n_alive, 4000)
+    o, d, aabb = _rays(N, 43, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    rng = np.random.default_rng(9)
+    alive = rng.permutation(N).astype(np.int32)[:n_alive]
+    rt = (nears[alive] + rng.random(n_alive).astype(np.float32) * 2.0).astype(np.float32)     # some rays are nearly done
+    M = n_alive * n_step
+    M += 128 - M % 128
+    args = (n_alive, n_step, cu(alive), cu(rt), cu(o), cu(d), bound, dt_gamma, 1024, C, H, cu(bits), cu(nears), cu(fars))
+    z = [torch.zeros(M, k, device=DEV) for k in (3, 3, 2)]
+    rm.march_rays(*args, *z, 0)
+    e = [torch.full((M, k), float("nan"), device=DEV) for k in (3, 3, 2)]
+    rm.march_rays_ex(*args, *e, 0)
+    for a, b, name in zip(e, z, ("xyzs", "dirs", "deltas")):
+        assert torch.equal(a, b), name
+    filled = (z[2][:n_alive * n_step, 0] != 0).view(n_alive, n_step).sum(1)
+    assert int((filled < n_step).sum()) > 0 and int((filled == n_step).sum()) > 0     # both kinds of ray occur
+
+
 # ------------------------------------------------------------------ grid encoder
 def _table(offsets, C, seed):
     rng = np.random.default_rng(seed)
