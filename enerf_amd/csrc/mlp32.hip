@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
                                                          float* __restrict__ dX, float* __restrict__ partial, uint32_t B,
                                                          uint32_t out_dim, uint32_t act) {
     constexpr uint32_t NW_MAX = HID * IN + (NH - 1) * HID * HID + 32 * HID;
-    constexpr uint32_t PER_WAVE = 5 * T_SZ + (XL == 1 ? 16 * XT_LD : 0);
+    constexpr uint32_t PER_WAVE = 5 * T_SZ + (XL == 1 ? 16 * XT_LD : 32 * IN);
     __shared__ __attribute__((aligned(16))) float lds[NW_MAX + 4 * PER_WAVE];
     float* wl = lds;                                   // weights during set-up, block-level dW sums at the end
     const uint32_t NW = blob_size(NH, out_dim);
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
     float* ga[2] = {wv, wv + T_SZ};                    // activation gradients of the current layer (A operands)
     float* ft[2] = {wv + 2 * T_SZ, wv + 3 * T_SZ};     // forward activations feeding it (B operands)
     float* dyt = wv + 4 * T_SZ;                        // dL/dY tile
-    float* xt = wv + 5 * T_SZ;                         // level-major X tile (XL == 1)
+    float* xt = wv + 5 * T_SZ;                         // X tile: level-major rows (XL == 1) or [32 samples][32] (XL == 0)
 
     float woT[2][KPO], whT[NH > 1 ? NH - 1 : 1][2][2][16], wiT[2][16];
 #pragma unroll
@@ -521,6 +521,20 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
         const size_t s0 = (size_t)tile * 32;
         const size_t s = s0 + j;
         const bool valid = s < B;
+        if (XL == 0) {
+            // the row-major X tile goes straight from global memory into LDS (global_load_lds: no registers, nothing
+            // to wait for until the weight gradient of the first layer at the end of the tile): 4 x 1 KB, linear
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const size_t row = s0 + 8 * q + (lane >> 3);
+                if (row < B)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(X + row * IN + 4 * (lane & 7)),
+                        (__attribute__((address_space(3))) void*)(xt + 256 * q), 16, 0, 0);
+                else
+                    *reinterpret_cast<float4*>(xt + 256 * q + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
         // ---- output layer
         float dy[KPO];
 #pragma unroll
@@ -597,6 +611,8 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
         }
         // ---- input layer
         if (XL == 1) {
+            // (measured: neither 16 dword-wide global_load_lds at the top of the tile nor issuing these four loads
+            // early beats loading here)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int f = t * 256 + lane * 4, lv = f >> 6, off = f & 63;
@@ -627,13 +643,13 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
                 }
             }
         }
+        if (XL == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the X tile has landed in LDS
         wave_lds_fence();
         // dW0[o][i] += G_0[o][s] * X[s][i]
 #pragma unroll 4
         for (int p = 0; p < 16; p++) {
-            const size_t sx = s0 + 2 * p + h;
             float xin;
-            if (XL == 0) xin = sx < B ? X[sx * IN + j] : 0.0f;
+            if (XL == 0) xin = xt[(2 * p + h) * IN + j];
             else xin = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
             aw0[0] = mma(ga[0][j * T_LD + 2 * p + h], xin, aw0[0]);
             aw0[1] = mma(ga[1][j * T_LD + 2 * p + h], xin, aw0[1]);
