@@ -116,6 +116,32 @@ __device__ __forceinline__ int kmap(int p, int h) {
 }
 
 // ================================================================== forward
+// the 16 inputs lane (j, h) feeds to the first layer for sample 32 * tile + j (zeros past the end of the batch)
+template <int XL>
+__device__ __forceinline__ void load_x(const float* __restrict__ X, uint32_t tile, int j, int h, uint32_t B, uint32_t Bp,
+                                       float (&x)[16]) {
+    const size_t s = (size_t)tile * 32 + j;
+    const bool valid = s < B;
+    if (XL == 0) {
+        const size_t sc = valid ? s : (size_t)B - 1;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float4 t = *reinterpret_cast<const float4*>(X + sc * IN + 16 * h + 4 * v);
+            x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float2 t = *reinterpret_cast<const float2*>(X + ((size_t)(2 * q + h) * Bp + s) * 2);
+            x[2 * q] = t.x; x[2 * q + 1] = t.y;
+        }
+    }
+    if (!valid) {
+#pragma unroll
+        for (int p = 0; p < 16; p++) x[p] = 0.0f;
+    }
+}
+
 // SIG: only exp(output 0) is wanted (Y == NULL, y0_exp set: the density-grid update) -- the output layer is then one
 // 64-term dot product per sample on the VALU (each half-wave holds 32 of the 64 hidden activations of its sample)
 // instead of a 32-row MFMA tile of which 31 rows would be thrown away.
@@ -125,9 +151,15 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                                                    uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
                                                    float* __restrict__ y0_exp) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    stage_rot(wl, W, NH, out_dim);
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
+    // the first tile's inputs are requested before the weights are staged: one memory latency hidden behind the set-up
+    float x[16];
+    {
+        const uint32_t tile0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (tile0 < Bp / 32) load_x<XL>(X, tile0, j, h, B, Bp, x);
+    }
+    stage_rot(wl, W, NH, out_dim);
 
     float w0[2][16], wh[NH > 1 ? NH - 1 : 1][2][2][16], wo[2][16];
 #pragma unroll
@@ -160,25 +192,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s = (size_t)tile * 32 + j;
         const bool valid = s < B;
-        float x[16];
-        if (XL == 0) {
-            const size_t sc = valid ? s : (size_t)B - 1;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const float4 t = *reinterpret_cast<const float4*>(X + sc * IN + 16 * h + 4 * v);
-                x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const float2 t = *reinterpret_cast<const float2*>(X + ((size_t)(2 * q + h) * Bp + s) * 2);
-                x[2 * q] = t.x; x[2 * q + 1] = t.y;
-            }
-        }
-        if (!valid) {
-#pragma unroll
-            for (int p = 0; p < 16; p++) x[p] = 0.0f;
-        }
+        if (tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
         f32x16 a[2];
 #pragma unroll
         for (int ob = 0; ob < 2; ob++) {
