@@ -107,6 +107,32 @@ __device__ __forceinline__ void load_tile(const float* rowptr, int ib, int h, f3
     }
 }
 
+// The forward buffer `fb` is private to this file (written by the training forward, read by the backward), so it is
+// kept TILE-NATIVE instead of row-major: within the 2048 floats of a (layer, 32-sample tile) block, element (sample j,
+// neuron 32*ib + 8*g + 4*h + r) sits at ib*1024 + g*256 + (j + 32*h)*4 + r -- every store / load instruction of a wave
+// then covers 1 KB of contiguous memory (8 full lines) instead of 64 scattered 16-byte pieces of 32 different rows.
+// `rowptr` = what the row-major address of sample j's row would be (fb + (l*Bp + s)*64); the tile base follows from it.
+__device__ __forceinline__ void store_tile_fb(float* rowptr, int ib, int h, const f32x16& v) {
+    const int j = lane_id() & 31;
+    float* tb = rowptr - j * HID + ib * 1024 + (j + 32 * h) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        *reinterpret_cast<float4*>(tb + g * 256) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+__device__ __forceinline__ void load_tile_fb(const float* rowptr, int ib, int h, f32x16& v) {
+    const int j = lane_id() & 31;
+    const float* tb = rowptr - j * HID + ib * 1024 + (j + 32 * h) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 t = *reinterpret_cast<const float4*>(tb + g * 256);
+        v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+    }
+}
+// single element (sample row `srow` of the tile starting at `tilebase`, neuron n) of a tile-native fb block
+__device__ __forceinline__ float fb_at(const float* tilebase, int srow, int n) {
+    return tilebase[(n >> 5) * 1024 + ((n >> 3) & 3) * 256 + (srow + 32 * ((n >> 2) & 1)) * 4 + (n & 3)];
+}
+
 // layer-0 contraction index handled by MFMA p of lane half h
 //   XL 0: pairs (p, 16 + p): lane half h reads the contiguous input columns 16h .. 16h+15
 //   XL 1: lane half h reads the float2 of level 2q + h (q = 0..7): MFMA 2q + c contracts columns 4q + c and 4q + 2 + c
@@ -201,7 +227,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             for (int p = 0; p < 16; p++) a[ob] = mma(w0[ob][p], x[p], a[ob]);
 #pragma unroll
             for (int q = 0; q < 16; q++) a[ob][q] = act_fwd(a[ob][q], act);
-            if (TRAIN) store_tile(fb + s * HID, ob, h, a[ob]);
+            if (TRAIN) store_tile_fb(fb + s * HID, ob, h, a[ob]);
         }
 #pragma unroll
         for (int l = 1; l < NH; l++) {
@@ -215,7 +241,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                     for (int q = 0; q < 16; q++) n[ob] = mma(wh[l - 1][ob][ib][q], a[ib][q], n[ob]);
 #pragma unroll
                 for (int q = 0; q < 16; q++) n[ob][q] = act_fwd(n[ob][q], act);
-                if (TRAIN) store_tile(fb + ((size_t)l * Bp + s) * HID, ob, h, n[ob]);
+                if (TRAIN) store_tile_fb(fb + ((size_t)l * Bp + s) * HID, ob, h, n[ob]);
             }
             a[0] = n[0];
             a[1] = n[1];
@@ -304,7 +330,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, const float
 #pragma unroll
             for (int p = 0; p < KPO; p++) g[ib] = mma(woT[ib][p], dy[p], g[ib]);
             f32x16 fw;
-            load_tile(fb + ((size_t)(NH - 1) * Bp + s) * HID, ib, h, fw);
+            load_tile_fb(fb + ((size_t)(NH - 1) * Bp + s) * HID, ib, h, fw);
 #pragma unroll
             for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(g[ib][q], fw[q], act);
             store_tile(bb + s * HID, ib, h, g[ib]);
@@ -321,7 +347,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, const float
 #pragma unroll
                     for (int q = 0; q < 16; q++) n[ib] = mma(whT[l - 1][ib][ob][q], g[ob][q], n[ib]);
                 f32x16 fw;
-                load_tile(fb + ((size_t)(l - 1) * Bp + s) * HID, ib, h, fw);
+                load_tile_fb(fb + ((size_t)(l - 1) * Bp + s) * HID, ib, h, fw);
 #pragma unroll
                 for (int q = 0; q < 16; q++) n[ib][q] = act_bwd(n[ib][q], fw[q], act);
                 store_tile(bb + ((size_t)jj * Bp + s) * HID, ib, h, n[ib]);
@@ -413,19 +439,19 @@ __global__ void __launch_bounds__(256, 2) k_mlp32_bwd_w(DySource dys, const floa
             // hidden layers
 #pragma unroll
             for (int m = 1; m < NH; m++) {
-                const float* in = fb + ((size_t)(m - 1) * Bp + s) * HID;
+                const float* in = fb + ((size_t)(m - 1) * Bp + s0) * HID;          // tile-native block
                 const float* go = bb + ((size_t)(NH - 1 - m) * Bp + s) * HID;
-                const float i0 = in[j], i1 = in[32 + j], o0 = go[j], o1 = go[32 + j];
+                const float i0 = fb_at(in, 2 * p + h, j), i1 = fb_at(in, 2 * p + h, 32 + j), o0 = go[j], o1 = go[32 + j];
                 awh[m - 1][0][0] = mma(o0, i0, awh[m - 1][0][0]);
                 awh[m - 1][0][1] = mma(o0, i1, awh[m - 1][0][1]);
                 awh[m - 1][1][0] = mma(o1, i0, awh[m - 1][1][0]);
                 awh[m - 1][1][1] = mma(o1, i1, awh[m - 1][1][1]);
             }
             // output layer
-            const float* in = fb + ((size_t)(NH - 1) * Bp + s) * HID;
+            const float* in = fb + ((size_t)(NH - 1) * Bp + s0) * HID;             // tile-native block
             const float dyv = ((uint32_t)j < out_dim && s < B) ? load_dy(dys, s, (uint32_t)j) : 0.0f;
-            awo[0] = mma(dyv, in[j], awo[0]);
-            awo[1] = mma(dyv, in[32 + j], awo[1]);
+            awo[0] = mma(dyv, fb_at(in, 2 * p + h, j), awo[0]);
+            awo[1] = mma(dyv, fb_at(in, 2 * p + h, 32 + j), awo[1]);
         }
     }
     auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows) {
@@ -562,7 +588,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
 #pragma unroll
         for (int l = NH - 1; l >= 0; l--)
 #pragma unroll
-            for (int ib = 0; ib < 2; ib++) load_tile(fb + ((size_t)l * Bp + s) * HID, ib, h, fwl[l][ib]);
+            for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + s) * HID, ib, h, fwl[l][ib]);
         f32x16(&fw)[2] = fwl[NH - 1];
         wave_lds_fence();
 #pragma unroll
@@ -795,7 +821,8 @@ int enerf_nerf_pack_weights(const float* ws0, const float* ws1, const float* wc0
 
 // Fused fp32 MLP: X -> (64 x num_hidden, ReLU/none) -> Y [B,out_dim], out_dim <= 32, no bias.  B is ragged; with
 // Bp = B rounded up to 32: X is [B,32] row-major (x_layout 0) or [16,Bp,2] level-major (x_layout 1);
-// weights: [W0 64x32 | Wh (num_hidden-1) x 64x64 | Wout out_dim x 64]; fb [num_hidden,Bp,64] or NULL (inference).
+// weights: [W0 64x32 | Wh (num_hidden-1) x 64x64 | Wout out_dim x 64]; fb: num_hidden*Bp*64 floats of forward
+// activations in this file's own tile order (opaque to the caller; only enerf_mlp32_backward reads it) or NULL (inference).
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
                         uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream) {

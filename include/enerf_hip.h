@@ -269,7 +269,8 @@ int enerf_free_splitk(void);
  * Y [B,out_dim <= 32], no bias; W = [W0 64x32 | Wh (num_hidden-1)x64x64 | Wout out_dim x 64], each W[out][in].
  * B is ragged; Bp = B rounded up to a multiple of 32.  x_layout 0: X is [B,32] row-major; x_layout 1: X is the
  * level-major [16,Bp,2] tensor enerf_grid_encode_forward writes with out_layout 2 (column k = 2*level + c).
- * fb [num_hidden,Bp,64] receives the post-activation hidden states (NULL = inference).
+ * fb (num_hidden * Bp * 64 floats) receives the post-activation hidden states in the library's own tile order -- opaque
+ * to the caller, read back only by enerf_mlp32_backward (NULL = inference).
  * activation: relu (0) / none (6); output_activation additionally sigmoid (3).  Rows of Y are y_stride floats apart
  * (0 = out_dim), so the result can land in a slice of a wider buffer; y0_exp (optional, [B]) receives
  * exp(Y[:,0]) -- the trunc_exp forward of the density column (activation.py:5-17); Y may be NULL when only y0_exp is
