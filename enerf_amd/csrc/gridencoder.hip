@@ -581,10 +581,32 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     if (!decode_block(nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
     const BinPlan plan = bin_plan(offsets, level, R, min_tiles);
-    if (plan.bins == 0) return;
-    const uint32_t cap = region / plan.bins;
     const uint32_t b = chunk * PTS + threadIdx.x;
     const int lane = lane_id();
+    if (plan.bins == 0) {
+        // a level too small to bin (less than one tile): scatter it with atomics right here (block-uniform branch)
+        // instead of launching the atomic kernel for it
+        const uint32_t off0 = (uint32_t)offsets[level];
+        const LevelGeom<D> geom = make_geom<D>(gridtype, (uint32_t)offsets[level + 1] - off0, tab.resolution[level]);
+        float* rows = grad_grid + (size_t)off0 * C;
+        float in[D], g[C], pos[D], v[(1 << D) * C];
+        uint32_t pos_grid[D], cr[1 << D];
+        const bool valid = load_sample<float, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, tab.in_add,
+                                                    tab.in_mul, in, g);
+        cell_of<D>(in, tab.scale[level], pos_grid, pos);
+        corner_contrib<D, C>(pos, g, v);
+        if (!aggregate_runs<D, C>(valid, lane, pos_grid, v)) return;
+        corner_rows<D>(geom, pos_grid, cr);
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) {
+            float gg[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) gg[c] = v[idx * C + c];
+            scatter_add<C>(rows + (size_t)cr[idx] * C, 1.0f, gg);
+        }
+        return;
+    }
+    const uint32_t cap = region / plan.bins;
     const uint32_t replica = chunk % plan.replicas;
 
     for (uint32_t t = threadIdx.x; t < plan.bins; t += PTS) s_ofs[t] = 0;
@@ -836,8 +858,9 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
     const uint32_t min_tiles = binned ? g_binned_min_tiles : 0u;
 #define ENERF_GB(CC)                                                                                             \
     do {                                                                                                         \
-        k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab, gridtype, \
-                                                              layout, nchunks, min_tiles);                       \
+        if (!binned)                                                                                             \
+            k_grid_bwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(grad, inputs, offsets, grad_emb, B, L, tab,    \
+                                                                  gridtype, layout, nchunks, min_tiles);         \
         if constexpr (std::is_same<T, float>::value) {                                                           \
             if (binned) {                                                                                        \
                 constexpr int kBinPts = bin_pts(CC);                                                             \
