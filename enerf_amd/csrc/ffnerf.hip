@@ -17,44 +17,11 @@
 // Roundings follow the op-by-op route (16-bit net outputs, exp / sigmoid evaluated in fp32 on the rounded value and
 // rounded again), fp32 accumulation throughout.
 #include "ffmlp_common.h"
+#include "sh_basis.h"
 
 using namespace enerf_ffmlp;
 
 namespace {
-
-struct ShNorm4 {
-    float n[4][4];      // n[l][m], m <= l, includes sqrt(2) for m > 0 (shencoder.hip: fill_norm)
-};
-
-// the 16 real spherical harmonics of degree < 4, same recurrences as shencoder.hip's k_sh_fwd<4>
-__device__ __forceinline__ void sh4(float x, float y, float z, const ShNorm4& nrm, float (&Y)[16]) {
-    float A[4], Bm[4];
-    A[0] = 1.0f;
-    Bm[0] = 0.0f;
-#pragma unroll
-    for (int m = 1; m < 4; m++) {
-        A[m] = x * A[m - 1] - y * Bm[m - 1];
-        Bm[m] = x * Bm[m - 1] + y * A[m - 1];
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-        float qmm = 1.0f;
-#pragma unroll
-        for (int k = 1; k <= m; k++) qmm *= -(2.0f * k - 1.0f);
-        float Q[4];
-        Q[m] = qmm;
-        if (m + 1 < 4) Q[m + 1] = (2.0f * m + 1.0f) * z * qmm;
-#pragma unroll
-        for (int l = m + 2; l < 4; l++)
-            Q[l] = ((2.0f * l - 1.0f) * z * Q[l - 1] - (float)(l + m - 1) * Q[l - 2]) * (1.0f / (float)(l - m));
-#pragma unroll
-        for (int l = m; l < 4; l++) {
-            const float nq = nrm.n[l][m] * Q[l];
-            Y[l * l + l + m] = nq * A[m];
-            if (m) Y[l * l + l - m] = nq * Bm[m];
-        }
-    }
-}
 
 constexpr uint32_t kSigmaW = HID * (32 + HID + OUT);          // 7168:  W0 64x32 | Wh 64x64 | Wout 16x64
 constexpr uint32_t kColorW = HID * (32 + 2 * HID + OUT);      // 11264: W0 64x32 | Wh 2 x 64x64 | Wout 16x64
@@ -315,18 +282,7 @@ int enerf_ffnerf_inference(const float* feats, const float* dirs, const float* w
     if (dtype != ENERF_BF16 && dtype != ENERF_F16) ENERF_BADARG("ffnerf_inference: dtype must be bf16 or f16");
     if ((((uintptr_t)w_sigma | (uintptr_t)w_color | (uintptr_t)feats) & 15) != 0)
         ENERF_BADARG("ffnerf_inference: feats / weights must be 16-byte aligned");
-    ShNorm4 nrm;
-    for (int l = 0; l < 4; l++)
-        for (int m = 0; m < 4; m++) {
-            double v = 0.0;
-            if (m <= l) {
-                double ratio = 1.0;
-                for (int k = l - m + 1; k <= l + m; k++) ratio /= (double)k;
-                v = sqrt((2.0 * l + 1.0) / (4.0 * M_PI) * ratio);
-                if (m) v *= sqrt(2.0);
-            }
-            nrm.n[l][m] = (float)v;
-        }
+    const ShNorm4 nrm = make_sh_norm4();
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_FFMLP_FWD, s);
     const uint32_t tiles = div_up(M, 32);

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "sh_basis.h"
 
 using namespace enerf;
 
@@ -171,11 +172,14 @@ __device__ __forceinline__ void load_x(const float* __restrict__ X, uint32_t til
 // SIG: only exp(output 0) is wanted (Y == NULL, y0_exp set: the density-grid update) -- the output layer is then one
 // 64-term dot product per sample on the VALU (each half-wave holds 32 of the 64 hidden activations of its sample)
 // instead of a 32-row MFMA tile of which 31 rows would be thrown away.
-template <int NH, bool TRAIN, int XL, bool SIG = false>
+// SH: the kernel also writes the degree-4 SH encoding of sh_dirs[s] into columns 16..31 of row s of Y (the colour
+// net's direction inputs, nerf/network.py:95): the separate encoder launch and its 10 us disappear into the MFMA shadow.
+template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false>
 __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                    float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
                                                    uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
-                                                   float* __restrict__ y0_exp) {
+                                                   float* __restrict__ y0_exp, const float* __restrict__ sh_dirs = nullptr,
+                                                   ShNorm4 nrm = ShNorm4{}) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
@@ -219,6 +223,10 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
         const size_t s = (size_t)tile * 32 + j;
         const bool valid = s < B;
         if (tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
+        float dir0 = 0.0f, dir1 = 0.0f, dir2 = 0.0f;            // requested now, used after the MFMAs
+        if (SH && valid) {
+            dir0 = sh_dirs[s * 3]; dir1 = sh_dirs[s * 3 + 1]; dir2 = sh_dirs[s * 3 + 2];
+        }
         f32x16 a[2];
 #pragma unroll
         for (int ob = 0; ob < 2; ob++) {
@@ -269,6 +277,19 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                 const uint32_t r = (uint32_t)nrow(q, h);
                 if (Y && r < out_dim) Y[s * y_stride + r] = out_act_fwd(o[q], out_act);
                 if (r == 0 && y0_exp) y0_exp[s] = expf(o[q]);      // trunc_exp forward of output column 0
+            }
+            if (SH) {
+                float sh[16];
+                sh4(dir0, dir1, dir2, nrm, sh);
+                // lane half h stores components 8h .. 8h+7 (bit select: `h ? :` would index the array through scratch)
+                const uint32_t m = 0u - (uint32_t)h;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    v[e] = __uint_as_float((__float_as_uint(sh[e]) & ~m) | (__float_as_uint(sh[8 + e]) & m));
+                float* dst = Y + s * y_stride + 16 + 8 * h;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
         }
     }
@@ -826,7 +847,17 @@ int enerf_nerf_pack_weights(const float* ws0, const float* ws1, const float* wc0
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
                         uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream) {
+    return enerf_mlp32_forward_sh(X, W, B, in_dim, out_dim, num_hidden, activation, output_activation, fb, Y, x_layout,
+                                  y_stride, y0_exp, nullptr, stream);
+}
+
+int enerf_mlp32_forward_sh(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
+                           uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
+                           uint32_t x_layout, uint32_t y_stride, float* y0_exp, const float* sh_dirs,
+                           enerf_stream_t stream) {
     if (B == 0) return 0;
+    if (sh_dirs && !(num_hidden == 1 && x_layout == 1 && Y && out_dim <= 16 && (y_stride == 0 ? out_dim : y_stride) >= 32))
+        ENERF_BADARG("mlp32_forward_sh: needs one hidden layer, level-major input, out_dim <= 16 and rows of >= 32 floats");
     if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32 (pad the input), got %u", in_dim);
     if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
@@ -854,7 +885,15 @@ int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_
             else MLP32_FWD2(NHV, false, 1);                   \
         }                                                     \
     } while (0)
-    if (num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1)
+    if (sh_dirs) {
+        const ShNorm4 nrm = make_sh_norm4();
+        if (fb)
+            k_mlp32_fwd<1, true, 1, false, true><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation,
+                                                                        output_activation, y_stride, y0_exp, sh_dirs, nrm);
+        else
+            k_mlp32_fwd<1, false, 1, false, true><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation,
+                                                                         output_activation, y_stride, y0_exp, sh_dirs, nrm);
+    } else if (num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1)
         k_mlp32_fwd<1, false, 1, true><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation,
                                                               y_stride, y0_exp);
     else if (num_hidden == 1) MLP32_FWD(1);

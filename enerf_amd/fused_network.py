@@ -101,11 +101,10 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2)
             "nerf_pack_weights")
     blob_s, blob_c = blob[:3072], blob[3072:]
     fb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev) if train else None
-    L.check(lib.enerf_mlp32_forward(feats.data_ptr(), blob_s.data_ptr(), B, 32, 16, 1, 0, 6,
-                                    fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
-                                    stream), "mlp32_forward(sigma)")
-    L.check(lib.enerf_sh_encode_forward_strided(d.data_ptr(), h32.data_ptr() + 64, B, 4, 32, stream),
-            "sh_encode_forward_strided")
+    # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
+    L.check(lib.enerf_mlp32_forward_sh(feats.data_ptr(), blob_s.data_ptr(), B, 32, 16, 1, 0, 6,
+                                       fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
+                                       d.data_ptr(), stream), "mlp32_forward_sh(sigma)")
     # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
     fb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev) if train else None
     L.check(lib.enerf_mlp32_forward(h32.data_ptr(), blob_c.data_ptr(), B, 32, out_c, 2, 0, 3,

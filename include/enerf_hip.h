@@ -297,6 +297,14 @@ int enerf_nerf_pack_weights(const float* ws0, const float* ws1, const float* wc0
 int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
                         uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
                         uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream);
+/* enerf_mlp32_forward that also writes the degree-4 SH encoding of sh_dirs [B,3] (shencoder.cu:27-128) into columns
+ * 16..31 of each row of Y: for the sigma net of nerf/network.py, whose output row is the colour net's input row
+ * (num_hidden 1, level-major X, out_dim <= 16, y_stride >= 32).  sh_dirs == NULL: plain enerf_mlp32_forward. */
+int enerf_mlp32_forward_sh(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
+                           uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
+                           uint32_t x_layout, uint32_t y_stride, float* y0_exp, const float* sh_dirs,
+                           enerf_stream_t stream);
+
 /* dY [B,out_dim] with rows dy_stride floats apart (0 = out_dim); bb [num_hidden,Bp,64] is scratch (written); dX NULL
  * or laid out like X (x_layout 1: pad rows are written as zeros, ready for enerf_grid_encode_backward with
  * grad_layout 2); dW (fp32 blob) is accumulated (+=).  Optional fused epilogue gradients:
