@@ -38,8 +38,13 @@ struct ProfScope {
     int id;
     hipStream_t s;
     void* slot;
-    ProfScope(int kernel_id, hipStream_t stream);
+    bool ext;
+    // ext = true: the caller launches ONE kernel with hipExtLaunchKernelGGL(..., start(), stop(), ...), which stamps the
+    // events with the kernel's own begin / end (what rocprofv3 reports) instead of the time between two event packets
+    ProfScope(int kernel_id, hipStream_t stream, bool ext = false);
     ~ProfScope();
+    hipEvent_t start() const;      // nullptr when this launch is not being timed
+    hipEvent_t stop() const;
 };
 
 // ---- workspace owned by the library (grow-only, per process) --------------

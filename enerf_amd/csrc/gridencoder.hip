@@ -22,6 +22,7 @@
 //    half2 atomics for fp16 tables.
 //
 // Compiled with -ffp-contract=off; fused multiply-adds are explicit.
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
 
@@ -822,12 +823,20 @@ int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H, float in_add,
 
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
-               const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s) {
+               const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s,
+               hipEvent_t ev_start, hipEvent_t ev_stop) {
     const uint32_t nchunks = div_up(layout == 2 ? ((B + 31u) & ~31u) : B, kPtsPerBlock);
     const uint32_t nblocks = fwd_blocks(nchunks, L);
-#define ENERF_GF(CC)                                                                                              \
-    k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, \
-                                                          gridtype, layout, nchunks)
+#define ENERF_GF(CC)                                                                                               \
+    do {                                                                                                           \
+        if (ev_start)                                                                                              \
+            hipExtLaunchKernelGGL((k_grid_fwd<T, D, CC>), dim3(nblocks), dim3(kPtsPerBlock), 0, s, ev_start,       \
+                                  ev_stop, 0, inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, gridtype,     \
+                                  layout, nchunks);                                                                \
+        else                                                                                                       \
+            k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc,  \
+                                                                  dy_dx, gridtype, layout, nchunks);               \
+    } while (0)
     switch (C) {
         case 1: ENERF_GF(1); break;
         case 2: ENERF_GF(2); break;
@@ -915,16 +924,16 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
     if (out_layout < 0 || out_layout > 2) ENERF_BADARG("GridEncoding: out_layout must be 0, 1 or 2, got %d", out_layout);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(ENERF_K_GRID_FWD, s);
+    ProfScope prof(ENERF_K_GRID_FWD, s, true);   // timed with the kernel's own begin / end stamps
     int rc = 0;
     const bool calc = calc_grad_inputs != 0;
     if (dtype == ENERF_F32) {
-        if (D == 3) rc = launch_fwd<float, 3>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, calc, (float*)dy_dx, gridtype, out_layout, s);
-        else if (D == 2) rc = launch_fwd<float, 2>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, calc, (float*)dy_dx, gridtype, out_layout, s);
+        if (D == 3) rc = launch_fwd<float, 3>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, calc, (float*)dy_dx, gridtype, out_layout, s, prof.start(), prof.stop());
+        else if (D == 2) rc = launch_fwd<float, 2>(inputs, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, calc, (float*)dy_dx, gridtype, out_layout, s, prof.start(), prof.stop());
         else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
     } else {
-        if (D == 3) rc = launch_fwd<__half, 3>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, C, L, tab, calc, (__half*)dy_dx, gridtype, out_layout, s);
-        else if (D == 2) rc = launch_fwd<__half, 2>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, C, L, tab, calc, (__half*)dy_dx, gridtype, out_layout, s);
+        if (D == 3) rc = launch_fwd<__half, 3>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, C, L, tab, calc, (__half*)dy_dx, gridtype, out_layout, s, prof.start(), prof.stop());
+        else if (D == 2) rc = launch_fwd<__half, 2>(inputs, (const __half*)embeddings, offsets, (__half*)outputs, B, C, L, tab, calc, (__half*)dy_dx, gridtype, out_layout, s, prof.start(), prof.stop());
         else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
     }
     if (rc) return rc;

@@ -50,7 +50,7 @@ static std::vector<EvPair> g_prof_ev[ENERF_K_COUNT];      // created once, reuse
 static size_t g_prof_used[ENERF_K_COUNT] = {};
 static const size_t kMaxPairs = 1 << 16;
 
-ProfScope::ProfScope(int kernel_id, hipStream_t stream) : id(kernel_id), s(stream), slot(nullptr) {
+ProfScope::ProfScope(int kernel_id, hipStream_t stream, bool ext_) : id(kernel_id), s(stream), slot(nullptr), ext(ext_) {
     if (!((g_prof_mask >> id) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_used[id] >= kMaxPairs) return;
@@ -63,13 +63,24 @@ ProfScope::ProfScope(int kernel_id, hipStream_t stream) : id(kernel_id), s(strea
         }
         g_prof_ev[id].push_back(p);
     }
-    (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].a, s);
+    if (!ext) (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].a, s);
     g_prof_used[id]++;
     slot = (void*)(uintptr_t)g_prof_used[id];  // 1-based index
 }
 
+hipEvent_t ProfScope::start() const {
+    if (!slot) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return g_prof_ev[id][(size_t)(uintptr_t)slot - 1].a;
+}
+hipEvent_t ProfScope::stop() const {
+    if (!slot) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return g_prof_ev[id][(size_t)(uintptr_t)slot - 1].b;
+}
+
 ProfScope::~ProfScope() {
-    if (!slot) return;
+    if (!slot || ext) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     size_t i = (size_t)(uintptr_t)slot - 1;
     if (i < g_prof_used[id]) (void)hipEventRecord(g_prof_ev[id][i].b, s);
