@@ -149,19 +149,34 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_w(const E* __restrict__ dY, c
 }
 
 template <typename E>
-__global__ void __launch_bounds__(256) k_ffmlp_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                                        E* __restrict__ gw) {
-    __shared__ float acc[4][64];
+__global__ void __launch_bounds__(1024) k_ffmlp_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
+                                                         E* __restrict__ gw) {
+    // 64 weights per workgroup; each of the 16 waves sums every 16th partial block with four independent chains (a
+    // single chain of 64 dependent loads per thread took 20 us), then the waves' sums are combined in a fixed order:
+    // deterministic
+    __shared__ float acc[16][64];
     const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t part = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (i < NW)
-        for (uint32_t b = part; b < nblocks; b += 4) s += partial[(size_t)b * NW + i];
-    acc[part][threadIdx.x & 63] = s;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (i < NW) {
+        uint32_t b = part;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += partial[(size_t)b * NW + i];
+            s1 += partial[(size_t)(b + 16) * NW + i];
+            s2 += partial[(size_t)(b + 32) * NW + i];
+            s3 += partial[(size_t)(b + 48) * NW + i];
+        }
+        for (; b < nblocks; b += 16) s0 += partial[(size_t)b * NW + i];
+    }
+    acc[part][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     // grad_weights arrives zero-filled; accumulate like the reference's beta = 0/1 GEMMs
-    if (part == 0 && i < NW)
-        gw[i] = (E)((float)gw[i] + ((acc[0][threadIdx.x] + acc[1][threadIdx.x]) + (acc[2][threadIdx.x] + acc[3][threadIdx.x])));
+    if (part == 0 && i < NW) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += acc[w][threadIdx.x];
+        gw[i] = (E)((float)gw[i] + t);
+    }
 }
 
 
@@ -180,12 +195,12 @@ int ffmlp_wgrad_launch(int dtype, const void* dY, const void* X, const void* fb,
         using E = __bf16;
         FFMLP_DISPATCH(E, (k_ffmlp_bwd_w<E, KB, NL><<<wgrid, 256, 0, s>>>((const E*)dY, (const E*)X, (const E*)fb,
                                                                            (const E*)bb, partial, B)));
-        k_ffmlp_reduce_w<E><<<div_up(NWn, 64), 256, 0, s>>>(partial, wgrid, NWn, (E*)grad_weights);
+        k_ffmlp_reduce_w<E><<<div_up(NWn, 64), 1024, 0, s>>>(partial, wgrid, NWn, (E*)grad_weights);
     } else {
         using E = _Float16;
         FFMLP_DISPATCH(E, (k_ffmlp_bwd_w<E, KB, NL><<<wgrid, 256, 0, s>>>((const E*)dY, (const E*)X, (const E*)fb,
                                                                            (const E*)bb, partial, B)));
-        k_ffmlp_reduce_w<E><<<div_up(NWn, 64), 256, 0, s>>>(partial, wgrid, NWn, (E*)grad_weights);
+        k_ffmlp_reduce_w<E><<<div_up(NWn, 64), 1024, 0, s>>>(partial, wgrid, NWn, (E*)grad_weights);
     }
     return 0;
 }
