@@ -318,3 +318,35 @@ def test_event_step_with_closed_render_backward_matches_autograd_step(monkeypatc
     assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 2e-4
     for n in p0:
         assert float((p0[n] - p1[n]).abs().mean()) <= 1e-3 * float(p0[n].abs().mean()), n
+
+
+def test_long_run_with_learned_occupancy_converges():
+    """600 steps with the occupancy grid maintained by update_extra_state itself (not the analytic one): through the 16
+    full sweeps and into the partial-update regime, with the closed-form step, the side-stream march and the device-side
+    density update all active.  The loss must keep falling, the grid must neither die nor fill up, and a held-out view
+    must come out close to the analytic render of the scene."""
+    from enerf_amd import scene
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    h = TrainHarness(model, lr=1e-2, occupancy="learned", update_interval=16)
+    h.update_interval = 2                     # 16 full sweeps + 284 partial updates in 600 steps
+    data = _batches(16, 4096, 2, seed=5)
+    losses = []
+    for i in range(600):
+        nxt = data[(i + 1) % len(data)]
+        losses.append(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1])).clone())
+    losses = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(losses).all()
+    assert losses[-50:].mean() < 0.25 * losses[:10].mean(), (losses[:10].mean(), losses[-50:].mean())
+    assert losses[-50:].mean() < losses[250:300].mean()                       # still improving under partial updates
+    assert model.iter_density == 300 and model.mean_count > 0
+    occ = float((model.density_grid > min(model.mean_density, model.density_thresh)).float().mean())
+    assert 0.0005 < occ < 0.6, occ                                             # neither dead nor everything occupied
+    ro, rd, tgt = _batches(1, 8192, 2, seed=77)[0]
+    model.eval()
+    with torch.no_grad():
+        img = model.render(ro, rd, staged=False, bg_color=None, perturb=False)["image"].reshape(-1, 3)
+    mse = float(((img - tgt) ** 2).mean())
+    assert -10 * math.log10(mse) > 18.0, mse                                   # PSNR of a held-out batch of pixels
