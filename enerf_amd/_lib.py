@@ -45,8 +45,11 @@ SIGNATURES = {
     "enerf_ffmlp_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _int, _vp, _vp, _vp,
                              _int, _vp],
     "enerf_ffnerf_inference": [_vp, _vp, _vp, _vp, _u32, _int, _vp, _vp, _vp],
-    "enerf_nerf_pack_weights": [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp],
     "enerf_mlp32_forward": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp],
+    "enerf_mlp32_forward_p": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp,
+                              _vp],
+    "enerf_mlp32_backward_p": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32,
+                               _u32, _vp, _u32, _vp, _vp, _u32, _vp],
     "enerf_mlp32_forward_sh": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "enerf_mlp32_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _vp,
                              _u32, _vp],

@@ -22,6 +22,8 @@ Same parameters (nn.Linear weights, `encoder.embeddings`), same values to fp32 r
 sums its 31 products in a different order).  Anything it does not cover (CPU tensors, autocast, other widths, inputs
 that need gradients, disable_view_direction) takes the unfused route in network.py.
 """
+import ctypes
+
 import numpy as np
 import torch
 from torch.autograd import Function
@@ -50,6 +52,9 @@ def _architecture_supported(net):
     if not (isinstance(encd, SHEncoder) and encd.degree == 4):
         return False
     s, c = net.sigma_net, net.color_net
+    if not all(m.weight.is_contiguous() and m.weight.dtype == torch.float32 and m.bias is None
+               for m in list(s) + list(c)):
+        return False
     return (len(s) == 2 and tuple(s[0].weight.shape) == (64, 32) and tuple(s[1].weight.shape) == (16, 64)
             and len(c) == 3 and tuple(c[0].weight.shape) == (64, 31) and tuple(c[1].weight.shape) == (64, 64)
             and c[2].weight.shape[1] == 64 and c[2].weight.shape[0] <= 32)
@@ -93,37 +98,41 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2)
                             layout=2, affine=affine)
     stream = L.stream_handle()
     h32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
-    # both weight blobs (and, when training, the zeroed dW accumulator of the backward) in one launch
-    blob = torch.empty(3072 + 6144 + 64 * out_c, dtype=torch.float32, device=dev)
-    dw = torch.empty_like(blob) if train else None
-    L.check(lib.enerf_nerf_pack_weights(ws0.data_ptr(), ws1.data_ptr(), wc0.data_ptr(), wc1.data_ptr(), wc2.data_ptr(),
-                                        out_c, blob.data_ptr(), dw.data_ptr() if train else None, stream),
-            "nerf_pack_weights")
-    blob_s, blob_c = blob[:3072], blob[3072:]
+    # the MLP kernels stage the nn.Linear weights straight from the parameters (the colour net's first-layer column
+    # order [SH | geo_feat] -> [0 | geo_feat | SH] is applied on the way into LDS): nothing is packed per step
+    seg_s, seg_c = _segments(ws0, None, None, ws1), _segments(wc0, wc1, None, wc2)
     fb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev) if train else None
     # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
-    L.check(lib.enerf_mlp32_forward_sh(feats.data_ptr(), blob_s.data_ptr(), B, 32, 16, 1, 0, 6,
-                                       fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
-                                       d.data_ptr(), stream), "mlp32_forward_sh(sigma)")
+    L.check(lib.enerf_mlp32_forward_p(feats.data_ptr(), seg_s, 32, 0, B, 32, 16, 1, 0, 6,
+                                      fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
+                                      d.data_ptr(), stream), "mlp32_forward_p(sigma)")
     # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
     fb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev) if train else None
-    L.check(lib.enerf_mlp32_forward(h32.data_ptr(), blob_c.data_ptr(), B, 32, out_c, 2, 0, 3,
-                                    fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, stream),
-            "mlp32_forward(color)")
+    L.check(lib.enerf_mlp32_forward_p(h32.data_ptr(), seg_c, 31, 1, B, 32, out_c, 2, 0, 3,
+                                      fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, None, stream),
+            "mlp32_forward_p(color)")
     saved = None
     if train:
-        saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, blob_s=blob_s, dw=dw,
-                     blob_c=blob_c, rgb=rgb, B=B, S=S, H=base_resolution, gridtype=gridtype, affine=affine,
-                     out_c=out_c, param=embeddings)
+        saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, seg_s=seg_s, seg_c=seg_c,
+                     weights=(ws0, ws1, wc0, wc1, wc2), rgb=rgb, B=B, S=S, H=base_resolution, gridtype=gridtype,
+                     affine=affine, out_c=out_c, param=embeddings)
     return sigma, rgb, saved
 
 
+def _segments(w0, h0, h1, wout):
+    """ctypes {first layer, hidden 0, hidden 1, output layer} pointer array of enerf_mlp32_*_p."""
+    return (ctypes.c_void_p * 4)(*[None if t is None else t.data_ptr() for t in (w0, h0, h1, wout)])
+
+
+# flat gradient buffer of the five MLP weights, in parameter order: ws0 | ws1 | wc0 [64,31] | wc1 | wc2 [out_c,64]
+_DW_OFFSETS = (0, 2048, 3072, 5056, 9152)
+
+
 def unpack_weight_grads(dw, out_c):
-    """The five MLP weight gradients as laid out by the parameters, from the flat dW accumulator
-    [ws0 | ws1 | W0c | wc1 | wc2] of the backward (views, except wc0 whose columns are put back in order)."""
-    g0 = dw[3072:5120].view(64, 32)
-    return (dw[:2048].view(64, 32), dw[2048:3072].view(16, 64), torch.cat([g0[:, 16:], g0[:, 1:16]], dim=1),
-            dw[5120:9216].view(64, 64), dw[9216:].view(out_c, 64))
+    """The five MLP weight gradients (views of the backward's flat buffer, which is laid out in parameter order)."""
+    o = _DW_OFFSETS
+    return (dw[o[0]:o[1]].view(64, 32), dw[o[1]:o[2]].view(16, 64), dw[o[2]:o[3]].view(64, 31),
+            dw[o[3]:o[4]].view(64, 64), dw[o[4]:].view(out_c, 64))
 
 
 def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False):
@@ -136,24 +145,25 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False):
     dev = sv["x"].device
     lib = L.lib()
     stream = L.stream_handle()
-    blob_s, blob_c = sv["blob_s"], sv["blob_c"]
     if sigma_scale != 1.0:
         g_sigma = g_sigma * sigma_scale
+    # weight gradients: written (not accumulated) by the backward's reduce pass, straight in parameter order
+    dw = torch.empty(_DW_OFFSETS[4] + 64 * out_c, dtype=torch.float32, device=dev)
+    o = _DW_OFFSETS
+    p0 = dw.data_ptr()
+    dseg_s = (ctypes.c_void_p * 4)(p0 + 4 * o[0], None, None, p0 + 4 * o[1])
+    dseg_c = (ctypes.c_void_p * 4)(p0 + 4 * o[2], p0 + 4 * o[3], None, p0 + 4 * o[4])
     bb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev)
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
-    dw = sv.pop("dw", None)                         # zeroed by the forward's pack launch; a second backward refills
-    if dw is None:
-        dw = torch.zeros(blob_s.numel() + blob_c.numel(), dtype=torch.float32, device=dev)
-    dw_s, dw_c = dw[:blob_s.numel()], dw[blob_s.numel():]
-    L.check(lib.enerf_mlp32_backward(g_rgb.data_ptr(), sv["h32"].data_ptr(), blob_c.data_ptr(), sv["fb_c"].data_ptr(),
-                                     B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), dw_c.data_ptr(), 0, 0,
-                                     sv["rgb"].data_ptr(), out_c, None, None, 0, stream), "mlp32_backward(color)")
+    L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, 31, 1, 1,
+                                       sv["fb_c"].data_ptr(), B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), 0, 0,
+                                       sv["rgb"].data_ptr(), out_c, None, None, 0, stream), "mlp32_backward_p(color)")
     bb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev)
     dfeat = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
-    L.check(lib.enerf_mlp32_backward(dx32.data_ptr(), sv["feats"].data_ptr(), blob_s.data_ptr(),
-                                     sv["fb_s"].data_ptr(), B, 32, 16, 1, 0, bb_s.data_ptr(), dfeat.data_ptr(),
-                                     dw_s.data_ptr(), 1, 32, None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32,
-                                     stream), "mlp32_backward(sigma)")
+    L.check(lib.enerf_mlp32_backward_p(dx32.data_ptr(), sv["feats"].data_ptr(), sv["seg_s"], dseg_s, 32, 0, 1,
+                                       sv["fb_s"].data_ptr(), B, 32, 16, 1, 0, bb_s.data_ptr(), dfeat.data_ptr(), 1, 32,
+                                       None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32, stream),
+            "mlp32_backward_p(sigma)")
     param, emb = sv["param"], sv["emb"]
     direct = (_ge.ACCUMULATE_INTO_PARAM_GRAD and param.is_leaf and param.grad is not None
               and param.grad.dtype == torch.float32 and param.grad.is_contiguous()
@@ -218,8 +228,7 @@ def density_sigma(net, x):
     feats = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
     _gb.grid_encode_forward(x, enc.embeddings.detach().contiguous(), enc.offsets, feats, B, 3, 2, 16, S,
                             enc.base_resolution, False, feats, enc.gridtype_id, layout=2, affine=affine)
-    ws0, ws1 = net.sigma_net[0].weight, net.sigma_net[1].weight
-    blob = torch.cat([ws0.detach().reshape(-1), ws1.detach().reshape(-1)])
-    L.check(L.lib().enerf_mlp32_forward(feats.data_ptr(), blob.data_ptr(), B, 32, 16, 1, 0, 6, None, None, 1, 0,
-                                        sigma.data_ptr(), L.stream_handle()), "mlp32_forward(sigma only)")
+    seg = _segments(net.sigma_net[0].weight, None, None, net.sigma_net[1].weight)
+    L.check(L.lib().enerf_mlp32_forward_p(feats.data_ptr(), seg, 32, 0, B, 32, 16, 1, 0, 6, None, None, 1, 0,
+                                          sigma.data_ptr(), None, L.stream_handle()), "mlp32_forward_p(sigma only)")
     return sigma

@@ -286,17 +286,23 @@ int enerf_free_splitk(void);
 int enerf_ffnerf_inference(const float* feats, const float* dirs, const float* w_sigma, const float* w_color, uint32_t M,
                            int dtype, float* sigma, float* rgb, enerf_stream_t stream);
 
-/* Weight blobs of the fused fp32 NeRF network (nerf/network.py:60-105: sigma_net 32-64-16, color_net 31-64-64-out_c,
- * both bias-free) from the five nn.Linear weights in one launch:
- *   blob = [ws0 64x32 | ws1 16x64 | W0c 64x32 | wc1 64x64 | wc2 out_c x 64]   (3072 + 6144 + 64*out_c floats)
- * W0c re-orders color_net[0].weight [64,31] (inputs: SH 16 | geo_feat 15) for the [raw density | geo_feat | SH] rows the
- * kernels exchange: column 0 = 0.  `zero` (optional, same length) is cleared in the same pass. */
-int enerf_nerf_pack_weights(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
-                            uint32_t out_c, float* blob, float* zero, enerf_stream_t stream);
+/* enerf_mlp32_forward / _backward with the weights (and weight gradients) where the caller keeps them, instead of one
+ * packed blob: wseg / dwseg = {first layer [64, w0_cols], hidden 0 [64,64], hidden 1 [64,64], output layer
+ * [out_dim,64]} (unused hidden slots NULL).  nerf_perm != 0 (w0_cols = 31): the first layer is color_net[0].weight of
+ * nerf/network.py:95 as it is -- memory columns [SH 16 | geo_feat 15] -- while the kernels' input rows are [raw density
+ * | geo_feat 15 | SH 16]; the permutation and the zero column are applied while the weights are staged into LDS, and
+ * undone when the weight gradient is written.  overwrite != 0: dwseg receives the gradient (may be uninitialised). */
+int enerf_mlp32_forward_p(const float* X, const float* const* wseg, uint32_t w0_cols, uint32_t nerf_perm, uint32_t B,
+                          uint32_t in_dim, uint32_t out_dim, uint32_t num_hidden, uint32_t activation,
+                          uint32_t output_activation, float* fb, float* Y, uint32_t x_layout, uint32_t y_stride,
+                          float* y0_exp, const float* sh_dirs, enerf_stream_t stream);
+int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* wseg, float* const* dwseg,
+                           uint32_t w0_cols, uint32_t nerf_perm, uint32_t overwrite, const float* fb, uint32_t B,
+                           uint32_t in_dim, uint32_t out_dim, uint32_t num_hidden, uint32_t activation, float* bb,
+                           float* dX, uint32_t x_layout, uint32_t dy_stride, const float* y_sigmoid,
+                           uint32_t y_sigmoid_stride, const float* dsigma, const float* h0, uint32_t h0_stride,
+                           enerf_stream_t stream);
 
-int enerf_mlp32_forward(const float* X, const float* W, uint32_t B, uint32_t in_dim, uint32_t out_dim,
-                        uint32_t num_hidden, uint32_t activation, uint32_t output_activation, float* fb, float* Y,
-                        uint32_t x_layout, uint32_t y_stride, float* y0_exp, enerf_stream_t stream);
 /* enerf_mlp32_forward that also writes the degree-4 SH encoding of sh_dirs [B,3] (shencoder.cu:27-128) into columns
  * 16..31 of each row of Y: for the sigma net of nerf/network.py, whose output row is the colour net's input row
  * (num_hidden 1, level-major X, out_dim <= 16, y_stride >= 32).  sh_dirs == NULL: plain enerf_mlp32_forward. */
