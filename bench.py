@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
     # development aids: exercise the N > 1 code path on a single-GPU box (gloo all-reduce, every rank on one device)
+    ap.add_argument("--no-comm-tune", action="store_true", help="N > 1: keep comm_chunks = 4 instead of timing 1/2/4/8")
     ap.add_argument("--backend", default=None, help="torch.distributed backend override (default: nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="put every rank on this device index")
     return ap.parse_args()
@@ -220,6 +221,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    comm_tuning = None
+    if world > 1 and args.mode == "rgb" and not args.no_comm_tune:
+        comm_tuning = harness.tune_comm(one_step)       # untimed: chooses how the gradient all-reduce is cut
+        if comm_tuning:
+            comm_tuning = {"ms_per_step": comm_tuning, "chosen_chunks": harness.comm_chunks}
     # warm-up runs with the same timing hooks as the timed region, so their events exist before the clock starts
     _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
     for i in range(args.warmup):
@@ -367,6 +373,7 @@ def main():
             "samples_per_step_per_gpu": total_samples / args.steps / world,
             "render": render,
             "graph_replay": graph_replay,
+            "comm_tuning": comm_tuning,
             "kernels": kernels,
             "roofline": roofline,
             "cpu_baseline": cpu,

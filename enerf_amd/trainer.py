@@ -231,6 +231,36 @@ class TrainHarness:
             p.grad = g.view_as(p)
         self.opt.step_now(only=small)
 
+    def tune_comm(self, step_fn, candidates=(1, 2, 4, 8), window=None):
+        """Data parallel: pick `comm_chunks` by measurement.  How the table-gradient all-reduce is best cut depends on
+        the link topology and the number of ranks (per-collective latency against Adam / collective overlap), so each
+        candidate runs `window` steps of `step_fn(i)` -- one update_extra_state period, so every window holds the same
+        work -- timed between device synchronisations; the slowest rank's time decides (MAX all-reduce, hence the same
+        choice on every rank).  -> {chunks: ms_per_step}, {} when there is nothing to tune."""
+        import time
+        import torch.distributed as dist
+        if self.avg is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return {}
+        window = int(window or self.update_interval)
+        dev = next(self.model.parameters()).device
+        i = 0
+        timings = {}
+        for n, c in enumerate((candidates[0],) + tuple(candidates)):       # the first window only warms up
+            self.comm_chunks = int(c)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(window):
+                step_fn(i)
+                i += 1
+            torch.cuda.synchronize(dev)
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            if n:
+                timings[int(c)] = float(dt.item()) / window * 1e3
+        self.comm_chunks = min(timings, key=timings.get)
+        return timings
+
     def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
         side = self._side_prefetch(next_rays) if not render_kw else None
         chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")

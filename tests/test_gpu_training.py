@@ -281,6 +281,56 @@ def test_data_parallel_chunked_allreduce_adam_pipeline_matches_bucket_path():
         assert float((a - b).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
 
 
+def _tune_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from enerf_amd.network import NeRFNetwork
+        from enerf_amd.trainer import TrainHarness
+        torch.cuda.set_device(0)
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=world)
+        data = _batches(4, 1024, 2, seed=10 + rank)
+
+        def step(i):
+            nxt = data[(i + 1) % len(data)]
+            return h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]))
+        timings = h.tune_comm(step, candidates=(1, 3, 8), window=4)
+        loss = float(step(100))
+        torch.cuda.synchronize()
+        out[rank] = (timings, h.comm_chunks, h.global_step, loss,
+                     {n: p.detach().cpu() for n, p in model.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_tuning_agrees_across_ranks():
+    """tune_comm: every candidate is timed over the same number of steps, all ranks see the same timings (MAX
+    all-reduce) and therefore choose the same cut; the replicas stay identical through the changes of cut (3 pieces:
+    a cut that does not divide the table)."""
+    import socket
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_tune_worker, args=(2, port, out), nprocs=2, join=True)
+    (t0, c0, g0, l0, p0), (t1, c1, g1, l1, p1) = out[0], out[1]
+    assert set(t0) == {1, 3, 8} and t0 == t1 and all(v > 0 for v in t0.values())
+    assert c0 == c1 == min(t0, key=t0.get)
+    assert g0 == g1 == 4 * 4 + 1 and math.isfinite(l0)
+    assert all(torch.equal(p0[n], p1[n]) for n in p0)
+
+
+def test_comm_tuning_is_a_noop_on_one_rank():
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    h = TrainHarness(model, occupancy="synthetic")
+    assert h.tune_comm(lambda i: None) == {} and h.comm_chunks == 4 and h.global_step == 0
+
+
 def test_event_step_with_closed_render_backward_matches_autograd_step(monkeypatch):
     """step_events: the two renders run without autograd, the event loss alone goes through it and hands its gradient
     to the renders' closed backward.  Same loss trajectory, counters and (in the mean) weights as the autograd step."""
