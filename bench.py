@@ -226,6 +226,8 @@ def main():
         comm_tuning = harness.tune_comm(one_step)       # untimed: chooses how the gradient all-reduce is cut
         if comm_tuning:
             comm_tuning = {"ms_per_step": comm_tuning, "chosen_chunks": harness.comm_chunks}
+            if harness.comm_dtype is None:      # reported only: what the opt-in 16-bit wire format would give here
+                comm_tuning["bf16_wire_ms_per_step"] = harness.probe_comm_dtype(one_step, torch.bfloat16)
     # warm-up runs with the same timing hooks as the timed region, so their events exist before the clock starts
     _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
     for i in range(args.warmup):

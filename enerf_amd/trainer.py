@@ -261,6 +261,29 @@ class TrainHarness:
         self.comm_chunks = min(timings, key=timings.get)
         return timings
 
+    def probe_comm_dtype(self, step_fn, dtype=torch.bfloat16, window=None, first_step=0):
+        """Data parallel: ms per step over one window with the table gradient on the wire in `dtype` (the opt-in
+        `comm_dtype`), for reporting next to the fp32 figure; the setting itself is restored.  None on one rank."""
+        import time
+        import torch.distributed as dist
+        if self.avg is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        window = int(window or self.update_interval)
+        dev = next(self.model.parameters()).device
+        keep, self.comm_dtype = self.comm_dtype, dtype
+        try:
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(first_step, first_step + window):
+                step_fn(i)
+            torch.cuda.synchronize(dev)
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        finally:
+            self.comm_dtype = keep
+        return float(dt.item()) / window * 1e3
+
     def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
         side = self._side_prefetch(next_rays) if not render_kw else None
         chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")

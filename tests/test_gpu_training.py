@@ -299,6 +299,8 @@ def _tune_worker(rank, world, port, out):
             nxt = data[(i + 1) % len(data)]
             return h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]))
         timings = h.tune_comm(step, candidates=(1, 3, 8), window=4)
+        probe = h.probe_comm_dtype(step, torch.bfloat16, window=3)
+        assert probe > 0 and h.comm_dtype is None
         loss = float(step(100))
         torch.cuda.synchronize()
         out[rank] = (timings, h.comm_chunks, h.global_step, loss,
@@ -319,7 +321,7 @@ def test_comm_tuning_agrees_across_ranks():
     (t0, c0, g0, l0, p0), (t1, c1, g1, l1, p1) = out[0], out[1]
     assert set(t0) == {1, 3, 8} and t0 == t1 and all(v > 0 for v in t0.values())
     assert c0 == c1 == min(t0, key=t0.get)
-    assert g0 == g1 == 4 * 4 + 1 and math.isfinite(l0)
+    assert g0 == g1 == 4 * 4 + 3 + 1 and math.isfinite(l0)
     assert all(torch.equal(p0[n], p1[n]) for n in p0)
 
 
