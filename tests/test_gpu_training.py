@@ -281,6 +281,50 @@ def test_data_parallel_chunked_allreduce_adam_pipeline_matches_bucket_path():
         assert float((a - b).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
 
 
+def _rccl_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from enerf_amd.network import NeRFNetwork
+        from enerf_amd.trainer import TrainHarness
+        data = _batches(4, 1024, 2, seed=10)
+        for tag, dp, dtype in (("single", 1, None), ("rccl", 2, None), ("rccl16", 2, torch.bfloat16)):
+            torch.manual_seed(0)
+            model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+            h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=dp)     # dp = 2: the data-parallel tail runs
+            h.comm_dtype = dtype
+            losses = []
+            for i in range(36):
+                nxt = data[(i + 1) % len(data)]
+                losses.append(float(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]))))
+            torch.cuda.synchronize()
+            out[tag] = (losses, {n: p.detach().cpu() for n, p in model.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_tail_over_rccl_single_rank():
+    """The data-parallel tail on the real backend (RCCL, `ReduceOp.AVG`, async collectives on RCCL's stream, chunked
+    Adam) with a world of one rank -- all this box offers: averaging over one rank is the identity, so the run must
+    reproduce the single-process step (to the run-to-run noise of the coarse levels' float atomics); the 16-bit wire
+    format must stay close to it."""
+    import socket
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    (la, pa), (lb, pb), (lc, pc) = out["single"], out["rccl"], out["rccl16"]
+    la, lb = np.array(la), np.array(lb)
+    print("max rel loss difference single vs RCCL tail:", np.abs(la - lb).max() / np.abs(la).max())
+    assert np.abs(la - lb).max() <= 1e-4 * np.abs(la).max()       # (float atomics on the coarsest levels: not bitwise)
+    for n, a in pa.items():
+        assert float((a - pb[n]).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
+    assert np.abs(np.array(lc) - np.array(la)).max() <= 0.05 * np.abs(np.array(la)).max()
+
+
 def _tune_worker(rank, world, port, out):
     import os
     import torch.distributed as dist
