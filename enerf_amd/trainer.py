@@ -243,17 +243,18 @@ class TrainHarness:
             return {}
         window = int(window or self.update_interval)
         dev = next(self.model.parameters()).device
+        sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
         i = 0
         timings = {}
         for n, c in enumerate((candidates[0],) + tuple(candidates)):       # the first window only warms up
             self.comm_chunks = int(c)
-            torch.cuda.synchronize(dev)
+            sync()
             dist.barrier()
             t0 = time.perf_counter()
             for _ in range(window):
                 step_fn(i)
                 i += 1
-            torch.cuda.synchronize(dev)
+            sync()
             dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             if n:

@@ -123,3 +123,41 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
         import importlib
         import enerf_amd.raymarching as rm, enerf_amd.gridencoder as ge, enerf_amd.shencoder as sh
         importlib.reload(rm); importlib.reload(ge); importlib.reload(sh)
+
+
+def _tune_worker(rank, world, port, outdir):
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from enerf_amd import parallel
+    from enerf_amd.trainer import TrainHarness
+    parallel.init_from_env(backend="gloo")
+    try:
+        h = object.__new__(TrainHarness)                 # only what tune_comm reads: no renderer, no GPU
+        h.model = torch.nn.Linear(2, 2)
+        h.avg = object()
+        h.update_interval = 16
+        h.comm_chunks = 4
+        # rank 0 is slow with 1 piece, rank 1 with 8: the slowest rank decides, so both must settle on 2
+        cost = {0: {1: 0.020, 2: 0.004, 8: 0.002}, 1: {1: 0.002, 2: 0.004, 8: 0.020}}[rank]
+        seen = []
+
+        def step(i):
+            seen.append((i, h.comm_chunks))
+            time.sleep(cost[h.comm_chunks])
+        timings = h.tune_comm(step, candidates=(1, 2, 8), window=3)
+        torch.save({"timings": timings, "chosen": h.comm_chunks, "seen": seen}, os.path.join(outdir, f"tune{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_tuning_slowest_rank_decides(tmp_path):
+    """tune_comm over gloo, world_size 2: the timing of a candidate is the MAX over ranks, every rank sees the same
+    numbers and makes the same choice; candidates run `window` consecutive steps each after one warm-up window."""
+    import torch.multiprocessing as mp
+    mp.spawn(_tune_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), f"tune{r}.pt")) for r in (0, 1))
+    assert a["timings"] == b["timings"] and set(a["timings"]) == {1, 2, 8}
+    assert a["chosen"] == b["chosen"] == 2
+    assert a["timings"][1] >= 19.0 and a["timings"][8] >= 19.0 and a["timings"][2] < 15.0       # ms per step
+    assert [c for _, c in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 and [i for i, _ in a["seen"]] == list(range(12))

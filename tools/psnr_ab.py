@@ -1,0 +1,85 @@
+"""Does the MI355X-first training path train to the same quality as the reference-shaped route?
+
+A = what bench.py times: closed-form MSE step, one fused render node, fused fp32 MFMA networks, device-side
+    update_extra_state, side-stream march, fused Adam.
+B = the reference's structure over the same HIP entry points: run_cuda op by op through the four autograd Functions
+    (raymarching.py / grid.py / sphere_harmonics.py), nn.Linear networks, F.mse_loss + autograd, the Python
+    update_extra_state (nerf/renderer.py:472-560), torch.optim.Adam.
+
+Same model seed, same batches, the occupancy grid learned by update_extra_state itself.  Reports held-out PSNR
+(16 K pixels never trained on) for several seeds of each; writes a JSON summary.
+python tools/psnr_ab.py [steps] [seeds] [out.json]"""
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from enerf_amd import density_update, fused_network, fused_render  # noqa: E402
+from enerf_amd.network import NeRFNetwork  # noqa: E402
+from enerf_amd.trainer import TrainHarness  # noqa: E402
+from test_gpu_training import _batches  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+out_path = sys.argv[3] if len(sys.argv) > 3 else None
+data = _batches(32, 4096, 2, seed=5)
+held = _batches(1, 16384, 2, seed=77)[0]
+
+
+def run(route, seed):
+    fused = route == "A"
+    fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = fused
+    torch.manual_seed(seed)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).cuda()
+    h = TrainHarness(model, lr=1e-2, occupancy="learned")
+    h.manual_mse = h.prefetch = fused
+    if not fused:
+        h.opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        h._params = [p for g in h.opt.param_groups for p in g["params"]]
+        h._opt_step = h.opt.step
+    torch.cuda.synchronize()
+    t0 = time.time()
+    psnrs = []
+    for i in range(steps):
+        nxt = data[(i + 1) % len(data)]
+        loss = h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]) if fused else None)
+        if i + 1 > steps - steps // 5 and (steps - 1 - i) % (steps // 25) == 0:      # 5 evaluations over the last fifth
+            model.eval()
+            with torch.no_grad():
+                img = model.render(held[0], held[1], staged=False, bg_color=None, perturb=False)["image"].reshape(-1, 3)
+            model.train()
+            psnrs.append(-10 * math.log10(float(((img - held[2]) ** 2).mean())))
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.time() - t0) / steps
+    psnr = sum(psnrs) / len(psnrs)
+    occ = float((model.density_grid > min(model.mean_density, model.density_thresh)).float().mean())
+    return {"route": route, "seed": seed, "psnr_db": psnr, "final_loss": float(loss), "occupied_frac": occ,
+            "ms_per_step_incl_evals": ms, "evaluations": len(psnrs), "samples_per_step": int(model.mean_count)}
+
+
+rows = []
+for seed in range(seeds):
+    for route in ("A", "B"):
+        r = run(route, seed)
+        rows.append(r)
+        print(route, seed, round(r["psnr_db"], 3), flush=True)
+fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = True
+mean = {k: sum(r["psnr_db"] for r in rows if r["route"] == k) / seeds for k in ("A", "B")}
+spread = {k: max(r["psnr_db"] for r in rows if r["route"] == k) - min(r["psnr_db"] for r in rows if r["route"] == k)
+          for k in ("A", "B")}
+diffs = [a["psnr_db"] - b["psnr_db"] for a, b in zip(rows[0::2], rows[1::2])]           # paired by seed
+dmean = sum(diffs) / len(diffs)
+dstd = (sum((d - dmean) ** 2 for d in diffs) / max(len(diffs) - 1, 1)) ** 0.5
+summary = {"steps": steps, "seeds": seeds, "mean_psnr_db": mean, "seed_spread_db": spread,
+           "A_minus_B_db": dmean, "paired_std_db": dstd, "standard_error_db": dstd / len(diffs) ** 0.5,
+           "runs": rows}
+print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
+if out_path:
+    with open(out_path, "w") as f:
+        json.dump(summary, f, indent=1)
