@@ -75,7 +75,7 @@ def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, 
                                               float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
                                               int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
                                               _f32(dirs, "dirs"), _f32(deltas, "deltas"), _i32(rays, "rays"),
-                                              _i32(counter, "counter"), int(perturb), int(bool(zero_unwritten)),
+                                              _i32(counter, "counter"), int(perturb), int(zero_unwritten),
                                               L.stream_handle()), "march_rays_train_ex")
 
 

@@ -57,17 +57,6 @@ uint32_t* g_bin_cursors = nullptr;
 
 uint32_t* bin_cursors();
 
-uint32_t num_cus() {
-    static uint32_t n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        n = (uint32_t)cus;
-    }
-    return n;
-}
 
 template <typename T, int C>
 struct alignas((sizeof(T) * C) > 16 ? 16 : (sizeof(T) * C)) Feat {

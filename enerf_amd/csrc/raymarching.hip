@@ -615,17 +615,21 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
     const bool fast = march_fast_ok(H);
     if (fast) build_march_tabs(s_face, s_expand, H);
     const MarchTabs tabs = {s_face, s_expand};
-    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (n >= N) return;
-    RayCtx c;
-    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
-    float t0 = nears[n];
-    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
-    const uint32_t cnt = fast ? lattice_march_fast<false, true>(c, tabs, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                                log + (size_t)n * kLogCap, nlog + n)
-                              : lattice_march<false, true, false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                                  log + (size_t)n * kLogCap, nlog + n);
-    if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
+    // one ray per wavefront and pass; a launch with fewer wavefronts than rays (background mode) walks the rest
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); n < N;
+         n += nw) {
+        RayCtx c;
+        ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
+        float t0 = nears[n];
+        if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+        const uint32_t cnt =
+            fast ? lattice_march_fast<false, true>(c, tabs, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                   log + (size_t)n * kLogCap, nlog + n)
+                 : lattice_march<false, true, false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                     log + (size_t)n * kLogCap, nlog + n);
+        if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
+    }
 }
 
 // rows [lo, hi) of the three sample buffers <- 0 (thread `tid` of `nthreads`)
@@ -1200,6 +1204,8 @@ int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t*
     return 0;
 }
 
+static uint32_t g_march_bg_blocks = 0;
+
 int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                            const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
@@ -1224,6 +1230,8 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays_train: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
+    const bool background = (zero_unwritten & 2u) != 0;
+    zero_unwritten &= 1u;
     if (dt_gamma == 0.0f) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
@@ -1232,8 +1240,12 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
         if (!ws) return ENERF_E_NOMEM;
         ChunkEntry* log = (ChunkEntry*)ws;
         uint32_t* nlog = (uint32_t*)(ws + log_bytes);
-        k_march_count_w<<<div_up(N, 4), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays,
-                                                     perturb, log, nlog);
+        // flag bit 1: the batch is prepared ahead on a side stream.  There the marcher's latency is hidden anyway, and
+        // what it costs the step running beside it is its register footprint (66 VGPRs x 4 resident waves per SIMD
+        // leave the fused-MLP kernels one wave per SIMD instead of two): one marching wave per SIMD, rays in turn.
+        const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : num_cus();
+        k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
+            rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog);
         k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
         const uint32_t ray_blocks = div_up(N, 4);
         k_march_write_w<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
@@ -1320,6 +1332,12 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
                 1.0f / (3.0f * (float)N)},
         ray_blocks);
     ENERF_LAUNCH_CHECK("composite_rays_train_backward_mse");
+    return 0;
+}
+
+// tuning aid: workgroups of the background training march (0: one per CU)
+int enerf_debug_march_bg_blocks(uint32_t n) {
+    g_march_bg_blocks = n;
     return 0;
 }
 

@@ -40,6 +40,18 @@ void* workspace(int slot, size_t bytes) {
     return p;
 }
 
+uint32_t num_cus() {
+    static uint32_t n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n = (uint32_t)cus;
+    }
+    return n;
+}
+
 // ---- event timing ---------------------------------------------------------
 struct EvPair {
     hipEvent_t a, b;

@@ -30,7 +30,8 @@ def supported(model, rays_o, rays_d, bg_color, dt_gamma):
     return fnet.supported(model, probe, probe)
 
 
-def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps):
+def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps,
+                background=False):
     """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
     Returns the sample buffers; a data-parallel harness runs it for the NEXT batch while the gradient all-reduce of
     the current step is in flight (TrainHarness.prefetch_march)."""
@@ -60,7 +61,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
         deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
         _rb.march_rays_train_ex(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
                                 model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
-                                perturb, True)
+                                perturb, 3 if background else 1)
     return dict(nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas, rays=rays, M=M, counter=counter)
 
 
@@ -147,7 +148,7 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
-                              float(dt_gamma), int(max_steps))
+                              float(dt_gamma), int(max_steps), background=True)
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)

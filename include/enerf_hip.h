@@ -120,7 +120,9 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
 /* Extension of march_rays_train for callers that hand over UNINITIALISED sample buffers (zero_unwritten != 0): every
  * row no ray writes -- past the last reservation, and a dropped ray's reservation clipped to M -- is zero-filled by the
  * write pass itself, so the three torch.zeros of raymarching.py:205-207 become torch.empty.  zero_unwritten == 0 is
- * exactly enerf_march_rays_train. */
+ * exactly enerf_march_rays_train.  `zero_unwritten` is a flag word: bit 0 as above; bit 1 says the batch is being
+ * prepared ahead of its step on a side stream: the count pass then runs with one wavefront per SIMD (rays in turn) so
+ * that it leaves the registers of the chip to the step it runs beside.  Same rows, same counts, bit for bit. */
 int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                               const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
@@ -331,6 +333,8 @@ int enerf_debug_mlp32_fused_backward(int on);
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
 /* tuning aid: largest alive-ray count for which enerf_march_rays runs one wavefront per ray (when n_step < 16) */
 int enerf_debug_march_wave_max_rays(uint32_t n);
+/* tuning aid: workgroups of the background training march (enerf_march_rays_train_ex flag bit 1); 0 = one per CU */
+int enerf_debug_march_bg_blocks(uint32_t n);
 /* tuning aid: workgroup caps of the mlp32 forward and fused-backward grids (0 = built-in defaults) */
 int enerf_debug_mlp32_grid_caps(uint32_t fwd_blocks, uint32_t bwd_blocks);
 

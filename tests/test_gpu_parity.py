@@ -149,6 +149,31 @@ def test_march_rays_train_ex_zero_fills_unwritten_rows(rm, scenes, overflow, dt_
     assert (got[4][0] > M) == overflow
 
 
+@pytest.mark.parametrize("overflow", [False, True])
+def test_march_rays_train_background_mode_is_bit_identical(rm, scenes, overflow):
+    """Flag bit 1 of march_rays_train_ex (batch prepared ahead on a side stream: one marching wavefront per SIMD,
+    rays in turn) == the oracle, bit for bit, with more rays than the launch has wavefronts."""
+    bound = 2
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(3000, 29, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    N = len(o)
+    for perturb in (0, 1):
+        tot = int(O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, N * 1024, nears, fars, perturb)[4][0])
+        M = tot // 2 if overflow else tot + 1000
+        M += 128 - M % 128
+        ref = O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, M, nears, fars, perturb)
+        xyzs = torch.full((M, 3), float("nan"), device=DEV); dirs = torch.full((M, 3), float("nan"), device=DEV)
+        deltas = torch.full((M, 2), float("nan"), device=DEV)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+        counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        rm.march_rays_train_ex(cu(o), cu(d), cu(bits), bound, 0.0, 1024, N, C, H, M, cu(nears), cu(fars), xyzs, dirs,
+                               deltas, rays, counter, perturb, 3)
+        got = [x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)]
+        for a, b, name in zip(got, ref, ("xyzs", "dirs", "deltas", "rays", "counter")):
+            assert np.array_equal(a, b), (name, perturb)
+
+
 def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm):
     """Every cell occupied: rays emit a sample at every lattice point until max_steps (1024) -- the maximum the path
     can produce per ray, and more emitting 64-point chunks than the count pass's per-ray log holds for the longest

@@ -34,9 +34,14 @@ def memoised(model, rays_o, rays_d, counter, mean_count, *a, **k):
     return out
 
 
-for tag, fn, prefetch in (("march on the side stream", orig, True), ("march inline", orig, False),
-                          ("no march work (memoised)", memoised, True)):
+from enerf_amd import _lib  # noqa: E402
+configs = (("side stream, 1 block per CU", orig, True, 0), ("march inline", orig, False, 0),
+           ("no march work (memoised)", memoised, True, 0),
+           ("side stream, 1024 blocks (all rays at once)", orig, True, 1024),
+           ("side stream, 512 blocks", orig, True, 512), ("side stream, 128 blocks", orig, True, 128))
+for tag, fn, prefetch, blocks in configs + configs[::-1]:
     fused_render.march_stage = fn
+    _lib.lib().enerf_debug_march_bg_blocks(blocks)
     memo.clear()
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(dev)
@@ -55,3 +60,4 @@ for tag, fn, prefetch in (("march on the side stream", orig, True), ("march inli
     torch.cuda.synchronize()
     print(f"{tag:28s} {(time.perf_counter() - t0) / 160 * 1e3:.3f} ms/step")
 fused_render.march_stage = orig
+_lib.lib().enerf_debug_march_bg_blocks(0)
