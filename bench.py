@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
     # development aids: exercise the N > 1 code path on a single-GPU box (gloo all-reduce, every rank on one device)
+    ap.add_argument("--march-bg-blocks", type=int, default=0, help="tuning: workgroups of the side-stream march (0 = auto)")
     ap.add_argument("--no-comm-tune", action="store_true", help="N > 1: keep comm_chunks = 4 instead of timing 1/2/4/8")
     ap.add_argument("--backend", default=None, help="torch.distributed backend override (default: nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="put every rank on this device index")
@@ -187,6 +188,8 @@ def main():
     from enerf_amd.trainer import TrainHarness
     from enerf_amd.events import EventOptions
 
+    if args.march_bg_blocks:
+        _lib.lib().enerf_debug_march_bg_blocks(args.march_bg_blocks)
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
     model.infer_batch_mult = args.render_batch_mult
@@ -225,7 +228,9 @@ def main():
     if world > 1 and args.mode == "rgb" and not args.no_comm_tune:
         comm_tuning = harness.tune_comm(one_step)       # untimed: chooses how the gradient all-reduce is cut
         if comm_tuning:
-            comm_tuning = {"ms_per_step": comm_tuning, "chosen_chunks": harness.comm_chunks}
+            comm_tuning = {"ms_per_step": comm_tuning, "chosen_chunks": harness.comm_chunks,
+                           "prefetch_at_ms_per_step": harness.tuned["prefetch_at_ms_per_step"],
+                           "chosen_prefetch_at": harness.prefetch_at}
             if harness.comm_dtype is None:      # reported only: what the opt-in 16-bit wire format would give here
                 comm_tuning["bf16_wire_ms_per_step"] = harness.probe_comm_dtype(one_step, torch.bfloat16)
     # warm-up runs with the same timing hooks as the timed region, so their events exist before the clock starts

@@ -129,14 +129,16 @@ def _next_counter(model):
     return counter
 
 
-def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None):
+def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None, background=True):
     """Run the parameter-independent stage of the NEXT training render now (e.g. under a gradient all-reduce).  The
     result is picked up by the next render_train call on the same ray tensors; anything that changes what the stage
     reads (update_extra_state: bitfield, sample budget) must not happen in between -- the caller's responsibility.
 
     With `stream` the stage is issued on that HIP stream, ordered after everything queued so far on the current one
     (so it never overlaps a march of the current stream: the marcher's chunk-log workspace is shared), and runs
-    concurrently with what the current stream does next -- the marcher is latency / VALU bound and hides under the
+    concurrently with what the current stream does next (`background`: beside compute kernels, where the count pass
+    runs one wavefront per SIMD; False beside collectives, where nothing competes for registers) -- the marcher is
+    latency / VALU bound and hides under the
     MFMA- and HBM-bound backward kernels.  The consumer waits on the stage's event."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
@@ -148,7 +150,7 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
-                              float(dt_gamma), int(max_steps), background=True)
+                              float(dt_gamma), int(max_steps), background=background)
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)

@@ -40,6 +40,9 @@ class TrainHarness:
         self._side = None             # HIP stream of the next batch's march (created on first use)
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
         self.comm_dtype = None        # torch.bfloat16: halve the table gradient's bytes on the wire (changes rounding)
+        # data parallel: the next batch's march is issued once the "forward" is queued (runs beside the backward) or
+        # once the "collectives" are (runs beside the gradient all-reduce, where nothing else wants the CUs)
+        self.prefetch_at = "forward"
         self._raw_grads = None
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
         self._loss_ring_clean = False
@@ -157,9 +160,9 @@ class TrainHarness:
         if self._side is None:
             self._side = torch.cuda.Stream()
 
-        def issue():
+        def issue(background=True):
             for ro, rd in next_rays:
-                fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side)
+                fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side, background=background)
         return issue
 
     def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None, raw=False):
@@ -191,7 +194,7 @@ class TrainHarness:
         with torch.no_grad():
             return torch.nn.functional.mse_loss(image, target.view(-1, 3))
 
-    def _finish_distributed(self):
+    def _finish_distributed(self, issue_prefetch=None):
         """Data-parallel tail of the closed-form step: the hash-table gradient is all-reduced in `comm_chunks` pieces
         and Adam runs on each piece as it lands (the optimizer pass over the table hides under the remaining
         collectives); the MLP gradients travel as the backward's one flat dW buffer."""
@@ -216,6 +219,8 @@ class TrainHarness:
             wire = [flat[lo:hi].to(self.comm_dtype) for lo, hi in bounds]
         works = [dist.all_reduce(t, op=op, async_op=True) for t in wire]
         w_dw = dist.all_reduce(dw, op=op, async_op=True)
+        if issue_prefetch is not None:
+            issue_prefetch(background=False)                  # marches while the gradients are on the wire
         for (lo, hi), t, w in zip(bounds, wire, works):
             w.wait()
             if self.comm_dtype is not None:
@@ -260,6 +265,22 @@ class TrainHarness:
             if n:
                 timings[int(c)] = float(dt.item()) / window * 1e3
         self.comm_chunks = min(timings, key=timings.get)
+        # with the cut settled: where the next batch's march is issued (beside the backward, or beside the collectives)
+        placements = {}
+        for at in ("forward", "collectives"):
+            self.prefetch_at = at
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(window):
+                step_fn(i)
+                i += 1
+            sync()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            placements[at] = float(dt.item()) / window * 1e3
+        self.prefetch_at = min(placements, key=placements.get)
+        self.tuned = {"chunks_ms_per_step": dict(timings), "prefetch_at_ms_per_step": placements}
         return timings
 
     def probe_comm_dtype(self, step_fn, dtype=torch.bfloat16, window=None, first_step=0):
@@ -289,9 +310,11 @@ class TrainHarness:
         side = self._side_prefetch(next_rays) if not render_kw else None
         chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")
                    and self.comm_chunks > 0)
-        loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=side, raw=chunked, **render_kw)
+        late = chunked and side is not None and self.prefetch_at == "collectives"
+        loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=None if late else side, raw=chunked,
+                                    **render_kw)
         if chunked:
-            self._finish_distributed()
+            self._finish_distributed(side if late else None)
             return loss
         self._reduce_grads(None if side is not None else next_rays)
         self._opt_step()

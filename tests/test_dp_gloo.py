@@ -138,6 +138,7 @@ def _tune_worker(rank, world, port, outdir):
         h.avg = object()
         h.update_interval = 16
         h.comm_chunks = 4
+        h.prefetch_at = "forward"
         # rank 0 is slow with 1 piece, rank 1 with 8: the slowest rank decides, so both must settle on 2
         cost = {0: {1: 0.020, 2: 0.004, 8: 0.002}, 1: {1: 0.002, 2: 0.004, 8: 0.020}}[rank]
         seen = []
@@ -160,4 +161,5 @@ def test_comm_tuning_slowest_rank_decides(tmp_path):
     assert a["timings"] == b["timings"] and set(a["timings"]) == {1, 2, 8}
     assert a["chosen"] == b["chosen"] == 2
     assert a["timings"][1] >= 19.0 and a["timings"][8] >= 19.0 and a["timings"][2] < 15.0       # ms per step
-    assert [c for _, c in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 and [i for i, _ in a["seen"]] == list(range(12))
+    # warm-up + 3 candidates, then two windows (march placement) with the chosen cut
+    assert [c for _, c in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 + [2] * 6 and [i for i, _ in a["seen"]] == list(range(18))
