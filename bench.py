@@ -35,7 +35,7 @@ GRID_FWD_BYTES_PER_POINT = 1164   # 12 in + 16 levels x 8 corner
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)   # 125 ms timed: one scheduling hiccup no longer moves the figure
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--bound", type=int, default=3)
