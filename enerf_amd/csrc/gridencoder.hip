@@ -668,8 +668,10 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
         const uint32_t key = s_key[j], list = key >> 16, loc = key & 0xffffu;
         const uint32_t slot = s_gbase[list] + (j - s_ofs[list]);
         if (slot < cap) {
-            uint32_t* r = lrecs + (size_t)list * cap * (1 + C) + slot;
-            r[0] = loc;
+            // record = 16-bit row within the tile (first half of the list's index plane) + C value planes
+            uint32_t* lbase = lrecs + (size_t)list * cap * (1 + C);
+            reinterpret_cast<uint16_t*>(lbase)[slot] = (uint16_t)loc;
+            uint32_t* r = lbase + slot;
 #pragma unroll
             for (int c = 0; c < C; c++) r[(size_t)(1 + c) * cap] = __float_as_uint(s_val[c][j]);
         } else {
@@ -731,7 +733,7 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
                 for (int u = 0; u < U; u++) {
                     const uint32_t i = i0 + u * kTileThreads;
                     const uint32_t ic = i < n ? i : n - 1;
-                    loc[u] = r[ic];
+                    loc[u] = reinterpret_cast<const uint16_t*>(r)[ic];
 #pragma unroll
                     for (int c = 0; c < C; c++) val[u][c] = __uint_as_float(r[(size_t)(1 + c) * cap + ic]);
                 }
