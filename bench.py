@@ -233,6 +233,10 @@ def main():
                            "chosen_prefetch_at": harness.prefetch_at}
             if harness.comm_dtype is None:      # reported only: what the opt-in 16-bit wire format would give here
                 comm_tuning["bf16_wire_ms_per_step"] = harness.probe_comm_dtype(one_step, torch.bfloat16)
+        # the tuning steps must not change what the timed region holds: back to step 0 of the density-grid schedule
+        # (full sweeps for the first 16 updates, renderer.py:484), as in the N = 1 run
+        harness.global_step = 0
+        model.iter_density = 0
     # warm-up runs with the same timing hooks as the timed region, so their events exist before the clock starts
     _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
     for i in range(args.warmup):
