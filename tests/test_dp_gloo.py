@@ -5,7 +5,6 @@ import os
 import socket
 import sys
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

@@ -2,11 +2,10 @@
 numpy.packbits, scipy spherical harmonics, torch autograd, and the reference's own cumprod compositing
 (tests/golden/ref_composite_vs_run.npz, minted from NeRFRenderer.run by oracle/make_golden.py)."""
 import numpy as np
-import pytest
 import torch
 
 from oracle import oracle as O
-from util import golden, assert_close
+from util import golden
 
 
 def test_pcg32_canonical_stream():
@@ -63,7 +62,13 @@ def test_packbits_vs_numpy():
 
 
 def _real_sh_scipy(deg, v):
-    from scipy.special import sph_harm
+    try:                                 # SciPy >= 1.15: sph_harm_y(l, m, polar, azimuth)
+        from scipy.special import sph_harm_y
+
+        def sph_harm(m, l, azimuth, polar):
+            return sph_harm_y(l, m, polar, azimuth)
+    except ImportError:
+        from scipy.special import sph_harm
     x, y, z = v[:, 0].astype(np.float64), v[:, 1].astype(np.float64), v[:, 2].astype(np.float64)
     theta = np.arctan2(y, x)           # azimuth
     phi = np.arccos(np.clip(z, -1, 1))   # polar

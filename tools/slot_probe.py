@@ -17,7 +17,6 @@ for bound in (2, 3):
         log.append((n_alive, n_step, n_alive * n_step, real))
         return out
     raymarching.march_rays = spy
-    import enerf_amd.renderer as R
     with torch.no_grad():
         m.render(ro, rd, staged=False, bg_color=None, perturb=False)
     raymarching.march_rays = orig
