@@ -15,6 +15,12 @@ Extra objects on that line:
   cpu_baseline  the reference's pure-PyTorch route (NeRFRenderer.run, 512 stratified samples per ray, nn.Linear nets,
                 fwd + bwd + Adam) re-stated in enerf_amd and run on the host cores with the C oracle as the native
                 backend, on a bounded sample (256 rays/step); rank 0, N=1 only.
+  render        full 640x480 frame through the inference loop (fp32 nets, and the FFMLP bf16 nets: BASELINE configs[4])
+  graph_replay  the same steps with render + loss + backward replayed as a HIP graph (N = 1)
+  comm_tuning   N > 1: measured ms/step per cut of the table-gradient all-reduce and per placement of the next batch's
+                march (TrainHarness.tune_comm, untimed, before the warm-up) with the choices made, and the step time the
+                opt-in bf16 wire format would give (reported only)
+Defaults: N = 1, 20 warm-up + 200 timed steps (0.13 s), then the render / graph / CPU legs: about a minute in all.
 """
 import argparse
 import json
