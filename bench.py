@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
     # development aids: exercise the N > 1 code path on a single-GPU box (gloo all-reduce, every rank on one device)
+    ap.add_argument("--verify-samples", action="store_true",
+                    help="also count the timed steps' samples with one launch per render and compare (development aid)")
     ap.add_argument("--march-bg-blocks", type=int, default=0, help="tuning: workgroups of the side-stream march (0 = auto)")
     ap.add_argument("--no-comm-tune", action="store_true", help="N > 1: keep comm_chunks = 4 instead of timing 1/2/4/8")
     ap.add_argument("--backend", default=None, help="torch.distributed backend override (default: nccl = RCCL)")
@@ -256,17 +258,44 @@ def main():
     # are in profiles/ (rocprofv3) -- timing all of them costs ~25 event records per step, 5 % of a 1 ms step
     _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
     sync()
+
+    # ray samples of the timed steps: the march's scan pass keeps a running total on the device
+    # (enerf_march_train_samples) -- no bookkeeping launch inside the timed region.  A march issued ahead of its step
+    # (side-stream prefetch) belongs to the step that renders it: its count is moved across the region's two borders.
+    def pending_marches():
+        stash = getattr(model, "_premarched", None) or {}
+        return sum(int(model.step_counter[p["slot"], 0]) for p in stash.values() if p.get("slot") is not None)
+
+    def marched_total(reset):
+        import ctypes
+        v = ctypes.c_uint64(0)
+        _lib.check(_lib.lib().enerf_march_train_samples(ctypes.byref(v), int(reset), _lib.stream_handle()),
+                   "march_train_samples")
+        return int(v.value)
+
+    torch.cuda.synchronize()
+    ahead_at_start = pending_marches()
+    marched_total(reset=True)
+    sync()
     t0 = time.perf_counter()
+    # (graph mode counts per step: a capture inside the timed region runs warm-up marches that are not steps)
+    per_step = torch.zeros((), dtype=torch.int64, device=device) if args.verify_samples or args.graphs else None
     for i in range(args.warmup, args.warmup + args.steps):
         one_step(i)
-        # slot of the render(s) this step consumed (a prefetched march of the next step may already own the newest one)
-        slot = getattr(model, "rendered_counter_slot", None)
-        slot = (model.local_step - 1) % 16 if slot is None else slot
-        samples_acc.add_(model.step_counter[slot, 0])              # bookkeeping: one tiny launch per render
-        if args.mode == "events":
-            samples_acc.add_(model.step_counter[(slot - 1) % 16, 0])
+        if per_step is not None:      # the per-step bookkeeping the running total replaces (one tiny launch per render)
+            slot = getattr(model, "rendered_counter_slot", None)
+            slot = (model.local_step - 1) % 16 if slot is None else slot
+            per_step.add_(model.step_counter[slot, 0])
+            if args.mode == "events":
+                per_step.add_(model.step_counter[(slot - 1) % 16, 0])
     sync()
     t1 = time.perf_counter()
+    if args.graphs:
+        samples_acc += per_step
+    else:
+        samples_acc += marched_total(reset=False) + ahead_at_start - pending_marches()
+        if per_step is not None:
+            assert int(per_step.item()) == int(samples_acc.item()), (int(per_step.item()), int(samples_acc.item()))
     _lib.prof.enable(False)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if world > 1:

@@ -67,6 +67,7 @@ SIGNATURES = {
     "enerf_adam_step": [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u32, _int, _vp],
     "enerf_allocate_splitk": [_sz],
     "enerf_free_splitk": [],
+    "enerf_march_train_samples": [_c.POINTER(_c.c_uint64), _int, _vp],
     "enerf_prof_enable": [_int],
     "enerf_prof_reset": [],
     "enerf_prof_read": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],

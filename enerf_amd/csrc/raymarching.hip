@@ -693,6 +693,10 @@ __global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ ra
     rays[(size_t)n * 3 + 2] = (int32_t)march_one_ray<false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr);
 }
 
+// samples reserved by all march_rays_train calls since the last reset (enerf_march_train_samples): lets a harness
+// report ray-samples/s without a bookkeeping launch per step
+__device__ unsigned long long g_train_samples = 0ull;
+
 __global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* counter, uint32_t N) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
@@ -718,6 +722,7 @@ __global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* cou
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        g_train_samples += (unsigned long long)(carry_s - (uint32_t)counter[0]);
         counter[0] = (int32_t)carry_s;
         counter[1] += (int32_t)N;
     }
@@ -1205,6 +1210,22 @@ int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t*
 }
 
 static uint32_t g_march_bg_blocks = 0;
+
+int enerf_march_train_samples(uint64_t* total, int reset, enerf_stream_t stream) {
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) ENERF_BADARG("march_train_samples: stream sync failed");
+    unsigned long long v = 0ull;
+    if (total) {
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_train_samples), sizeof(v)) != hipSuccess)
+            ENERF_BADARG("march_train_samples: read failed");
+        *total = (uint64_t)v;
+    }
+    if (reset) {
+        v = 0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_train_samples), &v, sizeof(v)) != hipSuccess)
+            ENERF_BADARG("march_train_samples: reset failed");
+    }
+    return 0;
+}
 
 int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,

@@ -370,6 +370,10 @@ int enerf_debug_grid_bwd_binned(uint32_t min_batch, uint32_t min_tiles);
 #define ENERF_K_COMPOSITE_INFER 9
 #define ENERF_K_COUNT 10
 
+/* Measurement aid: samples reserved (counter[0] increments) by all enerf_march_rays_train[_ex] calls of this process
+ * since the last reset, kept on the device by the march's own scan pass.  Synchronises `stream`, then reads (total may
+ * be NULL) and optionally resets. */
+int enerf_march_train_samples(uint64_t* total, int reset, enerf_stream_t stream);
 int enerf_prof_enable(int on);
 /* bit k of `mask` enables timing of kernel family k only (each timed call costs two event records on the stream) */
 int enerf_prof_enable_mask(uint32_t mask);
