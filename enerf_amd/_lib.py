@@ -27,6 +27,8 @@ SIGNATURES = {
                                                  _vp],
     "enerf_composite_rays_train_backward_mse": [_vp, _vp, _f32, _vp, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 _u32, _u32, _vp, _vp, _vp, _vp],
+    "enerf_composite_rays_train_fwd_bwd_mse": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _f32, _vp, _vp, _f32,
+                                               _vp, _vp, _vp, _vp, _vp],
     "enerf_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "enerf_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                          _vp, _u32, _vp],

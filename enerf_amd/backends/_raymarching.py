@@ -115,6 +115,18 @@ def composite_rays_train_backward_mse(out_image, target, grad_scale, bg_color, c
         None if loss is None else _f32(loss, "loss"), L.stream_handle()), "composite_rays_train_backward_mse")
 
 
+def composite_rays_train_fwd_bwd_mse(sigmas, rgbs, deltas, rays, M, N, weights_sum, image, bg_color, out_image, target,
+                                     grad_scale, counter, grad_sigmas, grad_rgbs, loss=None):
+    """forward_blend + backward_mse(target) in one launch (include/enerf_hip.h)."""
+    bg, stride, scalar = _background(bg_color, N)
+    L.check(L.lib().enerf_composite_rays_train_fwd_bwd_mse(
+        _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"), _f32(deltas, "deltas"), _i32(rays, "rays"), int(M), int(N),
+        _f32(weights_sum, "weights_sum"), _f32(image, "image"), bg, stride, scalar, _f32(out_image, "out_image"),
+        _f32(target, "target"), float(grad_scale), _i32(counter, "counter"), _f32(grad_sigmas, "grad_sigmas"),
+        _f32(grad_rgbs, "grad_rgbs"), None if loss is None else _f32(loss, "loss"), L.stream_handle()),
+        "composite_rays_train_fwd_bwd_mse")
+
+
 def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image):
     L.check(L.lib().enerf_composite_rays_train_forward(_f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"),
                                                        _f32(deltas, "deltas"), _i32(rays, "rays"), int(M), int(N),

@@ -941,6 +941,115 @@ __global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
     }
 }
 
+// Forward, blend, MSE gradient and backward of composite_rays_train for one ray in one wavefront: the closed-form
+// training step needs nothing between the two compositing kernels, so the second pass over the ray's samples follows
+// the first while they are still in L2, image / weights_sum stay in registers, and one launch (and the gap before it)
+// disappears.  Same arithmetic, in the same order, as k_composite_train_fwd + k_composite_train_bwd<true>.
+__global__ void __launch_bounds__(1024) k_composite_train_fwd_bwd_mse(
+    const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
+    const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float* weights_sum, float* image, float* out_image,
+    float* grad_sigmas, float* grad_rgbs, MseTail mse, uint32_t ray_blocks) {
+    if (blockIdx.x >= ray_blocks) {
+        const uint32_t used = min((uint32_t)mse.counter[0], M);
+        const uint32_t tid = (blockIdx.x - ray_blocks) * blockDim.x + threadIdx.x;
+        const uint32_t nth = (gridDim.x - ray_blocks) * blockDim.x;
+        for (size_t i = (size_t)used + tid; i < (size_t)M; i += nth) grad_sigmas[i] = 0.0f;
+        for (size_t i = (size_t)used * 3 + tid; i < (size_t)M * 3; i += nth) grad_rgbs[i] = 0.0f;
+        return;
+    }
+    const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    const bool live = n < N;
+    uint32_t index = 0, offset = 0, num_steps = 0;
+    if (live) {
+        index = (uint32_t)rays[(size_t)n * 3];
+        offset = (uint32_t)rays[(size_t)n * 3 + 1];
+        num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    }
+    const bool marched = live && num_steps != 0 && offset + num_steps < M;
+    // ---- forward
+    CompCarry k = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (marched) {
+        for (uint32_t s0 = 0; s0 < num_steps; s0 += 64) {
+            const uint32_t s = s0 + lane;
+            const bool active = s < num_steps;
+            const size_t p = (size_t)offset + (active ? s : 0);
+            const float sigma = sigmas[p];
+            const float2 dl = reinterpret_cast<const float2*>(deltas)[p];
+            const float c0 = rgbs[p * 3], c1 = rgbs[p * 3 + 1], c2 = rgbs[p * 3 + 2];
+            float w, T_post, r_i, g_i, b_i, ws_i;
+            comp_chunk(active, sigma, dl.x, dl.y, c0, c1, c2, lane, k, w, T_post, r_i, g_i, b_i, ws_i);
+        }
+    }
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    if (live) {
+        if (marched) {
+            const float rest = 1.0f - k.ws;
+            o0 = __fadd_rn(k.r, __fmul_rn(rest, mse.bg.at(index, 0)));
+            o1 = __fadd_rn(k.g, __fmul_rn(rest, mse.bg.at(index, 1)));
+            o2 = __fadd_rn(k.b, __fmul_rn(rest, mse.bg.at(index, 2)));
+        } else {
+            o0 = mse.bg.at(index, 0); o1 = mse.bg.at(index, 1); o2 = mse.bg.at(index, 2);
+        }
+        if (lane == 0) {
+            weights_sum[index] = marched ? k.ws : 0.0f;
+            image[(size_t)index * 3] = marched ? k.r : 0.0f;
+            image[(size_t)index * 3 + 1] = marched ? k.g : 0.0f;
+            image[(size_t)index * 3 + 2] = marched ? k.b : 0.0f;
+            out_image[(size_t)index * 3] = o0; out_image[(size_t)index * 3 + 1] = o1; out_image[(size_t)index * 3 + 2] = o2;
+        }
+    }
+    // ---- loss value (every ray contributes, marched or not)
+    if (mse.loss) {
+        __shared__ float s_err[16];
+        float e = 0.0f;
+        if (live && lane < 3) {
+            const float d = (lane == 0 ? o0 : lane == 1 ? o1 : o2) - mse.target[(size_t)index * 3 + lane];
+            e = d * d;
+        }
+        e += __shfl_down(e, 2, 64);
+        e += __shfl_down(e, 1, 64);
+        if (lane == 0) s_err[threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += s_err[w];
+            atomicAdd(mse.loss, t * mse.loss_scale);
+        }
+    }
+    // ---- backward
+    if (!marched) {
+        if (live && num_steps != 0 && offset < M) {          // a dropped ray's reservation, clipped to the buffer
+            for (size_t i = (size_t)offset + lane; i < (size_t)M; i += 64) grad_sigmas[i] = 0.0f;
+            for (size_t i = (size_t)offset * 3 + lane; i < (size_t)M * 3; i += 64) grad_rgbs[i] = 0.0f;
+        }
+        return;
+    }
+    float gi0 = o0 - mse.target[(size_t)index * 3], gi1 = o1 - mse.target[(size_t)index * 3 + 1],
+          gi2 = o2 - mse.target[(size_t)index * 3 + 2];
+    gi0 *= mse.scale; gi1 *= mse.scale; gi2 *= mse.scale;
+    const float gws = -(gi0 * mse.bg.at(index, 0) + gi1 * mse.bg.at(index, 1) + gi2 * mse.bg.at(index, 2));
+    const float r_final = k.r, g_final = k.g, b_final = k.b, ws_final = k.ws;
+    CompCarry kb = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t s0 = 0; s0 < num_steps; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool active = s < num_steps;
+        const size_t p = (size_t)offset + (active ? s : 0);
+        const float sigma = sigmas[p];
+        const float2 dl = reinterpret_cast<const float2*>(deltas)[p];
+        const float c0 = rgbs[p * 3], c1 = rgbs[p * 3 + 1], c2 = rgbs[p * 3 + 2];
+        float w, T, r_i, g_i, b_i, ws_i;
+        comp_chunk(active, sigma, dl.x, dl.y, c0, c1, c2, lane, kb, w, T, r_i, g_i, b_i, ws_i);
+        if (active) {
+            grad_rgbs[p * 3] = gi0 * w;
+            grad_rgbs[p * 3 + 1] = gi1 * w;
+            grad_rgbs[p * 3 + 2] = gi2 * w;
+            grad_sigmas[p] = dl.x * (gi0 * (T * c0 - (r_final - r_i)) + gi1 * (T * c1 - (g_final - g_i)) +
+                                     gi2 * (T * c2 - (b_final - b_i)) + gws * (T - (ws_final - ws_i)));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ inference: march / composite / compact
 // One thread per ray, dt_gamma == 0, with the fast cell evaluator and the empty-voxel skip in closed form.  The
 // reference's `do { t += dt; } while (t < tt);` walks the lattice t, fl(t + dt), ... one addition at a time; inside a
@@ -1356,6 +1465,34 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
                 1.0f / (3.0f * (float)N)},
         ray_blocks);
     ENERF_LAUNCH_CHECK("composite_rays_train_backward_mse");
+    return 0;
+}
+
+int enerf_composite_rays_train_fwd_bwd_mse(const float* sigmas, const float* rgbs, const float* deltas,
+                                           const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
+                                           float* image, const float* bg_color, uint32_t bg_stride, float bg_scalar,
+                                           float* out_image, const float* target, float grad_scale,
+                                           const int32_t* counter, float* grad_sigmas, float* grad_rgbs, float* loss,
+                                           enerf_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (M) {
+            (void)hipMemsetAsync(grad_sigmas, 0, (size_t)M * 4, s);
+            (void)hipMemsetAsync(grad_rgbs, 0, (size_t)M * 12, s);
+        }
+        return 0;
+    }
+    if (!counter || !target || !out_image || !weights_sum || !image)
+        ENERF_BADARG("composite_rays_train_fwd_bwd_mse: counter, target, out_image, weights_sum and image are required");
+    if (bg_color && bg_stride != 0 && bg_stride != 3) ENERF_BADARG("composite_rays_train_fwd_bwd_mse: bg_stride %u", bg_stride);
+    ProfScope prof(ENERF_K_COMPOSITE_BWD, s);
+    const uint32_t ray_blocks = div_up(N, 16);
+    k_composite_train_fwd_bwd_mse<<<ray_blocks + 16, 1024, 0, s>>>(
+        sigmas, rgbs, deltas, rays, M, N, weights_sum, image, out_image, grad_sigmas, grad_rgbs,
+        MseTail{nullptr, target, grad_scale, Background{bg_color, bg_stride, bg_scalar}, counter, loss,
+                1.0f / (3.0f * (float)N)},
+        ray_blocks);
+    ENERF_LAUNCH_CHECK("composite_rays_train_fwd_bwd_mse");
     return 0;
 }
 

@@ -195,9 +195,14 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
     return pre
 
 
-def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024):
+FUSED_COMPOSITE = True        # train_step_mse: compositing forward + MSE backward as one launch
+
+
+def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, composite=True):
     """Forward half of a training render without autograd: -> (image [N,3] blended with bg_color, ctx).  Feed the
-    gradient of whatever loss was computed on `image` to backward_raw(ctx, ...).  No depth."""
+    gradient of whatever loss was computed on `image` to backward_raw(ctx, ...).  No depth.  composite=False leaves
+    the compositing to backward_raw(target=...), which then runs it fused with its backward (the image is valid once
+    that call is queued)."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     N = rays_o.shape[0]
@@ -221,10 +226,11 @@ def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0
         out_image = torch.empty(N, 3, dtype=torch.float32, device=dev)
         if isinstance(bg_color, torch.Tensor):
             bg_color = bg_color.detach().to(torch.float32).contiguous()
-        _rb.composite_rays_train_forward_blend(sigmas, rgb, deltas, rays, M, N, weights_sum, None, image, bg_color,
-                                               out_image)
+        if composite:
+            _rb.composite_rays_train_forward_blend(sigmas, rgb, deltas, rays, M, N, weights_sum, None, image, bg_color,
+                                                   out_image)
     ctx = dict(sv=sv, sigmas=sigmas, rgb=rgb, deltas=deltas, rays=rays, weights_sum=weights_sum, image=image,
-               out_image=out_image, bg=bg_color, counter=pre["counter"], M=M, N=N, scale=scale)
+               out_image=out_image, bg=bg_color, counter=pre["counter"], M=M, N=N, scale=scale, composited=composite)
     return out_image, ctx
 
 
@@ -237,12 +243,18 @@ def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, ra
     with torch.no_grad():
         g_sigmas = torch.empty_like(ctx["sigmas"])
         g_rgbs = torch.empty_like(ctx["rgb"])
-        if target is not None:
+        if target is not None and not ctx["composited"]:
+            _rb.composite_rays_train_fwd_bwd_mse(ctx["sigmas"], ctx["rgb"], ctx["deltas"], ctx["rays"], M, N,
+                                                 ctx["weights_sum"], ctx["image"], ctx["bg"], ctx["out_image"],
+                                                 target.contiguous().view(-1, 3), 2.0 * float(upstream) / (3 * N),
+                                                 ctx["counter"], g_sigmas, g_rgbs, loss_out)
+        elif target is not None:
             _rb.composite_rays_train_backward_mse(ctx["out_image"], target.contiguous().view(-1, 3),
                                                   2.0 * float(upstream) / (3 * N), ctx["bg"], ctx["counter"],
                                                   ctx["sigmas"], ctx["rgb"], ctx["deltas"], ctx["rays"],
                                                   ctx["weights_sum"], ctx["image"], M, N, g_sigmas, g_rgbs, loss_out)
         else:
+            assert ctx["composited"], "render_train_raw(composite=False) needs backward_raw(target=...)"
             _rb.composite_rays_train_backward_mse(g_image.detach().to(torch.float32).contiguous().view(-1, 3), None,
                                                   1.0, ctx["bg"], ctx["counter"], ctx["sigmas"], ctx["rgb"],
                                                   ctx["deltas"], ctx["rays"], ctx["weights_sum"], ctx["image"], M, N,
@@ -262,7 +274,8 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
     AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued;
     `loss_out` (a zeroed device scalar) receives the loss value from the backward kernel itself; raw=True returns the
     gradients as (embedding gradient, flat MLP dW accumulator) -- see fused_network.nerf_backward."""
-    out_image, ctx = render_train_raw(model, rays_o, rays_d, bg_color, perturb, dt_gamma, max_steps)
+    out_image, ctx = render_train_raw(model, rays_o, rays_d, bg_color, perturb, dt_gamma, max_steps,
+                                      composite=not FUSED_COMPOSITE)
     if after_forward is not None:
         after_forward()                         # e.g. prefetch_march of the next batch on a side stream
     return out_image, backward_raw(ctx, target=target, upstream=upstream, loss_out=loss_out, raw=raw)

@@ -166,6 +166,18 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
                                             const float* image, uint32_t M, uint32_t N, float* grad_sigmas,
                                             float* grad_rgbs, float* loss, enerf_stream_t stream);
 
+/* composite_rays_train forward (+ blend) and its MSE backward in ONE launch, for steps whose loss is
+ * mean((out_image - target)^2) * upstream (the reference's default criterion, nerf/utils.py:628): equals
+ * enerf_composite_rays_train_forward_blend (depth not computed) followed by
+ * enerf_composite_rays_train_backward_mse(out_image, target, ...), bit for bit; weights_sum / image / out_image are
+ * still written. */
+int enerf_composite_rays_train_fwd_bwd_mse(const float* sigmas, const float* rgbs, const float* deltas,
+                                           const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
+                                           float* image, const float* bg_color, uint32_t bg_stride, float bg_scalar,
+                                           float* out_image, const float* target, float grad_scale,
+                                           const int32_t* counter, float* grad_sigmas, float* grad_rgbs, float* loss,
+                                           enerf_stream_t stream);
+
 /* raymarching.cu:807-813  march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
  *                                    max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, perturb) */
 int enerf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,

@@ -327,6 +327,18 @@ def test_composite_blend_forward_and_mse_backward(rm, scenes, bg_kind, overflow)
         if n and off + n < M:
             covered[off:off + n] = True
     assert not gs1[~covered].any() and not gc1[~covered].any() and (~covered).sum() > (0 if overflow else 2000)
+    # both halves in one launch (..._fwd_bwd_mse): images and gradients bit-identical to forward_blend + backward_mse
+    ws2 = torch.full((N,), float("nan"), device=DEV); im2 = torch.full((N, 3), float("nan"), device=DEV)
+    out2 = torch.full((N, 3), float("nan"), device=DEV)
+    gs2 = torch.full((M,), float("nan"), device=DEV); gc2 = torch.full((M, 3), float("nan"), device=DEV)
+    loss2 = torch.full((1,), 2.0, device=DEV)
+    rm.composite_rays_train_fwd_bwd_mse(sig, rgb, dl, rays_t, M, N, ws2, im2, bg, out2, target, scale, cnt, gs2, gc2, loss2)
+    assert torch.equal(ws2, ws0) and torch.equal(im2, im0) and torch.equal(out2, out)
+    assert torch.equal(gs2, gs1) and torch.equal(gc2, gc1)
+    assert abs(float(loss2) - float(loss)) <= 1e-6 * float(loss)       # (per-workgroup float atomics: order varies)
+    gs3 = torch.full((M,), float("nan"), device=DEV); gc3 = torch.full((M, 3), float("nan"), device=DEV)
+    rm.composite_rays_train_fwd_bwd_mse(sig, rgb, dl, rays_t, M, N, ws2, im2, bg, out2, target, scale, cnt, gs3, gc3)
+    assert torch.equal(gs3, gs1) and torch.equal(gc3, gc1)                    # without the loss value
 
 
 # ------------------------------------------------------------------ inference trio
