@@ -69,6 +69,7 @@ SIGNATURES = {
     "enerf_adam_step": [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u32, _int, _vp],
     "enerf_allocate_splitk": [_sz],
     "enerf_free_splitk": [],
+    "enerf_mlp32_defer_reduce": [_int],
     "enerf_march_train_samples": [_c.POINTER(_c.c_uint64), _int, _vp],
     "enerf_prof_enable": [_int],
     "enerf_prof_reset": [],

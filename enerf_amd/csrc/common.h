@@ -51,7 +51,7 @@ struct ProfScope {
 // Returns a device buffer of at least `bytes`; nullptr on failure.  Slots are independent.
 void* workspace(int slot, size_t bytes);
 uint32_t num_cus();                    // compute units of the current device (256 when it cannot be asked)
-enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_SLOTS = 6 };
+enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_SLOTS = 7 };
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 

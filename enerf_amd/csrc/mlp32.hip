@@ -814,12 +814,18 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
     for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
 }
 
-__global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                                         WDst gw) {
+struct ReduceJob {
+    const float* partial;
+    uint32_t nblocks, NW;
+    WDst dst;
+};
+
+__device__ __forceinline__ void reduce_w_body(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
+                                              const WDst& gw, uint32_t blk) {
     // 64 weights per workgroup; each of the 16 waves sums every 16th partial block with four independent chains
     // (fixed order), then the waves' sums are combined in a fixed order: deterministic.
     __shared__ float acc[16][64];
-    const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t i = blk * 64 + (threadIdx.x & 63);
     const uint32_t part = threadIdx.x >> 6;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (i < NW) {
@@ -842,6 +848,22 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict
         if (dst) *dst = gw.overwrite ? t : *dst + t;
     }
 }
+
+__global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
+                                                         WDst gw) {
+    reduce_w_body(partial, nblocks, NW, gw, blockIdx.x);
+}
+
+// two networks' weight gradients in one launch (the first job was left pending by enerf_mlp32_defer_reduce)
+__global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob b) {
+    const uint32_t na = (a.NW + 63u) / 64u;
+    if (blockIdx.x < na) reduce_w_body(a.partial, a.nblocks, a.NW, a.dst, blockIdx.x);
+    else reduce_w_body(b.partial, b.nblocks, b.NW, b.dst, blockIdx.x - na);
+}
+
+static bool g_defer_next = false;        // one-shot: set by enerf_mlp32_defer_reduce
+static bool g_have_pending = false;
+static ReduceJob g_pending;
 
 bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
@@ -1027,7 +1049,12 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     // workspace for the weight-gradient kernel (whose inner loop is load-bound)
     const bool fused_dy = !fused && (y_sigmoid != nullptr || dsigma != nullptr || dys.stride != out_dim);
     const size_t part_bytes = sizeof(float) * (size_t)wgrid * NW;
-    float* partial = (float*)workspace(WS_FFMLP, part_bytes + (fused_dy ? sizeof(float) * (size_t)B * out_dim : 0));
+    // one-shot deferral (enerf_mlp32_defer_reduce): this call's partial sums wait, in their own workspace, for the next
+    // call's reduce launch
+    const bool defer = g_defer_next && !g_have_pending;
+    g_defer_next = false;
+    float* partial = (float*)workspace(defer ? WS_MLP32_DEFER : WS_FFMLP,
+                                       part_bytes + (fused_dy ? sizeof(float) * (size_t)B * out_dim : 0));
     if (!partial) return ENERF_E_NOMEM;
     float* dy_eff = fused_dy ? partial + (size_t)wgrid * NW : nullptr;
     DySource dys_w = dys;
@@ -1072,8 +1099,22 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
 #undef MLP32_BWD
 #undef MLP32_BWD2
 #undef MLP32_BA
-    k_mlp32_reduce_w<<<div_up(NW, 64), 1024, 0, s>>>(partial, wgrid, NW, dW);
+    if (defer) {
+        g_pending = ReduceJob{partial, wgrid, NW, dW};
+        g_have_pending = true;
+    } else if (g_have_pending) {
+        g_have_pending = false;
+        k_mlp32_reduce_w2<<<div_up(g_pending.NW, 64) + div_up(NW, 64), 1024, 0, s>>>(g_pending,
+                                                                                     ReduceJob{partial, wgrid, NW, dW});
+    } else {
+        k_mlp32_reduce_w<<<div_up(NW, 64), 1024, 0, s>>>(partial, wgrid, NW, dW);
+    }
     ENERF_LAUNCH_CHECK("mlp32_backward");
+    return 0;
+}
+
+int enerf_mlp32_defer_reduce(int on) {
+    g_defer_next = on != 0;
     return 0;
 }
 

@@ -155,6 +155,7 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False):
     dseg_c = (ctypes.c_void_p * 4)(p0 + 4 * o[2], p0 + 4 * o[3], None, p0 + 4 * o[4])
     bb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev)
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
+    lib.enerf_mlp32_defer_reduce(1)          # the colour net's dW partial sums are reduced by the sigma net's launch
     L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, 31, 1, 1,
                                        sv["fb_c"].data_ptr(), B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), 0, 0,
                                        sv["rgb"].data_ptr(), out_c, None, None, 0, stream), "mlp32_backward_p(color)")

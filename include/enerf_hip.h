@@ -340,6 +340,11 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
 /* Testing aid: 1 (default) lets enerf_mlp32_backward use its fused dgrad + wgrad kernel (num_hidden <= 2; `bb` is then
  * not written), 0 forces the separate dgrad / wgrad kernels. */
 int enerf_debug_mlp32_fused_backward(int on);
+/* One-shot: the NEXT enerf_mlp32_backward[_p] call on this process leaves its weight-gradient partial sums pending,
+ * and the call after it reduces both networks' sums in a single launch (a network's two MLPs are always run
+ * back to back: one reduce launch and one launch gap less per step).  The pending sums live in their own workspace;
+ * nothing is written to the first call's dW until the second call. */
+int enerf_mlp32_defer_reduce(int on);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
