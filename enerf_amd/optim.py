@@ -24,14 +24,16 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
-    def step_now(self, only=None, ranges=None):
+    def step_now(self, only=None, ranges=None, zero_grads=False):
         """The update itself.  `step()` is wrapped by torch.optim.Optimizer with profiler / hook plumbing that costs
         ~40 us per call; a training loop that needs neither can call this directly.
 
         only   : restrict the update to these parameters (a data-parallel loop updates each bucket as soon as its
                  all-reduce has landed).  Every parameter must be stepped exactly once per optimisation step.
         ranges : {parameter: (lo, hi)} -- update only elements [lo, hi) of that (fused-path) parameter; the step
-                 count advances on the range starting at 0."""
+                 count advances on the range starting at 0.
+        zero_grads : the fused kernel also clears the gradients it has just read (same pass, no extra launch): a
+                 loop that keeps its gradient buffers can skip the next step's zero-fill."""
         batches = {}          # (beta1, beta2, eps) -> parameters the fused kernel takes, all in one launch
         only = None if only is None else {id(p) for p in only}
         for group in self.param_groups:
@@ -75,4 +77,5 @@ class FusedAdam(torch.optim.Optimizer):
                     vp(*[st["exp_avg"].data_ptr() for _, _, st, _ in chunk]),
                     vp(*[st["exp_avg_sq"].data_ptr() for _, _, st, _ in chunk]),
                     sz(*[p.numel() for p, _, _, _ in chunk]), fl(*[lr for _, _, _, lr in chunk]),
-                    u32(*[st["step"] for _, _, st, _ in chunk]), b1, b2, eps, 0, L.stream_handle()), "adam_step_multi")
+                    u32(*[st["step"] for _, _, st, _ in chunk]), b1, b2, eps, int(bool(zero_grads)),
+                    L.stream_handle()), "adam_step_multi")

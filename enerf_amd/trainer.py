@@ -44,6 +44,7 @@ class TrainHarness:
         # once the "collectives" are (runs beside the gradient all-reduce, where nothing else wants the CUs)
         self.prefetch_at = "forward"
         self._raw_grads = None
+        self._cleared_grad = None     # the embeddings' gradient buffer as the last Adam pass left it (all zeros)
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
         self._loss_ring_clean = False
         self.use_graphs = bool(use_graphs)
@@ -171,8 +172,17 @@ class TrainHarness:
         Leaves the gradients in p.grad, returns the loss."""
         from . import fused_network, fused_render
         m = self.model
-        for p in self._params:                      # nothing accumulates across steps (zero_grad(set_to_none=True))
+        # nothing accumulates across steps (zero_grad(set_to_none=True)) -- except that the hash table's gradient
+        # buffer is kept when the previous step's Adam pass cleared it (step_now(zero_grads=True)): the grid backward
+        # then adds straight into it, with no 52 MB allocation and fill
+        emb = m.encoder.embeddings
+        keep = emb.grad if (not raw and not self.use_graphs and self._cleared_grad is not None
+                            and emb.grad is self._cleared_grad) else None
+        self._cleared_grad = None
+        for p in self._params:
             p.grad = None
+        if keep is not None:
+            emb.grad = keep
         loss = None
         if not self.use_graphs:                     # (a captured graph would always accumulate into the same slot)
             # loss values land in a ring of device scalars, cleared once per lap: no loss kernels, no per-step fill
@@ -317,7 +327,11 @@ class TrainHarness:
             self._finish_distributed(side if late else None)
             return loss
         self._reduce_grads(None if side is not None else next_rays)
-        self._opt_step()
+        if self.avg is None and hasattr(self.opt, "step_now") and not self.use_graphs:
+            self.opt.step_now(zero_grads=True)          # Adam clears what it has read: the next step needs no fill
+            self._cleared_grad = self.model.encoder.embeddings.grad
+        else:
+            self._opt_step()
         return loss
 
     def step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
