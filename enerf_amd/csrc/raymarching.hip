@@ -1373,10 +1373,10 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
         // flag bit 1: the batch is prepared ahead on a side stream.  There the marcher's latency is hidden anyway, and
         // what it costs the step running beside it is its register footprint (66 VGPRs x 4 resident waves per SIMD
         // leave the fused-MLP kernels one wave per SIMD instead of two): one marching wave per SIMD, rays in turn.
-        // (measured, ms/step at 2048 / 8192 / 16384 rays: 0.50 / 0.87 / 1.46 against 0.51 / 0.93 / 1.52 with every ray
-        // in flight; at 65536 rays the turn-taking is too slow for the window -- 5.50 against 4.94 -- so large batches
-        // keep the full launch)
-        const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : (N <= 16384u ? num_cus() : div_up(N, 4));
+        // (measured, ms/step at 2048 / 8192 rays: 0.50 / 0.87 against 0.51 / 0.93 with every ray in flight; at 16384
+        // rays the turn-taking only just fits the window -- 1.46 to 1.62 from run to run against a steady 1.52 -- and
+        // at 65536 it does not: 5.50 against 4.94; larger batches keep the full launch)
+        const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : (N <= 8192u ? num_cus() : div_up(N, 4));
         k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
             rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog);
         k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
