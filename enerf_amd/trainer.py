@@ -176,7 +176,7 @@ class TrainHarness:
         # buffer is kept when the previous step's Adam pass cleared it (step_now(zero_grads=True)): the grid backward
         # then adds straight into it, with no 52 MB allocation and fill
         emb = m.encoder.embeddings
-        keep = emb.grad if (not raw and not self.use_graphs and self._cleared_grad is not None
+        keep = emb.grad if (not self.use_graphs and self._cleared_grad is not None
                             and emb.grad is self._cleared_grad) else None
         self._cleared_grad = None
         for p in self._params:
@@ -214,7 +214,10 @@ class TrainHarness:
         g_emb, dw = self._raw_grads
         self._raw_grads = None
         emb = m.encoder.embeddings
-        emb.grad = g_emb
+        if g_emb is None:
+            g_emb = emb.grad                                  # the kept buffer: the grid backward added into it
+        else:
+            emb.grad = g_emb
         nccl = dist.get_backend() == "nccl"                 # RCCL averages in the collective; gloo only sums
         op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
         inv = 1.0 / dist.get_world_size()
@@ -237,7 +240,8 @@ class TrainHarness:
                 flat[lo:hi].copy_(t)
             if not nccl:
                 flat[lo:hi].mul_(inv)
-            self.opt.step_now(only=[emb], ranges={emb: (lo, hi)})
+            self.opt.step_now(only=[emb], ranges={emb: (lo, hi)}, zero_grads=True)
+        self._cleared_grad = emb.grad                         # every piece cleared by its Adam pass: kept for the next step
         w_dw.wait()
         if not nccl:
             dw.mul_(inv)
