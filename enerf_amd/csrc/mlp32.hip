@@ -1115,6 +1115,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
 
 int enerf_mlp32_defer_reduce(int on) {
     g_defer_next = on != 0;
+    g_have_pending = false;        // a pair always starts here: sums left behind by a pair that never completed are dropped
     return 0;
 }
 
