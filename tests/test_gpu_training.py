@@ -281,6 +281,34 @@ def test_data_parallel_chunked_allreduce_adam_pipeline_matches_bucket_path():
         assert float((a - b).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
 
 
+def test_one_reduce_launch_for_both_networks_is_bit_identical(monkeypatch):
+    """nerf_backward defers the colour net's weight-gradient reduction to the sigma net's reduce launch
+    (enerf_mlp32_defer_reduce): same sums in the same order as two launches, so every gradient is bit-identical."""
+    from enerf_amd import _lib, fused_network as fn
+    from enerf_amd.network import NeRFNetwork
+    torch.manual_seed(3)
+    net = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    B = 40000
+    x = (torch.rand(B, 3, device=DEV) * 2 - 1) * 1.9
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    params = fn.network_params(net)
+    g_sigma = torch.randn(B, device=DEV)
+    g_rgb = torch.randn(B, 3, device=DEV)
+
+    def grads(defer):
+        if not defer:
+            monkeypatch.setattr(_lib.lib(), "enerf_mlp32_defer_reduce", lambda on: 0)
+        with torch.no_grad():
+            _, _, sv = fn.nerf_forward(x, d, fn.network_cfg(net), True, params[0], net.encoder.offsets, *params[1:])
+            g_emb, dw = fn.nerf_backward(sv, g_sigma.clone(), g_rgb.clone(), raw=True)
+        torch.cuda.synchronize()
+        monkeypatch.undo()
+        return g_emb, dw
+    (ea, wa), (eb, wb) = grads(True), grads(False)
+    assert torch.equal(wa, wb) and bool(wa.abs().sum() > 0)
+    assert float((ea - eb).abs().max()) <= 1e-6 * float(ea.abs().max())      # (coarse levels: float atomics)
+
+
 def _rccl_worker(rank, world, port, out):
     import os
     import torch.distributed as dist
