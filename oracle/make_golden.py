@@ -289,6 +289,62 @@ def gold_misc():
     save("ref_misc", x=x, trunc_exp=y, trunc_exp_grad=x.grad, p=p, freq=f(p))
 
 
+def gold_sh_literals():
+    """The reference's SH kernel is a literal table of 64 polynomials + 3 x 64 partial derivatives
+    (shencoder/src/shencoder.cu:51-121 and :131-351).  This job PARSES those assignment statements at mint time and
+    evaluates them in float64 numpy at fixed points (on and off the unit sphere) -- i.e. it runs the reference's own
+    statement of the math, not ours.  Only the points and the evaluated numbers are stored."""
+    import re
+    src = open(os.path.join(ref_import.REFERENCE, "shencoder", "src", "shencoder.cu")).read().splitlines()
+    body = src[26:383]                                   # kernel_sh: lines 27..383
+    pat = re.compile(r"^\s*(outputs|dx|dy|dz)\[(\d+)\]\s*=\s*(.*?);")
+    table = {"outputs": {}, "dx": {}, "dy": {}, "dz": {}}
+    for line in body:
+        m = pat.match(line)
+        if not m:
+            continue
+        expr = re.sub(r"(\d+\.\d*(?:[eE][-+]?\d+)?|\d+)f\b", r"\1", m.group(3))     # 3.0f -> 3.0
+        expr = expr.replace("pow(z, 3)", "(z*z*z)")
+        table[m.group(1)][int(m.group(2))] = expr
+    assert all(sorted(t) == list(range(64)) for t in table.values()), {k: len(v) for k, v in table.items()}
+    g = torch.Generator().manual_seed(4242)
+    d = (torch.rand(96, 3, generator=g, dtype=torch.float64) * 2 - 1).numpy()
+    d[:64] /= np.linalg.norm(d[:64], axis=-1, keepdims=True)          # 64 unit directions, 32 raw points in [-1,1]^3
+    d[0] = (0.0, 0.0, 1.0)
+    d[1] = (1.0, 0.0, 0.0)
+    d[2] = (0.0, -1.0, 0.0)
+    d = d.astype(np.float32).astype(np.float64)                       # exactly representable in the kernels' fp32
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    env = dict(x=x, y=y, z=z, xy=x * y, xz=x * z, yz=y * z, x2=x * x, y2=y * y, z2=z * z)
+    env.update(x4=env["x2"] ** 2, y4=env["y2"] ** 2, z4=env["z2"] ** 2)
+    env.update(x6=env["x4"] * env["x2"], y6=env["y4"] * env["y2"], z6=env["z4"] * env["z2"])
+    ev = lambda e: np.broadcast_to(np.asarray(eval(e, {"__builtins__": {}}, env), np.float64), x.shape)  # noqa: E731
+    Y = np.stack([ev(table["outputs"][k]) for k in range(64)], -1)                        # [P, 64]
+    J = np.stack([np.stack([ev(table[a][k]) for k in range(64)], -1) for a in ("dx", "dy", "dz")], 1)   # [P, 3, 64]
+    save("ref_sh_literals", d=d.astype(np.float32), y=Y, dy_dx=J)
+
+
+def gold_near_far_from_bound():
+    """nerf/renderer.py:48-72 near_far_from_bound(type='cube') is the reference's own second statement of the slab
+    test of near_far_from_aabb (raymarching.cu:94-158).  Documented deltas: `+1e-15` in the divisor, misses -> 1e9
+    (kernel: FLT_MAX), min_near hard-coded to 0.05."""
+    from nerf.renderer import near_far_from_bound
+    out = {}
+    for bound in (1, 2, 3):
+        o, d = (t[0] for t in _rays(96, 300 + bound, bound))
+        g = torch.Generator().manual_seed(310 + bound)
+        o = torch.cat([o, (torch.rand(32, 3, generator=g) * 2 - 1) * bound * 0.9])      # origins inside the cube
+        dd = torch.rand(32, 3, generator=g) * 2 - 1
+        d = torch.cat([d, dd / dd.norm(dim=-1, keepdim=True)])
+        # rays that miss the cube: far outside, pointing sideways
+        o = torch.cat([o, torch.tensor([[5.0 * bound, 5.0 * bound, 0.1], [-4.0 * bound, 0.3, 6.0 * bound]])])
+        d = torch.cat([d, torch.tensor([[0.0, 0.6, 0.8], [0.6, 0.8, 0.0]])])
+        near, far = near_far_from_bound(o[None], d[None], bound, type="cube")
+        out[f"o_b{bound}"], out[f"d_b{bound}"] = o, d
+        out[f"near_b{bound}"], out[f"far_b{bound}"] = near.reshape(-1), far.reshape(-1)
+    save("ref_near_far_from_bound", **out)
+
+
 def gold_state_dict_schema():
     """state_dict layout (key -> shape, dtype) of the reference's two network classes with cuda_ray on, at the bounds
     of the BASELINE configs: what a reference `.pth` checkpoint's 'model' entry looks like (nerf/utils.py
@@ -318,7 +374,8 @@ def main():
     ref_import.install()
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
-            gold_composite_vs_run, gold_events, gold_misc, gold_state_dict_schema]
+            gold_composite_vs_run, gold_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
+            gold_state_dict_schema]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

@@ -53,6 +53,24 @@ def test_near_far_bit_exact(rm):
     assert np.array_equal(nears.cpu().numpy(), n_ref) and np.array_equal(fars.cpu().numpy(), f_ref)
 
 
+def test_near_far_vs_reference_near_far_from_bound(rm):
+    """HIP near_far_from_aabb against the imported reference's own near_far_from_bound (nerf/renderer.py:48-72; fixture
+    minted by oracle/make_golden.py; deltas: +1e-15 divisor, miss = 1e9 vs FLT_MAX, min_near 0.05)."""
+    from util import golden
+    g = golden("ref_near_far_from_bound")
+    FLT_MAX = np.float32(3.4028234663852886e38)
+    for bound in (1, 2, 3):
+        o, d = g[f"o_b{bound}"], g[f"d_b{bound}"]
+        aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+        nears = torch.empty(len(o), device=DEV); fars = torch.empty(len(o), device=DEV)
+        rm.near_far_from_aabb(cu(o), cu(d), cu(aabb), len(o), 0.05, nears, fars)
+        near, far = nears.cpu().numpy(), fars.cpu().numpy()
+        miss = g[f"far_b{bound}"] >= 1e9
+        assert np.array_equal(near == FLT_MAX, miss) and np.array_equal(far == FLT_MAX, miss)
+        np.testing.assert_allclose(near[~miss], g[f"near_b{bound}"][~miss], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(far[~miss], g[f"far_b{bound}"][~miss], rtol=2e-6, atol=1e-6)
+
+
 def test_morton_and_packbits_bit_exact(rm, scenes):
     rng = np.random.default_rng(2)
     c = rng.integers(0, 128, (100003, 3)).astype(np.int32)
@@ -622,6 +640,21 @@ def test_sh_encode(deg):
     gi = torch.zeros(B, 3, device=DEV)
     sh.sh_encode_backward(cu(g), cu(v), B, 3, deg, jac, gi)
     np.testing.assert_allclose(gi.cpu().numpy(), gi_ref, rtol=1e-3, atol=1e-4 * deg * deg)
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_encode_vs_reference_literal_tables(deg):
+    """HIP sh_encode against the reference's literal polynomial tables (shencoder.cu:51-121,131-351) evaluated in
+    float64 at mint time (tests/golden/ref_sh_literals.npz), on and off the unit sphere."""
+    from enerf_amd.backends import _shencoder as sh
+    from util import golden
+    g = golden("ref_sh_literals")
+    d, Y, J = g["d"], g["y"], g["dy_dx"]
+    B, C2 = len(d), deg * deg
+    out = torch.empty(B, C2, device=DEV); jac = torch.empty(B, 3 * C2, device=DEV)
+    sh.sh_encode_forward(cu(d), out, B, 3, deg, True, jac)
+    np.testing.assert_allclose(out.cpu().numpy(), Y[:, :C2], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(jac.cpu().numpy().reshape(B, 3, C2), J[:, :, :C2], rtol=1e-4, atol=3e-5)
 
 
 def test_sh_encode_half():
