@@ -22,6 +22,10 @@ SIGNATURES = {
                                _vp, _vp, _u32, _vp],
     "enerf_march_rays_train_ex": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _u32, _u32, _vp],
+    "enerf_march_rays_train_count": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32,
+                                     _vp],
+    "enerf_march_rays_train_write": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _u32, _u32, _vp],
     "enerf_composite_rays_train_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "enerf_composite_rays_train_forward_blend": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _f32, _vp,
                                                  _vp],
@@ -30,6 +34,7 @@ SIGNATURES = {
     "enerf_composite_rays_train_fwd_bwd_mse": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _f32, _vp, _vp, _f32,
                                                _vp, _vp, _vp, _vp, _vp],
     "enerf_composite_rays_train_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
+    "enerf_composite_rays_frame": [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp, _vp, _vp],
     "enerf_march_rays": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                          _vp, _u32, _vp],
     "enerf_march_rays_ex": [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
@@ -103,6 +108,8 @@ def lib():
             fn.restype = _int
         l.enerf_last_error.restype = _c.c_char_p
         l.enerf_last_error.argtypes = []
+        l.enerf_workspace_generation.restype = _c.c_uint64
+        l.enerf_workspace_generation.argtypes = []
         _lib = l
     return _lib
 

@@ -79,6 +79,38 @@ def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, 
                                               L.stream_handle()), "march_rays_train_ex")
 
 
+def march_rays_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, perturb,
+                           flags=0):
+    """Count + scan half of march_rays_train: fills rays / counter, writes no samples (include/enerf_hip.h)."""
+    L.check(L.lib().enerf_march_rays_train_count(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
+                                                 float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
+                                                 _f32(nears, "nears"), _f32(fars, "fars"), _i32(rays, "rays"),
+                                                 _i32(counter, "counter"), int(perturb), int(flags),
+                                                 L.stream_handle()), "march_rays_train_count")
+
+
+def march_rays_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                           rays, counter, perturb, zero_unwritten):
+    """Write half of march_rays_train for the batch last counted (include/enerf_hip.h)."""
+    L.check(L.lib().enerf_march_rays_train_write(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
+                                                 float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
+                                                 int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
+                                                 _f32(dirs, "dirs"), _f32(deltas, "deltas"), _i32(rays, "rays"),
+                                                 _i32(counter, "counter"), int(perturb), int(zero_unwritten),
+                                                 L.stream_handle()), "march_rays_train_write")
+
+
+def composite_rays_frame(sigmas, rgbs, deltas, rays, N, M, nears, fars, bg_color, weights_sum, depth, image,
+                         used_samples=None):
+    """Whole-frame inference compositing over contiguously marched samples (include/enerf_hip.h)."""
+    bg, stride, scalar = _background(bg_color, N)
+    L.check(L.lib().enerf_composite_rays_frame(
+        _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs"), _f32(deltas, "deltas"), _i32(rays, "rays"), int(N), int(M),
+        _f32(nears, "nears"), _f32(fars, "fars"), bg, stride, scalar, _f32(weights_sum, "weights_sum"),
+        _f32(depth, "depth"), _f32(image, "image"), None if used_samples is None else used_samples.data_ptr(),
+        L.stream_handle()), "composite_rays_frame")
+
+
 def _background(bg_color, N):
     """-> (pointer, stride, scalar) of the C ABI's background triple."""
     import torch

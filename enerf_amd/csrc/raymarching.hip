@@ -728,6 +728,73 @@ __global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* cou
     }
 }
 
+// Large ray counts (a whole 640x480 frame marched at once: 307 200 rays): the one-workgroup scan above would walk 300
+// tiles one after the other.  Three launches instead -- per-tile sums, one-workgroup scan of the sums (which also
+// updates the counter), per-tile scan + tile offset.  Same offsets (integer sums: order does not matter).
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wave_tot, uint32_t& block_total) {
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_add_u32(v, lane);
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+    for (int w = 0; w < 16; w++) {
+        const uint32_t x = wave_tot[w];
+        if (w < wid) wave_off += x;
+        tot += x;
+    }
+    block_total = tot;
+    return wave_off + incl - v;
+}
+
+__global__ void __launch_bounds__(1024) k_march_scan_tile_sums(const int32_t* __restrict__ rays, uint32_t N,
+                                                               uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t v = i < N ? (uint32_t)rays[(size_t)i * 3 + 2] : 0u;
+    uint32_t tot;
+    (void)block_excl_scan_1024(v, wave_tot, tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// tile_sums[ntiles] -> exclusive offsets (in place, counter[0] at entry included); counter += (sum, N)
+__global__ void __launch_bounds__(1024) k_march_scan_tiles(uint32_t* tile_sums, uint32_t ntiles, int32_t* counter,
+                                                           uint32_t N) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = (uint32_t)counter[0];
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < ntiles ? tile_sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t excl = block_excl_scan_1024(v, wave_tot, tot);
+        const uint32_t carry = carry_s;
+        if (i < ntiles) tile_sums[i] = carry + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        g_train_samples += (unsigned long long)(carry_s - (uint32_t)counter[0]);
+        counter[0] = (int32_t)carry_s;
+        counter[1] += (int32_t)N;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_march_scan_apply(int32_t* rays, uint32_t N,
+                                                           const uint32_t* __restrict__ tile_offsets) {
+    __shared__ uint32_t wave_tot[16];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t v = i < N ? (uint32_t)rays[(size_t)i * 3 + 2] : 0u;
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan_1024(v, wave_tot, tot);
+    if (i < N) {
+        rays[(size_t)i * 3 + 0] = (int32_t)i;
+        rays[(size_t)i * 3 + 1] = (int32_t)(tile_offsets[blockIdx.x] + excl);
+    }
+}
+
 __global__ void __launch_bounds__(64) k_march_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                     const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -1209,6 +1276,57 @@ __global__ void __launch_bounds__(256) k_composite_rays(uint32_t n_alive, uint32
     image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
 }
 
+// Whole-frame inference compositing (enerf_composite_rays_frame): every ray's samples lie contiguously (the training
+// marcher's layout, rays = (id, offset, count)), so the round structure of the reference's inference loop --
+// march n_step samples, evaluate, accumulate, compact, repeat -- collapses into one pass.  Per ray the arithmetic is
+// that of k_composite_rays applied to the same samples in the same order, sequentially (T = 1 - weight_sum is a running
+// fp32 sum: a parallel scan would round differently), including its termination rule: the sample whose pre-sample
+// transmittance is already < 1e-5 is still accumulated, then the ray stops.  The background blend and the depth
+// normalisation of run_cuda (nerf/renderer.py:398-401) are the epilogue.
+__global__ void __launch_bounds__(256) k_composite_rays_frame(const float* __restrict__ sigmas,
+                                                              const float* __restrict__ rgbs,
+                                                              const float* __restrict__ deltas,
+                                                              const int32_t* __restrict__ rays, uint32_t N, uint32_t M,
+                                                              const float* __restrict__ nears,
+                                                              const float* __restrict__ fars, Background bg,
+                                                              float* weights_sum, float* depth, float* image,
+                                                              uint32_t* __restrict__ used) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[(size_t)n * 3];
+    const uint32_t offset = (uint32_t)rays[(size_t)n * 3 + 1];
+    uint32_t count = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (offset + count >= M) count = 0;                         // the marcher's drop rule (cannot happen with M exact)
+    const float near = nears[index], far = fars[index];
+    float t = near;
+    float weight_sum = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    const float* s = sigmas + offset;
+    const float* c = rgbs + (size_t)offset * 3;
+    const float* dl = deltas + (size_t)offset * 2;
+    uint32_t step = 0;
+    while (step < count) {
+        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dl[1];
+        d = fmaf(weight, t, d);
+        r = fmaf(weight, c[0], r);
+        g = fmaf(weight, c[1], g);
+        b = fmaf(weight, c[2], b);
+        step++;
+        if ((double)T < 1e-5) break;
+        s++; c += 3; dl += 2;
+    }
+    if (used) atomicAdd(used, step);
+    weights_sum[index] = weight_sum;
+    const float rest = 1.0f - weight_sum;
+    image[(size_t)index * 3] = r + rest * bg.at(index, 0);
+    image[(size_t)index * 3 + 1] = g + rest * bg.at(index, 1);
+    image[(size_t)index * 3 + 2] = b + rest * bg.at(index, 2);
+    depth[index] = fmaxf(d - near, 0.0f) / (far - near);
+}
+
 // Stable stream compaction in three small launches: per-block survivor counts (ballot + popcount),
 // one-workgroup scan of the block counts, order-preserving scatter.
 constexpr int kCompactBlock = 1024;
@@ -1344,6 +1462,72 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
                                      dirs, deltas, rays, counter, perturb, 0, stream);
 }
 
+// count pass (+ scan): rays[n] = (n, offset, count), counter += (sum, N); the fixed-step marcher also fills the chunk log
+static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
+                             const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
+                             hipStream_t s) {
+    if (dt_gamma == 0.0f) {
+        // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
+        // the count pass logs every emitting chunk; the write pass replays the log
+        const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
+        if (!ws) return ENERF_E_NOMEM;
+        ChunkEntry* log = (ChunkEntry*)ws;
+        uint32_t* nlog = (uint32_t*)(ws + log_bytes);
+        // `background`: the batch is prepared ahead on a side stream.  There the marcher's latency is hidden anyway, and
+        // what it costs the step running beside it is its register footprint (66 VGPRs x 4 resident waves per SIMD
+        // leave the fused-MLP kernels one wave per SIMD instead of two): one marching wave per SIMD, rays in turn.
+        // (measured, ms/step at 2048 / 8192 rays: 0.50 / 0.87 against 0.51 / 0.93 with every ray in flight; at 16384
+        // rays the turn-taking only just fits the window -- 1.46 to 1.62 from run to run against a steady 1.52 -- and
+        // at 65536 it does not: 5.50 against 4.94; larger batches keep the full launch)
+        const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : (N <= 8192u ? num_cus() : div_up(N, 4));
+        k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
+            rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog);
+    } else {
+        k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
+                                                   fars, rays, perturb);
+    }
+    if (N <= 16384u) {
+        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
+    } else {
+        const uint32_t ntiles = div_up(N, 1024);
+        uint32_t* tiles = (uint32_t*)workspace(WS_SCAN, (size_t)ntiles * sizeof(uint32_t));
+        if (!tiles) return ENERF_E_NOMEM;
+        k_march_scan_tile_sums<<<ntiles, 1024, 0, s>>>(rays, N, tiles);
+        k_march_scan_tiles<<<1, 1024, 0, s>>>(tiles, ntiles, counter, N);
+        k_march_scan_apply<<<ntiles, 1024, 0, s>>>(rays, N, tiles);
+    }
+    return 0;
+}
+
+// write pass: needs `rays` / `counter` (and, for the fixed-step marcher, the chunk log) of the matching count pass
+static int march_train_write(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                             const float* fars, float* xyzs, float* dirs, float* deltas, const int32_t* rays,
+                             const int32_t* counter, uint32_t perturb, uint32_t zero_unwritten, hipStream_t s) {
+    if (dt_gamma == 0.0f) {
+        const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
+        if (!ws) return ENERF_E_NOMEM;
+        const ChunkEntry* log = (const ChunkEntry*)ws;
+        const uint32_t* nlog = (const uint32_t*)(ws + log_bytes);
+        const uint32_t ray_blocks = div_up(N, 4);
+        k_march_write_w<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
+            rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, perturb, log, nlog,
+            zero_unwritten ? counter : nullptr, ray_blocks);
+    } else {
+        if (zero_unwritten) {
+            (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, s);
+            (void)hipMemsetAsync(dirs, 0, (size_t)M * 12, s);
+            (void)hipMemsetAsync(deltas, 0, (size_t)M * 8, s);
+        }
+        k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
+                                                   fars, xyzs, dirs, deltas, rays, perturb);
+    }
+    return 0;
+}
+
 int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                               const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
@@ -1360,43 +1544,53 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays_train: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
-    const bool background = (zero_unwritten & 2u) != 0;
-    zero_unwritten &= 1u;
-    if (dt_gamma == 0.0f) {
-        // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
-        // the count pass logs every emitting chunk; the write pass replays the log
-        const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
-        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
-        if (!ws) return ENERF_E_NOMEM;
-        ChunkEntry* log = (ChunkEntry*)ws;
-        uint32_t* nlog = (uint32_t*)(ws + log_bytes);
-        // flag bit 1: the batch is prepared ahead on a side stream.  There the marcher's latency is hidden anyway, and
-        // what it costs the step running beside it is its register footprint (66 VGPRs x 4 resident waves per SIMD
-        // leave the fused-MLP kernels one wave per SIMD instead of two): one marching wave per SIMD, rays in turn.
-        // (measured, ms/step at 2048 / 8192 rays: 0.50 / 0.87 against 0.51 / 0.93 with every ray in flight; at 16384
-        // rays the turn-taking only just fits the window -- 1.46 to 1.62 from run to run against a steady 1.52 -- and
-        // at 65536 it does not: 5.50 against 4.94; larger batches keep the full launch)
-        const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : (N <= 8192u ? num_cus() : div_up(N, 4));
-        k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
-            rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog);
-        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
-        const uint32_t ray_blocks = div_up(N, 4);
-        k_march_write_w<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
-            rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, perturb, log, nlog,
-            zero_unwritten ? counter : nullptr, ray_blocks);
-    } else {
-        if (zero_unwritten) {
-            (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, s);
-            (void)hipMemsetAsync(dirs, 0, (size_t)M * 12, s);
-            (void)hipMemsetAsync(deltas, 0, (size_t)M * 8, s);
-        }
-        k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
-                                                   fars, rays, perturb);
-        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
-        k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
-                                                   fars, xyzs, dirs, deltas, rays, perturb);
-    }
+    int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
+                               perturb, (zero_unwritten & 2u) != 0, s);
+    if (rc) return rc;
+    rc = march_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                           rays, counter, perturb, zero_unwritten & 1u, s);
+    if (rc) return rc;
     ENERF_LAUNCH_CHECK("march_rays_train");
+    return 0;
+}
+
+int enerf_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                 const float* nears, const float* fars, int32_t* rays, int32_t* counter,
+                                 uint32_t perturb, uint32_t flags, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    if (C == 0 || H < 2 || max_steps == 0)
+        ENERF_BADARG("march_rays_train_count: bad C=%u H=%u max_steps=%u", C, H, max_steps);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_MARCH_TRAIN, s);
+    const int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
+                                     perturb, (flags & 2u) != 0, s);
+    if (rc) return rc;
+    ENERF_LAUNCH_CHECK("march_rays_train_count");
+    return 0;
+}
+
+int enerf_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                 const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                 const int32_t* rays, const int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
+                                 enerf_stream_t stream) {
+    if (N == 0) {
+        if (zero_unwritten && M) {
+            (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, (hipStream_t)stream);
+            (void)hipMemsetAsync(dirs, 0, (size_t)M * 12, (hipStream_t)stream);
+            (void)hipMemsetAsync(deltas, 0, (size_t)M * 8, (hipStream_t)stream);
+        }
+        return 0;
+    }
+    if (C == 0 || H < 2 || max_steps == 0)
+        ENERF_BADARG("march_rays_train_write: bad C=%u H=%u max_steps=%u", C, H, max_steps);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_MARCH_TRAIN, s);
+    const int rc = march_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+                                     deltas, rays, counter, perturb, zero_unwritten & 1u, s);
+    if (rc) return rc;
+    ENERF_LAUNCH_CHECK("march_rays_train_write");
     return 0;
 }
 
@@ -1561,6 +1755,20 @@ int enerf_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_
     k_composite_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas,
                                                           weights_sum, depth, image);
     ENERF_LAUNCH_CHECK("composite_rays");
+    return 0;
+}
+
+int enerf_composite_rays_frame(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                               uint32_t N, uint32_t M, const float* nears, const float* fars, const float* bg_color,
+                               uint32_t bg_stride, float bg_scalar, float* weights_sum, float* depth, float* image,
+                               uint32_t* used_samples, enerf_stream_t stream) {
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_COMPOSITE_INFER, s);
+    const Background bg = {bg_color, bg_stride, bg_scalar};
+    k_composite_rays_frame<<<div_up(N, 256), 256, 0, s>>>(sigmas, rgbs, deltas, rays, N, M, nears, fars, bg, weights_sum,
+                                                          depth, image, used_samples);
+    ENERF_LAUNCH_CHECK("composite_rays_frame");
     return 0;
 }
 

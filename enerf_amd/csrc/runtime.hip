@@ -17,13 +17,25 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- workspaces -----------------------------------------------------------
+// Grow-only scratch buffers, one set per device.  Growing a slot retires the old buffer (drain, free) and bumps a
+// generation counter: anything that baked a workspace pointer into a captured HIP graph compares the counter before
+// replaying and re-captures when it moved (enerf_workspace_generation; TrainHarness does).
+static const int kMaxDevices = 16;
 static std::mutex g_ws_mu;
-static void* g_ws_ptr[WS_SLOTS] = {};
-static size_t g_ws_bytes[WS_SLOTS] = {};
+static void* g_ws_ptr[kMaxDevices][WS_SLOTS] = {};
+static size_t g_ws_bytes[kMaxDevices][WS_SLOTS] = {};
+static uint64_t g_ws_generation = 0;
+
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
 
 void* workspace(int slot, size_t bytes) {
+    const int dev = current_device();
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    if (g_ws_bytes[slot] >= bytes && g_ws_ptr[slot]) return g_ws_ptr[slot];
+    if (g_ws_bytes[dev][slot] >= bytes && g_ws_ptr[dev][slot]) return g_ws_ptr[dev][slot];
     size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
     void* p = nullptr;
     if (hipMalloc(&p, want) != hipSuccess) {
@@ -31,25 +43,30 @@ void* workspace(int slot, size_t bytes) {
         return nullptr;
     }
     // The old buffer may still be in use by kernels in flight on some stream: drain before freeing.
-    if (g_ws_ptr[slot]) {
+    if (g_ws_ptr[dev][slot]) {
         (void)hipDeviceSynchronize();
-        (void)hipFree(g_ws_ptr[slot]);
+        (void)hipFree(g_ws_ptr[dev][slot]);
     }
-    g_ws_ptr[slot] = p;
-    g_ws_bytes[slot] = want;
+    g_ws_ptr[dev][slot] = p;
+    g_ws_bytes[dev][slot] = want;
+    g_ws_generation++;
     return p;
 }
 
+uint64_t workspace_generation() {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    return g_ws_generation;
+}
+
 uint32_t num_cus() {
-    static uint32_t n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        n = (uint32_t)cus;
+    static uint32_t n[kMaxDevices] = {};
+    const int dev = current_device();
+    if (n[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n[dev] = (uint32_t)cus;
     }
-    return n;
+    return n[dev];
 }
 
 // ---- event timing ---------------------------------------------------------
@@ -104,6 +121,7 @@ extern "C" {
 
 const char* enerf_last_error(void) { return enerf::g_err; }
 int enerf_abi_version(void) { return 1; }
+uint64_t enerf_workspace_generation(void) { return enerf::workspace_generation(); }
 
 int enerf_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(enerf::g_prof_mu);

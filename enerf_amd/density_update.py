@@ -72,3 +72,90 @@ def mark_untrained(model, poses, intrinsic):
                                               cx, cy, int(model.cascade), int(model.grid_size), float(model.bound),
                                               model.density_grid.data_ptr(), L.stream_handle()),
             "mark_untrained_grid")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same two maintenance passes as plain tensor programs over the `raymarching` wrappers.  They serve whatever the
+# device-side passes above do not (a backend without them, e.g. the host-side test backend; ENABLED = False) and are the
+# comparator of tests/test_gpu_density_update.py.  Semantics: SURVEY.md 3.4 and Appendix A ("Renderer/network glue").
+
+def _all_cells(H, dev):
+    """Integer coordinates of every grid cell, x fastest (x-neighbours are adjacent rows of every hash-grid level, so a
+    sweep in this order gathers coalesced), and their Morton indices."""
+    ax = torch.arange(H, dtype=torch.int32, device=dev)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
+    return coords, _rm.morton3D(coords).long()
+
+
+def _jittered_density(model, coords, cas):
+    """density * density_scale * dt_min at one uniformly drawn point inside each of the given cells of cascade `cas`."""
+    H = model.grid_size
+    extent = min(2 ** cas, model.bound)
+    half_cell = extent / H
+    centre = (2 * coords.float() / (H - 1) - 1) * (extent - half_cell)
+    pts = centre + (torch.rand_like(centre) * 2 - 1) * half_cell
+    return _sigmas(model, pts) * (model.density_scale * 0.003383)
+
+
+@torch.no_grad()
+def update_torch(model, decay=0.95, chunk=1 << 21):
+    """update_extra_state op by op.  First 16 calls: every cell of every cascade is re-evaluated; afterwards, per
+    cascade, H^3/4 uniformly drawn cells plus H^3/4 draws (with replacement) from the cells whose density is positive.
+    Then: grid <- max(grid * decay, new) where both are valid (>= 0; -1 marks untrained cells), mean of the clamped
+    grid, bitfield at min(mean, density_thresh), sample budget from the step counters."""
+    H, C = model.grid_size, model.cascade
+    dev = model.density_grid.device
+    fresh = torch.full_like(model.density_grid, -1.0)
+    if model.iter_density < 16:
+        coords, cells = _all_cells(H, dev)
+        for cas in range(C):
+            for a in range(0, cells.shape[0], chunk):
+                fresh[cas, cells[a:a + chunk]] = _jittered_density(model, coords[a:a + chunk], cas)
+    else:
+        n = H ** 3 // 4
+        for cas in range(C):
+            uniform = _rm.morton3D(torch.randint(0, H, (n, 3), device=dev)).long()
+            occupied = torch.nonzero(model.density_grid[cas] > 0).squeeze(-1)
+            drawn = occupied[torch.randint(0, occupied.shape[0], [n], dtype=torch.long, device=dev)]
+            cells = torch.sort(torch.cat([uniform, drawn]))[0]          # Morton order: same cells, local gathers
+            fresh[cas, cells] = _jittered_density(model, _rm.morton3D_invert(cells), cas)
+
+    both = (model.density_grid >= 0) & (fresh >= 0)
+    model.density_grid[both] = torch.maximum(model.density_grid[both] * decay, fresh[both])
+    model.mean_density = torch.mean(model.density_grid.clamp(min=0)).item()
+    model.iter_density += 1
+    model.density_bitfield = _rm.packbits(model.density_grid, min(model.mean_density, model.density_thresh),
+                                          model.density_bitfield)
+    windows = min(16, model.local_step)
+    if windows > 0:
+        model.mean_count = int(model.step_counter[:windows, 0].sum().item() / windows)
+    model.local_step = 0
+
+
+@torch.no_grad()
+def mark_untrained_torch(model, poses, intrinsic, cam_chunk=64, cell_chunk=1 << 18):
+    """mark_untrained_grid op by op: a cell of a cascade stays trainable when at least one camera has its centre in
+    front of it (z > 0) and inside the image frustum widened by one cell (|x| < cx/fx * z + 2 * half_cell, same in y);
+    every other cell gets density -1."""
+    H, C = model.grid_size, model.cascade
+    dev = model.density_grid.device
+    poses = torch.as_tensor(poses, dtype=torch.float32).to(dev)
+    fx, fy, cx, cy = intrinsic
+    coords, cells = _all_cells(H, dev)
+    unit = 2 * coords.float() / (H - 1) - 1
+    seen = torch.zeros_like(model.density_grid, dtype=torch.bool)
+    for cas in range(C):
+        extent = min(2 ** cas, model.bound)
+        half_cell = extent / H
+        for a in range(0, cells.shape[0], cell_chunk):
+            world = unit[a:a + cell_chunk] * (extent - half_cell)                              # [P,3]
+            hit = torch.zeros(world.shape[0], dtype=torch.bool, device=dev)
+            for b in range(0, poses.shape[0], cam_chunk):
+                R, t = poses[b:b + cam_chunk, :3, :3], poses[b:b + cam_chunk, :3, 3]
+                cam = (world.unsqueeze(0) - t.unsqueeze(1)) @ R                                # [B,P,3] camera frame
+                x, y, z = cam.unbind(-1)
+                inside = (z > 0) & (x.abs() < cx / fx * z + 2 * half_cell) & (y.abs() < cy / fy * z + 2 * half_cell)
+                hit |= inside.any(0)
+            seen[cas, cells[a:a + cell_chunk]] = hit
+    model.density_grid[~seen] = -1

@@ -179,8 +179,11 @@ def train_step_events_manual(model, data, opt, after_forward=None):
     for p in params:
         p.grad = None
     g_emb, dw1 = fr.backward_raw(ctx1, g_image=g1, raw=True)
-    emb.grad = g_emb                                    # the second backward adds straight into it
-    _, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True)
+    if g_emb is not None:
+        emb.grad = g_emb                                # the second backward adds straight into it ...
+    g_emb2, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True)
+    if g_emb2 is not None:                              # ... unless it could not (then it returns its own buffer)
+        emb.grad.add_(g_emb2)
     dw1 += dw2
     for p, g in zip(params[1:], fnet.unpack_weight_grads(dw1, params[-1].shape[0])):
         p.grad = g.view_as(p)

@@ -135,10 +135,11 @@ def unpack_weight_grads(dw, out_c):
             dw[o[3]:o[4]].view(64, 64), dw[o[4]:].view(out_c, 64))
 
 
-def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False):
+def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False):
     """Gradients of (embeddings, ws0, ws1, wc0, wc1, wc2) given d(sigma) [B] and d(rgb) [B,out] (contiguous fp32).
     `sigma_scale` multiplies d(sigma) on the fly (the renderer's density_scale).  The embedding gradient is None when
-    it was added straight into the parameter's .grad.  raw=True: -> (embedding gradient, flat dW accumulator) -- what a
+    it was added straight into the parameter's .grad (`owner`: the caller drives this backward itself, outside autograd,
+    and owns that buffer; under autograd the shortcut is opt-in, gridencoder.ACCUMULATE_INTO_PARAM_GRAD).  raw=True: -> (embedding gradient, flat dW accumulator) -- what a
     data-parallel caller all-reduces (two buffers) before unpack_weight_grads."""
     B, out_c = sv["B"], sv["out_c"]
     Bp = pad32(B)
@@ -166,10 +167,9 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False):
                                        None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32, stream),
             "mlp32_backward_p(sigma)")
     param, emb = sv["param"], sv["emb"]
-    direct = (_ge.ACCUMULATE_INTO_PARAM_GRAD and param.is_leaf and param.grad is not None
-              and param.grad.dtype == torch.float32 and param.grad.is_contiguous()
-              and param.grad.shape == param.shape and not param._backward_hooks)
-    g_emb = param.grad if direct else torch.zeros_like(emb)
+    target = _ge.param_grad_target(param, torch.float32, owner=owner)
+    direct = target is not None
+    g_emb = target if direct else torch.zeros_like(emb)
     _gb.grid_encode_backward(dfeat, sv["x"], emb, sv["offsets"], g_emb, B, 3, 2, 16, sv["S"], sv["H"], False, dfeat,
                              dfeat, sv["gridtype"], layout=2, affine=sv["affine"])
     if raw:

@@ -24,45 +24,80 @@ def supported(model, rays_o, rays_d, bg_color, dt_gamma):
             and not torch.is_autocast_enabled() and not rays_o.requires_grad and not rays_d.requires_grad
             and _rm._DEVICE == "cuda" and torch.is_grad_enabled()):
         return False
-    if isinstance(bg_color, torch.Tensor) and bg_color.requires_grad:
-        return False
+    if isinstance(bg_color, torch.Tensor):
+        # the composite kernels take a scalar, one RGB or one RGB per ray, fp32 and dense; anything else the reference's
+        # `image + (1 - ws)[:, None] * bg_color` would broadcast goes the op-by-op route
+        if (bg_color.requires_grad or not bg_color.is_cuda or bg_color.dtype != torch.float32
+                or not bg_color.is_contiguous() or bg_color.numel() not in (1, 3, 3 * rays_o.view(-1, 3).shape[0])):
+            return False
     probe = rays_o.view(-1, 3)
     return fnet.supported(model, probe, probe)
 
 
 def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps,
-                background=False):
+                background=False, defer=False):
     """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
     Returns the sample buffers; a data-parallel harness runs it for the NEXT batch while the gradient all-reduce of
-    the current step is in flight (TrainHarness.prefetch_march)."""
+    the current step is in flight (TrainHarness.prefetch_march).
+
+    While no sample budget exists (`mean_count <= 0`: the first update_extra_state window; or `force_all_rays`) the
+    reference's wrapper allocates and zero-fills N * max_steps rows, marches, reads the count back and crops
+    (raymarching/raymarching.py:195-228).  The marcher here counts before it writes, so only the count pass runs first;
+    its total comes back through pinned memory and the write pass goes into buffers of exactly the cropped size
+    (same rows, same `rays` / `counter`: the drop rule still sees min(cropped size, N * max_steps)).  With `defer` the
+    read-back is left to finish_march(): a stage issued ahead of its step has long finished by then, so the wait is
+    free and the cold window runs the same launch sequence as the budgeted steady state."""
     N = rays_o.shape[0]
     dev = rays_o.device
     nears = torch.empty(N, dtype=torch.float32, device=dev)
     fars = torch.empty(N, dtype=torch.float32, device=dev)
     _rb.near_far_from_aabb(rays_o, rays_d, model.aabb_train, N, model.min_near, nears, fars)
-    M = N * max_steps
-    if not force_all_rays and mean_count > 0:
-        M = mean_count + (128 - mean_count % 128)            # raymarching.py:186-189 (align = 128)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
     if force_all_rays or mean_count <= 0:
-        xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-        dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-        deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
-        _rb.march_rays_train(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
-                             model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter, perturb)
-        m = int(counter[0].item())
-        m += 128 - m % 128
-        xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
-        M = m
-    else:
-        # budgeted buffers: the write pass zero-fills the rows no ray writes, so no torch.zeros passes over them
-        xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
-        _rb.march_rays_train_ex(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
-                                model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
-                                perturb, 3 if background else 1)
-    return dict(nears=nears, fars=fars, xyzs=xyzs, dirs=dirs, deltas=deltas, rays=rays, M=M, counter=counter)
+        _rb.march_rays_train_count(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+                                   model.cascade, model.grid_size, nears, fars, rays, counter, perturb,
+                                   2 if background else 0)
+        total = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        total.copy_(counter, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        pre["pending"] = (done, total, rays_o, rays_d, perturb, dt_gamma, max_steps)
+        if not defer:
+            finish_march(model, pre)
+        return pre
+    M = mean_count + (128 - mean_count % 128)                # raymarching.py:186-189 (align = 128)
+    # budgeted buffers: the write pass zero-fills the rows no ray writes, so no torch.zeros passes over them
+    xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    _rb.march_rays_train_ex(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+                            model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                            perturb, 3 if background else 1)
+    pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
+    return pre
+
+
+def finish_march(model, pre):
+    """Second half of an unbudgeted march_stage, on the current stream: wait for the count (host side; the pinned
+    total is the only thing read), size the sample buffers from it, run the write pass."""
+    pending = pre.pop("pending", None)
+    if pending is None:
+        return pre
+    done, total, rays_o, rays_d, perturb, dt_gamma, max_steps = pending
+    done.synchronize()
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    m = int(total[0])
+    M = min(m + (128 - m % 128), N * max_steps)              # the reference's crop of its N * max_steps buffers
+    xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    _rb.march_rays_train_write(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+                               model.cascade, model.grid_size, M, pre["nears"], pre["fars"], xyzs, dirs, deltas,
+                               pre["rays"], pre["counter"], perturb, 1)
+    pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
+    return pre
 
 
 class _FusedRenderTrain(Function):
@@ -145,12 +180,12 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
     key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
     if stream is None:
         pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
-                          float(dt_gamma), int(max_steps))
+                          float(dt_gamma), int(max_steps), defer=True)
     else:
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
-                              float(dt_gamma), int(max_steps), background=background)
+                              float(dt_gamma), int(max_steps), background=background, defer=True)
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)
@@ -192,7 +227,7 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
         for t in pre.values():
             if isinstance(t, torch.Tensor):
                 t.record_stream(cur)
-    return pre
+    return finish_march(model, pre)              # unbudgeted stage: the write pass runs here, sized from the count
 
 
 FUSED_COMPOSITE = True        # train_step_mse: compositing forward + MSE backward as one launch
@@ -259,7 +294,7 @@ def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, ra
                                                   1.0, ctx["bg"], ctx["counter"], ctx["sigmas"], ctx["rgb"],
                                                   ctx["deltas"], ctx["rays"], ctx["weights_sum"], ctx["image"], M, N,
                                                   g_sigmas, g_rgbs, None)
-        return fnet.nerf_backward(ctx["sv"], g_sigmas, g_rgbs, sigma_scale=ctx["scale"], raw=raw)
+        return fnet.nerf_backward(ctx["sv"], g_sigmas, g_rgbs, sigma_scale=ctx["scale"], raw=raw, owner=True)
 
 
 def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,

@@ -18,10 +18,25 @@ from .backends import _gridencoder as _backend
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 
 # The backward kernels *add* into the gradient buffer they are given.  When the embedding table is a leaf parameter
-# whose .grad already exists (zeroed by the optimizer), they add straight into it and autograd gets None for that
-# input: this removes a 52 MB zero-fill and a 156 MB grad += pass from every step.  Only taken with the HIP backend
-# (layout support) and when nothing hooks the parameter's gradient; set to False for the plain autograd behaviour.
-ACCUMULATE_INTO_PARAM_GRAD = True
+# whose .grad already exists (zeroed by the optimizer), they can add straight into it and hand autograd None for that
+# input: this removes a 52 MB zero-fill and a 156 MB grad += pass from every step.  It also bypasses AccumulateGrad, so
+# DistributedDataParallel's reducer hooks and register_post_accumulate_grad_hook callbacks would never fire, and
+# torch.autograd.grad(...) would mutate .grad: OPT-IN for autograd-driven loops (set True only by a loop that owns the
+# step and uses neither).  Loops that drive the backward themselves, without autograd (fused_render.backward_raw), own
+# the gradient buffer and always use it (param_grad_target(owner=True)).
+ACCUMULATE_INTO_PARAM_GRAD = False
+
+
+def param_grad_target(param, dtype, owner=False):
+    """-> param.grad if the backward may add straight into it, else None (see ACCUMULATE_INTO_PARAM_GRAD)."""
+    g = param.grad
+    if (g is None or not param.is_leaf or g.dtype != dtype or not g.is_contiguous() or g.shape != param.shape):
+        return None
+    if owner:
+        return g
+    if not ACCUMULATE_INTO_PARAM_GRAD or param._backward_hooks or getattr(param, "_post_accumulate_grad_hooks", None):
+        return None
+    return g
 
 
 _layout_support = {}
@@ -96,10 +111,9 @@ class _grid_encode(Function):
         calc_grad_inputs = ctx.calc_grad_inputs
 
         grad = grad.to(embeddings.dtype)
-        direct_param = (ACCUMULATE_INTO_PARAM_GRAD and ctx.direct and embeddings.is_leaf and embeddings.grad is not None
-                        and embeddings.grad.dtype == embeddings.dtype and embeddings.grad.is_contiguous()
-                        and embeddings.grad.shape == embeddings.shape and not embeddings._backward_hooks)
-        grad_embeddings = embeddings.grad if direct_param else torch.zeros_like(embeddings)
+        target = param_grad_target(embeddings, embeddings.dtype) if ctx.direct else None
+        direct_param = target is not None
+        grad_embeddings = target if direct_param else torch.zeros_like(embeddings)
         if calc_grad_inputs:
             grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype)
         else:

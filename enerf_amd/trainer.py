@@ -46,9 +46,10 @@ class TrainHarness:
         self._raw_grads = None
         self._cleared_grad = None     # the embeddings' gradient buffer as the last Adam pass left it (all zeros)
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
-        self._loss_ring_clean = False
+        self._loss_cursor = 0
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
+        self._graph_generation = 0
         if self.use_graphs:
             model.sample_budget_quantum = 8192
 
@@ -59,6 +60,24 @@ class TrainHarness:
             if self._syn is not None:
                 m.density_grid.copy_(self._syn[0])
                 m.density_bitfield.copy_(self._syn[1])
+            self._agree_on_budget()
+
+    def _agree_on_budget(self):
+        """Data parallel: every rank must take the same route through the step (the routes differ in the collectives
+        they issue), and the routes are chosen from static properties of the model plus -- for graph replay -- the
+        sample budget.  The budget comes from each rank's own step counters ("all-reduce-MAX it every 16
+        steps so M is uniform"): one 8-byte MAX all-reduce per update_extra_state window makes it the same everywhere
+        (a larger budget never drops a ray the local budget would keep)."""
+        if self.avg is None:
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        m = self.model
+        dev = next(m.parameters()).device
+        t = torch.tensor([int(m.mean_count)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        m.mean_count = int(t.item())
 
     # ------------------------------------------------------------------ HIP-graph replay of render + loss + backward
     def _graph_key(self, tag, rays_o):
@@ -91,13 +110,28 @@ class TrainHarness:
                 self.opt.zero_grad(set_to_none=True)
                 fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
+        gen = _lib.lib().enerf_workspace_generation()
+        if gen != self._graph_generation:             # the warm-up grew a scratch buffer: older captures point at
+            self._graphs.clear()                      # freed memory (see _graph_for)
+            self._graph_generation = gen
         self.opt.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             st["loss"] = fwd_bwd().detach()
         st["graph"] = g
         st["grads"] = [(p, p.grad) for p in params]
+        assert _lib.lib().enerf_workspace_generation() == gen, "a scratch buffer grew inside a graph capture"
         return st
+
+    def _graph_for(self, key):
+        """The captured state for `key`, or None.  The library's scratch buffers are grow-only: a launch that needed
+        more (a larger budget or ray count) re-allocated one since the captures were made, and every captured graph
+        holds the old pointers -- all of them are dropped and re-captured on demand."""
+        if self._graphs:
+            from . import _lib
+            if _lib.lib().enerf_workspace_generation() != self._graph_generation:
+                self._graphs.clear()
+        return self._graphs.get(key)
 
     def _replay(self, st, inputs, renders):
         m = self.model
@@ -130,7 +164,7 @@ class TrainHarness:
             return
         self.avg.start()
         m = self.model
-        if (next_rays is not None and self.prefetch and m.cuda_ray and m.mean_count > 0
+        if (next_rays is not None and self.prefetch and m.cuda_ray
                 and self.global_step % self.update_interval != 0):
             from . import fused_render
             ro, rd = next_rays
@@ -141,7 +175,7 @@ class TrainHarness:
     def _manual_ok(self, rays_o, rays_d, target, render_kw):
         from . import fused_render
         m = self.model
-        return (self.manual_mse and m.cuda_ray and m.mean_count > 0 and target.dtype == torch.float32
+        return (self.manual_mse and m.cuda_ray and target.dtype == torch.float32
                 and not set(render_kw) - {"dt_gamma", "max_steps"}
                 and fused_render.supported(m, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3), 1,
                                            render_kw.get("dt_gamma", 0)))
@@ -186,10 +220,11 @@ class TrainHarness:
         loss = None
         if not self.use_graphs:                     # (a captured graph would always accumulate into the same slot)
             # loss values land in a ring of device scalars, cleared once per lap: no loss kernels, no per-step fill
-            slot = self.global_step % self._loss_ring.numel()
-            if slot == 0 or not self._loss_ring_clean:
+            # (laps are counted on the ring's own cursor: steps of other kinds in between do not use slots)
+            slot = self._loss_cursor % self._loss_ring.numel()
+            self._loss_cursor += 1
+            if slot == 0:
                 self._loss_ring.zero_()
-                self._loss_ring_clean = True
             loss = self._loss_ring[slot]
         image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps,
                                                    after_forward=after_forward, loss_out=loss, raw=raw)
@@ -347,7 +382,7 @@ class TrainHarness:
         if self._graphable(rays_o, rays_d):
             m = self.model
             key = self._graph_key("rgb", rays_o)
-            if key not in self._graphs:
+            if self._graph_for(key) is None:
                 manual = self._manual_ok(rays_o, rays_d, target, render_kw)
                 self._graphs[key] = self._capture(
                     (rays_o, rays_d, target),
@@ -376,7 +411,7 @@ class TrainHarness:
             names = ("images", "rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols")
             key = self._graph_key("events", data["rays_evs_o1"])
             inputs = tuple(data[n] for n in names)
-            if key not in self._graphs:
+            if self._graph_for(key) is None:
                 self._graphs[key] = self._capture(
                     inputs, lambda *ts: train_step_events(self.model, dict(zip(names, ts)), opt)[0])
             return self._replay(self._graphs[key], inputs, 2)
@@ -402,7 +437,7 @@ class TrainHarness:
         from . import fused_render
         m = self.model
         ro, rd = data["rays_evs_o1"], data["rays_evs_d1"]
-        return (self.manual_mse and opt.event_only and m.cuda_ray and m.mean_count > 0
+        return (self.manual_mse and opt.event_only and m.cuda_ray
                 and not set(opt.render_kwargs) - {"dt_gamma", "max_steps", "out_dim_color"}
                 and fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1,
                                            opt.render_kwargs.get("dt_gamma", 0)))

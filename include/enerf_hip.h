@@ -50,6 +50,11 @@ typedef void* enerf_stream_t; /* hipStream_t */
 const char* enerf_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int enerf_abi_version(void);
+/* The library keeps grow-only scratch buffers per device (march chunk log, grid-backward record lists, ...).  Growing one
+ * frees the old allocation; the counter returned here moves every time that happens.  A caller that captured library
+ * launches into a HIP graph must re-capture when the counter has moved since the capture (the graph holds the old
+ * pointers). */
+uint64_t enerf_workspace_generation(void);
 
 /* ------------------------------------------------------------------ raymarching
  * raymarching/src/raymarching.cu; all float tensors are fp32 (the wrappers
@@ -129,6 +134,27 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
                               int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
                               enerf_stream_t stream);
 
+/* The two halves of enerf_march_rays_train_ex, for callers that size the sample buffers from the count instead of the
+ * reference's worst case (raymarching.py:195-228: while no sample budget exists the wrapper allocates and zero-fills
+ * M = N * max_steps rows -- 134 MB at 4096 rays -- marches, reads counter[0] back and crops to that count rounded up to
+ * `align`).  The count pass already knows the total on the device:
+ *   _count: near/far -> per-ray sample counts -> deterministic scan: rays[n] = (n, offset, count), counter[0] += sum,
+ *           counter[1] += N.  Nothing is written to sample buffers.  flags bit 1 = background launch (see _ex).
+ *   _write: the write pass of the SAME batch (same rays / nears / fars / grid / perturb; the fixed-step marcher keeps a
+ *           per-process chunk log between the two calls, so no other training march may run in between) into buffers of
+ *           M rows; `M` is also the M of the reference's drop rule (`offset + count >= M`: the ray writes nothing).
+ *           zero_unwritten bit 0 as in _ex.
+ * _count followed by _write with the same M is exactly enerf_march_rays_train_ex. */
+int enerf_march_rays_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                 const float* nears, const float* fars, int32_t* rays, int32_t* counter,
+                                 uint32_t perturb, uint32_t flags, enerf_stream_t stream);
+int enerf_march_rays_train_write(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                 const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                 const int32_t* rays, const int32_t* counter, uint32_t perturb,
+                                 uint32_t zero_unwritten, enerf_stream_t stream);
+
 /* raymarching.cu:581-589  composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, weights_sum, depth, image) */
 int enerf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                        const int32_t* rays, uint32_t M, uint32_t N, float* weights_sum,
@@ -200,6 +226,20 @@ int enerf_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_a
 int enerf_composite_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, float* rays_t,
                          const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
                          float* depth, float* image, enerf_stream_t stream);
+
+/* Whole-frame inference compositing -- the reference's inference loop (nerf/renderer.py:364-401: per round
+ * compact_rays -> alive_counter.item() -> march_rays(n_step) -> network -> composite_rays) needs the rounds only because
+ * it marches a fixed n_step slots per alive ray.  With every ray's samples marched contiguously up front
+ * (enerf_march_rays_train_count / _write: rays = (id, offset, count); same cells, same lattice of t, perturb = 0) one
+ * pass composites a ray exactly as the rounds do: the arithmetic and order of composite_rays (raymarching.cu:817-909:
+ * T = 1 - weights_sum, termination once a sample's pre-sample T < 1e-5 -- that sample is still accumulated), starting
+ * from t = nears[id], then image += (1 - weights_sum) * bg and depth = clamp(depth - near, 0) / (far - near).  The image
+ * equals the iterated schedule's bit for bit whenever no ray reaches the loop's 1024-step cap.  bg: scalar (bg_color NULL),
+ * one RGB (stride 0) or one per ray (stride 3).  used_samples (device u32, may be NULL) += samples accumulated. */
+int enerf_composite_rays_frame(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                               uint32_t N, uint32_t M, const float* nears, const float* fars, const float* bg_color,
+                               uint32_t bg_stride, float bg_scalar, float* weights_sum, float* depth, float* image,
+                               uint32_t* used_samples, enerf_stream_t stream);
 
 /* raymarching.cu:933-939  compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter)
  * Order-preserving (stable) here; alive_counter[0] += number of survivors. */

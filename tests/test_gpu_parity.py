@@ -192,6 +192,43 @@ def test_march_rays_train_background_mode_is_bit_identical(rm, scenes, overflow)
             assert np.array_equal(a, b), (name, perturb)
 
 
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
+def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm, scenes, dt_gamma):
+    """While no sample budget exists the reference allocates N * max_steps zero rows, marches, reads the count back and
+    crops to the count rounded up past the next multiple of 128 (raymarching.py:195-228).  march_rays_train_count +
+    march_rays_train_write into NaN-filled buffers of exactly that cropped size: same rows, rays and counter as the
+    oracle run with the worst-case buffers, bit for bit -- including the corner where every ray takes max_steps samples,
+    so that the total equals N * max_steps and the reference's `>=` rule drops the last ray."""
+    bound = 2
+    grid, bits, C = scenes[bound]
+    cases = [(bits, 1024, 2500, 1), (bits, 1024, 2500, 0)]
+    if dt_gamma == 0.0:
+        sat = np.full(C * H ** 3 // 8, 0xff, np.uint8)
+        cases.append((sat, 8, 64, 0))                                  # every ray: 8 of 8 steps -> total == N * max_steps
+    for grid_bits, max_steps, N, perturb in cases:
+        o, d, aabb = _rays(N, 37, bound)
+        if max_steps == 8:
+            o[:] = np.array([0.1, 0.2, -0.3], np.float32)              # inside the cube, far from its faces
+        nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+        worst = N * max_steps
+        ref = O.march_rays_train(o, d, grid_bits, bound, dt_gamma, max_steps, C, H, worst, nears, fars, perturb)
+        tot = int(ref[4][0])
+        m = min(tot + 128 - tot % 128, worst)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+        counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        args = (cu(o), cu(d), cu(grid_bits), bound, dt_gamma, max_steps, N, C, H)
+        nf = (cu(nears), cu(fars))
+        rm.march_rays_train_count(*args, *nf, rays, counter, perturb, 0)
+        assert np.array_equal(counter.cpu().numpy(), ref[4]) and np.array_equal(rays.cpu().numpy(), ref[3])
+        xyzs = torch.full((m, 3), float("nan"), device=DEV); dirs = torch.full((m, 3), float("nan"), device=DEV)
+        deltas = torch.full((m, 2), float("nan"), device=DEV)
+        rm.march_rays_train_write(*args, m, *nf, xyzs, dirs, deltas, rays, counter, perturb, 1)
+        for a, b, name in zip((xyzs, dirs, deltas), ref[:3], ("xyzs", "dirs", "deltas")):
+            assert np.array_equal(a.cpu().numpy(), b[:m]), (name, max_steps, perturb)
+        if max_steps == 8:
+            assert tot == worst and m == worst and not ref[0][(N - 1) * 8:].any()      # the last ray was dropped
+
+
 def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm):
     """Every cell occupied: rays emit a sample at every lattice point until max_steps (1024) -- the maximum the path
     can produce per ray, and more emitting 64-point chunks than the count pass's per-ray log holds for the longest

@@ -114,7 +114,7 @@ def test_manual_mse_step_matches_autograd_step(monkeypatch):
         losses = [h.step_rgb(*data[i % len(data)]).clone() for i in range(40)]
         runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
                      {n: p.detach().clone() for n, p in model.named_parameters()}))
-        assert len(calls) == (40 - 16 if manual else 0)       # the first window has no sample budget yet
+        assert len(calls) == (40 if manual else 0)            # from the first step on: no sample budget needed
     (l0, c0, p0), (l1, c1, p1) = runs
     assert torch.equal(c0, c1)
     # Adam with eps = 1e-15 turns rounding-level gradient differences on rarely-hit table rows into lr-sized steps:
