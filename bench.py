@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--verify-samples", action="store_true",
                     help="also count the timed steps' samples with one launch per render and compare (development aid)")
     ap.add_argument("--march-bg-blocks", type=int, default=0, help="tuning: workgroups of the side-stream march (0 = auto)")
+    ap.add_argument("--no-march-clip", action="store_true",
+                    help="tuning: do not test rays against the occupied cells' bounding box before marching")
     ap.add_argument("--no-comm-tune", action="store_true", help="N > 1: keep comm_chunks = 4 instead of timing 1/2/4/8")
     ap.add_argument("--backend", default=None, help="torch.distributed backend override (default: nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="put every rank on this device index")
@@ -198,6 +200,8 @@ def main():
 
     if args.march_bg_blocks:
         _lib.lib().enerf_debug_march_bg_blocks(args.march_bg_blocks)
+    if args.no_march_clip:
+        _lib.lib().enerf_debug_march_clip(0)
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
     model.infer_batch_mult = args.render_batch_mult

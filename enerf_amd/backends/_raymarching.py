@@ -79,6 +79,12 @@ def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, 
                                               L.stream_handle()), "march_rays_train_ex")
 
 
+def occupied_box_update(grid, C, H, bound):
+    """(Re)compute the library's bounding box of the occupied cells of `grid` (include/enerf_hip.h)."""
+    L.check(L.lib().enerf_occupied_box_update(_u8(grid, "grid"), int(C), int(H), float(bound), L.stream_handle()),
+            "occupied_box_update")
+
+
 def march_rays_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, perturb,
                            flags=0):
     """Count + scan half of march_rays_train: fills rays / counter, writes no samples (include/enerf_hip.h)."""

@@ -52,7 +52,7 @@ struct ProfScope {
 void* workspace(int slot, size_t bytes);
 uint64_t workspace_generation();    // bumped whenever a slot is re-allocated (its old pointer dies)
 uint32_t num_cus();                    // compute units of the current device (256 when it cannot be asked)
-enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_SLOTS = 7 };
+enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_AABB = 7, WS_SLOTS = 8 };
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 

@@ -603,13 +603,87 @@ __device__ __forceinline__ void lattice_replay(const RayCtx& c, float t0, const 
     }
 }
 
+// ---- bounding box of the occupied cells ------------------------------------------------------------------------------
+// A sample can only be emitted at a position whose cell bit is set, and a cell of cascade level L is only ever consulted
+// for positions inside that cell's world-space box (the level is at least the position's own mip level, so the position
+// lies within the level's cube and maps to the cell that contains it).  Rays that miss the union of those boxes emit
+// nothing, and a ray emits nothing once it has left it -- exactly, whatever the visiting order of the lattice was up to
+// there.  The count pass tests each ray against the box (enlarged by two coarsest-level cells) before it marches and stops
+// at the box's far side instead of the volume's: on the training cameras of the synthetic scene half of the rays are
+// settled by the test and the rest march a third of their chord.
+// Keys: order-preserving int image of a float; six running minima (lo.xyz, -hi.xyz), initialised by memset(0x7f).
+__device__ __forceinline__ int aabb_key(float v) {
+    const int b = __float_as_int(v);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float aabb_unkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+__global__ void __launch_bounds__(256) k_occupied_aabb(const uint8_t* __restrict__ grid, uint32_t C, uint32_t H,
+                                                       float bound, int* __restrict__ keys) {
+    // one byte = 8 consecutive morton indices = one 2x2x2 block of cells of one level
+    const uint32_t bytes_per_level = H * H * H / 8;
+    const uint32_t total = C * bytes_per_level;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, nhi[3] = {3.0e38f, 3.0e38f, 3.0e38f};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (grid[i] == 0) continue;
+        const uint32_t level = i / bytes_per_level;
+        const uint32_t m = (i - level * bytes_per_level) * 8u;
+        const uint32_t cx = morton3_inv(m), cy = morton3_inv(m >> 1), cz = morton3_inv(m >> 2);
+        const float pw = (float)(1u << level);
+        const float mb = pw > bound ? bound : pw;
+        const float cell = 2.0f * mb / (float)H;
+        const uint32_t cc[3] = {cx, cy, cz};
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], fmaf((float)cc[a], cell, -mb));
+            nhi[a] = fminf(nhi[a], -fmaf((float)(cc[a] + 2u), cell, -mb));
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            nhi[a] = fminf(nhi[a], __shfl_xor(nhi[a], off, 64));
+        }
+    }
+    if (lane_id() == 0) {
+        for (int a = 0; a < 3; a++) {
+            if (lo[a] < 3.0e38f) atomicMin(keys + a, aabb_key(lo[a]));
+            if (nhi[a] < 3.0e38f) atomicMin(keys + 3 + a, aabb_key(nhi[a]));
+        }
+    }
+}
+
+// Ray against the enlarged occupied box: false = the ray cannot emit a sample; otherwise `far` is lowered to where the
+// ray leaves the box (plus a margin).  Axis-parallel rays: a zero direction component constrains only the origin.
+__device__ __forceinline__ bool clip_to_occupied(const RayCtx& c, const int* __restrict__ keys, float& far) {
+    const float pad = 4.0f * fminf((float)(1u << (c.C - 1)), c.bound) / (float)c.H;     // two cells of the coarsest level
+    const float o[3] = {c.ox, c.oy, c.oz}, d[3] = {c.dx, c.dy, c.dz};
+    float t_in = -3.0e38f, t_out = 3.0e38f;
+    for (int a = 0; a < 3; a++) {
+        const float lo = aabb_unkey(keys[a]) - pad, hi = -aabb_unkey(keys[3 + a]) + pad;
+        if (!(lo <= hi)) return false;                                      // no occupied cell at all
+        if (fabsf(d[a]) < 1e-12f) {
+            if (o[a] < lo || o[a] > hi) return false;
+            continue;
+        }
+        const float r = 1.0f / d[a];
+        const float t1 = (lo - o[a]) * r, t2 = (hi - o[a]) * r;
+        t_in = fmaxf(t_in, fminf(t1, t2));
+        t_out = fminf(t_out, fmaxf(t1, t2));
+    }
+    const float slack = 1e-3f * c.bound + 1e-5f * fabsf(t_out);
+    if (t_in > t_out + slack) return false;
+    far = fminf(far, t_out + slack);
+    return true;
+}
+
 __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__ rays_o,
                                                        const float* __restrict__ rays_d,
                                                        const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
                                                        uint32_t N, uint32_t C, uint32_t H,
                                                        const float* __restrict__ nears, const float* __restrict__ fars,
                                                        int32_t* rays, uint32_t perturb, ChunkEntry* __restrict__ log,
-                                                       uint32_t* __restrict__ nlog) {
+                                                       uint32_t* __restrict__ nlog,
+                                                       const int* __restrict__ occ_keys) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     const bool fast = march_fast_ok(H);
@@ -623,11 +697,16 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
         ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
         float t0 = nears[n];
         if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
-        const uint32_t cnt =
-            fast ? lattice_march_fast<false, true>(c, tabs, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                   log + (size_t)n * kLogCap, nlog + n)
-                 : lattice_march<false, true, false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                     log + (size_t)n * kLogCap, nlog + n);
+        float far = fars[n];
+        uint32_t cnt = 0;
+        if (occ_keys && !clip_to_occupied(c, occ_keys, far)) {
+            if (lane_id() == 0) nlog[n] = 0;                                   // nothing to replay
+        } else {
+            cnt = fast ? lattice_march_fast<false, true>(c, tabs, t0, far, max_steps, nullptr, nullptr, nullptr,
+                                                         log + (size_t)n * kLogCap, nlog + n)
+                       : lattice_march<false, true, false>(c, t0, far, max_steps, nullptr, nullptr, nullptr,
+                                                           log + (size_t)n * kLogCap, nlog + n);
+        }
         if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)cnt;
     }
 }
@@ -1437,6 +1516,11 @@ int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t*
 }
 
 static uint32_t g_march_bg_blocks = 0;
+static int g_march_clip = 1;        // enerf_debug_march_clip: test rays against the occupied cells' bounding box first
+// the bitfield the box in WS_AABB was last computed for (enerf_occupied_box_update)
+static const uint8_t* g_box_grid = nullptr;
+static uint32_t g_box_C = 0, g_box_H = 0;
+static float g_box_bound = 0.0f;
 
 int enerf_march_train_samples(uint64_t* total, int reset, enerf_stream_t stream) {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) ENERF_BADARG("march_train_samples: stream sync failed");
@@ -1462,12 +1546,19 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
                                      dirs, deltas, rays, counter, perturb, 0, stream);
 }
 
+// The wave-per-ray lattice marcher steps by dt_min: valid when the step is fixed (dt_gamma == 0) and the clamp
+// `clamp(t * dt_gamma, dt_min, dt_max)` really yields dt_min, i.e. dt_min <= dt_max <=> max_steps * 2^(C-1) >= H (always
+// true at the reference's max_steps = 1024, H = 128); anything else takes the one-thread-per-ray loop.
+static inline bool march_uses_lattice(float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    return dt_gamma == 0.0f && (uint64_t)max_steps * (1ull << (C - 1)) >= (uint64_t)H;
+}
+
 // count pass (+ scan): rays[n] = (n, offset, count), counter += (sum, N); the fixed-step marcher also fills the chunk log
 static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                              const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
-                             hipStream_t s) {
-    if (dt_gamma == 0.0f) {
+                             bool use_box, hipStream_t s) {
+    if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
         const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
@@ -1482,8 +1573,12 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         // rays the turn-taking only just fits the window -- 1.46 to 1.62 from run to run against a steady 1.52 -- and
         // at 65536 it does not: 5.50 against 4.94; larger batches keep the full launch)
         const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : (N <= 8192u ? num_cus() : div_up(N, 4));
+        // the occupied cells' box, if the caller says the one it had computed for this bitfield is current
+        const int* occ_keys = nullptr;
+        if (use_box && g_march_clip && g_box_grid == grid && g_box_C == C && g_box_H == H && g_box_bound == bound)
+            occ_keys = (const int*)workspace(WS_AABB, 6 * sizeof(int));
         k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
-            rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog);
+            rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys);
     } else {
         k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
                                                    fars, rays, perturb);
@@ -1506,7 +1601,7 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                              const float* fars, float* xyzs, float* dirs, float* deltas, const int32_t* rays,
                              const int32_t* counter, uint32_t perturb, uint32_t zero_unwritten, hipStream_t s) {
-    if (dt_gamma == 0.0f) {
+    if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
         char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
         if (!ws) return ENERF_E_NOMEM;
@@ -1545,7 +1640,7 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
-                               perturb, (zero_unwritten & 2u) != 0, s);
+                               perturb, (zero_unwritten & 2u) != 0, (zero_unwritten & 4u) != 0, s);
     if (rc) return rc;
     rc = march_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                            rays, counter, perturb, zero_unwritten & 1u, s);
@@ -1564,7 +1659,7 @@ int enerf_march_rays_train_count(const float* rays_o, const float* rays_d, const
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     const int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
-                                     perturb, (flags & 2u) != 0, s);
+                                     perturb, (flags & 2u) != 0, (flags & 4u) != 0, s);
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("march_rays_train_count");
     return 0;
@@ -1699,6 +1794,23 @@ int enerf_debug_march_bg_blocks(uint32_t n) {
 // tuning aid: largest ray count for which the inference march uses one wavefront per ray (n_step < 16)
 static uint32_t g_march_wave_max_rays = 65536u;
 static uint32_t g_march_wave_min_steps = 16u;
+int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float bound, enerf_stream_t stream) {
+    if (!grid || C == 0 || H < 2 || (H * H * H) % 8 != 0) ENERF_BADARG("occupied_box_update: bad C=%u H=%u", C, H);
+    hipStream_t s = (hipStream_t)stream;
+    int* keys = (int*)workspace(WS_AABB, 6 * sizeof(int));
+    if (!keys) return ENERF_E_NOMEM;
+    (void)hipMemsetAsync(keys, 0x7f, 6 * sizeof(int), s);
+    k_occupied_aabb<<<min(div_up(C * H * H * H / 8, 256), 2u * num_cus()), 256, 0, s>>>(grid, C, H, bound, keys);
+    g_box_grid = grid; g_box_C = C; g_box_H = H; g_box_bound = bound;
+    ENERF_LAUNCH_CHECK("occupied_box_update");
+    return 0;
+}
+
+int enerf_debug_march_clip(int on) {
+    g_march_clip = on ? 1 : 0;
+    return 0;
+}
+
 int enerf_debug_march_wave_max_rays(uint32_t n) {
     g_march_wave_max_rays = n & 0xffffffu;          // bits 24..31: minimum n_step for the wave marcher (0 = keep)
     if (n >> 24) g_march_wave_min_steps = n >> 24;

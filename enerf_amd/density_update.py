@@ -55,6 +55,7 @@ def update(model, decay=0.95):
                                           float(model.density_thresh), model.density_grid.data_ptr(),
                                           model.density_bitfield.data_ptr(), model.step_counter.data_ptr(), total_step,
                                           stats.data_ptr(), stream), "density_grid_update")
+    _rm.BITFIELD_EPOCH[0] += 1                                        # the bitfield was rewritten behind torch's back
     mean, counted = stats.tolist()                                    # the update's only host synchronisation
     model.mean_density = mean
     model.iter_density += 1

@@ -126,14 +126,15 @@ def event_loss(image1, image2, pols, opt):
     return loss, delta
 
 
-def train_step_events(model, data, opt, criterion=None):
-    """One event training step's forward: two renders (+ optional frame render) -> loss.  nerf/utils.py:482-546."""
+def train_step_events(model, data, opt, criterion=None, bg_color=None):
+    """One event training step's forward: two renders (+ optional frame render) -> loss.  nerf/utils.py:482-546.
+    `bg_color` [B,1,C] replaces the step's random background draw (tests)."""
     images = data["images"]
     B = images.shape[0]
     dev = data["rays_evs_o1"].device
     # the reference draws this on the host and copies it over (nerf/utils.py:497); a pageable host->device copy
     # drains the stream every step, so the same U[0,1) draw is made on the device
-    bg = torch.rand((B, 1, opt.out_dim_color), device=dev)
+    bg = torch.rand((B, 1, opt.out_dim_color), device=dev) if bg_color is None else bg_color
     kw = dict(opt.render_kwargs)
     kw.setdefault("out_dim_color", opt.out_dim_color)
     out1 = model.render(data["rays_evs_o1"], data["rays_evs_d1"], staged=False, bg_color=bg, perturb=True, **kw)
@@ -153,7 +154,7 @@ def train_step_events(model, data, opt, criterion=None):
     return loss, delta
 
 
-def train_step_events_manual(model, data, opt, after_forward=None):
+def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None):
     """The event-only step with the two renders driven without autograd (fused_render.render_train_raw /
     backward_raw): only the loss itself -- a few elementwise ops on two [N,3] images -- goes through autograd, and its
     gradient is handed to the renders' closed backward.  Same values as train_step_events + loss.backward()
@@ -162,7 +163,7 @@ def train_step_events_manual(model, data, opt, after_forward=None):
     from . import fused_render as fr
     B = data["images"].shape[0]
     dev = data["rays_evs_o1"].device
-    bg = torch.rand((B, 1, opt.out_dim_color), device=dev)
+    bg = torch.rand((B, 1, opt.out_dim_color), device=dev) if bg_color is None else bg_color
     kw = {k: v for k, v in opt.render_kwargs.items() if k in ("dt_gamma", "max_steps")}
     shape = data["rays_evs_o1"].shape[:-1]
     img1, ctx1 = fr.render_train_raw(model, data["rays_evs_o1"], data["rays_evs_d1"], bg, True, **kw)

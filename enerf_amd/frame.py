@@ -46,7 +46,8 @@ def render_frame(model, rays_o, rays_d, bg_color=1, max_steps=1024, trace=None):
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     counter = torch.zeros(2, dtype=torch.int32, device=dev)
     geom = (rays_o, rays_d, model.density_bitfield, model.bound, 0.0, max_steps, N, model.cascade, model.grid_size)
-    _rb.march_rays_train_count(*geom, nears, fars, rays, counter, 0, 0)
+    from .fused_render import occupied_box_flag
+    _rb.march_rays_train_count(*geom, nears, fars, rays, counter, 0, occupied_box_flag(model))
     total = int(counter[0].item())                      # the frame's one synchronisation: sizes the sample buffers
     M = total + 128 - total % 128
     xyzs, dirs, deltas = torch.empty(M, 3, **f32), torch.empty(M, 3, **f32), torch.empty(M, 2, **f32)

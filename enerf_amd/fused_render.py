@@ -34,6 +34,21 @@ def supported(model, rays_o, rays_d, bg_color, dt_gamma):
     return fnet.supported(model, probe, probe)
 
 
+_BOX_FOR = {}        # device index -> key of the bitfield the library's occupied box was last computed for
+
+
+def occupied_box_flag(model):
+    """-> the marcher flag (4) that enables the occupied-box test, after making sure the library's box belongs to this
+    model's current bitfield (recomputed on the current stream when the bitfield's storage, torch version or the
+    package's raw-write epoch changed: update_extra_state, packbits, copy_)."""
+    bf = model.density_bitfield
+    key = (bf.data_ptr(), bf._version, _rm.BITFIELD_EPOCH[0], int(model.cascade), int(model.grid_size), float(model.bound))
+    if _BOX_FOR.get(bf.device.index) != key:
+        _rb.occupied_box_update(bf, model.cascade, model.grid_size, model.bound)
+        _BOX_FOR[bf.device.index] = key
+    return 4
+
+
 def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps,
                 background=False, defer=False):
     """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
@@ -54,10 +69,11 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     _rb.near_far_from_aabb(rays_o, rays_d, model.aabb_train, N, model.min_near, nears, fars)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
+    box = occupied_box_flag(model)
     if force_all_rays or mean_count <= 0:
         _rb.march_rays_train_count(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
                                    model.cascade, model.grid_size, nears, fars, rays, counter, perturb,
-                                   2 if background else 0)
+                                   box | (2 if background else 0))
         total = torch.empty(2, dtype=torch.int32, pin_memory=True)
         total.copy_(counter, non_blocking=True)
         done = torch.cuda.Event()
@@ -73,7 +89,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
     _rb.march_rays_train_ex(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
                             model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
-                            perturb, 3 if background else 1)
+                            perturb, box | (3 if background else 1))
     pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
     return pre
 
@@ -178,6 +194,13 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     key = (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], bool(perturb), float(dt_gamma), int(max_steps))
+    stash = getattr(model, "_premarched", None)
+    if not isinstance(stash, dict):
+        stash = model._premarched = {}
+    if any("pending" in p for p in stash.values()):
+        # an unbudgeted stage is waiting for its write pass, and the marcher's chunk log (count -> write) is one
+        # per-process buffer: a second count now would overwrite it.  The second render of an event step marches inline.
+        return
     if stream is None:
         pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
                           float(dt_gamma), int(max_steps), defer=True)
@@ -189,9 +212,6 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)
-    stash = getattr(model, "_premarched", None)
-    if not isinstance(stash, dict):
-        stash = model._premarched = {}
     stash[key] = pre                                 # (an event step stashes both of its renders)
 
 

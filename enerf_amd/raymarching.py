@@ -82,6 +82,11 @@ class _morton3D_invert(Function):
 morton3D_invert = _morton3D_invert.apply
 
 
+# bumped by everything in this package that writes a density bitfield through a raw pointer (torch's own version counter
+# covers copy_ and friends): consumers that cache something derived from a bitfield key it on (data_ptr, _version, this)
+BITFIELD_EPOCH = [0]
+
+
 class _packbits(Function):
     @staticmethod
     def forward(ctx, grid, thresh, bitfield=None):
@@ -92,6 +97,7 @@ class _packbits(Function):
         if bitfield is None:
             bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
         _backend.packbits(grid, N, thresh, bitfield)
+        BITFIELD_EPOCH[0] += 1
         return bitfield
 
 

@@ -127,19 +127,31 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
  * write pass itself, so the three torch.zeros of raymarching.py:205-207 become torch.empty.  zero_unwritten == 0 is
  * exactly enerf_march_rays_train.  `zero_unwritten` is a flag word: bit 0 as above; bit 1 says the batch is being
  * prepared ahead of its step on a side stream: the count pass then runs with one wavefront per SIMD (rays in turn) so
- * that it leaves the registers of the chip to the step it runs beside.  Same rows, same counts, bit for bit. */
+ * that it leaves the registers of the chip to the step it runs beside; bit 2: test rays against the occupied cells'
+ * bounding box first (enerf_occupied_box_update).  Same rows, same counts, bit for bit. */
 int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                               const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                               int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
                               enerf_stream_t stream);
 
+/* Bounding box of the occupied cells of a density bitfield, kept by the library for the fixed-step training marcher.
+ * A sample can only be emitted inside an occupied cell's box, so a ray that misses the union's bounding box emits
+ * nothing and a ray emits nothing after leaving it: with flag bit 2 (value 4) of enerf_march_rays_train_ex /
+ * enerf_march_rays_train_count the count pass tests every ray against the box first and marches only to the box's far
+ * side -- identical rays / counter / samples (tests), half of the synthetic scene's rays settled without marching.
+ * The caller sets the flag only while the box computed here is current for `grid`: call this again (same stream
+ * order as the marches that follow) whenever the bitfield's contents change.  The flag is ignored when the box was
+ * computed for another pointer / C / H / bound. */
+int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float bound, enerf_stream_t stream);
+
 /* The two halves of enerf_march_rays_train_ex, for callers that size the sample buffers from the count instead of the
  * reference's worst case (raymarching.py:195-228: while no sample budget exists the wrapper allocates and zero-fills
  * M = N * max_steps rows -- 134 MB at 4096 rays -- marches, reads counter[0] back and crops to that count rounded up to
  * `align`).  The count pass already knows the total on the device:
  *   _count: near/far -> per-ray sample counts -> deterministic scan: rays[n] = (n, offset, count), counter[0] += sum,
- *           counter[1] += N.  Nothing is written to sample buffers.  flags bit 1 = background launch (see _ex).
+ *           counter[1] += N.  Nothing is written to sample buffers.  flags bit 1 = background launch (see _ex),
+ *           bit 2 = use the occupied box (enerf_occupied_box_update).
  *   _write: the write pass of the SAME batch (same rays / nears / fars / grid / perturb; the fixed-step marcher keeps a
  *           per-process chunk log between the two calls, so no other training march may run in between) into buffers of
  *           M rows; `M` is also the M of the reference's drop rule (`offset + count >= M`: the ray writes nothing).
@@ -390,6 +402,8 @@ int enerf_mlp32_defer_reduce(int on);
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
 /* tuning aid: largest alive-ray count for which enerf_march_rays runs one wavefront per ray (when n_step < 16) */
 int enerf_debug_march_wave_max_rays(uint32_t n);
+/* test / measurement aid: 0 switches off the occupied-box test (below) globally */
+int enerf_debug_march_clip(int on);
 /* tuning aid: workgroups of the background training march (enerf_march_rays_train_ex flag bit 1); 0 = one per CU */
 int enerf_debug_march_bg_blocks(uint32_t n);
 /* tuning aid: workgroup caps of the mlp32 forward and fused-backward grids (0 = built-in defaults) */

@@ -229,6 +229,53 @@ def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm,
             assert tot == worst and m == worst and not ref[0][(N - 1) * 8:].any()      # the last ray was dropped
 
 
+def test_march_count_occupied_box_test_changes_nothing(rm, scenes):
+    """The count pass first tests each ray against the bounding box of the occupied cells and marches only to the box's
+    far side (raymarching.hip: clip_to_occupied).  Same rays / counter / samples with the test switched off, and both
+    equal the oracle, on a grid whose occupied region is a small off-centre block (most rays miss it, some graze it,
+    some are axis-parallel) and on an empty grid."""
+    bound = 3
+    C = 1 + math.ceil(math.log2(bound))
+    grid = np.zeros((C, H ** 3), np.float32)
+    ax = np.arange(H, dtype=np.int32)
+    cc = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    blk = (np.abs(cc[:, 0] - 80) < 9) & (np.abs(cc[:, 1] - 60) < 6) & (np.abs(cc[:, 2] - 70) < 12)
+    idx = O.morton3D(cc[blk]).astype(np.int64)
+    grid[0, idx] = 1.0
+    grid[1, idx[::3]] = 1.0
+    for g in (grid, np.zeros_like(grid)):
+        bits = O.packbits(g.reshape(-1), 0.01)
+        o, d, aabb = _rays(3000, 91, bound)
+        d[5] = [1, 0, 0]; o[5] = [-2.5, -0.05, 0.1]                    # axis-parallel, through the block
+        d[6] = [0, 0, 1]; o[6] = [2.0, 2.0, -2.9]                      # axis-parallel, misses it
+        nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+        M = len(o) * 1024
+        ref = O.march_rays_train(o, d, bits, bound, 0.0, 1024, C, H, M, nears, fars, 1)
+        outs = []
+        N = len(o)
+        gbits = cu(bits)
+        rm.occupied_box_update(gbits, C, H, bound)
+        for flags in (4 | 1, 1):                                        # with and without the box test
+            xyzs = torch.full((M, 3), float("nan"), device=DEV); dirs = torch.full((M, 3), float("nan"), device=DEV)
+            deltas = torch.full((M, 2), float("nan"), device=DEV)
+            rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+            counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+            rm.march_rays_train_ex(cu(o), cu(d), gbits, bound, 0.0, 1024, N, C, H, M, cu(nears), cu(fars), xyzs, dirs,
+                                   deltas, rays, counter, 1, flags)
+            outs.append([x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)])
+        # a box computed for another bitfield pointer is ignored, not trusted
+        other = gbits.clone()
+        rays2 = torch.empty(N, 3, dtype=torch.int32, device=DEV); counter2 = torch.zeros(2, dtype=torch.int32, device=DEV)
+        rm.march_rays_train_count(cu(o), cu(d), other, bound, 0.0, 1024, N, C, H, cu(nears), cu(fars), rays2, counter2, 1, 4)
+        assert np.array_equal(rays2.cpu().numpy(), ref[3])
+        for got in outs:
+            for a, b, name in zip(got, ref, ("xyzs", "dirs", "deltas", "rays", "counter")):
+                assert np.array_equal(a, b), name
+        if g is grid:
+            hit = (ref[3][:, 2] > 0).mean()
+            assert 0.02 < hit < 0.6 and ref[3][5, 2] > 0 and ref[3][6, 2] == 0
+
+
 def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm):
     """Every cell occupied: rays emit a sample at every lattice point until max_steps (1024) -- the maximum the path
     can produce per ray, and more emitting 64-point chunks than the count pass's per-ray log holds for the longest

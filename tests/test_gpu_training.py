@@ -180,7 +180,8 @@ def test_prefetched_march_gives_the_same_steps(monkeypatch, manual):
     (l0, s0, m0), (l1, s1, m1) = runs
     assert len(streams) >= 30 and all((st is not None) == manual for st in streams)
     assert s0 == s1 and m0 == m1
-    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
+    # (the grid backward's float atomics land in a different order from run to run; 52 Adam steps amplify that)
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 5e-4
 
 
 def test_step_is_deterministic_in_integer_state():
@@ -436,7 +437,7 @@ def test_event_step_with_closed_render_backward_matches_autograd_step(monkeypatc
             losses.append(h.step_events(batch(i), opt, next_data=batch(i + 1) if manual else None).clone())
         runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
                      {n: p.detach().clone() for n, p in model.named_parameters()}))
-        assert len(calls) == (40 - 16 if manual else 0)
+        assert len(calls) == (40 if manual else 0)
     (l0, c0, p0), (l1, c1, p1) = runs
     assert torch.equal(c0, c1)
     assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 2e-4

@@ -1,0 +1,94 @@
+"""Diagnostics (GPU): whole-frame inference vs the round schedule (differences, stage timings)."""
+import math, sys, os, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from enerf_amd import frame, scene
+from enerf_amd.backends import _raymarching as rb
+
+DEV = "cuda"
+
+def stats(a, b, name):
+    d = (a - b).abs()
+    d = d[torch.isfinite(d)]
+    print(f"{name}: max abs diff {float(d.max()):.3e}, differing {float((d > 0).float().mean()):.4f}")
+
+def run(net):
+    if net == "ff":
+        from enerf_amd.network_ff import NeRFNetwork
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to(DEV).eval()
+    else:
+        from enerf_amd.network import NeRFNetwork
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV).eval()
+    model.encoder.embeddings.data.uniform_(-1, 1)
+    scene.install_occupancy(model)
+    inds = torch.arange(scene.H * scene.W, device=DEV)
+    ro, rd = scene.pixel_rays(scene.pose(3), inds, DEV)
+    ro, rd = ro[0].contiguous(), rd[0].contiguous()
+    with torch.no_grad():
+        d1, i1 = frame.render_frame(model, ro, rd, 1)
+        d0, i0 = frame.render_rounds(model, ro, rd, 1)
+        model.infer_batch_mult = 8
+        d8, i8 = frame.render_rounds(model, ro, rd, 1)
+        stats(i1, i0, f"[{net}] frame vs rounds K=1 image")
+        stats(i0, i8, f"[{net}] rounds K=1 vs K=8 image")
+        stats(i1, i8, f"[{net}] frame vs rounds K=8 image")
+        stats(d1, d0, f"[{net}] frame vs rounds K=1 depth")
+        # timings
+        for fn, name in ((lambda: frame.render_frame(model, ro, rd, 1), "frame"), (lambda: frame.render_rounds(model, ro, rd, 1), "rounds K=8")):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5): fn()
+            torch.cuda.synchronize()
+            print(f"[{net}] {name}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms/frame")
+        # stage timing of render_frame
+        N = ro.shape[0]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        f32 = dict(dtype=torch.float32, device=DEV)
+        nears, fars = torch.empty(N, **f32), torch.empty(N, **f32)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=DEV); counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        geom = (ro, rd, model.density_bitfield, model.bound, 0.0, 1024, N, model.cascade, model.grid_size)
+        ev[0].record()
+        rb.near_far_from_aabb(ro, rd, model.aabb_infer, N, model.min_near, nears, fars)
+        from enerf_amd.fused_render import occupied_box_flag
+        rb.march_rays_train_count(*geom, nears, fars, rays, counter, 0, occupied_box_flag(model))
+        ev[1].record()
+        total = int(counter[0].item()); M = total + 128 - total % 128
+        xyzs, dirs, deltas = torch.empty(M, 3, **f32), torch.empty(M, 3, **f32), torch.empty(M, 2, **f32)
+        ev[2].record()
+        rb.march_rays_train_write(*geom, M, nears, fars, xyzs, dirs, deltas, rays, counter, 0, 1)
+        ev[3].record()
+        sig, rgb = torch.empty(M, **f32), torch.empty(M, 3, **f32)
+        for a in range(0, M, frame.CHUNK):
+            s, c = model(xyzs[a:a + frame.CHUNK], dirs[a:a + frame.CHUNK]); sig[a:a + frame.CHUNK] = s; rgb[a:a + frame.CHUNK] = c
+        ev[4].record()
+        ws, dp, im = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
+        rb.composite_rays_frame(sig, rgb, deltas, rays, N, M, nears, fars, 1, ws, dp, im, None)
+        ev[5].record()
+        torch.cuda.synchronize()
+        print(f"[{net}] samples {total}, max/ray {int(rays[:,2].max())}: count+scan {ev[0].elapsed_time(ev[1]):.3f} ms, write {ev[2].elapsed_time(ev[3]):.3f}, "
+              f"network {ev[3].elapsed_time(ev[4]):.3f}, composite {ev[4].elapsed_time(ev[5]):.3f}")
+
+def march_cases():
+    from oracle import oracle as O
+    from util import synthetic_density_grid, camera_rays
+    bound = 2; H = 128; C = 2
+    bits = O.packbits(synthetic_density_grid(bound, H).reshape(-1), 0.01)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    sat = np.full(C * H ** 3 // 8, 0xff, np.uint8)
+    for grid_bits, max_steps, N, perturb in [(bits, 1024, 2500, 1), (bits, 1024, 2500, 0), (sat, 8, 64, 0), (sat, 1024, 64, 0)]:
+        o, d = camera_rays(N, 37, bound)
+        if max_steps == 8: o[:] = np.array([0.1, 0.2, -0.3], np.float32)
+        aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+        nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+        ref = O.march_rays_train(o, d, grid_bits, bound, 0.0, max_steps, C, H, N * max_steps, nears, fars, perturb)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=DEV); counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        rb.march_rays_train_count(cu(o), cu(d), cu(grid_bits), bound, 0.0, max_steps, N, C, H, cu(nears), cu(fars), rays, counter, perturb, 0)
+        r = rays.cpu().numpy()
+        print("case", max_steps, N, perturb, "counter", counter.cpu().numpy(), ref[4], "rays equal", np.array_equal(r, ref[3]),
+              "n diff", int((r != ref[3]).any(1).sum()), r[:3].tolist(), ref[3][:3].tolist())
+
+march_cases()
+run("ff")
+run("linear")
