@@ -36,6 +36,12 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 GRID_FWD_BYTES_PER_POINT = 1164   # 12 in + 16 levels x 8 corners x 8 B + 128 out
+MFMA_F32_PEAK_TF = 157.3          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 MFMA
+MLP_LINEAR_FLOP_FWD = 18688       # nn.Linear nets, sigma 6144 + colour 12544 FLOP/sample forward
+MLP_LINEAR_FLOP_STEP = 56064      # forward + dgrad + wgrad = 3 x forward
+FFMLP_FLOP_FWD = 36864            # FFMLP nets (padded dims), sigma 14336 + colour 22528
+PMC_FILE = "profiles/r02_pmc_hbm_bench.json"
 
 
 def parse():
@@ -47,8 +53,8 @@ def parse():
     ap.add_argument("--bound", type=int, default=3)
     ap.add_argument("--mode", choices=["rgb", "events"], default="rgb")
     ap.add_argument("--render-frames", type=int, default=2, help="full 640x480 inference frames timed after training")
-    ap.add_argument("--render-batch-mult", type=int, default=8,
-                    help="samples per inference iteration relative to the reference schedule (image is identical)")
+    ap.add_argument("--render-rounds", action="store_true",
+                    help="render leg: the reference's round schedule (8x wider rounds) instead of the whole-frame pass")
     ap.add_argument("--net", choices=["linear", "ff"], default="linear",
                     help="linear = nerf/network.py (BASELINE configs[1-3]); ff = nerf/network_ff.py FFMLP bf16 (configs[4])")
     ap.add_argument("--graphs", action="store_true",
@@ -67,6 +73,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch / OpenMP threads of the cpu_baseline leg (0 = all cores)")
+    ap.add_argument("--probe-steps", type=int, default=15,
+                    help="extra steps after the timed region with every kernel family hipEvent-timed (MFMA roofline); 0 = skip")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="CPU work to spend on the cpu_baseline sample")
     # development aids: exercise the N > 1 code path on a single-GPU box (gloo all-reduce, every rank on one device)
     ap.add_argument("--verify-samples", action="store_true",
@@ -100,14 +109,27 @@ def pmc_traffic(points_per_launch):
     averaged over), rescaled by points per launch.  FETCH_SIZE is in KB and, per MI355X_MICROARCH.md (HBM), counts
     64 B per 128-byte request on gfx950, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).  None if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_bench.json")) as f:
+        path = os.path.join(ROOT, PMC_FILE)
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_bench.json")
+        with open(path) as f:
             j = json.load(f)
         d = j["k_grid_fwd<float, 3, 2>"]
         ref_pts = float(j["_meta"]["grid_fwd_points_per_launch"])
         per_point = (2.0 * d["FETCH_SIZE_avg"] + d["WRITE_SIZE_avg"]) * 1024.0 / ref_pts
-        return per_point * points_per_launch
+        return per_point * points_per_launch, os.path.relpath(path, ROOT)
     except Exception:
-        return None
+        return None, None
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args):
@@ -123,9 +145,11 @@ def cpu_baseline(args):
                                                          ob.shencoder_backend)
     try:
         # 16 hash-grid levels = 16 OpenMP tasks; more torch threads than that only adds fork/join cost on the
-        # small (131k x 64) GEMMs.  `cores` reports the threads actually used.
+        # small (131k x 64) GEMMs: tools/cpu_threads_sweep.py on the GPU box (profiles/r02_cpu_threads_sweep.json)
+        # measured 16 threads fastest.  `cores` reports the threads actually used, `cores_total` what the box has.
         from oracle import oracle as O
-        cores = min(os.cpu_count() or 1, 16)
+        cores_total = os.cpu_count() or 1
+        cores = min(cores_total, args.cpu_threads) if args.cpu_threads > 0 else cores_total
         prev_threads = torch.get_num_threads()
         torch.set_num_threads(cores)
         O.set_threads(cores)
@@ -154,7 +178,8 @@ def cpu_baseline(args):
             if t_total > args.cpu_budget_s:
                 break
         rays_s = steps * n / t_total
-        return {"value": rays_s, "unit": "rays/s", "cores": cores, "kind": "port",
+        return {"value": rays_s, "unit": "rays/s", "cores": cores, "cores_total": cores_total, "cpu_model": _cpu_model(),
+                "kind": "port",
                 "network_evals_per_sec": rays_s * T,
                 "sample": f"{steps} steps x {n} rays x {T} stratified samples/ray (NeRFRenderer.run + nn.Linear, "
                           f"fwd+bwd+Adam, hash grid via the C oracle with one OpenMP task per level), "
@@ -204,7 +229,10 @@ def main():
         _lib.lib().enerf_debug_march_clip(0)
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
-    model.infer_batch_mult = args.render_batch_mult
+    if args.render_rounds:
+        from enerf_amd import frame
+        frame.FRAME_ENABLED = False
+        model.infer_batch_mult = 8
     harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs)
     harness.prefetch = not args.no_prefetch
     if args.comm_bf16:
@@ -284,8 +312,16 @@ def main():
     t0 = time.perf_counter()
     # (graph mode counts per step: a capture inside the timed region runs warm-up marches that are not steps)
     per_step = torch.zeros((), dtype=torch.int64, device=device) if args.verify_samples or args.graphs else None
+    # one event per step boundary (no synchronisation): splits the window into the steps that ran before the first
+    # sample budget existed ("cold": the reference's first 16 steps) and after ("steady")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    cold = []
+    marks[0].record()
     for i in range(args.warmup, args.warmup + args.steps):
+        cold.append(model.mean_count <= 0 and harness.global_step % harness.update_interval != 0
+                    or (harness.global_step % harness.update_interval == 0 and harness.global_step < harness.update_interval))
         one_step(i)
+        marks[i - args.warmup + 1].record()
         if per_step is not None:      # the per-step bookkeeping the running total replaces (one tiny launch per render)
             slot = getattr(model, "rendered_counter_slot", None)
             slot = (model.local_step - 1) % 16 if slot is None else slot
@@ -301,6 +337,19 @@ def main():
         if per_step is not None:
             assert int(per_step.item()) == int(samples_acc.item()), (int(per_step.item()), int(samples_acc.item()))
     _lib.prof.enable(False)
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    updates = [(args.warmup + k) % harness.update_interval == 0 for k in range(args.steps)]
+
+    def _mean(sel):
+        v = [t for t, ok in zip(step_ms, sel) if ok]
+        return (sum(v) / len(v), len(v)) if v else (None, 0)
+
+    split = {}
+    for name, sel in (("cold", [c and not u for c, u in zip(cold, updates)]),
+                      ("steady", [not c and not u for c, u in zip(cold, updates)]),
+                      ("with_update_extra_state", updates)):
+        ms, n = _mean(sel)
+        split[name] = {"ms_per_step": ms, "steps": n}
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -319,13 +368,52 @@ def main():
     if "grid_fwd" in kernels and gb.STATS["fwd_calls"]:
         pts = gb.STATS["fwd_points"] / gb.STATS["fwd_calls"]
         achieved = pts * GRID_FWD_BYTES_PER_POINT / (kernels["grid_fwd"]["avg_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(pts)
         roofline = {"bound": "hbm", "kernel": "grid_encode_forward", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pts),
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": None if traffic is None else
+                    f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run), "
+                    f"bytes per point x this run's points per launch",
                     "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"]}
         if "grid_bwd" in kernels and gb.STATS["bwd_calls"]:
             ptsb = gb.STATS["bwd_points"] / gb.STATS["bwd_calls"]
             roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / \
                 (kernels["grid_bwd"]["avg_ms"] * 1e-3) / 1e9
+
+    # ---- MFMA probe (not part of `value`): a few more steps with the MLP kernel families hipEvent-timed as well, no
+    # density-grid update in between (its sigma-only sweep is a different launch shape).  Timing every family costs
+    # ~5 % of a step, which is why the timed region above only times the grid kernels.
+    roofline_mfma = None
+    if args.probe_steps > 0 and args.net == "linear" and args.mode == "rgb" and not args.graphs:
+        keep_interval = harness.update_interval
+        harness.update_interval = 10 ** 9
+        try:
+            base = args.warmup + args.steps
+            one_step(base)
+            sync()
+            _lib.prof.reset()
+            _lib.prof.enable(True, only=("ffmlp_fwd", "ffmlp_bwd"))
+            before = marched_total(reset=False)
+            for i in range(base + 1, base + 1 + args.probe_steps):
+                one_step(i)
+            sync()
+            _lib.prof.enable(False)
+            probe_samples = (marched_total(reset=False) - before) / args.probe_steps      # (one march is always ahead)
+            fwd_ms, nf = _lib.prof.read("ffmlp_fwd")
+            bwd_ms, nb = _lib.prof.read("ffmlp_bwd")
+            if nf and nb:
+                per_step_ms = (fwd_ms + bwd_ms) / args.probe_steps
+                tf = probe_samples * MLP_LINEAR_FLOP_STEP / (per_step_ms * 1e-3) / 1e12
+                roofline_mfma = {"bound": "mfma", "kernel": "mlp32 sigma + colour nets, forward + fused dgrad/wgrad "
+                                 "(v_mfma_f32_32x32x2_f32)", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": tf / MFMA_F32_PEAK_TF, "flop_per_sample": MLP_LINEAR_FLOP_STEP,
+                                 "samples_per_step": probe_samples, "kernel_ms_per_step": per_step_ms,
+                                 "forward_ms_per_step": fwd_ms / args.probe_steps,
+                                 "backward_ms_per_step": bwd_ms / args.probe_steps,
+                                 "launches": int(nf + nb), "steps": args.probe_steps,
+                                 "timing": "hipEvent pairs around each launch (read ~6 % long on 30 us kernels)"}
+        finally:
+            harness.update_interval = keep_interval
 
     # ---- graph-replay leg (not part of `value`; single GPU, fp32 fused path): the same steps with render + loss +
     # backward replayed as a HIP graph.  Reported beside the eager number because the per-kernel hipEvent timing that
@@ -347,45 +435,63 @@ def main():
                         "rays_per_sec": args.rays * (2 if args.mode == "events" else 1) / tg,
                         "steps": args.graph_leg_steps, "graphs_captured": len(harness._graphs)}
 
-    # ---- render leg (not part of `value`): full 640x480 frame through the inference loop
+    # ---- render leg (not part of `value`): full 640x480 frame, pixels sharded over the ranks + all_gather of the tiles
+    # (SURVEY.md 8e).  msamples_per_sec is the whole job's: samples marched on all ranks / slowest rank's time.
     render = None
     if args.render_frames > 0:
         from enerf_amd import scene
-        model.eval()
-        inds = torch.arange(scene.H * scene.W, device=device)
-        ro, rd = scene.pixel_rays(scene.pose(3), inds, device)
-        with torch.no_grad():
-            model.render(ro, rd, staged=False, bg_color=None, perturb=False)      # warm-up
-            torch.cuda.synchronize()
-            rb.STATS.update(infer_samples=0, infer_calls=0)
-            tr0 = time.perf_counter()
-            for _ in range(args.render_frames):
-                model.render(ro, rd, staged=False, bg_color=None, perturb=False)
-            torch.cuda.synchronize()
-            tr = time.perf_counter() - tr0
-        render = {"msamples_per_sec": rb.STATS["infer_samples"] / tr / 1e6, "frames": args.render_frames,
-                  "batch_mult": args.render_batch_mult, "net": args.net,
-                  "rays_per_frame": scene.H * scene.W, "ms_per_frame": tr / args.render_frames * 1e3,
-                  "march_iterations_per_frame": rb.STATS["infer_calls"] / args.render_frames}
+
+        def time_frames(net):
+            inds = torch.arange(scene.H * scene.W, device=device)
+            ro, rd = scene.pixel_rays(scene.pose(3), inds, device)
+            net.eval()
+            with torch.no_grad():
+                parallel.render_sharded(net, ro, rd, bg_color=None, perturb=False)      # warm-up
+                sync()
+                rb.STATS.update(infer_samples=0, infer_calls=0)
+                _lib.prof.reset()
+                _lib.prof.enable(True, only=("ffmlp_fwd",))
+                tr0 = time.perf_counter()
+                for _ in range(args.render_frames):
+                    out = parallel.render_sharded(net, ro, rd, bg_color=None, perturb=False)
+                sync()
+                tr = time.perf_counter() - tr0
+                _lib.prof.enable(False)
+            mlp_ms, mlp_n = _lib.prof.read("ffmlp_fwd")
+            stat = torch.tensor([tr, float(rb.STATS["infer_samples"])], dtype=torch.float64, device=device)
+            if world > 1:
+                t_max = stat[:1].clone()
+                dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+                dist.all_reduce(stat[1:], op=dist.ReduceOp.SUM)
+                stat[0] = t_max[0]
+            tr, samples = float(stat[0]), float(stat[1])
+            assert out["image"].shape == (1, scene.H * scene.W, 3)
+            return {"msamples_per_sec": samples / tr / 1e6, "ms_per_frame": tr / args.render_frames * 1e3,
+                    "samples_per_frame": samples / args.render_frames,
+                    "launch_rounds_per_frame_per_rank": rb.STATS["infer_calls"] / args.render_frames}, \
+                (mlp_ms / args.render_frames, rb.STATS["infer_samples"] / args.render_frames)
+
+        r, _ = time_frames(model)
+        render = dict(r, frames=args.render_frames, net=args.net, rays_per_frame=scene.H * scene.W,
+                      schedule="whole frame: march all samples once, one compositing pass (enerf_amd/frame.py)",
+                      sharding=f"pixels over {world} rank(s) + all_gather of the tiles")
         model.train()
-        if args.net != "ff" and rank == 0:
+        if args.net != "ff":
             # BASELINE configs[4]: the same frame through the fully-fused (bf16 MFMA) networks of nerf/network_ff.py
             from enerf_amd.network_ff import NeRFNetwork as FFNet
             torch.manual_seed(0)
             ffm = FFNet(encoding="hashgrid", bound=args.bound, cuda_ray=True).to(device).eval()
             scene.install_occupancy(ffm)
-            ffm.infer_batch_mult = args.render_batch_mult
-            with torch.no_grad():
-                ffm.render(ro, rd, staged=False, bg_color=None, perturb=False)
-                torch.cuda.synchronize()
-                rb.STATS.update(infer_samples=0, infer_calls=0)
-                tr0 = time.perf_counter()
-                for _ in range(args.render_frames):
-                    ffm.render(ro, rd, staged=False, bg_color=None, perturb=False)
-                torch.cuda.synchronize()
-                tr = time.perf_counter() - tr0
-            render["ffmlp_nets"] = {"msamples_per_sec": rb.STATS["infer_samples"] / tr / 1e6,
-                                    "ms_per_frame": tr / args.render_frames * 1e3, "dtype": "bf16"}
+            ffm.infer_batch_mult = 8
+            r, (mlp_ms, mlp_samples) = time_frames(ffm)
+            render["ffmlp_nets"] = dict(r, dtype="bf16")
+            if mlp_ms > 0:
+                tf = mlp_samples * FFMLP_FLOP_FWD / (mlp_ms * 1e-3) / 1e12
+                render["ffmlp_nets"]["roofline_mfma"] = {
+                    "bound": "mfma", "kernel": "k_ffnerf_infer (both FFMLP nets of network_ff in one launch, bf16 MFMA; "
+                    "this rank)", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": tf / MFMA_BF16_PEAK_TF, "flop_per_sample": FFMLP_FLOP_FWD,
+                    "samples_per_frame": mlp_samples, "kernel_ms_per_frame": mlp_ms}
             del ffm
 
     cpu = None
@@ -395,7 +501,8 @@ def main():
         env = dict(os.environ)
         env.pop("HIP_VISIBLE_DEVICES", None)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-rays",
-                            str(args.cpu_rays), "--cpu-budget-s", str(args.cpu_budget_s), "--bound", str(args.bound)],
+                            str(args.cpu_rays), "--cpu-budget-s", str(args.cpu_budget_s), "--bound", str(args.bound),
+                            "--cpu-threads", str(args.cpu_threads)],
                            capture_output=True, text=True, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         cpu = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]}
@@ -422,6 +529,8 @@ def main():
             "train_ray_samples_per_sec": total_samples / elapsed,
             "samples_per_step_per_gpu": total_samples / args.steps / world,
             "render": render,
+            "step_split": split,
+            "roofline_mfma": roofline_mfma,
             "graph_replay": graph_replay,
             "comm_tuning": comm_tuning,
             "kernels": kernels,

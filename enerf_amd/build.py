@@ -23,6 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # v_accvgpr_read/write pair per element.  The weight-gradient kernels hold up to 192 accumulator registers and need
 # the AGPR half of the register file, so they live in their own translation unit without the flag.
 EXTRA = {"ffmlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# development aid: extra -D flags for every file (e.g. ENERF_DEFINES="-DENERF_BIN_TIMING" python -m enerf_amd.build --force)
+FLAGS += os.environ.get("ENERF_DEFINES", "").split()
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ffmlp_common.h"),
            os.path.join(_HERE, "..", "include", "enerf_hip.h")]
 

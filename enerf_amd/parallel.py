@@ -102,6 +102,30 @@ class GradAverager:
         self.finish()
 
 
+@torch.no_grad()
+def render_sharded(model, rays_o, rays_d, **render_kw):
+    """Inference at N > 1: rank r renders the contiguous slice shard_range(N, r, world) of the rays
+    [1,N,3] and the tiles are all-gathered (the reference's evaluation loop does the same with its predictions,
+    nerf/utils.py:1069-1071): every rank returns the full {"image": [1,N,3], "depth": [1,N]}.  One collective of
+    16 B per ray (4.9 MB for a 640x480 frame); slices are padded to equal length so that a single
+    all_gather_into_tensor serves any N.  A single process (no process group) just renders."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model.render(rays_o, rays_d, staged=False, **render_kw)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    N = rays_o.shape[1]
+    lo, hi = shard_range(N, rank, world)
+    out = model.render(rays_o[:, lo:hi].contiguous(), rays_d[:, lo:hi].contiguous(), staged=False, **render_kw)
+    width = -(-N // world)
+    tile = torch.zeros(width, 4, dtype=torch.float32, device=rays_o.device)          # (r, g, b, depth) per ray
+    tile[:hi - lo, :3] = out["image"].reshape(-1, 3)
+    tile[:hi - lo, 3] = out["depth"].reshape(-1)
+    full = torch.empty(world * width, 4, dtype=torch.float32, device=rays_o.device)
+    dist.all_gather_into_tensor(full, tile)
+    rows = torch.cat([full[r * width:r * width + (shard_range(N, r, world)[1] - shard_range(N, r, world)[0])]
+                      for r in range(world)]) if world * width != N else full
+    return {"image": rows[:, :3].reshape(1, N, 3), "depth": rows[:, 3].reshape(1, N)}
+
+
 def broadcast_state(model, src=0):
     """Make replicas identical (parameters and buffers, incl. the occupancy grid / bitfield)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -162,3 +162,44 @@ def test_comm_tuning_slowest_rank_decides(tmp_path):
     assert a["timings"][1] >= 19.0 and a["timings"][8] >= 19.0 and a["timings"][2] < 15.0       # ms per step
     # warm-up + 3 candidates, then two windows (march placement) with the chosen cut
     assert [c for _, c in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 + [2] * 6 and [i for i, _ in a["seen"]] == list(range(18))
+
+
+def _render_worker(rank, world, port, n_rays, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    _inject_oracle()
+    from enerf_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    m, ro, rd, _ = _model_and_data(n_rays)
+    m.eval()
+    out = parallel.render_sharded(m, ro, rd, bg_color=None, perturb=False)
+    torch.save({k: v.clone() for k, v in out.items()}, os.path.join(outdir, f"render{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_render_equals_single_process_render(tmp_path):
+    """Inference at N = 2: each rank renders its slice of the rays, all_gather of the tiles -> every rank holds the
+    full frame, equal to the single-process render (an odd ray count exercises the padded last tile)."""
+    n_rays, world = 51, 2
+    port = _free_port()
+    mp.spawn(_render_worker, args=(world, port, n_rays, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "render0.pt"), torch.load(tmp_path / "render1.pt")
+    sys.path.insert(0, ROOT)
+    _inject_oracle()
+    try:
+        m, ro, rd, _ = _model_and_data(n_rays)
+        m.eval()
+        with torch.no_grad():
+            ref = m.render(ro, rd, staged=False, bg_color=None, perturb=False)
+        for got in (r0, r1):
+            assert got["image"].shape == (1, n_rays, 3) and got["depth"].shape == (1, n_rays)
+            assert torch.equal(got["image"], ref["image"])
+            assert torch.equal(got["depth"].nan_to_num(-7.0), ref["depth"].nan_to_num(-7.0))
+    finally:
+        import importlib
+        import enerf_amd.raymarching as rm, enerf_amd.gridencoder as ge, enerf_amd.shencoder as sh
+        importlib.reload(rm); importlib.reload(ge); importlib.reload(sh)
