@@ -345,6 +345,33 @@ def gold_near_far_from_bound():
     save("ref_near_far_from_bound", **out)
 
 
+def gold_binding_signatures():
+    """Argument kinds and names, in order, of the 20 functions the reference binds (raymarching/src/raymarching.h:7-19,
+    gridencoder/src/gridencoder.h:12-13, shencoder/src/shencoder.h:9,12, ffmlp/src/ffmlp.h:8-14), parsed from those
+    headers at mint time.  Data only: {module: {function: [[kind, name], ...]}}."""
+    import json
+    import re
+    headers = {"_raymarching": "raymarching/src/raymarching.h", "_gridencoder": "gridencoder/src/gridencoder.h",
+               "_shencoder": "shencoder/src/shencoder.h", "_ffmlp": "ffmlp/src/ffmlp.h"}
+    kinds = {"at::Tensor": "Tensor", "uint32_t": "int", "size_t": "int", "float": "float", "bool": "bool"}
+    out = {}
+    for mod, rel in headers.items():
+        text = open(os.path.join(ref_import.REFERENCE, rel)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        fns = {}
+        for m in re.finditer(r"\bvoid\s+(\w+)\s*\(([^)]*)\)\s*;", text):
+            params = []
+            for a in filter(None, (x.strip() for x in m.group(2).split(","))):
+                toks = a.replace("const", "").split()
+                params.append([kinds[toks[0]], toks[1]])
+            fns[m.group(1)] = params
+        out[mod] = fns
+    assert sum(len(v) for v in out.values()) == 20, {k: len(v) for k, v in out.items()}
+    with open(os.path.join(OUT, "ref_binding_signatures.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("  wrote ref_binding_signatures.json", {k: len(v) for k, v in out.items()})
+
+
 def gold_state_dict_schema():
     """state_dict layout (key -> shape, dtype) of the reference's two network classes with cuda_ray on, at the bounds
     of the BASELINE configs: what a reference `.pth` checkpoint's 'model' entry looks like (nerf/utils.py
@@ -375,7 +402,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_state_dict_schema]
+            gold_binding_signatures, gold_state_dict_schema]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

@@ -57,17 +57,40 @@ def test_product_path_refuses_cpu_tensors():
                                          4, 3, 2, 1, 0.0, 16, False, torch.zeros(1), 0)
 
 
-def test_dropin_modules_importable_as_top_level():
+def test_extension_modules_import_as_top_level_and_match_the_reference_prototypes():
+    """The four pybind11 modules (enerf_amd/ext, built by __graft_entry__.build) import under the names the reference's
+    wrappers look for, and every function takes the reference's arguments -- kinds and order -- as recorded from the
+    reference's own headers (tests/golden/ref_binding_signatures.json: raymarching.h:7-19, gridencoder.h:12-13,
+    shencoder.h:9,12, ffmlp.h:8-14).  The ctypes face of the same entry points (enerf_amd/backends) is held to the same
+    parameter names."""
     import importlib
+    import inspect
+    import json
     import sys
-    d = os.path.join(ROOT, "enerf_amd", "dropin")
-    sys.path.insert(0, d)
+    from enerf_amd import ext
+    from enerf_amd.ext import build as eb
+    eb.build(verbose=False)
+    sigs = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_binding_signatures.json")))
+    d = ext.activate()
+    kind_of = {"Tensor": "torch.Tensor", "int": "SupportsInt", "float": "SupportsFloat", "bool": "bool"}
     try:
-        for n in ("_raymarching", "_gridencoder", "_shencoder", "_ffmlp"):
-            sys.modules.pop(n, None)
-            m = importlib.import_module(n)
+        for mod_name, functions in sigs.items():
+            sys.modules.pop(mod_name, None)
+            m = importlib.import_module(mod_name)
             assert m.__file__.startswith(d)
+            back = importlib.import_module("enerf_amd.backends." + mod_name)
+            assert sorted(functions) == sorted(n for n in dir(m) if not n.startswith("_"))
+            for fname, params in functions.items():
+                doc = getattr(m, fname).__doc__.split("->")[0]
+                got = [a.split(":")[1].strip() for a in doc[doc.index("(") + 1:doc.rindex(")")].split(",") if ":" in a]
+                assert len(got) == len(params), (mod_name, fname, got, params)
+                for g, (kind, _) in zip(got, params):
+                    assert kind_of[kind] in g, (mod_name, fname, g, kind)
+                names = [p.rstrip("_") for p in inspect.signature(getattr(back, fname)).parameters]
+                ref_names = [n.rstrip("_") for _, n in params]
+                assert names[:len(ref_names)] == ref_names, (mod_name, fname, names, ref_names)
     finally:
-        sys.path.remove(d)
-        for n in ("_raymarching", "_gridencoder", "_shencoder", "_ffmlp"):
+        if d in sys.path:
+            sys.path.remove(d)
+        for n in sigs:
             sys.modules.pop(n, None)
