@@ -248,15 +248,45 @@ def main():
             return harness.step_rgb(ro, rd, target, next_rays=(nxt[0], nxt[1]))
         return harness.step_events(event_data(i), ev_opt, next_data=event_data(i + 1))
 
-    def event_data(i):
-        ro, rd, target = batches[i % len(batches)]
-        ro2, rd2, _ = batches[(i + 1) % len(batches)]
-        if i % len(batches) not in pols_cache:
-            pols_cache[i % len(batches)] = torch.sign(target[..., 0] - 0.5)
-        return {"images": target, "rays_evs_o1": ro, "rays_evs_d1": rd, "rays_evs_o2": ro2, "rays_evs_d2": rd2,
-                "pols": pols_cache[i % len(batches)]}
+    # --mode events: the step starts at the event stream, not at ready-made rays -- per step ONE launch draws 4096
+    # event pairs from a pixel-grouped table of 2 M synthetic events, sums their polarities, interpolates the camera
+    # pose at both event times from a 64-pose track (Slerp + cubic, as the reference's provider does with scipy on the
+    # host) and emits the two ray sets (enerf_amd/event_sampler.event_pair_rays, csrc/event_pairs.hip)
+    ev_state = {}
 
-    pols_cache = {}
+    def event_stream():
+        from enerf_amd import scene
+        from enerf_amd.event_sampler import build_event_tables
+        from enerf_amd.pose_interp import PoseTrack
+        g = torch.Generator(device=device).manual_seed(4321 + rank)
+        n = 2_000_000
+        span_ns = 2.0e8
+        ev = torch.stack([torch.randint(0, scene.W, (n,), device=device, generator=g).float(),
+                          torch.randint(0, scene.H, (n,), device=device, generator=g).float(),
+                          torch.rand(n, device=device, generator=g) * span_ns,
+                          torch.randint(0, 2, (n,), device=device, generator=g).float() * 2 - 1], dim=1)
+        K = 64
+        times = torch.linspace(-1.0, span_ns + 1.0, K, dtype=torch.float64)
+        c2w = torch.stack([scene.pose(3.0 + 0.8 * k / (K - 1)) for k in range(K)])        # 9 degrees along the circle
+        track = PoseTrack(times.numpy(), c2w[:, :3, :3].numpy(), c2w[:, :3, 3].numpy(), device=device)
+        return build_event_tables(ev), track, g
+
+    def event_data(i):
+        from enerf_amd import scene
+        from enerf_amd.event_sampler import event_pair_rays
+        if "tables" not in ev_state:
+            ev_state["tables"], ev_state["track"], ev_state["gen"] = event_stream()
+            ev_state["images"] = torch.zeros(1, args.rays, 3, device=device)
+        cache = ev_state.setdefault("cache", {})
+        if i not in cache:
+            for k in [k for k in cache if k < i - 1]:
+                del cache[k]
+            d = event_pair_rays(ev_state["tables"], ev_state["track"], scene.INTRINSICS, args.rays, 0,
+                                generator=ev_state["gen"])
+            cache[i] = {"images": ev_state["images"], "rays_evs_o1": d["rays_evs_o1"], "rays_evs_d1": d["rays_evs_d1"],
+                        "rays_evs_o2": d["rays_evs_o2"], "rays_evs_d2": d["rays_evs_d2"], "pols": d["pols"]}
+        return cache[i]
+
 
     def sync():
         torch.cuda.synchronize()

@@ -67,6 +67,8 @@ SIGNATURES = {
     "enerf_debug_march_wave_max_rays": [_u32],
     "enerf_debug_march_bg_blocks": [_u32],
     "enerf_debug_march_clip": [_int],
+    "enerf_event_pair_rays": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _f32, _f32, _f32,
+                              _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_occupied_box_update": [_vp, _u32, _u32, _f32, _vp],
     "enerf_debug_mlp32_fused_backward": [_int],
     "enerf_debug_grid_bwd_binned": [_u32, _u32],

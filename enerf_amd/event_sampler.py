@@ -113,3 +113,39 @@ def event_pair_batch(tables, poses_evs, intrinsics, batch_size, accumulate=True,
     rays = get_event_rays(xs, ys, poses_evs[start].unsqueeze(0), poses_evs[end].unsqueeze(0), intrinsics)
     rays["pols"] = pols
     return rays
+
+
+def event_pair_rays(tables, track, intrinsics, batch_size, acc_max_num_evs=0, generator=None, draws=None):
+    """One step's event entries of collate (provider.py:1364-1441, accumulate_evs, poses computed online) as ONE launch
+    on the device: pair selection + polarity sums + pose interpolation at both event times (PoseTrack) + ray generation
+    (csrc/event_pairs.hip).  `tables` from build_event_tables on the device, `track` a PoseTrack on the same device.
+    -> {"rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2"} [1,M,3], "pols" [1,M], "start" / "end" [M]."""
+    from . import _lib as L
+    ev = tables["events"]
+    dev = ev.device
+    if not ev.is_cuda:
+        raise RuntimeError("event_pair_rays runs on the device; the host route is event_pair_batch")
+    N, M = ev.shape[0], int(batch_size)
+    draws = draws or {}
+    start = draws["start"].to(dev) if "start" in draws else torch.randint(0, N, (M,), device=dev, generator=generator)
+    u = draws["u_end"].to(dev) if "u_end" in draws else torch.rand(M, device=dev, generator=generator, dtype=torch.float64)
+    if "_packed" not in tables:        # the layout the kernel reads, built once per event batch
+        tables["_packed"] = (ev.float().contiguous(), tables["no_successor"].to(torch.uint8).contiguous(),
+                             tables["num_successor"].to(torch.int64).contiguous(),
+                             tables["pol_cumsum"].to(torch.float64).contiguous())
+    evf, nos, nsucc, cs = tables["_packed"]
+    f32 = dict(dtype=torch.float32, device=dev)
+    o1, d1, o2, d2 = (torch.empty(M, 3, **f32) for _ in range(4))
+    pols = torch.empty(M, **f32)
+    s_out = torch.empty(M, dtype=torch.int64, device=dev)
+    e_out = torch.empty(M, dtype=torch.int64, device=dev)
+    outside = torch.zeros(1, dtype=torch.int32, device=dev)
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    L.check(L.lib().enerf_event_pair_rays(
+        evf.data_ptr(), nos.data_ptr(), nsucc.data_ptr(), cs.data_ptr(), N, start.to(torch.int64).contiguous().data_ptr(),
+        u.to(torch.float64).contiguous().data_ptr(), M, int(acc_max_num_evs), track.knots.data_ptr(), track.rot.data_ptr(),
+        track.rotvec.data_ptr(), track.tcoef.data_ptr(), track.K, fx, fy, cx, cy, o1.data_ptr(), d1.data_ptr(),
+        o2.data_ptr(), d2.data_ptr(), pols.data_ptr(), s_out.data_ptr(), e_out.data_ptr(), outside.data_ptr(),
+        L.stream_handle()), "event_pair_rays")
+    return {"rays_evs_o1": o1[None], "rays_evs_d1": d1[None], "rays_evs_o2": o2[None], "rays_evs_d2": d2[None],
+            "pols": pols[None], "start": s_out, "end": e_out, "outside_track": outside}

@@ -409,6 +409,25 @@ int enerf_debug_march_bg_blocks(uint32_t n);
 /* tuning aid: workgroup caps of the mlp32 forward and fused-backward grids (0 = built-in defaults) */
 int enerf_debug_mlp32_grid_caps(uint32_t fwd_blocks, uint32_t bwd_blocks);
 
+/* Event-pair ray generation (the caller that feeds the event step: EventNeRFDataset.collate, nerf/provider.py:1364-1441,
+ * accumulate_evs branch with poses "computed online", + get_event_rays, nerf/utils.py:184-216), one thread per pair:
+ *   s = start_draw[k] - no_successor[start_draw[k]];  ns = min(num_successor[s], acc_max_num_evs + 1) (0 = no cap);
+ *   e = s + 1 + min(floor(u_end[k] * ns), ns - 1);    pols[k] = pol_cumsum[e + 1] - pol_cumsum[s + 1];
+ *   pose(t) for t = events[s].t and events[e].t from the track: R = rot[i] * exp(alpha * rotvec[i]) (scipy Slerp),
+ *   translation = cubic tcoef[i] in (t - knots[i]) (interp1d(kind="cubic") as a piecewise polynomial), segment i by
+ *   binary search over knots[K], evaluated in double, rounded to fp32; rays: pixel (x, y) of event s -> unit camera
+ *   direction -> rays_d = R d, rays_o = translation, at both poses.
+ * events [N,4] fp32 rows (x, y, t, polarity) grouped by pixel (enerf_amd/event_sampler.build_event_tables);
+ * no_successor u8 [N]; num_successor i64 [N]; pol_cumsum f64 [N+1]; start_draw i64 [M] in [0,N); u_end f64 [M] in [0,1);
+ * rot f64 [K,9]; rotvec f64 [K-1,3]; tcoef f64 [K-1,4,3] (highest power first); outputs [M,3] fp32, pols [M] fp32,
+ * start/end i64 [M]; *outside_track += pairs whose times fall outside [knots[0], knots[K-1]]. */
+int enerf_event_pair_rays(const float* events, const uint8_t* no_successor, const int64_t* num_successor,
+                          const double* pol_cumsum, uint32_t N, const int64_t* start_draw, const double* u_end,
+                          uint32_t M, uint32_t acc_max_num_evs, const double* knots, const double* rot,
+                          const double* rotvec, const double* tcoef, uint32_t K, float fx, float fy, float cx, float cy,
+                          float* rays_o1, float* rays_d1, float* rays_o2, float* rays_d2, float* pols,
+                          int64_t* start_out, int64_t* end_out, int32_t* outside_track, enerf_stream_t stream);
+
 /* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
  * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */
 int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,

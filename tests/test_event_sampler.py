@@ -109,3 +109,75 @@ def test_device_tables_and_pairs_match_cpu():
     evg = tg["events"]
     assert bool((evg[s, 0] == evg[e, 0]).all()) and bool((evg[s, 1] == evg[e, 1]).all())
     assert bool((evg[s, 2] < evg[e, 2]).all()) and int((e - s).max()) <= 9 and int((e - s).min()) >= 1
+
+
+def _track(K, t_lo, t_hi, seed):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    gaps = rng.uniform(0.5, 2.0, K - 1)
+    t = t_lo - 1.0 + np.concatenate([[0.0], np.cumsum(gaps)]) * ((t_hi - t_lo + 2.0) / gaps.sum())
+    R = Rotation.from_rotvec(np.cumsum(rng.normal(size=(K, 3)) * 0.04, 0))
+    p = np.cumsum(rng.normal(size=(K, 3)) * 0.02, 0) + np.array([1.5, 0.3, 0.0])
+    return t, R, p
+
+
+def test_pose_track_equals_scipy_slerp_and_cubic_interp1d():
+    """enerf_amd/pose_interp.PoseTrack (per-segment rotation vectors + cubic coefficients, evaluated as a tensor
+    program) against what the reference calls per step: scipy's Slerp and interp1d(kind="cubic")
+    (nerf/provider.py:1142-1143) -- the reference's own dependency is the oracle here."""
+    from scipy.interpolate import interp1d
+    from scipy.spatial.transform import Slerp
+    from enerf_amd.pose_interp import PoseTrack
+    t, R, p = _track(60, 1.0e9, 1.2e9, 3)
+    tr = PoseTrack(t, R.as_matrix(), p)
+    rng = np.random.default_rng(4)
+    q = rng.uniform(t[0], t[-1], 5000)
+    q[:4] = [t[0], t[-1], t[17], np.nextafter(t[18], 0)]                   # knots and a hair before a knot
+    got = tr.poses_at(torch.from_numpy(q)).double().numpy()
+    ref_R = Slerp(t, R)(q).as_matrix()
+    ref_p = interp1d(x=t, y=p, axis=0, kind="cubic", bounds_error=True)(q)
+    assert np.abs(got[:, :, :3] - ref_R).max() < 2e-7 and np.abs(got[:, :, 3] - ref_p).max() < 2e-7
+    with pytest.raises(ValueError):
+        tr.poses_at(torch.tensor([t[-1] + 1.0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("acc_max", [0, 6])
+def test_event_pair_rays_kernel_vs_reference_loop_scipy_and_get_event_rays(acc_max):
+    """csrc/event_pairs.hip (one launch: pair selection, polarity sums, pose interpolation, rays) at 4096 pairs of a
+    200 k-event batch, against the host route the reference takes per step: the collate loop (oracle/event_collate.py),
+    scipy's Slerp + cubic interp1d at the event times, get_event_rays."""
+    from scipy.interpolate import interp1d
+    from scipy.spatial.transform import Slerp
+    from enerf_amd.event_sampler import build_event_tables, event_pair_rays
+    from enerf_amd.events import get_event_rays
+    from enerf_amd.pose_interp import PoseTrack
+    ev = _events(200000, 346, 260, 12)
+    g = EC.group_events(ev)
+    tables = build_event_tables(torch.from_numpy(ev).cuda())
+    assert np.array_equal(tables["events"].cpu().numpy(), g["events"])
+    N, M = len(g["events"]), 4096
+    t, R, p = _track(500, float(ev[:, 2].min()), float(ev[:, 2].max()), 5)
+    track = PoseTrack(t, R.as_matrix(), p, device="cuda")
+    rng = np.random.default_rng(6)
+    eidx, u = rng.integers(0, N, M), rng.random(M)
+    intr = (320.0, 320.0, 173.0, 130.0)
+    out = event_pair_rays(tables, track, intr, M, acc_max, draws={"start": torch.from_numpy(eidx),
+                                                                   "u_end": torch.from_numpy(u)})
+    torch.cuda.synchronize()
+    rs, re_, rp, rx, ry = EC.collate_pairs(g, eidx, u, acc_max)
+    assert np.array_equal(out["start"].cpu().numpy(), rs) and np.array_equal(out["end"].cpu().numpy(), re_)
+    assert np.array_equal(out["pols"][0].cpu().numpy(), rp) and int(out["outside_track"]) == 0
+
+    def host_pose(idx):                                                    # provider.py:1411-1415
+        ts = g["events"][idx, 2].astype(np.float64)
+        rots = Slerp(t, R)(ts).as_matrix()
+        trans = interp1d(x=t, y=p, axis=0, kind="cubic", bounds_error=True)(ts)
+        return torch.Tensor(np.concatenate([rots, trans[:, :, None]], -1)).unsqueeze(0)
+
+    ref = get_event_rays(torch.from_numpy(rx)[None], torch.from_numpy(ry)[None], host_pose(rs), host_pose(re_), intr)
+    for k in ("rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=2e-6, err_msg=k)
+    # times outside the track are counted, as interp1d(bounds_error=True) would have raised
+    short = PoseTrack(t[:250], R[:250].as_matrix(), p[:250], device="cuda")
+    assert int(event_pair_rays(tables, short, intr, M, acc_max)["outside_track"]) > 0
