@@ -24,7 +24,8 @@ common = dict(
     library_dirs=[os.path.join(ROOT, "enerf_amd", "lib"), os.path.join(ROCM, "lib")],
     libraries=["enerf_hip", "amdhip64", "c10_hip"],
     runtime_library_dirs=["$ORIGIN/../lib"],
-    extra_compile_args=["-O2", "-std=c++17", "-Wno-deprecated-declarations"],
+    extra_compile_args=["-O2", "-g0", "-std=c++17", "-Wno-deprecated-declarations"],
+    extra_link_args=["-s"],
 )
 
 if __name__ == "__main__":

@@ -4,8 +4,10 @@
 // Host code only: the kernels live in libenerf_hip.so (include/enerf_hip.h).
 #pragma once
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// torch on ROCm presents the GPU as device type `cuda`: its guard / stream classes for extension code are the
+// "masquerading" ones (c10::hip::HIPGuard proper refuses a cuda-typed device)
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "enerf_hip.h"
 
@@ -48,10 +50,11 @@ inline int abi_dtype(const at::Tensor& t, const char* name, bool allow_bf16 = fa
 
 // RAII: make the tensor's device current and expose torch's current stream on it
 struct Launch {
-    c10::hip::HIPGuard guard;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard;
     enerf_stream_t stream;
     explicit Launch(const at::Tensor& t)
-        : guard(t.device()), stream((enerf_stream_t)c10::hip::getCurrentHIPStream(t.device().index()).stream()) {}
+        : guard(t.device()),
+          stream((enerf_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream()) {}
 };
 
 inline void ok(int status, const char* what) {
