@@ -53,7 +53,7 @@ struct Launch {
     c10::hip::HIPGuardMasqueradingAsCUDA guard;
     enerf_stream_t stream;
     explicit Launch(const at::Tensor& t)
-        : guard(t.device()),
+        : guard((need_device(t, "the first tensor argument"), t.device())),
           stream((enerf_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream()) {}
 };
 

@@ -68,6 +68,8 @@ def test_raymarching_module_vs_oracle(ext):
     assert_close(im, im_ref, rtol=1e-4, atol=1e-6)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         rm.morton3D(torch.zeros(4, 3, dtype=torch.int32), 4, torch.zeros(4, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        rm.morton3D(torch.zeros(4, 3, dtype=torch.int32, device=DEV), 4, torch.zeros(4, dtype=torch.int32))
     with pytest.raises(RuntimeError, match="contiguous"):
         rm.near_far_from_aabb(cu(o).t().contiguous().t(), cu(d), cu(aabb), N, 0.2, nears, fars)     # strided view
 
