@@ -299,6 +299,8 @@ def main():
         comm_tuning = harness.tune_comm(one_step)       # untimed: chooses how the gradient all-reduce is cut
         if comm_tuning:
             comm_tuning = {"ms_per_step": comm_tuning, "chosen_chunks": harness.comm_chunks,
+                           "sharded_tail_ms_per_step": harness.tuned["sharded_ms_per_step"],
+                           "chosen_tail": harness.comm_mode,
                            "prefetch_at_ms_per_step": harness.tuned["prefetch_at_ms_per_step"],
                            "chosen_prefetch_at": harness.prefetch_at}
             if harness.comm_dtype is None:      # reported only: what the opt-in 16-bit wire format would give here

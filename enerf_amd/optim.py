@@ -24,14 +24,15 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
-    def step_now(self, only=None, ranges=None, zero_grads=False):
+    def step_now(self, only=None, ranges=None, zero_grads=False, advance=None):
         """The update itself.  `step()` is wrapped by torch.optim.Optimizer with profiler / hook plumbing that costs
         ~40 us per call; a training loop that needs neither can call this directly.
 
         only   : restrict the update to these parameters (a data-parallel loop updates each bucket as soon as its
                  all-reduce has landed).  Every parameter must be stepped exactly once per optimisation step.
-        ranges : {parameter: (lo, hi)} -- update only elements [lo, hi) of that (fused-path) parameter; the step
-                 count advances on the range starting at 0.
+        ranges : {parameter: (lo, hi)} -- update only elements [lo, hi) of that parameter; the step count advances on
+                 the range starting at 0 (a loop that walks all ranges), or on every call with advance=True (a rank
+                 that only ever updates its own slice).
         zero_grads : the fused kernel also clears the gradients it has just read (same pass, no extra launch): a
                  loop that keeps its gradient buffers can skip the next step's zero-fill."""
         batches = {}          # (beta1, beta2, eps) -> parameters the fused kernel takes, all in one launch
@@ -48,7 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 lo, hi = (0, p.numel()) if ranges is None or p not in ranges else ranges[p]
-                if lo == 0:
+                if lo == 0 if advance is None else advance:
                     st["step"] += 1
                 g = p.grad
                 if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() \
@@ -62,11 +63,16 @@ class FusedAdam(torch.optim.Optimizer):
                         continue
                     batches.setdefault((b1, b2, eps), []).append((p, g, st, lr))
                 else:
-                    m, v, t = st["exp_avg"], st["exp_avg_sq"], st["step"]
-                    m.lerp_(g, 1 - b1)
-                    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                    # host tensors / other dtypes: the same update in torch ops, on the same element range
+                    t = st["step"]
+                    pv, gv = p.view(-1)[lo:hi], g.reshape(-1)[lo:hi]
+                    m, v = st["exp_avg"].view(-1)[lo:hi], st["exp_avg_sq"].view(-1)[lo:hi]
+                    m.lerp_(gv, 1 - b1)
+                    v.mul_(b2).addcmul_(gv, gv, value=1 - b2)
                     denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
-                    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+                    pv.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+                    if zero_grads:
+                        g.view(-1)[lo:hi].zero_()
         for (b1, b2, eps), items in batches.items():
             for k in range(0, len(items), 16):
                 chunk = items[k:k + 16]

@@ -22,9 +22,10 @@ from .parallel import GradAverager
 
 
 class TrainHarness:
-    def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16, use_graphs=False):
+    def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16, use_graphs=False,
+                 optimizer=None):
         self.model = model
-        adam = FusedAdam if next(model.parameters()).is_cuda else torch.optim.Adam
+        adam = optimizer or (FusedAdam if next(model.parameters()).is_cuda else torch.optim.Adam)
         self.opt = adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.occupancy = occupancy
         self.update_interval = update_interval
@@ -39,6 +40,7 @@ class TrainHarness:
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self._side = None             # HIP stream of the next batch's march (created on first use)
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
+        self.comm_mode = "allreduce"  # or "sharded": reduce-scatter -> Adam on this rank's slice -> all-gather
         self.comm_dtype = None        # torch.bfloat16: halve the table gradient's bytes on the wire (changes rounding)
         # data parallel: the next batch's march is issued once the "forward" is queued (runs beside the backward) or
         # once the "collectives" are (runs beside the gradient all-reduce, where nothing else wants the CUs)
@@ -285,6 +287,73 @@ class TrainHarness:
             p.grad = g.view_as(p)
         self.opt.step_now(only=small)
 
+    def _finish_sharded(self, issue_prefetch=None):
+        """The other data-parallel tail (SURVEY.md 8e "scaling risk (b)"): the table gradient is reduce-scattered, every
+        rank runs Adam on its own 1/N of the table only (the 28 B/element optimizer pass shrinks N-fold) and the updated
+        slices are all-gathered into every replica's table.  Same bytes on the wire as the ring all-reduce
+        (2 (N-1)/N x 52 MB), but the gather half moves parameters, which the next step needs only at its first grid
+        encode.  Replicas stay bit-identical: every element is updated by exactly one rank and copied to the others.
+        The MLP gradients (37 KB) keep their all-reduce; their Adam runs everywhere."""
+        import torch.distributed as dist
+        from . import fused_network
+        m = self.model
+        g_emb, dw = self._raw_grads
+        self._raw_grads = None
+        emb = m.encoder.embeddings
+        if g_emb is None:
+            g_emb = emb.grad
+        else:
+            emb.grad = g_emb
+        world, rank = dist.get_world_size(), dist.get_rank()
+        nccl = dist.get_backend() == "nccl"
+        flat = g_emb.view(-1)
+        n = flat.numel()
+        shard = -(-n // world)
+        shard += (-shard) % 4                                 # FusedAdam ranges start on multiples of 4 elements
+        lo, hi = min(rank * shard, n), min((rank + 1) * shard, n)
+        even = shard * world == n
+        w_dw = dist.all_reduce(dw, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
+        if nccl and even:
+            mine = torch.empty(shard, dtype=flat.dtype, device=flat.device)
+            work = dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.AVG, async_op=True)
+        else:                                                 # gloo has no reduce-scatter; ragged tables: all-reduce
+            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
+            mine = None
+        if issue_prefetch is not None:
+            issue_prefetch(background=False)
+        work.wait()
+        if mine is not None:
+            flat[lo:hi].copy_(mine)
+        elif not nccl:
+            flat[lo:hi].mul_(1.0 / world)
+        if hi > lo:
+            self.opt.step_now(only=[emb], ranges={emb: (lo, hi)}, zero_grads=True, advance=True)
+        # this rank's local contributions to the other slices are spent: clear them for the next step
+        flat[:lo].zero_()
+        flat[hi:].zero_()
+        self._cleared_grad = emb.grad
+        p = emb.data.view(-1)
+        if even and nccl:
+            gather = dist.all_gather_into_tensor(p, p[lo:hi], async_op=True)       # in place: slice r of p <- rank r
+        else:                                                 # equal-sized (padded) pieces for any backend / ragged table
+            send = torch.zeros(shard, dtype=p.dtype, device=p.device)
+            send[:hi - lo] = p[lo:hi]
+            pieces = [torch.empty(shard, dtype=p.dtype, device=p.device) for _ in range(world)]
+            gather = dist.all_gather(pieces, send, async_op=True)
+        w_dw.wait()
+        if not nccl:
+            dw.mul_(1.0 / world)
+        small = fused_network.network_params(m)[1:]
+        for q, g in zip(small, fused_network.unpack_weight_grads(dw, small[-1].shape[0])):
+            q.grad = g.view_as(q)
+        self.opt.step_now(only=small)
+        gather.wait()
+        if not (even and nccl):
+            for r, piece in enumerate(pieces):
+                a, b = min(r * shard, n), min((r + 1) * shard, n)
+                if r != rank and b > a:
+                    p[a:b].copy_(piece[:b - a])
+
     def tune_comm(self, step_fn, candidates=(1, 2, 4, 8), window=None):
         """Data parallel: pick `comm_chunks` by measurement.  How the table-gradient all-reduce is best cut depends on
         the link topology and the number of ranks (per-collective latency against Adam / collective overlap), so each
@@ -300,6 +369,7 @@ class TrainHarness:
         sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
         i = 0
         timings = {}
+        self.comm_mode = "allreduce"
         for n, c in enumerate((candidates[0],) + tuple(candidates)):       # the first window only warms up
             self.comm_chunks = int(c)
             sync()
@@ -314,6 +384,21 @@ class TrainHarness:
             if n:
                 timings[int(c)] = float(dt.item()) / window * 1e3
         self.comm_chunks = min(timings, key=timings.get)
+        # the other tail: reduce-scatter -> Adam on this rank's slice -> all-gather (two windows: the first warms up)
+        self.comm_mode = "sharded"
+        sharded_ms = None
+        for n in range(2):
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(window):
+                step_fn(i)
+                i += 1
+            sync()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            sharded_ms = float(dt.item()) / window * 1e3
+        self.comm_mode = "sharded" if sharded_ms < timings[self.comm_chunks] else "allreduce"
         # with the cut settled: where the next batch's march is issued (beside the backward, or beside the collectives)
         placements = {}
         for at in ("forward", "collectives"):
@@ -329,7 +414,8 @@ class TrainHarness:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             placements[at] = float(dt.item()) / window * 1e3
         self.prefetch_at = min(placements, key=placements.get)
-        self.tuned = {"chunks_ms_per_step": dict(timings), "prefetch_at_ms_per_step": placements}
+        self.tuned = {"chunks_ms_per_step": dict(timings), "sharded_ms_per_step": sharded_ms,
+                      "mode": self.comm_mode, "prefetch_at_ms_per_step": placements}
         return timings
 
     def probe_comm_dtype(self, step_fn, dtype=torch.bfloat16, window=None, first_step=0):
@@ -363,7 +449,8 @@ class TrainHarness:
         loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=None if late else side, raw=chunked,
                                     **render_kw)
         if chunked:
-            self._finish_distributed(side if late else None)
+            tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
+            tail(side if late else None)
             return loss
         self._reduce_grads(None if side is not None else next_rays)
         if self.avg is None and hasattr(self.opt, "step_now") and not self.use_graphs:

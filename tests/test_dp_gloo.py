@@ -137,16 +137,19 @@ def _tune_worker(rank, world, port, outdir):
         h.avg = object()
         h.update_interval = 16
         h.comm_chunks = 4
+        h.comm_mode = "allreduce"
         h.prefetch_at = "forward"
-        # rank 0 is slow with 1 piece, rank 1 with 8: the slowest rank decides, so both must settle on 2
+        # rank 0 is slow with 1 piece, rank 1 with 8: the slowest rank decides, so both must settle on 2; the sharded
+        # tail is slow on rank 1 only -- still rejected everywhere
         cost = {0: {1: 0.020, 2: 0.004, 8: 0.002}, 1: {1: 0.002, 2: 0.004, 8: 0.020}}[rank]
         seen = []
 
         def step(i):
-            seen.append((i, h.comm_chunks))
-            time.sleep(cost[h.comm_chunks])
+            seen.append((i, h.comm_chunks, h.comm_mode))
+            time.sleep(0.012 * rank if h.comm_mode == "sharded" else cost[h.comm_chunks])
         timings = h.tune_comm(step, candidates=(1, 2, 8), window=3)
-        torch.save({"timings": timings, "chosen": h.comm_chunks, "seen": seen}, os.path.join(outdir, f"tune{rank}.pt"))
+        torch.save({"timings": timings, "chosen": h.comm_chunks, "mode": h.comm_mode, "tuned": h.tuned, "seen": seen},
+                   os.path.join(outdir, f"tune{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -160,8 +163,11 @@ def test_comm_tuning_slowest_rank_decides(tmp_path):
     assert a["timings"] == b["timings"] and set(a["timings"]) == {1, 2, 8}
     assert a["chosen"] == b["chosen"] == 2
     assert a["timings"][1] >= 19.0 and a["timings"][8] >= 19.0 and a["timings"][2] < 15.0       # ms per step
-    # warm-up + 3 candidates, then two windows (march placement) with the chosen cut
-    assert [c for _, c in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 + [2] * 6 and [i for i, _ in a["seen"]] == list(range(18))
+    # warm-up + 3 candidates, two windows of the sharded tail, then two windows (march placement) with what was chosen
+    assert [c for _, c, _ in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 + [2] * 12
+    assert [m for _, _, m in a["seen"]] == ["allreduce"] * 12 + ["sharded"] * 6 + ["allreduce"] * 6
+    assert [i for i, _, _ in a["seen"]] == list(range(24))
+    assert a["mode"] == b["mode"] == "allreduce" and a["tuned"]["sharded_ms_per_step"] == b["tuned"]["sharded_ms_per_step"] >= 11.0
 
 
 def _render_worker(rank, world, port, n_rays, outdir):
@@ -199,6 +205,71 @@ def test_two_rank_sharded_render_equals_single_process_render(tmp_path):
             assert got["image"].shape == (1, n_rays, 3) and got["depth"].shape == (1, n_rays)
             assert torch.equal(got["image"], ref["image"])
             assert torch.equal(got["depth"].nan_to_num(-7.0), ref["depth"].nan_to_num(-7.0))
+    finally:
+        import importlib
+        import enerf_amd.raymarching as rm, enerf_amd.gridencoder as ge, enerf_amd.shencoder as sh
+        importlib.reload(rm); importlib.reload(ge); importlib.reload(sh)
+
+
+def _pack_dw(model):
+    """flat dW buffer in fused_network's parameter order (sigma 0, sigma 1, colour 0, colour 1, colour 2)"""
+    ps = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight, model.color_net[1].weight,
+          model.color_net[2].weight]
+    return torch.cat([p.grad.reshape(-1) for p in ps]).clone()
+
+
+def _tail_worker(rank, world, port, n_rays, mode, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    _inject_oracle()
+    from enerf_amd import parallel
+    from enerf_amd.optim import FusedAdam
+    from enerf_amd.trainer import TrainHarness
+    parallel.init_from_env(backend="gloo")
+    m, ro, rd, target = _model_and_data(n_rays)
+    h = TrainHarness(m, lr=1e-2, occupancy=None, world=world, optimizer=FusedAdam)
+    h.comm_chunks, h.comm_mode = 3, mode
+    lo, hi = parallel.shard_range(n_rays, rank, world)
+    for _ in range(2):
+        m.train()
+        for p in m.parameters():
+            p.grad = None
+        out = m.render(ro[:, lo:hi], rd[:, lo:hi], staged=False, bg_color=None, perturb=False, force_all_rays=True)
+        (((out["image"] - target[:, lo:hi]) ** 2).sum() * (world / (3.0 * n_rays))).backward()
+        # hand the tail what the closed-form step hands it: (table gradient, flat MLP dW)
+        h._raw_grads = (m.encoder.embeddings.grad, _pack_dw(m))
+        (h._finish_sharded if mode == "sharded" else h._finish_distributed)()
+    torch.save({k: v.clone() for k, v in m.state_dict().items()}, os.path.join(outdir, f"tail_{mode}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
+def test_two_rank_closed_form_tails_equal_single_process_adam(tmp_path, mode):
+    """TrainHarness._finish_distributed (table gradient all-reduced in 3 pieces, Adam per piece) and _finish_sharded
+    (reduce-scatter -> Adam on the rank's slice -> all-gather) on 2 real ranks over gloo: replicas identical, and equal
+    to one process stepping the full batch (the oracle backend computes the gradients; the tails are what is tested)."""
+    n_rays, world = 40, 2
+    mp.spawn(_tail_worker, args=(world, _free_port(), n_rays, mode, str(tmp_path)), nprocs=world, join=True)
+    s0, s1 = (torch.load(tmp_path / f"tail_{mode}_{r}.pt") for r in (0, 1))
+    for k in s0:
+        if k not in ("step_counter", "density_grid"):
+            assert torch.equal(s0[k], s1[k]), f"replicas diverged in {k}"
+    sys.path.insert(0, ROOT)
+    _inject_oracle()
+    try:
+        from enerf_amd.optim import FusedAdam
+        m, ro, rd, target = _model_and_data(n_rays)
+        opt = FusedAdam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        for _ in range(2):
+            _step(m, ro, rd, target, opt, None, scale=1.0 / (3.0 * n_rays))
+        ref = m.state_dict()
+        for k in ("encoder.embeddings", "sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight",
+                  "color_net.1.weight", "color_net.2.weight"):
+            assert float((s0[k] - ref[k]).abs().max()) <= 1e-5 * float(ref[k].abs().max()) + 2e-6, k
     finally:
         import importlib
         import enerf_amd.raymarching as rm, enerf_amd.gridencoder as ge, enerf_amd.shencoder as sh
