@@ -320,11 +320,14 @@ def _rccl_worker(rank, world, port, out):
         from enerf_amd.network import NeRFNetwork
         from enerf_amd.trainer import TrainHarness
         data = _batches(4, 1024, 2, seed=10)
-        for tag, dp, dtype in (("single", 1, None), ("rccl", 2, None), ("rccl16", 2, torch.bfloat16)):
+        for tag, dp, dtype in (("single", 1, None), ("rccl", 2, None), ("rccl16", 2, torch.bfloat16),
+                               ("rccl_sharded", 2, None)):
             torch.manual_seed(0)
             model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
             h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=dp)     # dp = 2: the data-parallel tail runs
             h.comm_dtype = dtype
+            if tag == "rccl_sharded":      # reduce_scatter_tensor -> Adam on the slice -> in-place all_gather_into_tensor
+                h.comm_mode = "sharded"
             losses = []
             for i in range(36):
                 nxt = data[(i + 1) % len(data)]
@@ -352,6 +355,10 @@ def test_data_parallel_tail_over_rccl_single_rank():
     for n, a in pa.items():
         assert float((a - pb[n]).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
     assert np.abs(np.array(lc) - np.array(la)).max() <= 0.05 * np.abs(np.array(la)).max()
+    ld, pd = out["rccl_sharded"]
+    assert np.abs(la - np.array(ld)).max() <= 1e-4 * np.abs(la).max()
+    for n, a in pa.items():
+        assert float((a - pd[n]).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
 
 
 def _tune_worker(rank, world, port, out):
@@ -394,7 +401,7 @@ def test_comm_tuning_agrees_across_ranks():
     (t0, c0, g0, l0, p0), (t1, c1, g1, l1, p1) = out[0], out[1]
     assert set(t0) == {1, 3, 8} and t0 == t1 and all(v > 0 for v in t0.values())
     assert c0 == c1 == min(t0, key=t0.get)
-    assert g0 == g1 == 4 * 4 + 2 * 4 + 3 + 1 and math.isfinite(l0)
+    assert g0 == g1 == 4 * 4 + 2 * 4 + 2 * 4 + 3 + 1 and math.isfinite(l0)
     assert all(torch.equal(p0[n], p1[n]) for n in p0)
 
 
