@@ -32,9 +32,8 @@ def needs_build():
 def build(force=False, verbose=True):
     if not (force or needs_build()):
         return [built(n) for n in NAMES]
-    cmd = [sys.executable, os.path.join(HERE, "setup.py"), "build_ext", "--inplace", "-j", "4"]
-    if force:
-        cmd.append("--force")
+    # --force: setuptools only compares the .cpp files' times, not the shared headers' that needs_build() watches
+    cmd = [sys.executable, os.path.join(HERE, "setup.py"), "build_ext", "--inplace", "-j", "4", "--force"]
     out = None if verbose else subprocess.DEVNULL
     subprocess.check_call(cmd, cwd=HERE, stdout=out, stderr=out)
     return [built(n) for n in NAMES]

@@ -354,6 +354,32 @@ class TrainHarness:
                 if r != rank and b > a:
                     p[a:b].copy_(piece[:b - a])
 
+    def gather_sharded_optimizer_state(self):
+        """After steps taken with the sharded tail every rank holds current Adam moments only for its own slice of the
+        table.  Before anything that needs them whole -- switching back to the all-reduce tail, saving a checkpoint --
+        the slices are all-gathered (2 x 52 MB, once)."""
+        import torch.distributed as dist
+        emb = getattr(getattr(self.model, "encoder", None), "embeddings", None)
+        opt = getattr(self, "opt", None)
+        st = opt.state.get(emb) if emb is not None and opt is not None else None
+        if not st or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = emb.numel()
+        shard = -(-n // world)
+        shard += (-shard) % 4
+        lo, hi = min(rank * shard, n), min((rank + 1) * shard, n)
+        for key in ("exp_avg", "exp_avg_sq"):
+            flat = st[key].view(-1)
+            send = torch.zeros(shard, dtype=flat.dtype, device=flat.device)
+            send[:hi - lo] = flat[lo:hi]
+            pieces = [torch.empty(shard, dtype=flat.dtype, device=flat.device) for _ in range(world)]
+            dist.all_gather(pieces, send)
+            for r, piece in enumerate(pieces):
+                a, b = min(r * shard, n), min((r + 1) * shard, n)
+                if r != rank and b > a:
+                    flat[a:b].copy_(piece[:b - a])
+
     def tune_comm(self, step_fn, candidates=(1, 2, 4, 8), window=None):
         """Data parallel: pick `comm_chunks` by measurement.  How the table-gradient all-reduce is best cut depends on
         the link topology and the number of ranks (per-collective latency against Adam / collective overlap), so each
@@ -398,6 +424,7 @@ class TrainHarness:
             dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             sharded_ms = float(dt.item()) / window * 1e3
+        self.gather_sharded_optimizer_state()                 # whichever tail runs next starts from whole moments
         self.comm_mode = "sharded" if sharded_ms < timings[self.comm_chunks] else "allreduce"
         # with the cut settled: where the next batch's march is issued (beside the backward, or beside the collectives)
         placements = {}
