@@ -35,7 +35,7 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H,
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L_, S, H, calc_grad_inputs,
-                         dy_dx, grad_inputs, gridtype, *, layout=0, affine=(0.0, 1.0)):
+                         dy_dx, grad_inputs, gridtype, *, layout=0, affine=(0.0, 1.0), defer=False, reserve=0):
     import torch
     if inputs.dtype != torch.float32:
         raise RuntimeError("inputs must be a float32 tensor")
@@ -46,11 +46,12 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                  (grad_inputs, "grad_inputs")):
         if t.dtype != grad.dtype:
             raise RuntimeError(f"{n} must have the dtype of grad")
-    L.check(L.lib().enerf_grid_encode_backward(_chk(grad, "grad"), _chk(inputs, "inputs"),
-                                               _chk(embeddings, "embeddings"), _chk(offsets, "offsets", False),
-                                               _chk(grad_embeddings, "grad_embeddings"), int(B), int(D), int(C),
-                                               int(L_), float(S), int(H), int(bool(calc_grad_inputs)),
-                                               _chk(dy_dx, "dy_dx"), _chk(grad_inputs, "grad_inputs"),
-                                               int(gridtype), dt, int(layout), affine[0], affine[1],
-                                               L.stream_handle()),
+    # defer: leave the binned levels' record lists to enerf_grid_adam_from_records (include/enerf_hip.h)
+    L.check(L.lib().enerf_grid_encode_backward_ex(_chk(grad, "grad"), _chk(inputs, "inputs"),
+                                                  _chk(embeddings, "embeddings"), _chk(offsets, "offsets", False),
+                                                  _chk(grad_embeddings, "grad_embeddings"), int(B), int(D), int(C),
+                                                  int(L_), float(S), int(H), int(bool(calc_grad_inputs)),
+                                                  _chk(dy_dx, "dy_dx"), _chk(grad_inputs, "grad_inputs"),
+                                                  int(gridtype), dt, int(layout), affine[0], affine[1],
+                                                  1 if defer else 0, int(reserve), L.stream_handle()),
             "grid_encode_backward")

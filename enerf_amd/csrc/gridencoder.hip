@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
                                                                LevelTab tab, uint32_t gridtype, int grad_layout,
                                                                uint32_t nchunks, uint32_t min_tiles,
                                                                uint32_t* __restrict__ recs, uint32_t* __restrict__ cursors,
-                                                               uint32_t region) {
+                                                               uint32_t region, uint32_t* __restrict__ overflow) {
     constexpr uint32_t R = kTileElems / C;
     constexpr uint32_t NREC = PTS << D;
     __shared__ uint32_t s_ofs[kMaxBins];         // records per list, then exclusive offset of the list in the staging area
@@ -679,6 +679,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
 #pragma unroll
             for (int c = 0; c < C; c++) gg[c] = s_val[c][j];
             scatter_add<C>(grad_grid + ((size_t)off0 + (size_t)(list / plan.replicas) * R + loc) * C, 1.0f, gg);
+            if (overflow) atomicAdd(overflow, 1u);          // (a deferred flush must then also read the dense gradient)
         }
     }
 }
@@ -768,6 +769,120 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
     }
 }
 
+// ---- deferred flush: pass B fused with the optimizer --------------------------------------------------------------
+// The table's gradient is consumed exactly once, by Adam (main_nerf.py:211), which streams over the whole table anyway
+// (p, m, v: 24 B per element).  k_grid_tile_adam therefore takes over from pass B when the caller defers the flush
+// (enerf_grid_encode_backward_ex, flag bit 0): every 128-KiB tile of every level is visited once; the tile's record
+// lists are summed into the fp64 LDS accumulators as in k_grid_bwd_tile and the Adam update of the tile's rows reads its
+// gradient straight from LDS.  The dense gradient table is never written, read or cleared for the binned levels
+// (3 x 52 MB of traffic and pass B's read-modify-write of the table go away), and the LDS atomics run in the shadow
+// of the p / m / v stream.  Levels that are not binned (their contributions went into the dense gradient with
+// atomics) and runs in which a record list overflowed read -- and clear -- the dense gradient as well.
+// Update arithmetic: optim.hip's adam1, term for term.
+struct AdamScalars {
+    float b1, b2, eps, step_size, inv_bc2_sqrt;
+};
+__device__ __forceinline__ void tile_adam1(float& p, float g, float& m, float& v, const AdamScalars& a) {
+    m = fmaf(g - m, 1.0f - a.b1, m);
+    v = fmaf((1.0f - a.b2) * g, g, v * a.b2);
+    const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+template <int C>
+__global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* __restrict__ offsets, float* __restrict__ P,
+                                                                 float* __restrict__ G, float* __restrict__ M,
+                                                                 float* __restrict__ V, uint32_t L, uint32_t min_tiles,
+                                                                 const uint32_t* __restrict__ recs,
+                                                                 uint32_t* __restrict__ cursors, uint32_t region,
+                                                                 uint32_t* __restrict__ overflow, AdamScalars ad) {
+    __shared__ __attribute__((aligned(16))) double acc[kTileElems];
+    __shared__ uint32_t s_n[64];
+    constexpr uint32_t R = kTileElems / C;
+    constexpr int U = 4;
+    const bool have_records = region != 0;
+    const bool spilled = have_records && overflow[0] != 0;
+    uint32_t total = 0;
+    for (uint32_t lv = 0; lv < L; lv++) total += div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t level = 0, tile = 0, rem = item;
+        for (uint32_t lv = L; lv-- > 0;) {                      // finest (fullest) levels first
+            const uint32_t t = div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
+            if (rem < t) { level = lv; tile = rem; break; }
+            rem -= t;
+        }
+        const uint32_t off0 = (uint32_t)offsets[level];
+        const uint32_t rows = (uint32_t)offsets[level + 1] - off0;
+        const uint32_t row0 = tile * R;
+        const uint32_t nrows = rows - row0 < R ? rows - row0 : R;
+        const BinPlan plan = bin_plan(offsets, level, R, min_tiles);
+        const bool binned = have_records && plan.bins != 0;
+        if (binned) {
+            const uint32_t cap = region / plan.bins;
+            if (threadIdx.x < plan.replicas && threadIdx.x < 64) {
+                const uint32_t li = level * kMaxBins + tile * plan.replicas + threadIdx.x;
+                const uint32_t n = cursors[li];
+                s_n[threadIdx.x] = n < cap ? n : cap;
+                cursors[li] = 0;
+            }
+            for (uint32_t i = threadIdx.x * 2; i < nrows * C; i += kTileThreads * 2)
+                *reinterpret_cast<double2*>(acc + i) = make_double2(0.0, 0.0);
+            __syncthreads();
+            for (uint32_t rep = 0; rep < plan.replicas; rep++) {
+                const uint32_t n = s_n[rep < 64 ? rep : 63];
+                const uint32_t list = tile * plan.replicas + rep;
+                const uint32_t* r = recs + ((size_t)level * region + (size_t)list * cap) * (1 + C);
+                for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kTileThreads * U) {
+                    uint32_t loc[U];
+                    float val[U][C];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t i = i0 + u * kTileThreads;
+                        const uint32_t ic = i < n ? i : n - 1;
+                        loc[u] = reinterpret_cast<const uint16_t*>(r)[ic];
+#pragma unroll
+                        for (int c = 0; c < C; c++) val[u][c] = __uint_as_float(r[(size_t)(1 + c) * cap + ic]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (i0 + u * kTileThreads < n) {
+#pragma unroll
+                            for (int c = 0; c < C; c++) atomicAdd(acc + loc[u] * C + c, (double)val[u][c]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const bool dense = !binned || spilled;
+        const size_t base = ((size_t)off0 + row0) * C;          // level offsets are multiples of 8 rows: 16-byte aligned
+        for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTileThreads * 4) {
+            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (binned) {
+                const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
+                const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
+                g4 = make_float4((float)a0.x, (float)a0.y, (float)a1.x, (float)a1.y);
+            }
+            if (dense) {
+                const float4 d = *reinterpret_cast<const float4*>(G + base + i);
+                g4.x += d.x; g4.y += d.y; g4.z += d.z; g4.w += d.w;
+                *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 p4 = *reinterpret_cast<const float4*>(P + base + i);
+            float4 m4 = *reinterpret_cast<const float4*>(M + base + i);
+            float4 v4 = *reinterpret_cast<const float4*>(V + base + i);
+            tile_adam1(p4.x, g4.x, m4.x, v4.x, ad);
+            tile_adam1(p4.y, g4.y, m4.y, v4.y, ad);
+            tile_adam1(p4.z, g4.z, m4.z, v4.z, ad);
+            tile_adam1(p4.w, g4.w, m4.w, v4.w, ad);
+            *reinterpret_cast<float4*>(P + base + i) = p4;
+            *reinterpret_cast<float4*>(M + base + i) = m4;
+            *reinterpret_cast<float4*>(V + base + i) = v4;
+        }
+        __syncthreads();
+    }
+}
+
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (gridencoder.cu:314-340)
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ grad, const T* __restrict__ dy_dx,
@@ -839,23 +954,57 @@ int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* out
     return 0;
 }
 
+// A deferred flush in progress: record lists written by one or more backward calls wait for k_grid_tile_adam.  The
+// list geometry (`region`) is fixed by the first call of the session.
+struct PendingRecords {
+    uint32_t region = 0, L = 0, C = 0, D = 0, min_tiles = 0;
+};
+static PendingRecords g_pending;
+static uint32_t* g_overflow = nullptr;          // device counter: records that did not fit their list
+
+static uint32_t* overflow_counter() {
+    if (!g_overflow) {
+        if (hipMalloc((void**)&g_overflow, sizeof(uint32_t)) != hipSuccess) return nullptr;
+        if (hipMemset(g_overflow, 0, sizeof(uint32_t)) != hipSuccess) return nullptr;
+    }
+    return g_overflow;
+}
+
 template <typename T, int D>
 int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* grad_emb, uint32_t B, uint32_t C,
                uint32_t L, const LevelTab& tab, bool calc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
-               int layout, hipStream_t s) {
+               int layout, hipStream_t s, uint32_t flags = 0, uint32_t reserve_B = 0) {
     const uint32_t nchunks = div_up(B, kPtsPerBlock);
     const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
     // fp32 tables and enough samples: the binned path (the atomic kernel then only sees levels it cannot bin)
     const bool binned = std::is_same<T, float>::value && B >= g_binned_min_batch;
+    const bool defer = binned && (flags & 1u) != 0;
     uint32_t* recs = nullptr;
     uint32_t* cursors = nullptr;
-    const uint32_t region = 2u * (1u << D) * B;      // records per level: twice the 2^D * B a level can produce
+    uint32_t* overflow = nullptr;
+    // records per level: twice the 2^D * B a level can produce (a deferred session: of all its calls together)
+    uint32_t region = 2u * (1u << D) * (defer && reserve_B > B ? reserve_B : B);
+    if (g_pending.region != 0) {
+        if (!defer || g_pending.L != L || g_pending.C != C || g_pending.D != (uint32_t)D) {
+            set_error("grid_encode_backward: a deferred flush is pending (enerf_grid_adam_from_records must run first; "
+                      "calls that join it pass the defer flag, the same L / C / D and a binned batch)");
+            return ENERF_E_BADARG;
+        }
+        region = g_pending.region;                    // later calls of the session append to the same lists
+    }
     if (binned) {
         recs = (uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C));
         cursors = bin_cursors();
-        if (!recs || !cursors) return ENERF_E_NOMEM;
+        overflow = overflow_counter();
+        if (!recs || !cursors || !overflow) return ENERF_E_NOMEM;
     }
     const uint32_t min_tiles = binned ? g_binned_min_tiles : 0u;
+    if (defer && g_pending.region == 0) {
+        g_pending.region = region; g_pending.L = L; g_pending.C = C; g_pending.D = (uint32_t)D;
+        g_pending.min_tiles = min_tiles;
+        (void)hipMemsetAsync(overflow, 0, sizeof(uint32_t), s);
+    }
+    const bool flush_now = g_pending.region == 0;
 #define ENERF_GB(CC)                                                                                             \
     do {                                                                                                         \
         if (!binned)                                                                                             \
@@ -867,9 +1016,10 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
                 const uint32_t bchunks = div_up(B, (uint32_t)kBinPts);                                           \
                 k_grid_bwd_bin<D, CC, kBinPts><<<8u * bchunks * div_up(L, 8u), kBinPts, 0, s>>>(                 \
                     grad, inputs, offsets, grad_emb, B, L, tab, gridtype, layout, bchunks, min_tiles, recs, cursors, \
-                    region);                                                                                     \
-                k_grid_bwd_tile<CC><<<num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, recs, \
-                                                                       cursors, region);                         \
+                    region, flush_now ? nullptr : overflow);                                                     \
+                if (flush_now)                                                                                   \
+                    k_grid_bwd_tile<CC><<<num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, \
+                                                                           recs, cursors, region);               \
             }                                                                                                    \
         }                                                                                                        \
         if (calc)                                                                                                \
@@ -932,10 +1082,11 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
     return 0;
 }
 
-int enerf_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
-                               void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                               int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int dtype,
-                               int grad_layout, float in_add, float in_mul, enerf_stream_t stream) {
+int enerf_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                  void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                  int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int dtype,
+                                  int grad_layout, float in_add, float in_mul, uint32_t flags, uint32_t reserve_B,
+                                  enerf_stream_t stream) {
     (void)embeddings;
     if (B == 0) return 0;
     LevelTab tab;
@@ -947,8 +1098,8 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
     int rc = 0;
     const bool calc = calc_grad_inputs != 0;
     if (dtype == ENERF_F32) {
-        if (D == 3) rc = launch_bwd<float, 3>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, C, L, tab, calc, (const float*)dy_dx, (float*)grad_inputs, gridtype, grad_layout, s);
-        else if (D == 2) rc = launch_bwd<float, 2>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, C, L, tab, calc, (const float*)dy_dx, (float*)grad_inputs, gridtype, grad_layout, s);
+        if (D == 3) rc = launch_bwd<float, 3>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, C, L, tab, calc, (const float*)dy_dx, (float*)grad_inputs, gridtype, grad_layout, s, flags, reserve_B);
+        else if (D == 2) rc = launch_bwd<float, 2>((const float*)grad, inputs, offsets, (float*)grad_embeddings, B, C, L, tab, calc, (const float*)dy_dx, (float*)grad_inputs, gridtype, grad_layout, s, flags, reserve_B);
         else ENERF_BADARG("GridEncoding: D must be 2 or 3.");
     } else {
         if (D == 3) rc = launch_bwd<__half, 3>((const __half*)grad, inputs, offsets, (__half*)grad_embeddings, B, C, L, tab, calc, (const __half*)dy_dx, (__half*)grad_inputs, gridtype, grad_layout, s);
@@ -957,6 +1108,44 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
     }
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("grid_encode_backward");
+    return 0;
+}
+
+int enerf_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                               void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                               int calc_grad_inputs, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int dtype,
+                               int grad_layout, float in_add, float in_mul, enerf_stream_t stream) {
+    return enerf_grid_encode_backward_ex(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
+                                         calc_grad_inputs, dy_dx, grad_inputs, gridtype, dtype, grad_layout, in_add, in_mul,
+                                         0u, 0u, stream);
+}
+
+int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
+                                 float lr, float beta1, float beta2, float eps, uint32_t step, enerf_stream_t stream) {
+    if (!p || !g || !m || !v || !offsets || L == 0 || L > (uint32_t)kMaxLevels || step == 0)
+        ENERF_BADARG("grid_adam_from_records: bad arguments (L=%u step=%u)", L, step);
+    if (g_pending.region != 0 && (g_pending.L != L || g_pending.C != C))
+        ENERF_BADARG("grid_adam_from_records: the pending records belong to a table with L=%u C=%u", g_pending.L, g_pending.C);
+    hipStream_t s = (hipStream_t)stream;
+    // torch.optim.Adam's scalars, as enerf_adam_step_multi computes them
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamScalars ad = {beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2))};
+    uint32_t* cursors = bin_cursors();
+    uint32_t* overflow = overflow_counter();
+    if (!cursors || !overflow) return ENERF_E_NOMEM;
+    const uint32_t region = g_pending.region;
+    const uint32_t* recs = region ? (const uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C))
+                                  : nullptr;
+    const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;
+    switch (C) {
+        case 1: k_grid_tile_adam<1><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 2: k_grid_tile_adam<2><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 4: k_grid_tile_adam<4><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 8: k_grid_tile_adam<8><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        default: ENERF_BADARG("grid_adam_from_records: C must be 1, 2, 4, or 8.");
+    }
+    g_pending = PendingRecords();
+    ENERF_LAUNCH_CHECK("grid_adam_from_records");
     return 0;
 }
 

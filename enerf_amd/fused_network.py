@@ -135,7 +135,7 @@ def unpack_weight_grads(dw, out_c):
             dw[o[3]:o[4]].view(64, 64), dw[o[4]:].view(out_c, 64))
 
 
-def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False):
+def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, defer_table=0):
     """Gradients of (embeddings, ws0, ws1, wc0, wc1, wc2) given d(sigma) [B] and d(rgb) [B,out] (contiguous fp32).
     `sigma_scale` multiplies d(sigma) on the fly (the renderer's density_scale).  The embedding gradient is None when
     it was added straight into the parameter's .grad (`owner`: the caller drives this backward itself, outside autograd,
@@ -170,8 +170,11 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False):
     target = _ge.param_grad_target(param, torch.float32, owner=owner)
     direct = target is not None
     g_emb = target if direct else torch.zeros_like(emb)
+    # defer_table = total samples of the step's renders: the table gradient's record lists are left for the optimizer's
+    # fused flush (FusedAdam.step_grid_table) instead of being summed into g_emb
     _gb.grid_encode_backward(dfeat, sv["x"], emb, sv["offsets"], g_emb, B, 3, 2, 16, sv["S"], sv["H"], False, dfeat,
-                             dfeat, sv["gridtype"], layout=2, affine=sv["affine"])
+                             dfeat, sv["gridtype"], layout=2, affine=sv["affine"], defer=defer_table > 0,
+                             reserve=defer_table)
     if raw:
         return (None if direct else g_emb, dw)
     return (None if direct else g_emb,) + unpack_weight_grads(dw, out_c)

@@ -289,7 +289,7 @@ def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0
     return out_image, ctx
 
 
-def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, raw=False):
+def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, raw=False, defer_table=0):
     """Backward half.  Either g_image = d loss / d image [N,3], or target [N,3] for loss = mean((image - target)^2) *
     upstream (gradient and, with loss_out, value formed inside the composite backward).  -> the gradients of
     fused_network.network_params(model) (raw=True: (embedding gradient, flat dW), see fused_network.nerf_backward);
@@ -314,11 +314,12 @@ def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, ra
                                                   1.0, ctx["bg"], ctx["counter"], ctx["sigmas"], ctx["rgb"],
                                                   ctx["deltas"], ctx["rays"], ctx["weights_sum"], ctx["image"], M, N,
                                                   g_sigmas, g_rgbs, None)
-        return fnet.nerf_backward(ctx["sv"], g_sigmas, g_rgbs, sigma_scale=ctx["scale"], raw=raw, owner=True)
+        return fnet.nerf_backward(ctx["sv"], g_sigmas, g_rgbs, sigma_scale=ctx["scale"], raw=raw, owner=True,
+                                  defer_table=defer_table)
 
 
 def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,
-                   after_forward=None, loss_out=None, raw=False):
+                   after_forward=None, loss_out=None, raw=False, defer_table=False):
     """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
     -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
     embedding gradient was added straight into the parameter's .grad).
@@ -333,4 +334,5 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
                                       composite=not FUSED_COMPOSITE)
     if after_forward is not None:
         after_forward()                         # e.g. prefetch_march of the next batch on a side stream
-    return out_image, backward_raw(ctx, target=target, upstream=upstream, loss_out=loss_out, raw=raw)
+    return out_image, backward_raw(ctx, target=target, upstream=upstream, loss_out=loss_out, raw=raw,
+                                   defer_table=ctx["M"] if defer_table else 0)

@@ -24,6 +24,26 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
+    def step_grid_table(self, p, offsets, level_dim):
+        """Adam on a hash-grid table whose backward left its gradient as record lists (grid_encode_backward(defer=True),
+        csrc/gridencoder.hip: k_grid_tile_adam): one pass over the table sums each 128-KiB tile's records in LDS and
+        updates the tile's rows of p / m / v from there -- the gradient table is neither written nor read nor cleared
+        for the binned levels.  p.grad (dense, zero-initialised, kept across steps) receives what was not binned and
+        comes back cleared.  Same update as step_now on the summed gradient."""
+        group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        L.check(L.lib().enerf_grid_adam_from_records(
+            p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), offsets.data_ptr(),
+            offsets.numel() - 1, int(level_dim), float(group["lr"]), b1, b2, float(group["eps"]), st["step"],
+            L.stream_handle()), "grid_adam_from_records")
+
+    @torch.no_grad()
     def step_now(self, only=None, ranges=None, zero_grads=False, advance=None):
         """The update itself.  `step()` is wrapped by torch.optim.Optimizer with profiler / hook plumbing that costs
         ~40 us per call; a training loop that needs neither can call this directly.

@@ -36,6 +36,7 @@ class TrainHarness:
             self._syn = scene.install_occupancy(model)
         self.prefetch = True          # data parallel: march the next batch underneath the gradient all-reduce
         self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
+        self.fuse_table_adam = True   # one GPU: the table gradient's tile sums feed Adam straight from LDS
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self._side = None             # HIP stream of the next batch's march (created on first use)
@@ -202,7 +203,8 @@ class TrainHarness:
                 fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side, background=background)
         return issue
 
-    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None, raw=False):
+    def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None, raw=False,
+                        defer_table=False):
         """Render + MSE + backward with the loss gradient in closed form (fused_render.train_step_mse): same kernels
         for the render and its backward, no autograd graph, no loss-backward / blend / depth / fill launches.
         Leaves the gradients in p.grad, returns the loss."""
@@ -228,8 +230,11 @@ class TrainHarness:
             if slot == 0:
                 self._loss_ring.zero_()
             loss = self._loss_ring[slot]
+        if defer_table and emb.grad is None:        # the dense part of the gradient (levels too small to bin) needs a home
+            emb.grad = torch.zeros_like(emb)
         image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps,
-                                                   after_forward=after_forward, loss_out=loss, raw=raw)
+                                                   after_forward=after_forward, loss_out=loss, raw=raw,
+                                                   defer_table=defer_table)
         if raw:
             self._raw_grads = grads                 # (embedding gradient, flat dW): _finish_distributed takes over
         else:
@@ -473,14 +478,23 @@ class TrainHarness:
         chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")
                    and self.comm_chunks > 0)
         late = chunked and side is not None and self.prefetch_at == "collectives"
+        # one GPU: nobody but Adam reads the table's gradient, so the backward leaves it as record lists and the
+        # optimizer's pass over the table sums them tile by tile in LDS (FusedAdam.step_grid_table)
+        fuse_table = (self.fuse_table_adam and self.avg is None and hasattr(self.opt, "step_grid_table")
+                      and not self.use_graphs)
         loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=None if late else side, raw=chunked,
-                                    **render_kw)
+                                    defer_table=fuse_table, **render_kw)
         if chunked:
             tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
             tail(side if late else None)
             return loss
         self._reduce_grads(None if side is not None else next_rays)
-        if self.avg is None and hasattr(self.opt, "step_now") and not self.use_graphs:
+        if fuse_table:
+            enc = self.model.encoder
+            self.opt.step_grid_table(enc.embeddings, enc.offsets, enc.level_dim)
+            self.opt.step_now(only=[p for p in self._params if p is not enc.embeddings])
+            self._cleared_grad = enc.embeddings.grad
+        elif self.avg is None and hasattr(self.opt, "step_now") and not self.use_graphs:
             self.opt.step_now(zero_grads=True)          # Adam clears what it has read: the next step needs no fill
             self._cleared_grad = self.model.encoder.embeddings.grad
         else:

@@ -283,6 +283,23 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
                                uint32_t gridtype, int dtype, int grad_layout, float in_add, float in_mul,
                                enerf_stream_t stream);
 
+/* Deferred flush: the table gradient's only consumer in training is the optimizer (main_nerf.py:211, Adam), which streams
+ * over the whole table anyway.  With flags bit 0 set, enerf_grid_encode_backward_ex leaves the binned levels' record
+ * lists pending instead of summing them into `grad_embeddings` (levels too small to bin, and batches below the binning
+ * threshold, still add into it); further calls with the flag append to the same lists (`reserve_B`: samples of ALL calls
+ * of the session, which sizes the lists; 0 = this call's B).  enerf_grid_adam_from_records then visits every 128-KiB
+ * tile of the table once: sums the tile's records in LDS (fp64), adds the dense gradient where one was written (and
+ * clears it), and applies torch.optim.Adam's update (no weight decay / amsgrad; `step` counts from 1) to the tile's
+ * rows of p, m, v.  With nothing pending it is a plain fused Adam over the dense gradient.  Until it runs, only calls
+ * that join the session are accepted.  flags == 0 is exactly enerf_grid_encode_backward. */
+int enerf_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                  void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                  uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs,
+                                  uint32_t gridtype, int dtype, int grad_layout, float in_add, float in_mul,
+                                  uint32_t flags, uint32_t reserve_B, enerf_stream_t stream);
+int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
+                                 float lr, float beta1, float beta2, float eps, uint32_t step, enerf_stream_t stream);
+
 /* ------------------------------------------------------------------ shencoder
  * shencoder/src/shencoder.cu:402-441; `dtype` ENERF_F32 or ENERF_F16 for every tensor. */
 

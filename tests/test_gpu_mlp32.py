@@ -209,3 +209,45 @@ def test_density_sigma_only_path_matches_density():
         got = fn.density_sigma(m, x)
     assert got.shape == ref.shape
     assert float(((got - ref).abs() / ref.abs().clamp(min=1e-6)).max()) < 2e-5
+
+
+def test_grid_table_adam_from_records_equals_backward_then_adam():
+    """FusedAdam.step_grid_table (deferred grid backward: the tiles' record lists are summed in LDS by the optimizer's
+    own pass over the table, csrc/gridencoder.hip k_grid_tile_adam) against grid_encode_backward into a dense gradient
+    followed by the fused Adam kernel: same moments, same parameters, the dense gradient buffer comes back clean; two
+    backward calls joining one flush (an event step's two renders) included; below the binning threshold the same
+    entry point is a plain Adam over the dense gradient."""
+    from enerf_amd.backends import _gridencoder as ge
+    from enerf_amd.gridencoder import GridEncoder
+    from enerf_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    for sizes in ((70000,), (40000, 52000), (3000,)):
+        encs = [GridEncoder(desired_resolution=2048 * 2).to("cuda") for _ in range(2)]
+        encs[1].embeddings.data.copy_(encs[0].embeddings.data)
+        opts = [FusedAdam([{"params": [e.embeddings], "lr": 1e-2}], betas=(0.9, 0.99), eps=1e-15) for e in encs]
+        S = float(np.log2(encs[0].per_level_scale))
+        dummy = torch.empty(1, device="cuda")
+        for step in range(3):
+            xs = [torch.rand(n, 3, device="cuda") for n in sizes]
+            gs = [torch.randn(n, 32, device="cuda") * (0.1 + step) for n in sizes]
+            for k, (enc, opt) in enumerate(zip(encs, opts)):
+                p = enc.embeddings
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                for x, g in zip(xs, gs):
+                    ge.grid_encode_backward(g, x, p.data, enc.offsets, p.grad, x.shape[0], 3, 2, 16, S, 16, False, dummy,
+                                            dummy, 0, layout=1, defer=(k == 1), reserve=sum(sizes) if k == 1 else 0)
+                if k == 1:
+                    opt.step_grid_table(p, enc.offsets, 2)
+                    assert not bool(p.grad.any())                      # what was written densely has been consumed
+                else:
+                    opt.step_now(zero_grads=True)
+            a, b = (o.state[e.embeddings] for o, e in zip(opts, encs))
+            for key in ("exp_avg", "exp_avg_sq"):
+                scale = float(a[key].abs().max())
+                assert float((a[key] - b[key]).abs().max()) <= 2e-6 * scale, (sizes, step, key)
+            pa, pb = encs[0].embeddings.data, encs[1].embeddings.data
+            # Adam's first steps move every touched row by ~lr whatever the gradient's size: rows whose gradient is
+            # round-off-sized noise may flip; everything else must agree to fp32
+            assert float(((pa - pb).abs() > 1e-6).float().mean()) < 2e-4, (sizes, step)
+            assert a["step"] == b["step"] == step + 1

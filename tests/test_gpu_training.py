@@ -483,3 +483,30 @@ def test_long_run_with_learned_occupancy_converges():
         img = model.render(ro, rd, staged=False, bg_color=None, perturb=False)["image"].reshape(-1, 3)
     mse = float(((img - tgt) ** 2).mean())
     assert -10 * math.log10(mse) > 18.0, mse                                   # PSNR of a held-out batch of pixels
+
+
+def test_fused_table_adam_step_matches_dense_gradient_step():
+    """TrainHarness.fuse_table_adam (one GPU: the table gradient never becomes a dense tensor -- the optimizer's pass
+    sums each tile's records in LDS) against the same closed-form step with the dense gradient + fused Adam kernel:
+    same loss trajectory and counters over 40 steps, across update_extra_state boundaries and the cold window."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 4096, 2)
+    runs = []
+    for fuse in (False, True):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.fuse_table_adam = fuse
+        losses = []
+        for i in range(40):
+            nxt = data[(i + 1) % len(data)]
+            losses.append(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1])).clone())
+        runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
+                     {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (l0, c0, p0), (l1, c1, p1) = runs
+    assert torch.equal(c0, c1)
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 5e-4
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().mean()) <= 1e-3 * float(p0[n].abs().mean()), n
+    assert float(l1[-4:].mean()) < 0.7 * float(l1[:4].mean())
