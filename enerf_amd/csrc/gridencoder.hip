@@ -493,8 +493,14 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 // tiles keeps several replica lists per tile (filled by different workgroups, flushed with a few atomics) so that
 // its records do not pile up on one CU.  Everything that depends on the table geometry is derived from `offsets`
 // on the device.  Levels with more than kMaxBins lists (tables beyond 2^24 rows per level) stay with the atomic kernel.
-constexpr uint32_t kTileElems = 16384;       // fp64 accumulators: 128 KiB of the CU's 160 KiB LDS
-constexpr uint32_t kTileThreads = 1024;
+// 64-KiB tiles (8192 fp64 accumulators), two tile workgroups per CU: against 128-KiB tiles with one workgroup per CU the
+// tile kernels gain ~8 % (finer-grained last round, two workgroups' phases interleave) at no cost to the binning pass
+#ifndef ENERF_TILE_ELEMS
+#define ENERF_TILE_ELEMS 8192
+#endif
+constexpr uint32_t kTileElems = ENERF_TILE_ELEMS;
+constexpr uint32_t kTileThreads = ENERF_TILE_ELEMS / 16;
+constexpr uint32_t kTilesPerCu = 16384 / ENERF_TILE_ELEMS;     // resident tile workgroups per CU
 constexpr uint32_t kMaxBins = 1024;          // record lists per level
 struct BinPlan {
     uint32_t tiles, replicas, bins;          // bins = tiles * replicas (0: level not binned)
@@ -774,7 +780,8 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
 // (p, m, v: 24 B per element).  k_grid_tile_adam therefore takes over from pass B when the caller defers the flush
 // (enerf_grid_encode_backward_ex, flag bit 0): every 128-KiB tile of every level is visited once; the tile's record
 // lists are summed into the fp64 LDS accumulators as in k_grid_bwd_tile and the Adam update of the tile's rows reads its
-// gradient straight from LDS.  The dense gradient table is never written, read or cleared for the binned levels
+// gradient straight from LDS (measured: the streaming part alone runs at the dense Adam kernel's 56 us, the LDS sums add
+// ~45 us -- a split of the workgroup into accumulating and streaming waves did not overlap them).  The dense gradient table is never written, read or cleared for the binned levels
 // (3 x 52 MB of traffic and pass B's read-modify-write of the table go away), and the LDS atomics run in the shadow
 // of the p / m / v stream.  Levels that are not binned (their contributions went into the dense gradient with
 // atomics) and runs in which a record list overflowed read -- and clear -- the dense gradient as well.
@@ -817,6 +824,21 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
         const uint32_t nrows = rows - row0 < R ? rows - row0 : R;
         const BinPlan plan = bin_plan(offsets, level, R, min_tiles);
         const bool binned = have_records && plan.bins != 0;
+        const bool dense = !binned || spilled;
+        const size_t base = ((size_t)off0 + row0) * C;          // level offsets are multiples of 8 rows: 16-byte aligned
+        // the tile's p / m / v (and dense gradient) are requested first: they travel while the records are summed
+        constexpr int F = kTileElems / (4 * kTileThreads);
+        float4 p4[F], m4[F], v4[F], d4[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            const uint32_t i = (threadIdx.x + f * kTileThreads) * 4;
+            if (i < nrows * C) {
+                p4[f] = *reinterpret_cast<const float4*>(P + base + i);
+                m4[f] = *reinterpret_cast<const float4*>(M + base + i);
+                v4[f] = *reinterpret_cast<const float4*>(V + base + i);
+                d4[f] = dense ? *reinterpret_cast<const float4*>(G + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         if (binned) {
             const uint32_t cap = region / plan.bins;
             if (threadIdx.x < plan.replicas && threadIdx.x < 64) {
@@ -854,30 +876,26 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
             }
             __syncthreads();
         }
-        const bool dense = !binned || spilled;
-        const size_t base = ((size_t)off0 + row0) * C;          // level offsets are multiples of 8 rows: 16-byte aligned
-        for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTileThreads * 4) {
-            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (binned) {
-                const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
-                const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
-                g4 = make_float4((float)a0.x, (float)a0.y, (float)a1.x, (float)a1.y);
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            const uint32_t i = (threadIdx.x + f * kTileThreads) * 4;
+            if (i < nrows * C) {
+                float4 g4 = d4[f];
+                if (binned) {
+                    const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
+                    const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
+                    // (fp64 sum rounded once, then the dense part: what pass B + the dense buffer would have held)
+                    g4.x += (float)a0.x; g4.y += (float)a0.y; g4.z += (float)a1.x; g4.w += (float)a1.y;
+                }
+                tile_adam1(p4[f].x, g4.x, m4[f].x, v4[f].x, ad);
+                tile_adam1(p4[f].y, g4.y, m4[f].y, v4[f].y, ad);
+                tile_adam1(p4[f].z, g4.z, m4[f].z, v4[f].z, ad);
+                tile_adam1(p4[f].w, g4.w, m4[f].w, v4[f].w, ad);
+                *reinterpret_cast<float4*>(P + base + i) = p4[f];
+                *reinterpret_cast<float4*>(M + base + i) = m4[f];
+                *reinterpret_cast<float4*>(V + base + i) = v4[f];
+                if (dense) *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (dense) {
-                const float4 d = *reinterpret_cast<const float4*>(G + base + i);
-                g4.x += d.x; g4.y += d.y; g4.z += d.z; g4.w += d.w;
-                *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            float4 p4 = *reinterpret_cast<const float4*>(P + base + i);
-            float4 m4 = *reinterpret_cast<const float4*>(M + base + i);
-            float4 v4 = *reinterpret_cast<const float4*>(V + base + i);
-            tile_adam1(p4.x, g4.x, m4.x, v4.x, ad);
-            tile_adam1(p4.y, g4.y, m4.y, v4.y, ad);
-            tile_adam1(p4.z, g4.z, m4.z, v4.z, ad);
-            tile_adam1(p4.w, g4.w, m4.w, v4.w, ad);
-            *reinterpret_cast<float4*>(P + base + i) = p4;
-            *reinterpret_cast<float4*>(M + base + i) = m4;
-            *reinterpret_cast<float4*>(V + base + i) = v4;
         }
         __syncthreads();
     }
@@ -1018,7 +1036,7 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
                     grad, inputs, offsets, grad_emb, B, L, tab, gridtype, layout, bchunks, min_tiles, recs, cursors, \
                     region, flush_now ? nullptr : overflow);                                                     \
                 if (flush_now)                                                                                   \
-                    k_grid_bwd_tile<CC><<<num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, \
+                    k_grid_bwd_tile<CC><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, \
                                                                            recs, cursors, region);               \
             }                                                                                                    \
         }                                                                                                        \
@@ -1138,10 +1156,10 @@ int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const i
                                   : nullptr;
     const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;
     switch (C) {
-        case 1: k_grid_tile_adam<1><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
-        case 2: k_grid_tile_adam<2><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
-        case 4: k_grid_tile_adam<4><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
-        case 8: k_grid_tile_adam<8><<<num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
         default: ENERF_BADARG("grid_adam_from_records: C must be 1, 2, 4, or 8.");
     }
     g_pending = PendingRecords();

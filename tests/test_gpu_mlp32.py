@@ -1,4 +1,5 @@
 """Fused fp32 MLP (v_mfma_f32_32x32x2_f32) vs the plain nn.Linear / ReLU stack it replaces: 1e-4 rel (fp32)."""
+import numpy as np
 import pytest
 import torch
 
