@@ -644,12 +644,18 @@ __global__ void __launch_bounds__(256) k_occupied_aabb(const uint8_t* __restrict
             nhi[a] = fminf(nhi[a], __shfl_xor(nhi[a], off, 64));
         }
     }
+    // wave -> workgroup (LDS) -> one global atomic per workgroup and key (same-address device atomics cost ~12 ns each)
+    __shared__ int s_keys[6];
+    if (threadIdx.x < 6) s_keys[threadIdx.x] = 0x7f7f7f7f;
+    __syncthreads();
     if (lane_id() == 0) {
         for (int a = 0; a < 3; a++) {
-            if (lo[a] < 3.0e38f) atomicMin(keys + a, aabb_key(lo[a]));
-            if (nhi[a] < 3.0e38f) atomicMin(keys + 3 + a, aabb_key(nhi[a]));
+            if (lo[a] < 3.0e38f) atomicMin(&s_keys[a], aabb_key(lo[a]));
+            if (nhi[a] < 3.0e38f) atomicMin(&s_keys[3 + a], aabb_key(nhi[a]));
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 6 && s_keys[threadIdx.x] != 0x7f7f7f7f) atomicMin(keys + threadIdx.x, s_keys[threadIdx.x]);
 }
 
 // Ray against the enlarged occupied box: false = the ray cannot emit a sample; otherwise `far` is lowered to where the

@@ -154,7 +154,7 @@ def train_step_events(model, data, opt, criterion=None, bg_color=None):
     return loss, delta
 
 
-def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None):
+def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None, defer_table=False):
     """The event-only step with the two renders driven without autograd (fused_render.render_train_raw /
     backward_raw): only the loss itself -- a few elementwise ops on two [N,3] images -- goes through autograd, and its
     gradient is handed to the renders' closed backward.  Same values as train_step_events + loss.backward()
@@ -177,12 +177,17 @@ def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None
         g1, g2 = torch.autograd.grad(loss, [a, b])
     params = fnet.network_params(model)
     emb = params[0]
+    keep = emb.grad if defer_table else None            # (deferred flush: the dense buffer is kept, and kept clean)
     for p in params:
         p.grad = None
-    g_emb, dw1 = fr.backward_raw(ctx1, g_image=g1, raw=True)
+    if defer_table:
+        emb.grad = keep if keep is not None else torch.zeros_like(emb)
+    # defer_table: both renders' table gradients stay record lists for FusedAdam.step_grid_table (one flush)
+    total = (ctx1["M"] + ctx2["M"]) if defer_table else 0
+    g_emb, dw1 = fr.backward_raw(ctx1, g_image=g1, raw=True, defer_table=total)
     if g_emb is not None:
         emb.grad = g_emb                                # the second backward adds straight into it ...
-    g_emb2, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True)
+    g_emb2, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True, defer_table=total)
     if g_emb2 is not None:                              # ... unless it could not (then it returns its own buffer)
         emb.grad.add_(g_emb2)
     dw1 += dw2

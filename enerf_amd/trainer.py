@@ -543,17 +543,29 @@ class TrainHarness:
                 self._graphs[key] = self._capture(
                     inputs, lambda *ts: train_step_events(self.model, dict(zip(names, ts)), opt)[0])
             return self._replay(self._graphs[key], inputs, 2)
-        self.opt.zero_grad(set_to_none=True)
         if self._events_manual_ok(data, opt):
             from .events import train_step_events_manual
             side = None
             if next_data is not None and not opt.render_kwargs:
                 side = self._side_prefetch((next_data["rays_evs_o1"], next_data["rays_evs_d1"]),
                                            (next_data["rays_evs_o2"], next_data["rays_evs_d2"]))
-            loss, _ = train_step_events_manual(self.model, data, opt, after_forward=side)
+            fuse_table = (self.fuse_table_adam and self.avg is None and hasattr(self.opt, "step_grid_table")
+                          and not self.use_graphs)
+            emb = self.model.encoder.embeddings
+            if emb.grad is not self._cleared_grad:          # only a buffer the last flush left clean may be added into
+                emb.grad = None
+            self._cleared_grad = None
+            loss, _ = train_step_events_manual(self.model, data, opt, after_forward=side, defer_table=fuse_table)
             self._reduce_grads()
-            self._opt_step()
+            if fuse_table:
+                enc = self.model.encoder
+                self.opt.step_grid_table(enc.embeddings, enc.offsets, enc.level_dim)
+                self.opt.step_now(only=[p for p in self._params if p is not enc.embeddings])
+                self._cleared_grad = enc.embeddings.grad
+            else:
+                self._opt_step()
             return loss
+        self.opt.zero_grad(set_to_none=True)
         loss, _ = train_step_events(self.model, data, opt)
         loss.backward()
         if self.avg is not None:
