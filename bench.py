@@ -411,6 +411,10 @@ def main():
             ptsb = gb.STATS["bwd_points"] / gb.STATS["bwd_calls"]
             roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / \
                 (kernels["grid_bwd"]["avg_ms"] * 1e-3) / 1e9
+            roofline["grid_encode_backward_scope"] = (
+                "binning pass (k_grid_bwd_bin) only: on one GPU the tile sums run inside the optimizer's pass over the "
+                "table (k_grid_tile_adam, profiles/r02_step_kernels_steady.txt)" if harness.fuse_table_adam and world == 1
+                else "binning pass + tile pass (k_grid_bwd_bin + k_grid_bwd_tile)")
 
     # ---- MFMA probe (not part of `value`): a few more steps with the MLP kernel families hipEvent-timed as well, no
     # density-grid update in between (its sigma-only sweep is a different launch shape).  Timing every family costs

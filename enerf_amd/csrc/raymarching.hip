@@ -1388,20 +1388,38 @@ __global__ void __launch_bounds__(256) k_composite_rays_frame(const float* __res
     const float* s = sigmas + offset;
     const float* c = rgbs + (size_t)offset * 3;
     const float* dl = deltas + (size_t)offset * 2;
+    // samples are fetched eight at a time (one memory latency per eight samples instead of one per sample: the ray's
+    // recurrence itself is a dozen flops) and consumed in order
+    constexpr int PF = 8;
     uint32_t step = 0;
-    while (step < count) {
-        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
-        const float T = 1 - weight_sum;
-        const float weight = alpha * T;
-        weight_sum += weight;
-        t += dl[1];
-        d = fmaf(weight, t, d);
-        r = fmaf(weight, c[0], r);
-        g = fmaf(weight, c[1], g);
-        b = fmaf(weight, c[2], b);
-        step++;
-        if ((double)T < 1e-5) break;
-        s++; c += 3; dl += 2;
+    bool done = false;
+    while (step < count && !done) {
+        float ps[PF], pd0[PF], pd1[PF], pc0[PF], pc1[PF], pc2[PF];
+        const uint32_t nb = count - step < (uint32_t)PF ? count - step : (uint32_t)PF;
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const uint32_t kk = (uint32_t)k < nb ? (uint32_t)k : nb - 1;
+            ps[k] = s[kk];
+            pd0[k] = dl[kk * 2]; pd1[k] = dl[kk * 2 + 1];
+            pc0[k] = c[kk * 3]; pc1[k] = c[kk * 3 + 1]; pc2[k] = c[kk * 3 + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if ((uint32_t)k < nb && !done) {
+                const float alpha = 1.0f - __expf(-ps[k] * pd0[k]);
+                const float T = 1 - weight_sum;
+                const float weight = alpha * T;
+                weight_sum += weight;
+                t += pd1[k];
+                d = fmaf(weight, t, d);
+                r = fmaf(weight, pc0[k], r);
+                g = fmaf(weight, pc1[k], g);
+                b = fmaf(weight, pc2[k], b);
+                step++;
+                if ((double)T < 1e-5) done = true;
+            }
+        }
+        s += nb; c += (size_t)nb * 3; dl += (size_t)nb * 2;
     }
     if (used) atomicAdd(used, step);
     weights_sum[index] = weight_sum;

@@ -54,10 +54,16 @@ def render_frame(model, rays_o, rays_d, bg_color=1, max_steps=1024, trace=None):
     _rb.march_rays_train_write(*geom, M, nears, fars, xyzs, dirs, deltas, rays, counter, 0, 1)
     sigmas, rgbs = torch.empty(M, **f32), torch.empty(M, 3, **f32)
     scale = float(model.density_scale)
+    into = getattr(model, "forward_into", None)
     for a in range(0, M, CHUNK):
-        s, c = model(xyzs[a:a + CHUNK], dirs[a:a + CHUNK])
-        sigmas[a:a + CHUNK] = s if scale == 1.0 else scale * s
-        rgbs[a:a + CHUNK] = c
+        if into is not None:                            # the network writes its slice of the frame's arrays itself
+            into(xyzs[a:a + CHUNK], dirs[a:a + CHUNK], sigmas[a:a + CHUNK], rgbs[a:a + CHUNK])
+        else:
+            s, c = model(xyzs[a:a + CHUNK], dirs[a:a + CHUNK])
+            sigmas[a:a + CHUNK] = s
+            rgbs[a:a + CHUNK] = c
+    if scale != 1.0:
+        sigmas *= scale
     weights_sum, depth, image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32)
     used = torch.zeros(1, dtype=torch.int32, device=dev) if trace is not None else None
     _rb.composite_rays_frame(sigmas, rgbs, deltas, rays, N, M, nears, fars, bg_color, weights_sum, depth, image, used)

@@ -74,9 +74,10 @@ def supported(net, x, d):
     return hit[1] and _ge._supports_layout()
 
 
-def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2):
+def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2, out=None):
     """The kernel sequence itself (no autograd): returns sigma [B], rgb [B,out], and -- when `train` -- the tensors
-    nerf_backward needs."""
+    nerf_backward needs.  `out` = (sigma [B], rgb [B,out]) contiguous fp32 tensors to write into (e.g. slices of a
+    frame's sample buffers)."""
     bound, per_level_scale, base_resolution, gridtype = cfg
     x = x.contiguous()
     d = d.contiguous()
@@ -85,8 +86,13 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2)
     dev = x.device
     lib = L.lib()
     out_c = wc2.shape[0]
-    sigma = torch.empty(B, dtype=torch.float32, device=dev)
-    rgb = torch.empty(B, out_c, dtype=torch.float32, device=dev)
+    if out is None:
+        sigma = torch.empty(B, dtype=torch.float32, device=dev)
+        rgb = torch.empty(B, out_c, dtype=torch.float32, device=dev)
+    else:
+        sigma, rgb = out
+        assert sigma.shape == (B,) and rgb.shape == (B, out_c) and sigma.is_contiguous() and rgb.is_contiguous() \
+            and sigma.dtype == rgb.dtype == torch.float32
     if B == 0:
         return sigma, rgb, None
     S = float(np.log2(per_level_scale))
@@ -214,6 +220,13 @@ def forward(net, x, d):
     params = network_params(net)
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     return _FusedNeRF.apply(x, d, network_cfg(net), train, params[0], net.encoder.offsets, *params[1:])
+
+
+@torch.no_grad()
+def forward_into(net, x, d, sigma_out, rgb_out):
+    """Inference forward writing straight into caller-owned buffers (no autograd, no copies)."""
+    params = network_params(net)
+    nerf_forward(x, d, network_cfg(net), False, params[0], net.encoder.offsets, *params[1:], out=(sigma_out, rgb_out))
 
 
 def density_sigma(net, x):

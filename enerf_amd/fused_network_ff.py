@@ -47,14 +47,20 @@ def supported(net, x, d):
 
 
 @torch.no_grad()
-def forward(net, x, d):
-    """sigma [N], rgb [N,3] (fp32 tensors holding 16-bit-rounded values) for x [N,3] in [-bound, bound], d [N,3]."""
+def forward(net, x, d, out=None):
+    """sigma [N], rgb [N,3] (fp32 tensors holding 16-bit-rounded values) for x [N,3] in [-bound, bound], d [N,3];
+    `out` = (sigma, rgb) contiguous fp32 tensors to write into."""
     x = x.contiguous()
     d = d.contiguous()
     B = x.shape[0]
     dev = x.device
-    sigma = torch.empty(B, dtype=torch.float32, device=dev)
-    rgb = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    if out is None:
+        sigma = torch.empty(B, dtype=torch.float32, device=dev)
+        rgb = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    else:
+        sigma, rgb = out
+        assert sigma.shape == (B,) and rgb.shape == (B, 3) and sigma.is_contiguous() and rgb.is_contiguous() \
+            and sigma.dtype == rgb.dtype == torch.float32
     if B == 0:
         return sigma, rgb
     enc = net.encoder

@@ -96,6 +96,16 @@ class NeRFNetwork(NeRFRenderer):
         h = _run_mlp(self.color_net, self._color_input(d, geo_feat))
         return sigma, torch.sigmoid(h)
 
+    def forward_into(self, x, d, sigma_out, rgb_out):
+        """forward() into caller-owned fp32 buffers (the whole-frame renderer's sample arrays)."""
+        if fused_network.supported(self, x, d) and not torch.is_grad_enabled() and sigma_out.is_contiguous() \
+                and rgb_out.is_contiguous():
+            fused_network.forward_into(self, x, d, sigma_out, rgb_out)
+        else:
+            sigma, rgb = self(x, d)
+            sigma_out.copy_(sigma)
+            rgb_out.copy_(rgb)
+
     def density(self, x):
         h = self._sigma_mlp(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}

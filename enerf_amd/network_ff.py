@@ -49,6 +49,15 @@ class NeRFNetwork(NeRFRenderer):
         h = self.color_net(self._color_in(d, geo_feat))
         return sigma, torch.sigmoid(h)
 
+    def forward_into(self, x, d, sigma_out, rgb_out):
+        """forward() into caller-owned fp32 buffers (the whole-frame renderer's sample arrays)."""
+        if fused_network_ff.supported(self, x, d):
+            fused_network_ff.forward(self, x, d, out=(sigma_out, rgb_out))
+        else:
+            sigma, rgb = self(x, d)
+            sigma_out.copy_(sigma)
+            rgb_out.copy_(rgb)
+
     def density(self, x):
         h = self.sigma_net(self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}

@@ -31,4 +31,21 @@ python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_kernels.json --by-grid --meta
 
 rm -rf /tmp/p_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma -o c -- python $R/tools/bench_ffmlp.py --batch 2097152 > $OUT/ffmlp_under_mfma.log 2>&1
 python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_mfma_ffmlp.json --by-grid --meta "command=tools/bench_ffmlp.py --batch 2097152" $(find /tmp/p_mfma -name "*counter_collection.csv")
+# MFMA-busy of the kernels the bench line's roofline_mfma objects are about (mlp32 training kernels, k_ffnerf_infer), in
+# the bench's own command
+rm -rf /tmp/p_mfma_bench; timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma_bench -o c -- $BENCH --graph-leg-steps 0 > $OUT/bench_under_mfma.log 2>&1
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_mfma_bench.json --meta "command=bench.py --no-cpu-baseline --graph-leg-steps 0" $(find /tmp/p_mfma_bench -name "*counter_collection.csv")
+
+# the deferred flush (records -> LDS tile sums -> Adam) against pass B + Adam: traffic of k_grid_tile_adam / k_grid_bwd_*
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/t_$C; timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/t_$C -o c -- python $R/tools/bench_tile_adam.py > $OUT/tile_adam_under_$C.log 2>&1
+done
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_tile_adam.json --meta "command=tools/bench_tile_adam.py" \
+  $(find /tmp/t_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/t_WRITE_SIZE -name "*counter_collection.csv")
+
+# full-frame render, per kernel (whole-frame schedule, FFMLP nets)
+bash $R/tools/render_kstats.sh --net ff > $OUT/${TAG}_render_ffmlp_kernels.txt 2>&1
+bash $R/tools/kstats.sh > $OUT/${TAG}_step_kernels_steady.txt 2>&1
+bash $R/tools/update_kstats.sh > $OUT/${TAG}_update_extra_state_kernels.txt 2>&1
+cp $OUT/${TAG}_*.json $OUT/${TAG}_*.csv $OUT/${TAG}_*.txt $R/gpurun_out/ 2>/dev/null
 ls -la $OUT
