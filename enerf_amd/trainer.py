@@ -23,7 +23,7 @@ from .parallel import GradAverager
 
 class TrainHarness:
     def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16, use_graphs=False,
-                 optimizer=None):
+                 optimizer=None, fp16=False):
         self.model = model
         adam = optimizer or (FusedAdam if next(model.parameters()).is_cuda else torch.optim.Adam)
         self.opt = adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
@@ -50,6 +50,11 @@ class TrainHarness:
         self._cleared_grad = None     # the embeddings' gradient buffer as the last Adam pass left it (all zeros)
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
         self._loss_cursor = 0
+        # fp16 = the shipped configs' `fp16 = True`: the step runs under torch.autocast(float16) with a GradScaler
+        # (nerf/utils.py:350,964-975): half hash table + half table gradient (gridencoder/grid.py:38-39,72), half SH,
+        # half nn.Linear GEMMs, fp32 marching / compositing.  The fused fp32 paths stand aside under autocast.
+        self.fp16 = bool(fp16)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=True) if self.fp16 else None
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         self._graph_generation = 0
@@ -154,7 +159,7 @@ class TrainHarness:
 
     def _graphable(self, rays_o, rays_d):
         from . import fused_render
-        return (self.use_graphs and self.model.mean_count > 0
+        return (self.use_graphs and not self.fp16 and self.model.mean_count > 0
                 and fused_render.supported(self.model, rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3),
                                            1, 0))
 
@@ -518,6 +523,17 @@ class TrainHarness:
                         m.render(ro, rd, staged=False, bg_color=None, perturb=True, **render_kw)["image"], tg),
                     (lambda ro, rd, tg: self._manual_fwd_bwd(ro, rd, tg, **render_kw)) if manual else None)
             return self._replay(self._graphs[key], (rays_o, rays_d, target), 1)
+        if self.fp16:
+            self.opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=True, **render_kw)
+                loss = torch.nn.functional.mse_loss(out["image"], target)
+            self.scaler.scale(loss).backward()
+            self.scaler.unscale_(self.opt)
+            self._reduce_grads(next_rays)
+            self.scaler.step(self.opt)
+            self.scaler.update()
+            return loss.detach()
         if self._manual_ok(rays_o, rays_d, target, render_kw):
             return self._step_rgb_manual(rays_o, rays_d, target, next_rays, **render_kw)
         self.opt.zero_grad(set_to_none=True)
