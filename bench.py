@@ -538,6 +538,33 @@ def main():
                     "samples_per_frame": mlp_samples, "kernel_ms_per_frame": mlp_ms}
             del ffm
 
+    # ---- the reference's own fully-fused MLP entry point (a16, ffmlp_inference) at the frame's sample count: colour net
+    # 32 -> 64 x 3 -> 16, bf16 storage, fp32 MFMA accumulation.  north_star's "MFMA utilisation for ffmlp" is about this
+    # kernel; the frame leg above uses the larger fusion (k_ffnerf_infer: both nets + SH + activations, VALU-bound).
+    ffmlp_kernel = None
+    if args.render_frames > 0 and rank == 0:
+        from enerf_amd.backends import _ffmlp as ffb
+        Bk, k = 2 * 1024 * 1024, 3
+        W = ((torch.rand(64 * (32 + 64 * (k - 1) + 16), device=device) - 0.5) * 0.5).to(torch.bfloat16)
+        x = (torch.rand(Bk, 32, device=device) - 0.5).to(torch.bfloat16)
+        y = torch.empty(Bk, 16, device=device, dtype=torch.bfloat16)
+        ib = torch.empty(Bk, 64, device=device, dtype=torch.bfloat16)
+        for _ in range(3):
+            ffb.ffmlp_inference(x, W, Bk, 32, 16, 64, k, 0, 6, ib, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ffb.ffmlp_inference(x, W, Bk, 32, 16, 64, k, 0, 6, ib, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        flop = 2.0 * Bk * (32 * 64 + (k - 1) * 64 * 64 + 64 * 16)
+        tf = flop / (ms * 1e-3) / 1e12
+        ffmlp_kernel = {"bound": "mfma", "kernel": "ffmlp_inference, colour net 32->64x3->16, bf16 (k_ffmlp_fwd)",
+                        "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                        "samples": Bk, "flop_per_sample": flop / Bk, "avg_launch_ms": ms, "launches": 20}
+        del W, x, y, ib
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # in a fresh, unpinned process: this one's thread pools were created under the 8-core pin
@@ -575,6 +602,7 @@ def main():
             "render": render,
             "step_split": split,
             "roofline_mfma": roofline_mfma,
+            "roofline_mfma_ffmlp": ffmlp_kernel,
             "graph_replay": graph_replay,
             "comm_tuning": comm_tuning,
             "kernels": kernels,
