@@ -366,6 +366,7 @@ def main():
             per_step.add_(model.step_counter[slot, 0])
             if args.mode == "events":
                 per_step.add_(model.step_counter[(slot - 1) % 16, 0])
+    t_enqueued = time.perf_counter()
     sync()
     t1 = time.perf_counter()
     if args.graphs:
@@ -601,6 +602,7 @@ def main():
             "samples_per_step_per_gpu": total_samples / args.steps / world,
             "render": render,
             "step_split": split,
+            "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
             "roofline_mfma": roofline_mfma,
             "roofline_mfma_ffmlp": ffmlp_kernel,
             "graph_replay": graph_replay,

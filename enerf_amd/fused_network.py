@@ -66,8 +66,11 @@ def supported(net, x, d):
         return False
     if x.requires_grad or d.requires_grad:
         return False
-    key = (id(net.encoder.embeddings) if hasattr(net, "encoder") and hasattr(net.encoder, "embeddings") else 0,
-           net.encoder.embeddings.dtype if hasattr(net, "encoder") and hasattr(net.encoder, "embeddings") else None)
+    # (registered sub-modules / parameters are read from the module's own dicts: nn.Module.__getattr__ is a slow path,
+    # and this runs several times per 0.5 ms training step)
+    enc = net._modules.get("encoder")
+    emb = enc._parameters.get("embeddings") if enc is not None else None
+    key = (id(emb), emb.dtype) if emb is not None else (0, None)
     hit = _arch_ok.get(id(net))
     if hit is None or hit[0] != key:
         hit = _arch_ok[id(net)] = (key, _architecture_supported(net))
@@ -205,28 +208,33 @@ class _FusedNeRF(Function):
 
 
 def network_params(net):
-    enc = net.encoder
-    return (enc.embeddings, net.sigma_net[0].weight, net.sigma_net[1].weight, net.color_net[0].weight,
-            net.color_net[1].weight, net.color_net[2].weight)
+    mods = net._modules
+    s, c = mods["sigma_net"]._modules, mods["color_net"]._modules
+    return (mods["encoder"]._parameters["embeddings"], s["0"]._parameters["weight"], s["1"]._parameters["weight"],
+            c["0"]._parameters["weight"], c["1"]._parameters["weight"], c["2"]._parameters["weight"])
 
 
 def network_cfg(net):
-    enc = net.encoder
+    enc = net._modules["encoder"]
     return (net.bound, enc.per_level_scale, enc.base_resolution, enc.gridtype_id)
+
+
+def encoder_offsets(net):
+    return net._modules["encoder"]._buffers["offsets"]
 
 
 def forward(net, x, d):
     """sigma [N], rgb [N, out_dim_color] for x [N,3] in [-bound, bound], d [N,3]."""
     params = network_params(net)
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    return _FusedNeRF.apply(x, d, network_cfg(net), train, params[0], net.encoder.offsets, *params[1:])
+    return _FusedNeRF.apply(x, d, network_cfg(net), train, params[0], encoder_offsets(net), *params[1:])
 
 
 @torch.no_grad()
 def forward_into(net, x, d, sigma_out, rgb_out):
     """Inference forward writing straight into caller-owned buffers (no autograd, no copies)."""
     params = network_params(net)
-    nerf_forward(x, d, network_cfg(net), False, params[0], net.encoder.offsets, *params[1:], out=(sigma_out, rgb_out))
+    nerf_forward(x, d, network_cfg(net), False, params[0], encoder_offsets(net), *params[1:], out=(sigma_out, rgb_out))
 
 
 def density_sigma(net, x):

@@ -41,7 +41,7 @@ def occupied_box_flag(model):
     """-> the marcher flag (4) that enables the occupied-box test, after making sure the library's box belongs to this
     model's current bitfield (recomputed on the current stream when the bitfield's storage, torch version or the
     package's raw-write epoch changed: update_extra_state, packbits, copy_)."""
-    bf = model.density_bitfield
+    bf = model._buffers["density_bitfield"]
     key = (bf.data_ptr(), bf._version, _rm.BITFIELD_EPOCH[0], int(model.cascade), int(model.grid_size), float(model.bound))
     if _BOX_FOR.get(bf.device.index) != key:
         _rb.occupied_box_update(bf, model.cascade, model.grid_size, model.bound)
@@ -66,12 +66,14 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     dev = rays_o.device
     nears = torch.empty(N, dtype=torch.float32, device=dev)
     fars = torch.empty(N, dtype=torch.float32, device=dev)
-    _rb.near_far_from_aabb(rays_o, rays_d, model.aabb_train, N, model.min_near, nears, fars)
+    bufs = model._buffers                            # (nn.Module.__getattr__ is a slow path)
+    bitfield = bufs["density_bitfield"]
+    _rb.near_far_from_aabb(rays_o, rays_d, bufs["aabb_train"], N, model.min_near, nears, fars)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
     box = occupied_box_flag(model)
     if force_all_rays or mean_count <= 0:
-        _rb.march_rays_train_count(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+        _rb.march_rays_train_count(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
                                    model.cascade, model.grid_size, nears, fars, rays, counter, perturb,
                                    box | (2 if background else 0))
         total = torch.empty(2, dtype=torch.int32, pin_memory=True)
@@ -87,7 +89,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
-    _rb.march_rays_train_ex(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+    _rb.march_rays_train_ex(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
                             model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
                             perturb, box | (3 if background else 1))
     pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
@@ -109,7 +111,7 @@ def finish_march(model, pre):
     xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
-    _rb.march_rays_train_write(rays_o, rays_d, model.density_bitfield, model.bound, dt_gamma, max_steps, N,
+    _rb.march_rays_train_write(rays_o, rays_d, model._buffers["density_bitfield"], model.bound, dt_gamma, max_steps, N,
                                model.cascade, model.grid_size, M, pre["nears"], pre["fars"], xyzs, dirs, deltas,
                                pre["rays"], pre["counter"], perturb, 1)
     pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
@@ -128,7 +130,7 @@ class _FusedRenderTrain(Function):
                                                                      "M"))
 
         train = any(p.requires_grad for p in (embeddings, ws0, ws1, wc0, wc1, wc2))
-        sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), train, embeddings, model.encoder.offsets,
+        sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), train, embeddings, fnet.encoder_offsets(model),
                                            ws0, ws1, wc0, wc1, wc2)
         scale = float(model.density_scale)
         sigmas = sigma if scale == 1.0 else sigma * scale
@@ -174,7 +176,7 @@ def _next_counter(model):
     counter = getattr(model, "graph_counter", None)
     if counter is None:
         model.last_counter_slot = model.local_step % 16
-        counter = model.step_counter[model.last_counter_slot]
+        counter = model._buffers["step_counter"][model.last_counter_slot]
         model.local_step += 1
     counter.zero_()
     return counter
@@ -272,8 +274,9 @@ def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0
             pre = march_stage(model, rays_o, rays_d, counter, _budget(model), bool(perturb), False, float(dt_gamma),
                               int(max_steps))
         xyzs, dirs, deltas, rays, M = (pre[k] for k in ("xyzs", "dirs", "deltas", "rays", "M"))
-        sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), True, model.encoder.embeddings,
-                                           model.encoder.offsets, *fnet.network_params(model)[1:])
+        params = fnet.network_params(model)
+        sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), True, params[0],
+                                           fnet.encoder_offsets(model), *params[1:])
         scale = float(model.density_scale)
         sigmas = sigma if scale == 1.0 else sigma * scale
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)

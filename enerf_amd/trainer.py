@@ -38,6 +38,9 @@ class TrainHarness:
         self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
         self.fuse_table_adam = True   # one GPU: the table gradient's tile sums feed Adam straight from LDS
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
+        enc = getattr(model, "encoder", None)
+        table = getattr(enc, "embeddings", None)
+        self._small_params = [p for p in self._params if p is not table]
         self._opt_step = getattr(self.opt, "step_now", self.opt.step)
         self._side = None             # HIP stream of the next batch's march (created on first use)
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
@@ -218,7 +221,7 @@ class TrainHarness:
         # nothing accumulates across steps (zero_grad(set_to_none=True)) -- except that the hash table's gradient
         # buffer is kept when the previous step's Adam pass cleared it (step_now(zero_grads=True)): the grid backward
         # then adds straight into it, with no 52 MB allocation and fill
-        emb = m.encoder.embeddings
+        emb = m._modules["encoder"]._parameters["embeddings"]
         keep = emb.grad if (not self.use_graphs and self._cleared_grad is not None
                             and emb.grad is self._cleared_grad) else None
         self._cleared_grad = None
@@ -495,10 +498,11 @@ class TrainHarness:
             return loss
         self._reduce_grads(None if side is not None else next_rays)
         if fuse_table:
-            enc = self.model.encoder
-            self.opt.step_grid_table(enc.embeddings, enc.offsets, enc.level_dim)
-            self.opt.step_now(only=[p for p in self._params if p is not enc.embeddings])
-            self._cleared_grad = enc.embeddings.grad
+            enc = self.model._modules["encoder"]
+            emb = enc._parameters["embeddings"]
+            self.opt.step_grid_table(emb, enc._buffers["offsets"], enc.level_dim)
+            self.opt.step_now(only=self._small_params)
+            self._cleared_grad = emb.grad
         elif self.avg is None and hasattr(self.opt, "step_now") and not self.use_graphs:
             self.opt.step_now(zero_grads=True)          # Adam clears what it has read: the next step needs no fill
             self._cleared_grad = self.model.encoder.embeddings.grad

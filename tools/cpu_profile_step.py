@@ -39,9 +39,16 @@ t2 = time.perf_counter()
 print(f"enqueue {1e3 * (t1 - t0) / 15:.3f} ms/step, drained after {1e3 * (t2 - t0) / 15:.3f} ms/step")
 pr = cProfile.Profile()
 pr.enable()
-for i in range(56, 56 + 8):
-    step(i)
+n_prof = 0
+for base in range(65, 65 + 16 * 8, 16):          # 8 windows of 14 steps between density-grid updates
+    pr.disable()
+    step(base - 1)                                # (the update step itself stays outside the profile)
+    pr.enable()
+    for i in range(base, base + 14):
+        step(i)
+        n_prof += 1
 pr.disable()
+print("profiled steps:", n_prof)
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(32)
+st.sort_stats("tottime").print_stats(40)
