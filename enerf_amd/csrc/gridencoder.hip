@@ -1138,6 +1138,16 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
                                          0u, 0u, stream);
 }
 
+int enerf_grid_records_discard(enerf_stream_t stream) {
+    // drop a pending deferred flush (the step that opened it failed before its optimizer pass): empty the lists
+    if (g_pending.region != 0) {
+        uint32_t* cursors = bin_cursors();
+        if (cursors) (void)hipMemsetAsync(cursors, 0, sizeof(uint32_t) * kMaxLevels * kMaxBins, (hipStream_t)stream);
+        g_pending = PendingRecords();
+    }
+    return 0;
+}
+
 int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
                                  float lr, float beta1, float beta2, float eps, uint32_t step, enerf_stream_t stream) {
     if (!p || !g || !m || !v || !offsets || L == 0 || L > (uint32_t)kMaxLevels || step == 0)

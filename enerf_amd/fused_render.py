@@ -35,14 +35,21 @@ def supported(model, rays_o, rays_d, bg_color, dt_gamma):
 
 
 _BOX_FOR = {}        # device index -> key of the bitfield the library's occupied box was last computed for
+_BOX_TOKENS = iter(range(1, 1 << 62))
 
 
 def occupied_box_flag(model):
     """-> the marcher flag (4) that enables the occupied-box test, after making sure the library's box belongs to this
-    model's current bitfield (recomputed on the current stream when the bitfield's storage, torch version or the
-    package's raw-write epoch changed: update_extra_state, packbits, copy_)."""
+    model's current bitfield: recomputed on the current stream when another model used the box last, or when this
+    model's bitfield changed storage, torch version (copy_, load_state_dict) or the package's raw-write epoch
+    (packbits, update_extra_state).  The model carries a unique token, so a new model whose bitfield happens to land
+    on a freed one's address is never mistaken for it."""
     bf = model._buffers["density_bitfield"]
-    key = (bf.data_ptr(), bf._version, _rm.BITFIELD_EPOCH[0], int(model.cascade), int(model.grid_size), float(model.bound))
+    token = model.__dict__.get("_occ_box_token")
+    if token is None:
+        token = model.__dict__["_occ_box_token"] = next(_BOX_TOKENS)
+    key = (token, bf.data_ptr(), bf._version, _rm.BITFIELD_EPOCH[0], int(model.cascade), int(model.grid_size),
+           float(model.bound))
     if _BOX_FOR.get(bf.device.index) != key:
         _rb.occupied_box_update(bf, model.cascade, model.grid_size, model.bound)
         _BOX_FOR[bf.device.index] = key

@@ -300,6 +300,13 @@ class TrainHarness:
             p.grad = g.view_as(p)
         self.opt.step_now(only=small)
 
+    @staticmethod
+    def _discard_pending_records():
+        """A step that left the table gradient as record lists died before its optimizer pass: empty the lists so that
+        the next backward is not refused."""
+        from . import _lib
+        _lib.lib().enerf_grid_records_discard(_lib.stream_handle())
+
     def _finish_sharded(self, issue_prefetch=None):
         """The other data-parallel tail (SURVEY.md 8e "scaling risk (b)"): the table gradient is reduce-scattered, every
         rank runs Adam on its own 1/N of the table only (the 28 B/element optimizer pass shrinks N-fold) and the updated
@@ -490,8 +497,12 @@ class TrainHarness:
         # optimizer's pass over the table sums them tile by tile in LDS (FusedAdam.step_grid_table)
         fuse_table = (self.fuse_table_adam and self.avg is None and hasattr(self.opt, "step_grid_table")
                       and not self.use_graphs)
-        loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=None if late else side, raw=chunked,
-                                    defer_table=fuse_table, **render_kw)
+        try:
+            loss = self._manual_fwd_bwd(rays_o, rays_d, target, after_forward=None if late else side, raw=chunked,
+                                        defer_table=fuse_table, **render_kw)
+        except BaseException:
+            self._discard_pending_records()
+            raise
         if chunked:
             tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
             tail(side if late else None)
@@ -575,7 +586,11 @@ class TrainHarness:
             if emb.grad is not self._cleared_grad:          # only a buffer the last flush left clean may be added into
                 emb.grad = None
             self._cleared_grad = None
-            loss, _ = train_step_events_manual(self.model, data, opt, after_forward=side, defer_table=fuse_table)
+            try:
+                loss, _ = train_step_events_manual(self.model, data, opt, after_forward=side, defer_table=fuse_table)
+            except BaseException:
+                self._discard_pending_records()
+                raise
             self._reduce_grads()
             if fuse_table:
                 enc = self.model.encoder

@@ -299,6 +299,8 @@ int enerf_grid_encode_backward_ex(const void* grad, const float* inputs, const v
                                   uint32_t flags, uint32_t reserve_B, enerf_stream_t stream);
 int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
                                  float lr, float beta1, float beta2, float eps, uint32_t step, enerf_stream_t stream);
+/* Abandon a pending deferred flush (error recovery: the record lists are emptied, nothing is applied). */
+int enerf_grid_records_discard(enerf_stream_t stream);
 
 /* ------------------------------------------------------------------ shencoder
  * shencoder/src/shencoder.cu:402-441; `dtype` ENERF_F32 or ENERF_F16 for every tensor. */

@@ -252,3 +252,31 @@ def test_grid_table_adam_from_records_equals_backward_then_adam():
             # round-off-sized noise may flip; everything else must agree to fp32
             assert float(((pa - pb).abs() > 1e-6).float().mean()) < 2e-4, (sizes, step)
             assert a["step"] == b["step"] == step + 1
+
+
+def test_pending_record_lists_refuse_foreign_calls_and_can_be_discarded():
+    """While a deferred flush is pending only calls that join it are accepted (a plain backward would silently lose
+    its binned levels to the session); enerf_grid_records_discard empties the lists, after which a plain backward gives
+    the same gradient as if nothing had happened."""
+    from enerf_amd import _lib
+    from enerf_amd.backends import _gridencoder as ge
+    from enerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(desired_resolution=2048 * 2).to("cuda")
+    S = float(np.log2(enc.per_level_scale))
+    dummy = torch.empty(1, device="cuda")
+    x = torch.rand(30000, 3, device="cuda")
+    g = torch.randn(30000, 32, device="cuda")
+
+    def bwd(out, **kw):
+        ge.grid_encode_backward(g, x, enc.embeddings.data, enc.offsets, out, 30000, 3, 2, 16, S, 16, False, dummy, dummy, 0,
+                                layout=1, **kw)
+    ref = torch.zeros_like(enc.embeddings.data)
+    bwd(ref)
+    scratch = torch.zeros_like(ref)
+    bwd(scratch, defer=True)
+    with pytest.raises(RuntimeError, match="deferred flush is pending"):
+        bwd(torch.zeros_like(ref))
+    _lib.check(_lib.lib().enerf_grid_records_discard(_lib.stream_handle()), "discard")
+    again = torch.zeros_like(ref)
+    bwd(again)
+    assert float((again - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
