@@ -82,7 +82,20 @@ struct WSrc {
     const float* seg[4];     // first layer, hidden 0, hidden 1, output layer
     uint32_t w0_cols;        // floats per first-layer row in memory: 32, or 31 with nerf_perm
     uint32_t nerf_perm;
+    // optional (enerf_mlp32_valid_rows): device int32, rows >= min(*valid_rows, B) are padding the caller never reads --
+    // a training batch is a budget of M rows of which the marcher filled counter[0].  The forward skips their tiles,
+    // the fused backward writes zero input gradients for them and skips the rest.  A wave's tiles are strided, so what
+    // is skipped is its LAST round: at 4163 tiles over 2048 (1024) resident waves, a batch of <= 4096 real tiles takes
+    // two (four) rounds instead of three (five).
+    const int32_t* valid_rows;
 };
+__device__ __forceinline__ uint32_t valid_tiles(const WSrc& W, uint32_t B, uint32_t ntiles) {
+    if (!W.valid_rows) return ntiles;
+    const int32_t v = W.valid_rows[0];
+    const uint32_t rows = v <= 0 ? 0u : ((uint32_t)v < B ? (uint32_t)v : B);
+    const uint32_t t = (rows + 31u) / 32u;
+    return t < ntiles ? t : ntiles;
+}
 struct WDst {                // the same for the weight gradients the reduce pass writes
     float* seg[4];
     uint32_t w0_cols, nerf_perm, overwrite;      // overwrite: dW = sum (no zero-filled accumulator needed), else +=
@@ -284,7 +297,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                                 : ((uint32_t)j < out_dim ? w64[rot(r0 + j, 32 * ib + nrow(q, h), HID)] : 0.0f);
     }
 
-    const uint32_t ntiles = Bp / 32;
+    const uint32_t ntiles = valid_tiles(W, B, Bp / 32);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
@@ -644,12 +657,34 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
     }
 
     const uint32_t ntiles = Bp / 32;
+    const uint32_t nreal = valid_tiles(W, B, ntiles);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wid;
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s0 = (size_t)tile * 32;
         const size_t s = s0 + j;
         const bool valid = s < B;
+        if (tile >= nreal) {
+            // padding rows: their upstream gradient is zero and nobody reads their activations -- the input gradient
+            // is zero, the weight gradients get nothing
+            if (dX) {
+                if (XL == 0) {
+                    if (valid) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++)
+                            *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const size_t lv = (size_t)(4 * gq + 2 * h);
+                        *reinterpret_cast<float2*>(dX + (lv * Bp + s) * 2) = make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(dX + ((lv + 1) * Bp + s) * 2) = make_float2(0.f, 0.f);
+                    }
+                }
+            }
+            continue;
+        }
         if (XL == 0) {
             // the row-major X tile goes straight from global memory into LDS (global_load_lds: no registers, nothing
             // to wait for until the weight gradient of the first layer at the end of the tile): 4 x 1 KB, linear
@@ -861,6 +896,7 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob
     else reduce_w_body(b.partial, b.nblocks, b.NW, b.dst, blockIdx.x - na);
 }
 
+static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
 static bool g_defer_next = false;        // one-shot: set by enerf_mlp32_defer_reduce
 static bool g_have_pending = false;
 static ReduceJob g_pending;
@@ -879,6 +915,12 @@ uint32_t pgrid(uint32_t B, uint32_t cap) {
 }  // namespace
 
 extern "C" {
+
+// Applies to the mlp32 forward / backward calls that follow, until set again (NULL: every row is real).
+int enerf_mlp32_valid_rows(const int32_t* device_count) {
+    g_valid_rows = device_count;
+    return 0;
+}
 
 // testing aid: 1 (default) = fused dgrad + wgrad kernel for num_hidden <= 2, 0 = separate dgrad / wgrad kernels
 int enerf_debug_mlp32_fused_backward(int on) {
@@ -912,6 +954,7 @@ static WSrc blob_src(const float* W, uint32_t num_hidden) {
     w.seg[3] = W + HID * IN + (num_hidden - 1) * HID * HID;
     w.w0_cols = IN;
     w.nerf_perm = 0;
+    w.valid_rows = g_valid_rows;
     return w;
 }
 static int segs_ok(const void* const* seg, uint32_t num_hidden, uint32_t w0_cols, uint32_t nerf_perm, const char* what) {
@@ -1011,6 +1054,7 @@ int enerf_mlp32_forward_p(const float* X, const float* const* wseg, uint32_t w0_
     if (num_hidden < 2) w.seg[1] = nullptr;
     w.w0_cols = w0_cols;
     w.nerf_perm = nerf_perm;
+    w.valid_rows = g_valid_rows;
     return mlp32_forward_impl(X, w, B, in_dim, out_dim, num_hidden, activation, output_activation, fb, Y, x_layout,
                               y_stride, y0_exp, sh_dirs, stream);
 }
@@ -1042,6 +1086,8 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     const size_t lds = sizeof(float) * NW;
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
     const bool fused = g_fused_bwd && num_hidden <= 2;
+    if (!fused && W.valid_rows)
+        ENERF_BADARG("mlp32_backward: enerf_mlp32_valid_rows needs the fused backward (num_hidden <= 2)");
     const uint32_t grid = pgrid(B, 1024);
     const uint32_t wgrid = fused ? pgrid(B, g_bwd_blocks ? g_bwd_blocks : 256)
                                  : pgrid(B, g_wgrad_blocks ? g_wgrad_blocks : (num_hidden == 1 ? 768u : 512u));
@@ -1154,6 +1200,7 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
     }
     w.w0_cols = d.w0_cols = w0_cols;
     w.nerf_perm = d.nerf_perm = nerf_perm;
+    w.valid_rows = g_valid_rows;
     d.overwrite = overwrite;
     return mlp32_backward_impl(dY, X, w, fb, B, in_dim, out_dim, num_hidden, activation, bb, dX, d, x_layout, dy_stride,
                                y_sigmoid, y_sigmoid_stride, dsigma, h0, h0_stride, stream);

@@ -77,10 +77,12 @@ def supported(net, x, d):
     return hit[1] and _ge._supports_layout()
 
 
-def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2, out=None):
+def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2, out=None, valid_rows=None):
     """The kernel sequence itself (no autograd): returns sigma [B], rgb [B,out], and -- when `train` -- the tensors
     nerf_backward needs.  `out` = (sigma [B], rgb [B,out]) contiguous fp32 tensors to write into (e.g. slices of a
-    frame's sample buffers)."""
+    frame's sample buffers).  `valid_rows`: device int32 tensor whose first element is the number of real rows (the
+    march's counter): rows beyond it are the sample budget's padding, which the MLP kernels then skip
+    (enerf_mlp32_valid_rows) -- their sigma / rgb stay unwritten and must not be read."""
     bound, per_level_scale, base_resolution, gridtype = cfg
     x = x.contiguous()
     d = d.contiguous()
@@ -111,6 +113,8 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2,
     # order [SH | geo_feat] -> [0 | geo_feat | SH] is applied on the way into LDS): nothing is packed per step
     seg_s, seg_c = _segments(ws0, None, None, ws1), _segments(wc0, wc1, None, wc2)
     fb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev) if train else None
+    if valid_rows is not None:
+        lib.enerf_mlp32_valid_rows(valid_rows.data_ptr())
     # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
     L.check(lib.enerf_mlp32_forward_p(feats.data_ptr(), seg_s, 32, 0, B, 32, 16, 1, 0, 6,
                                       fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
@@ -120,11 +124,13 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2,
     L.check(lib.enerf_mlp32_forward_p(h32.data_ptr(), seg_c, 31, 1, B, 32, out_c, 2, 0, 3,
                                       fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, None, stream),
             "mlp32_forward_p(color)")
+    if valid_rows is not None:
+        lib.enerf_mlp32_valid_rows(None)
     saved = None
     if train:
         saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, seg_s=seg_s, seg_c=seg_c,
                      weights=(ws0, ws1, wc0, wc1, wc2), rgb=rgb, B=B, S=S, H=base_resolution, gridtype=gridtype,
-                     affine=affine, out_c=out_c, param=embeddings)
+                     affine=affine, out_c=out_c, param=embeddings, valid_rows=valid_rows)
     return sigma, rgb, saved
 
 
@@ -165,6 +171,8 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
     dseg_c = (ctypes.c_void_p * 4)(p0 + 4 * o[2], p0 + 4 * o[3], None, p0 + 4 * o[4])
     bb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev)
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
+    if sv.get("valid_rows") is not None:     # the forward skipped the budget's padding rows: so must the backward
+        lib.enerf_mlp32_valid_rows(sv["valid_rows"].data_ptr())
     lib.enerf_mlp32_defer_reduce(1)          # the colour net's dW partial sums are reduced by the sigma net's launch
     L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, 31, 1, 1,
                                        sv["fb_c"].data_ptr(), B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), 0, 0,
@@ -175,6 +183,8 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
                                        sv["fb_s"].data_ptr(), B, 32, 16, 1, 0, bb_s.data_ptr(), dfeat.data_ptr(), 1, 32,
                                        None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32, stream),
             "mlp32_backward_p(sigma)")
+    if sv.get("valid_rows") is not None:
+        lib.enerf_mlp32_valid_rows(None)
     param, emb = sv["param"], sv["emb"]
     target = _ge.param_grad_target(param, torch.float32, owner=owner)
     direct = target is not None

@@ -260,6 +260,7 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
 
 
 FUSED_COMPOSITE = True        # train_step_mse: compositing forward + MSE backward as one launch
+SKIP_PADDING_ROWS = True      # raw renders: the MLP kernels skip the sample budget's unfilled rows (device-side count)
 
 
 def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, composite=True):
@@ -283,7 +284,8 @@ def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0
         xyzs, dirs, deltas, rays, M = (pre[k] for k in ("xyzs", "dirs", "deltas", "rays", "M"))
         params = fnet.network_params(model)
         sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), True, params[0],
-                                           fnet.encoder_offsets(model), *params[1:])
+                                           fnet.encoder_offsets(model), *params[1:],
+                                           valid_rows=pre["counter"] if SKIP_PADDING_ROWS else None)
         scale = float(model.density_scale)
         sigmas = sigma if scale == 1.0 else sigma * scale
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)

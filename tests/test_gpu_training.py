@@ -541,3 +541,37 @@ def test_fp16_autocast_training_variant():
     assert np.isfinite(l16).all() and abs(l16[0] - l32[0]) <= 0.02 * abs(l32[0])
     assert np.mean(l16[-8:]) < 0.6 * np.mean(l16[:8])
     assert float(h16.scaler.get_scale()) >= 1024.0                   # no run of overflow-halvings
+
+
+def test_padding_rows_of_the_sample_budget_are_skipped_without_changing_anything(monkeypatch):
+    """fused_render.SKIP_PADDING_ROWS: the MLP kernels take the march's device-side count and leave the budget's
+    unfilled rows alone (forward: not computed; backward: zero input gradient).  Image, loss and every gradient must
+    equal the run that computes all rows, with a budget well above and one below the batch's real sample count."""
+    from enerf_amd import fused_network, fused_render
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd import scene
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV).train()
+    model.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    scene.install_occupancy(model)
+    (ro, rd, tgt), = _batches(1, 4096, 2)
+    for budget in (180000, 100000):
+        outs = []
+        for skip in (True, False):
+            monkeypatch.setattr(fused_render, "SKIP_PADDING_ROWS", skip)
+            model.mean_count = budget
+            model.local_step = 0
+            for p in model.parameters():
+                p.grad = None
+            loss = torch.zeros((), device=DEV)
+            image, grads = fused_render.train_step_mse(model, ro, rd, tgt, 1, True, loss_out=loss)
+            torch.cuda.synchronize()
+            names = ["emb", "ws0", "ws1", "wc0", "wc1", "wc2"]
+            g = {n: (model.encoder.embeddings.grad if t is None else t).clone() for n, t in zip(names, grads)}
+            outs.append((image.clone(), float(loss), g, int(model.step_counter[0, 0])))
+            model.encoder.embeddings.grad = None
+        (i1, l1, g1, c1), (i0, l0, g0, c0) = outs
+        assert c1 == c0 and (c1 < budget) == (budget == 180000)
+        assert torch.equal(i1, i0) and l1 == l0
+        for n in g0:
+            assert float((g1[n] - g0[n]).abs().max()) <= 1e-6 * float(g0[n].abs().max()) + 1e-12, (budget, n)
