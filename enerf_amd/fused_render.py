@@ -260,7 +260,8 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
 
 
 FUSED_COMPOSITE = True        # train_step_mse: compositing forward + MSE backward as one launch
-SKIP_PADDING_ROWS = True      # raw renders: the MLP kernels skip the sample budget's unfilled rows (device-side count)
+import os as _os
+SKIP_PADDING_ROWS = _os.environ.get("ENERF_SKIP_PADDING_ROWS", "1") != "0"      # raw renders: the MLP kernels skip the sample budget's unfilled rows (device-side count)
 
 
 def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, composite=True):

@@ -572,6 +572,6 @@ def test_padding_rows_of_the_sample_budget_are_skipped_without_changing_anything
             model.encoder.embeddings.grad = None
         (i1, l1, g1, c1), (i0, l0, g0, c0) = outs
         assert c1 == c0 and (c1 < budget) == (budget == 180000)
-        assert torch.equal(i1, i0) and l1 == l0
+        assert torch.equal(i1, i0) and abs(l1 - l0) <= 1e-6 * abs(l0)       # (the loss is summed with float atomics)
         for n in g0:
             assert float((g1[n] - g0[n]).abs().max()) <= 1e-6 * float(g0[n].abs().max()) + 1e-12, (budget, n)
