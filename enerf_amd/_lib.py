@@ -49,6 +49,8 @@ SIGNATURES = {
                                    _u32, _int, _int, _f32, _f32, _u32, _u32, _vp],
     "enerf_grid_records_discard": [_vp],
     "enerf_mlp32_valid_rows": [_vp],
+    "enerf_grid_adam_from_records_ex": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_grid_adam_from_records": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _vp],
     "enerf_sh_encode_forward": [_vp, _vp, _u32, _u32, _u32, _int, _vp, _int, _vp],
     "enerf_sh_encode_backward": [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _int, _vp],

@@ -789,6 +789,17 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
 struct AdamScalars {
     float b1, b2, eps, step_size, inv_bc2_sqrt;
 };
+// the model's other (small) parameters ride along in the same launch: one workgroup each, after its tiles
+constexpr int kMaxSmallAdam = 8;
+struct SmallAdam {
+    float* p[kMaxSmallAdam];
+    const float* g[kMaxSmallAdam];
+    float* m[kMaxSmallAdam];
+    float* v[kMaxSmallAdam];
+    uint32_t n[kMaxSmallAdam];
+    float step_size[kMaxSmallAdam], inv_bc2_sqrt[kMaxSmallAdam];
+    uint32_t count;
+};
 __device__ __forceinline__ void tile_adam1(float& p, float g, float& m, float& v, const AdamScalars& a) {
     m = fmaf(g - m, 1.0f - a.b1, m);
     v = fmaf((1.0f - a.b2) * g, g, v * a.b2);
@@ -802,13 +813,16 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                                                                  float* __restrict__ V, uint32_t L, uint32_t min_tiles,
                                                                  const uint32_t* __restrict__ recs,
                                                                  uint32_t* __restrict__ cursors, uint32_t region,
-                                                                 uint32_t* __restrict__ overflow, AdamScalars ad) {
+                                                                 uint32_t* __restrict__ overflow,
+                                                                 uint32_t* __restrict__ other_overflow, AdamScalars ad,
+                                                                 SmallAdam small) {
     __shared__ __attribute__((aligned(16))) double acc[kTileElems];
     __shared__ uint32_t s_n[64];
     constexpr uint32_t R = kTileElems / C;
     constexpr int U = 4;
     const bool have_records = region != 0;
     const bool spilled = have_records && overflow[0] != 0;
+    if (other_overflow && blockIdx.x == 0 && threadIdx.x == 0) other_overflow[0] = 0;     // the next session's counter
     uint32_t total = 0;
     for (uint32_t lv = 0; lv < L; lv++) total += div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
@@ -899,6 +913,18 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
         }
         __syncthreads();
     }
+    // small parameters (MLP weights): workgroup k < small.count updates tensor k (dense gradient, not cleared)
+    if (blockIdx.x < small.count) {
+        const uint32_t k = blockIdx.x;
+        AdamScalars a2 = ad;
+        a2.step_size = small.step_size[k];
+        a2.inv_bc2_sqrt = small.inv_bc2_sqrt[k];
+        for (uint32_t i = threadIdx.x; i < small.n[k]; i += kTileThreads) {
+            float pv = small.p[k][i], mv = small.m[k][i], vv = small.v[k][i];
+            tile_adam1(pv, small.g[k][i], mv, vv, a2);
+            small.p[k][i] = pv; small.m[k][i] = mv; small.v[k][i] = vv;
+        }
+    }
 }
 
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (gridencoder.cu:314-340)
@@ -978,14 +1004,17 @@ struct PendingRecords {
     uint32_t region = 0, L = 0, C = 0, D = 0, min_tiles = 0;
 };
 static PendingRecords g_pending;
-static uint32_t* g_overflow = nullptr;          // device counter: records that did not fit their list
+// device counters of records that did not fit their list: two, used by alternate sessions -- the flush of one session
+// clears the other's, so opening a session costs no memset launch
+static uint32_t* g_overflow = nullptr;
+static uint32_t g_session = 0;                  // parity selects the counter of the open / next session
 
 static uint32_t* overflow_counter() {
     if (!g_overflow) {
-        if (hipMalloc((void**)&g_overflow, sizeof(uint32_t)) != hipSuccess) return nullptr;
-        if (hipMemset(g_overflow, 0, sizeof(uint32_t)) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&g_overflow, 2 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+        if (hipMemset(g_overflow, 0, 2 * sizeof(uint32_t)) != hipSuccess) return nullptr;
     }
-    return g_overflow;
+    return g_overflow + (g_session & 1u);
 }
 
 template <typename T, int D>
@@ -1020,7 +1049,6 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
     if (defer && g_pending.region == 0) {
         g_pending.region = region; g_pending.L = L; g_pending.C = C; g_pending.D = (uint32_t)D;
         g_pending.min_tiles = min_tiles;
-        (void)hipMemsetAsync(overflow, 0, sizeof(uint32_t), s);
     }
     const bool flush_now = g_pending.region == 0;
 #define ENERF_GB(CC)                                                                                             \
@@ -1143,6 +1171,7 @@ int enerf_grid_records_discard(enerf_stream_t stream) {
     if (g_pending.region != 0) {
         uint32_t* cursors = bin_cursors();
         if (cursors) (void)hipMemsetAsync(cursors, 0, sizeof(uint32_t) * kMaxLevels * kMaxBins, (hipStream_t)stream);
+        if (g_overflow) (void)hipMemsetAsync(g_overflow + (g_session & 1u), 0, sizeof(uint32_t), (hipStream_t)stream);
         g_pending = PendingRecords();
     }
     return 0;
@@ -1150,6 +1179,23 @@ int enerf_grid_records_discard(enerf_stream_t stream) {
 
 int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
                                  float lr, float beta1, float beta2, float eps, uint32_t step, enerf_stream_t stream) {
+    return enerf_grid_adam_from_records_ex(p, g, m, v, offsets, L, C, lr, beta1, beta2, eps, step, 0, nullptr, nullptr,
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
+                                    float lr, float beta1, float beta2, float eps, uint32_t step, uint32_t n_small,
+                                    float* const* sp, const float* const* sg, float* const* sm, float* const* sv,
+                                    const uint32_t* sn, const float* slr, const uint32_t* sstep, enerf_stream_t stream) {
+    if (n_small > (uint32_t)kMaxSmallAdam) ENERF_BADARG("grid_adam_from_records: at most %d extra tensors", kMaxSmallAdam);
+    SmallAdam small;
+    small.count = n_small;
+    for (uint32_t k = 0; k < n_small; k++) {
+        if (!sp[k] || !sg[k] || !sm[k] || !sv[k] || sstep[k] == 0) ENERF_BADARG("grid_adam_from_records: extra tensor %u", k);
+        small.p[k] = sp[k]; small.g[k] = sg[k]; small.m[k] = sm[k]; small.v[k] = sv[k]; small.n[k] = sn[k];
+        small.step_size[k] = (float)((double)slr[k] / (1.0 - pow((double)beta1, (double)sstep[k])));
+        small.inv_bc2_sqrt[k] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)sstep[k])));
+    }
     if (!p || !g || !m || !v || !offsets || L == 0 || L > (uint32_t)kMaxLevels || step == 0)
         ENERF_BADARG("grid_adam_from_records: bad arguments (L=%u step=%u)", L, step);
     if (g_pending.region != 0 && (g_pending.L != L || g_pending.C != C))
@@ -1161,17 +1207,19 @@ int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const i
     uint32_t* cursors = bin_cursors();
     uint32_t* overflow = overflow_counter();
     if (!cursors || !overflow) return ENERF_E_NOMEM;
+    uint32_t* other = g_overflow + ((g_session + 1u) & 1u);
     const uint32_t region = g_pending.region;
     const uint32_t* recs = region ? (const uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C))
                                   : nullptr;
     const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;
     switch (C) {
-        case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
-        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
-        case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
-        case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, ad); break;
+        case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         default: ENERF_BADARG("grid_adam_from_records: C must be 1, 2, 4, or 8.");
     }
+    if (g_pending.region != 0) g_session++;           // the next session counts overflows in the counter just cleared
     g_pending = PendingRecords();
     ENERF_LAUNCH_CHECK("grid_adam_from_records");
     return 0;

@@ -13,6 +13,7 @@ from . import _lib as L
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._group_of = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -24,23 +25,46 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     @torch.no_grad()
-    def step_grid_table(self, p, offsets, level_dim):
+    def step_grid_table(self, p, offsets, level_dim, extra=()):
         """Adam on a hash-grid table whose backward left its gradient as record lists (grid_encode_backward(defer=True),
-        csrc/gridencoder.hip: k_grid_tile_adam): one pass over the table sums each 128-KiB tile's records in LDS and
+        csrc/gridencoder.hip: k_grid_tile_adam): one pass over the table sums each 64-KiB tile's records in LDS and
         updates the tile's rows of p / m / v from there -- the gradient table is neither written nor read nor cleared
         for the binned levels.  p.grad (dense, zero-initialised, kept across steps) receives what was not binned and
-        comes back cleared.  Same update as step_now on the summed gradient."""
-        group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
-        st = self.state[p]
-        if not st:
-            st["step"] = 0
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        st["step"] += 1
+        comes back cleared.  `extra`: up to 8 small fp32 parameters with dense gradients (the MLP weights), updated by
+        the same launch.  Same update as step_now on the summed gradient."""
+        def state_of(q):
+            st = self.state[q]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(q, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(q, memory_format=torch.preserve_format)
+            st["step"] += 1
+            return st
+
+        groups = self._group_of
+        if groups is None:
+            groups = self._group_of = {id(q): g for g in self.param_groups for q in g["params"]}
+        group = groups[id(p)]
+        st = state_of(p)
         b1, b2 = group["betas"]
-        L.check(L.lib().enerf_grid_adam_from_records(
+        extra = [q for q in extra if q.grad is not None]
+        if len(extra) > 8 or any(not (q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
+                                      and q.grad.is_contiguous() and q.grad.dtype == torch.float32) for q in extra):
+            self.step_now(only=extra)                       # (more / other tensors than the launch carries)
+            extra = []
+        n = len(extra)
+        if n:
+            sts = [state_of(q) for q in extra]
+            vp, u32, fl = ctypes.c_void_p * n, ctypes.c_uint32 * n, ctypes.c_float * n
+            args = (n, vp(*[q.data_ptr() for q in extra]), vp(*[q.grad.data_ptr() for q in extra]),
+                    vp(*[t["exp_avg"].data_ptr() for t in sts]), vp(*[t["exp_avg_sq"].data_ptr() for t in sts]),
+                    u32(*[q.numel() for q in extra]), fl(*[float(groups[id(q)]["lr"]) for q in extra]),
+                    u32(*[t["step"] for t in sts]))
+        else:
+            args = (0, None, None, None, None, None, None, None)
+        L.check(L.lib().enerf_grid_adam_from_records_ex(
             p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), offsets.data_ptr(),
-            offsets.numel() - 1, int(level_dim), float(group["lr"]), b1, b2, float(group["eps"]), st["step"],
+            offsets.numel() - 1, int(level_dim), float(group["lr"]), b1, b2, float(group["eps"]), st["step"], *args,
             L.stream_handle()), "grid_adam_from_records")
 
     @torch.no_grad()

@@ -511,8 +511,7 @@ class TrainHarness:
         if fuse_table:
             enc = self.model._modules["encoder"]
             emb = enc._parameters["embeddings"]
-            self.opt.step_grid_table(emb, enc._buffers["offsets"], enc.level_dim)
-            self.opt.step_now(only=self._small_params)
+            self.opt.step_grid_table(emb, enc._buffers["offsets"], enc.level_dim, extra=self._small_params)
             self._cleared_grad = emb.grad
         elif self.avg is None and hasattr(self.opt, "step_now") and not self.use_graphs:
             self.opt.step_now(zero_grads=True)          # Adam clears what it has read: the next step needs no fill
@@ -594,8 +593,7 @@ class TrainHarness:
             self._reduce_grads()
             if fuse_table:
                 enc = self.model.encoder
-                self.opt.step_grid_table(enc.embeddings, enc.offsets, enc.level_dim)
-                self.opt.step_now(only=[p for p in self._params if p is not enc.embeddings])
+                self.opt.step_grid_table(enc.embeddings, enc.offsets, enc.level_dim, extra=self._small_params)
                 self._cleared_grad = enc.embeddings.grad
             else:
                 self._opt_step()

@@ -299,6 +299,13 @@ int enerf_grid_encode_backward_ex(const void* grad, const float* inputs, const v
                                   uint32_t flags, uint32_t reserve_B, enerf_stream_t stream);
 int enerf_grid_adam_from_records(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
                                  float lr, float beta1, float beta2, float eps, uint32_t step, enerf_stream_t stream);
+/* The same with up to 8 further (small, dense-gradient) fp32 parameters updated in the same launch -- the model's MLP
+ * weights: arrays of n_small device pointers / element counts / learning rates / step counts (host memory); their
+ * gradients are read, not cleared. */
+int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, const int32_t* offsets, uint32_t L, uint32_t C,
+                                    float lr, float beta1, float beta2, float eps, uint32_t step, uint32_t n_small,
+                                    float* const* sp, const float* const* sg, float* const* sm, float* const* sv,
+                                    const uint32_t* sn, const float* slr, const uint32_t* sstep, enerf_stream_t stream);
 /* Abandon a pending deferred flush (error recovery: the record lists are emptied, nothing is applied). */
 int enerf_grid_records_discard(enerf_stream_t stream);
 
