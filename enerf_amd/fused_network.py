@@ -115,17 +115,19 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, ws0, ws1, wc0, wc1, wc2,
     fb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev) if train else None
     if valid_rows is not None:
         lib.enerf_mlp32_valid_rows(valid_rows.data_ptr())
-    # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
-    L.check(lib.enerf_mlp32_forward_p(feats.data_ptr(), seg_s, 32, 0, B, 32, 16, 1, 0, 6,
-                                      fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
-                                      d.data_ptr(), stream), "mlp32_forward_p(sigma)")
-    # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
-    fb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev) if train else None
-    L.check(lib.enerf_mlp32_forward_p(h32.data_ptr(), seg_c, 31, 1, B, 32, out_c, 2, 0, 3,
-                                      fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, None, stream),
-            "mlp32_forward_p(color)")
-    if valid_rows is not None:
-        lib.enerf_mlp32_valid_rows(None)
+    try:
+        # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
+        L.check(lib.enerf_mlp32_forward_p(feats.data_ptr(), seg_s, 32, 0, B, 32, 16, 1, 0, 6,
+                                          fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
+                                          d.data_ptr(), stream), "mlp32_forward_p(sigma)")
+        # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
+        fb_c = torch.empty(2, Bp, 64, dtype=torch.float32, device=dev) if train else None
+        L.check(lib.enerf_mlp32_forward_p(h32.data_ptr(), seg_c, 31, 1, B, 32, out_c, 2, 0, 3,
+                                          fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, None, stream),
+                "mlp32_forward_p(color)")
+    finally:                                 # the row count is per call: never left behind for another model's launch
+        if valid_rows is not None:
+            lib.enerf_mlp32_valid_rows(None)
     saved = None
     if train:
         saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, seg_s=seg_s, seg_c=seg_c,
@@ -173,18 +175,22 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
     if sv.get("valid_rows") is not None:     # the forward skipped the budget's padding rows: so must the backward
         lib.enerf_mlp32_valid_rows(sv["valid_rows"].data_ptr())
-    lib.enerf_mlp32_defer_reduce(1)          # the colour net's dW partial sums are reduced by the sigma net's launch
-    L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, 31, 1, 1,
-                                       sv["fb_c"].data_ptr(), B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(), 0, 0,
-                                       sv["rgb"].data_ptr(), out_c, None, None, 0, stream), "mlp32_backward_p(color)")
-    bb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev)
-    dfeat = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
-    L.check(lib.enerf_mlp32_backward_p(dx32.data_ptr(), sv["feats"].data_ptr(), sv["seg_s"], dseg_s, 32, 0, 1,
-                                       sv["fb_s"].data_ptr(), B, 32, 16, 1, 0, bb_s.data_ptr(), dfeat.data_ptr(), 1, 32,
-                                       None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32, stream),
-            "mlp32_backward_p(sigma)")
-    if sv.get("valid_rows") is not None:
-        lib.enerf_mlp32_valid_rows(None)
+    try:
+        lib.enerf_mlp32_defer_reduce(1)      # the colour net's dW partial sums are reduced by the sigma net's launch
+        L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, 31, 1, 1,
+                                           sv["fb_c"].data_ptr(), B, 32, out_c, 2, 0, bb_c.data_ptr(), dx32.data_ptr(),
+                                           0, 0, sv["rgb"].data_ptr(), out_c, None, None, 0, stream),
+                "mlp32_backward_p(color)")
+        bb_s = torch.empty(1, Bp, 64, dtype=torch.float32, device=dev)
+        dfeat = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
+        L.check(lib.enerf_mlp32_backward_p(dx32.data_ptr(), sv["feats"].data_ptr(), sv["seg_s"], dseg_s, 32, 0, 1,
+                                           sv["fb_s"].data_ptr(), B, 32, 16, 1, 0, bb_s.data_ptr(), dfeat.data_ptr(), 1,
+                                           32, None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32, stream),
+                "mlp32_backward_p(sigma)")
+    finally:
+        lib.enerf_mlp32_defer_reduce(0)
+        if sv.get("valid_rows") is not None:
+            lib.enerf_mlp32_valid_rows(None)
     param, emb = sv["param"], sv["emb"]
     target = _ge.param_grad_target(param, torch.float32, owner=owner)
     direct = target is not None
