@@ -71,3 +71,44 @@ def collate_single(g, u_xy, choice):
     eidx = eidx[choice]
     pols = g["events"][eidx + 1, 3]
     return eidx, eidx + 1, pols, g["events"][eidx, 0], g["events"][eidx, 1]
+
+
+# ---- event time index (utils/event_utils.py) -------------------------------------------------------------------------
+def ms_to_idx_loop(t, unit_per_ms, ms_start=0):
+    """utils/event_utils.py:389-408 (compute_ms_to_idx) by its defining property, one millisecond at a time:
+    idx[ms] = first i with t[i] >= ms * unit_per_ms (len(t) if none); ms runs to floor(max(t)) / unit_per_ms."""
+    t = np.asarray(t)
+    ms_end = int(np.floor(t.max()) / unit_per_ms)
+    out = []
+    for ms in range(ms_start, ms_end + 1):
+        i = 0
+        while i < len(t) and t[i] < ms * unit_per_ms:
+            i += 1
+        out.append(i)
+    return np.asarray(out, dtype=np.int64)
+
+
+def slicer_window(t_us, ms_to_idx, t_start_us, t_end_us, t_offset=0):
+    """EventSlicer.get_events' index arithmetic (utils/event_utils.py:256-300, :303-322, :324-377, :379-383): the
+    conservative millisecond window, then the two linear scans.  Returns (first, one past last) or None."""
+    assert t_start_us < t_end_us
+    t_start_us -= t_offset
+    t_end_us -= t_offset
+    w0 = max(int(np.floor(t_start_us / 1000)), 0)
+    w1 = int(np.ceil(t_end_us / 1000))
+    if w0 >= len(ms_to_idx) or w1 >= len(ms_to_idx):
+        return None
+    a, b = int(ms_to_idx[w0]), int(ms_to_idx[w1])
+    arr = np.asarray(t_us[a:b])
+    if arr.size == 0 or arr[-1] < t_start_us:
+        return a + arr.size, a + arr.size
+    i0 = 0
+    while arr[i0] < t_start_us:
+        i0 += 1
+    i1 = arr.size
+    for k in range(arr.size - 1, -1, -1):
+        if arr[k] >= t_end_us:
+            i1 = k
+        else:
+            break
+    return a + i0, a + i1

@@ -181,3 +181,73 @@ def test_event_pair_rays_kernel_vs_reference_loop_scipy_and_get_event_rays(acc_m
     # times outside the track are counted, as interp1d(bounds_error=True) would have raised
     short = PoseTrack(t[:250], R[:250].as_matrix(), p[:250], device="cuda")
     assert int(event_pair_rays(tables, short, intr, M, acc_max)["outside_track"]) > 0
+
+
+# ---- event time index / esim loader (enerf_amd/event_window.py) ------------------------------------------------------
+def test_ms_to_idx_known_answer_of_the_reference_docstring():
+    """The worked example in utils/event_utils.py:241-249."""
+    from enerf_amd.event_window import EventTimeIndex
+    from oracle.event_collate import ms_to_idx_loop
+    t = [0, 500, 2100, 5000, 5000, 7100, 7200, 7200, 8100, 9000]
+    want = [0, 2, 2, 3, 3, 3, 5, 5, 8, 9]
+    assert ms_to_idx_loop(t, 1000).tolist() == want
+    assert EventTimeIndex(torch.tensor(t, dtype=torch.int64)).ms_to_idx.tolist() == want
+
+
+def _window_cases(device):
+    from enerf_amd.event_window import EventTimeIndex
+    from oracle.event_collate import ms_to_idx_loop, slicer_window
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.integers(0, 60_000, 4000)).astype(np.int64)          # microseconds, many ties
+    t[:3] = 0
+    index = EventTimeIndex(torch.from_numpy(t).to(device), t_offset=17)
+    ref_idx = ms_to_idx_loop(t, 1000)
+    assert index.ms_to_idx.cpu().numpy().tolist() == ref_idx.tolist()
+    for _ in range(300):
+        a = int(rng.integers(-2000, 62_000))
+        b = a + int(rng.integers(1, 9000))
+        want = slicer_window(t, ref_idx, a + 17, b + 17, t_offset=17)
+        got = index.window(a + 17, b + 17)
+        assert got == want, (a, b, got, want)
+        if want is not None:                                           # the defining property, by brute force
+            lo, hi = want
+            inside = (t >= a) & (t < b)
+            # the conservative millisecond window may cut the range at its far end only when ms_to_idx stops short
+            assert inside[lo:hi].all() and not inside[:lo].any()
+    assert index.t_final == int(t[-1]) + 17
+
+
+def test_event_window_matches_the_slicer_restatement():
+    _window_cases("cpu")
+
+
+@pytest.mark.gpu
+def test_event_window_on_the_device():
+    _window_cases("cuda")
+
+
+def test_esim_loader_batches_and_polarities(tmp_path):
+    from enerf_amd.event_window import load_esim_event_batches
+    rng = np.random.default_rng(2)
+    files = []
+    for k in range(5):
+        n = 20 + k
+        ev = np.stack([rng.integers(0, 64, n), rng.integers(0, 48, n), np.sort(rng.integers(0, 10**6, n)) + k * 10**6,
+                       rng.integers(0, 2, n), np.zeros(n)], axis=1).astype(np.float64)
+        np.save(tmp_path / f"{k:04d}.npy", ev)
+        files.append(ev)
+    (tmp_path / "notes.txt").write_text("ignored")
+    out = load_esim_event_batches(str(tmp_path), [0, 2, 3], hwf=(48, 64, 50.0))
+    assert [b.shape for b in out] == [(41, 4), (22, 4), (23, 4)]
+    assert np.array_equal(out[0][:, :3], np.concatenate([files[0], files[1]])[:, :3])
+    assert np.array_equal(out[0][:, 3], 2 * np.concatenate([files[0], files[1]])[:, 3] - 1)      # {0,1} -> {-1,+1}
+    assert np.array_equal(out[2][:, :3], files[3][:, :3])
+    one = load_esim_event_batches(str(tmp_path), [4], hwf=(48, 64, 50.0))
+    assert len(one) == 1 and one[0].shape == (24, 4)
+    with pytest.raises(AssertionError):
+        load_esim_event_batches(str(tmp_path), [0, 2], hwf=(32, 64, 50.0))                       # y up to 47 > sensor
+    signed = files[0].copy()
+    signed[:, 3] = 2 * signed[:, 3] - 1
+    signed[0, 3] = -1
+    np.save(tmp_path / "0000.npy", signed)
+    assert np.array_equal(load_esim_event_batches(str(tmp_path), [0], hwf=(48, 64, 1.0))[0][:, 3], signed[:, 3])
