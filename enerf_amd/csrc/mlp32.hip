@@ -142,25 +142,48 @@ __device__ __forceinline__ float* wdst_at(const WDst& w, uint32_t i) {     // nu
 
 // Copy the logical blob into LDS, matrix by matrix (a thread keeps its column, so the first layer's permutation is
 // resolved once per thread and nothing is divided per element).  ROT: rows rotated by their index (stage_rot below).
+// Every global load of the thread is issued before the first LDS store: the trip counts are compile-time (256
+// threads, at most 32 output rows), so the copy costs one memory latency -- as a plain load / store loop it cost one
+// per iteration, 36 of them for the colour net (measured: 15 us of fixed cost per forward launch, tools/mlp32_fit.sh).
 template <bool ROT>
 __device__ __forceinline__ void stage_segments(float* wl, const WSrc& w, uint32_t n) {
+    constexpr uint32_t R0 = 256 / IN, N0 = HID / R0;           // first layer: rows per pass, passes
+    constexpr uint32_t RH = 256 / HID, NHID = HID / RH;        // 64-wide matrices
+    const uint32_t c0 = threadIdx.x & (IN - 1), r0 = threadIdx.x / IN;
+    const uint32_t c = threadIdx.x & (HID - 1), rh = threadIdx.x / HID;
+    const int sc = w0_col(c0, w.nerf_perm);
+    float v0[N0], v[3][NHID];
+#pragma unroll
+    for (uint32_t k = 0; k < N0; k++) v0[k] = sc < 0 ? 0.0f : w.seg[0][(r0 + k * R0) * w.w0_cols + sc];
+    uint32_t cnt[3];
     {
-        const uint32_t c = threadIdx.x & (IN - 1);
-        const int sc = w0_col(c, w.nerf_perm);
-        for (uint32_t r = threadIdx.x / IN; r < HID; r += blockDim.x / IN)
-            wl[ROT ? r * IN + ((c + r) & (IN - 1)) : r * IN + c] = sc < 0 ? 0.0f : w.seg[0][r * w.w0_cols + sc];
-    }
-    uint32_t base = HID * IN, row0 = 0;           // row0: rows of the 64-wide matrices, numbered through
-    for (int m = 1; m < 4; m++) {
-        if (!w.seg[m]) continue;
-        const uint32_t cnt = m < 3 ? HID * HID : n - base;          // the output layer takes what is left
-        const uint32_t c = threadIdx.x & (HID - 1);
-        for (uint32_t r = threadIdx.x / HID; r * HID < cnt; r += blockDim.x / HID) {
-            const uint32_t rr = row0 + r;
-            wl[HID * IN + (ROT ? rr * HID + ((c + rr) & (HID - 1)) : rr * HID + c)] = w.seg[m][r * HID + c];
+        uint32_t base = HID * IN;
+#pragma unroll
+        for (int m = 1; m < 4; m++) {
+            cnt[m - 1] = !w.seg[m] ? 0u : (m < 3 ? HID * HID : n - base);    // the output layer takes what is left
+            base += cnt[m - 1];
+#pragma unroll
+            for (uint32_t k = 0; k < NHID; k++) {
+                const uint32_t r = rh + k * RH;
+                v[m - 1][k] = r * HID < cnt[m - 1] ? w.seg[m][r * HID + c] : 0.0f;
+            }
         }
-        base += cnt;
-        row0 += cnt / HID;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < N0; k++) {
+        const uint32_t r = r0 + k * R0;
+        wl[ROT ? r * IN + ((c0 + r) & (IN - 1)) : r * IN + c0] = v0[k];
+    }
+    uint32_t row0 = 0;                            // rows of the 64-wide matrices, numbered through
+#pragma unroll
+    for (int m = 1; m < 4; m++) {
+#pragma unroll
+        for (uint32_t k = 0; k < NHID; k++) {
+            const uint32_t r = rh + k * RH, rr = row0 + r;
+            if (r * HID < cnt[m - 1])
+                wl[HID * IN + (ROT ? rr * HID + ((c + rr) & (HID - 1)) : rr * HID + c)] = v[m - 1][k];
+        }
+        row0 += cnt[m - 1] / HID;
     }
     __syncthreads();
 }
@@ -255,6 +278,18 @@ __device__ __forceinline__ void load_x(const float* __restrict__ X, uint32_t til
 // instead of a 32-row MFMA tile of which 31 rows would be thrown away.
 // SH: the kernel also writes the degree-4 SH encoding of sh_dirs[s] into columns 16..31 of row s of Y (the colour
 // net's direction inputs, nerf/network.py:95): the separate encoder launch and its 10 us disappear into the MFMA shadow.
+#ifdef ENERF_MLP_TIMING
+// development aid: shader-clock cycles per phase of the fused backward, summed over waves (tools/bench_mlp32.py)
+__device__ unsigned long long g_mlp_phase[16];
+#define MLP_PH(k)                                                  \
+    do {                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        ph[k] += t_ - t_last;                                      \
+        t_last = t_;                                               \
+    } while (0)
+#else
+#define MLP_PH(k)
+#endif
 template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false>
 __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, WSrc W,
                                                    float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
@@ -265,12 +300,17 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
     // the first tile's inputs are requested before the weights are staged: one memory latency hidden behind the set-up
+#ifdef ENERF_MLP_TIMING
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     float x[16];
     {
         const uint32_t tile0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (tile0 < Bp / 32) load_x<XL>(X, tile0, j, h, B, Bp, x);
     }
     stage_rot(wl, W, NH, out_dim);
+    MLP_PH(0);          // weights -> LDS
 
     float w0[2][16], wh[NH > 1 ? NH - 1 : 1][2][2][16], wo[2][16];
 #pragma unroll
@@ -297,6 +337,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                                 : ((uint32_t)j < out_dim ? w64[rot(r0 + j, 32 * ib + nrow(q, h), HID)] : 0.0f);
     }
 
+    MLP_PH(1);          // fragments -> registers
     const uint32_t ntiles = valid_tiles(W, B, Bp / 32);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
@@ -318,6 +359,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             for (int q = 0; q < 16; q++) a[ob][q] = act_fwd(a[ob][q], act);
             if (TRAIN) store_tile_fb(fb + s * HID, ob, h, a[ob]);
         }
+        MLP_PH(2);      // inputs + first layer
 #pragma unroll
         for (int l = 1; l < NH; l++) {
             f32x16 n[2];
@@ -335,6 +377,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             a[0] = n[0];
             a[1] = n[1];
         }
+        MLP_PH(3);      // hidden layers
         if (SIG) {
             float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
@@ -373,11 +416,16 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
         }
+        MLP_PH(4);      // output layer + stores
     }
+#ifdef ENERF_MLP_TIMING
+    MLP_PH(5);
+    if (lane == 0)
+        for (int k = 0; k < 6; k++) atomicAdd(&g_mlp_phase[k], ph[k]);
+    if (threadIdx.x == 0) atomicAdd(&g_mlp_phase[15], 1ull);
+#endif
 }
 
-// ================================================================== backward: activation gradients
-// KPO = number of contraction pairs covering the output dimension (out_dim <= 2 * KPO): pair p = (p, KPO + p)
 template <int NH, int KPO, int XL>
 __global__ void __launch_bounds__(256) k_mlp32_bwd_act(DySource dys, WSrc W,
                                                        const float* __restrict__ fb, float* __restrict__ bb,
@@ -609,6 +657,10 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
     constexpr uint32_t PER_WAVE = 5 * T_SZ + (XL == 1 ? 16 * XT_LD : 32 * IN);
     __shared__ __attribute__((aligned(16))) float lds[NW_MAX + 4 * PER_WAVE];
     float* wl = lds;                                   // weights during set-up, block-level dW sums at the end
+#ifdef ENERF_MLP_TIMING
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t NW = blob_size(NH, out_dim);
     stage(wl, W, NW);
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
@@ -642,8 +694,6 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
     for (int ob = 0; ob < 2; ob++)
 #pragma unroll
         for (int q = 0; q < 16; q++) wiT[ob][q] = wl[(32 * ob + nrow(q, h)) * IN + j];
-    __syncthreads();                                   // every wave has its fragments: wl may be reused
-    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) wl[i] = 0.0f;
 
     f32x16 aw0[2], awh[NH > 1 ? NH - 1 : 1][2][2], awo[2];
 #pragma unroll
@@ -664,6 +714,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
         const size_t s0 = (size_t)tile * 32;
         const size_t s = s0 + j;
         const bool valid = s < B;
+        MLP_PH(0);      // set-up (first tile) / loop overhead
         if (tile >= nreal) {
             // padding rows: their upstream gradient is zero and nobody reads their activations -- the input gradient
             // is zero, the weight gradients get nothing
@@ -704,7 +755,11 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
 #pragma unroll
         for (int p = 0; p < KPO; p++) {
             const uint32_t o = (uint32_t)(p + KPO * h);
+#ifdef ENERF_MLP_NOLOAD
+            dy[p] = (float)(tile & 3);
+#else
             dy[p] = (valid && o < out_dim) ? load_dy(dys, s, o) : 0.0f;
+#endif
         }
         // every forward-activation tile of this sample tile is requested up front: with one wave per SIMD the
         // loads of the deeper layers travel while the output layer computes
@@ -712,7 +767,12 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
 #pragma unroll
         for (int l = NH - 1; l >= 0; l--)
 #pragma unroll
+#ifdef ENERF_MLP_NOLOAD
+            for (int ib = 0; ib < 2; ib++) fwl[l][ib] = (f32x16)((float)(tile & 7) - 3.0f);
+#else
             for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + s) * HID, ib, h, fwl[l][ib]);
+#endif
+        MLP_PH(1);      // loads of the tile issued
         f32x16(&fw)[2] = fwl[NH - 1];
         wave_lds_fence();
 #pragma unroll
@@ -727,6 +787,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
             for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(g[ib][q], fw[ib][q], act);
         }
         wave_lds_fence();
+        MLP_PH(2);      // output layer dgrad (waits for dY and the last layer's activations)
         // dWout[o][i] += dY[o][s] * fb_last[i][s]
 #pragma unroll 4
         for (int p = 0; p < 16; p++) {
@@ -737,6 +798,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
         wave_lds_fence();
         tile_to_lds(ga[0], j, h, g[0]);
         tile_to_lds(ga[1], j, h, g[1]);
+        MLP_PH(3);      // dWout
         // ---- hidden layers
 #pragma unroll
         for (int jj = 1; jj < NH; jj++) {
@@ -751,6 +813,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
 #pragma unroll
                     for (int q = 0; q < 16; q++) n[ib] = mma(whT[l - 1][ib][ob][q], g[ob][q], n[ib]);
             }
+            MLP_PH(4);  // hidden dgrad
             wave_lds_fence();
             tile_to_lds(ft[0], j, h, fw[0]);
             tile_to_lds(ft[1], j, h, fw[1]);
@@ -773,6 +836,7 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
             tile_to_lds(ga[0], j, h, g[0]);
             tile_to_lds(ga[1], j, h, g[1]);
         }
+        MLP_PH(5);      // hidden wgrad + activation mask
         // ---- input layer
         if (XL == 1) {
             // (measured: neither 16 dword-wide global_load_lds at the top of the tile nor issuing these four loads
@@ -785,6 +849,21 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
                 *reinterpret_cast<float2*>(xt + lv * XT_LD + off + 2) = make_float2(v.z, v.w);
             }
         }
+        MLP_PH(6);      // X tile (level-major)
+        // the first layer's weight gradient goes before its input gradient: the wait for the X tile (vmcnt) would
+        // otherwise also wait for the dX stores just issued
+        if (XL == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the X tile has landed in LDS
+        wave_lds_fence();
+        // dW0[o][i] += G_0[o][s] * X[s][i]
+#pragma unroll 4
+        for (int p = 0; p < 16; p++) {
+            float xin;
+            if (XL == 0) xin = xt[(2 * p + h) * IN + j];
+            else xin = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
+            aw0[0] = mma(ga[0][j * T_LD + 2 * p + h], xin, aw0[0]);
+            aw0[1] = mma(ga[1][j * T_LD + 2 * p + h], xin, aw0[1]);
+        }
+        MLP_PH(7);      // dW0
         if (dX) {
             f32x16 d = (f32x16)(0.0f);
 #pragma unroll
@@ -807,46 +886,43 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
                 }
             }
         }
-        if (XL == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the X tile has landed in LDS
-        wave_lds_fence();
-        // dW0[o][i] += G_0[o][s] * X[s][i]
-#pragma unroll 4
-        for (int p = 0; p < 16; p++) {
-            float xin;
-            if (XL == 0) xin = xt[(2 * p + h) * IN + j];
-            else xin = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
-            aw0[0] = mma(ga[0][j * T_LD + 2 * p + h], xin, aw0[0]);
-            aw0[1] = mma(ga[1][j * T_LD + 2 * p + h], xin, aw0[1]);
-        }
+        MLP_PH(8);      // input dgrad + dX stores
     }
 
-    // block-level sums in a fixed wave order (deterministic), then one partial per workgroup
-    float* red = wl;
+    // block-level sums, then one partial per workgroup: every wave spreads its accumulators over a region of its own
+    // (the tile buffers are free by now: 4 * NW floats fit in the kernel's LDS for the NH <= 2 this kernel serves), all
+    // four at once, and the sums are taken in wave order (deterministic) on the way out -- taking turns at one
+    // shared region cost four serialised passes of 128 read-modify-writes per lane
+    static_assert(4 * NW_MAX <= NW_MAX + 4 * PER_WAVE, "the four per-wave regions must fit");
+    __syncthreads();                                   // nobody reads a tile buffer or the staged weights any more
+    float* red = lds + (size_t)wid * NW;
     auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const uint32_t o = (uint32_t)(32 * ob + nrow(q, h));
-            if (o < nrows) red[base + o * ld + 32 * nb + j] += a[q];
+            if (o < nrows) red[base + o * ld + 32 * nb + j] = a[q];
         }
     };
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID);
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID);
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim);
     __syncthreads();
-    for (int turn = 0; turn < 4; turn++) {
-        if (wid == turn) {
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID);
-#pragma unroll
-            for (int l = 0; l < NH - 1; l++)
-#pragma unroll
-                for (int ob = 0; ob < 2; ob++)
-#pragma unroll
-                    for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID);
-#pragma unroll
-            for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim);
-        }
-        __syncthreads();
-    }
     float* dst = partial + (size_t)blockIdx.x * NW;
-    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = red[i];
+    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x)
+        dst[i] = ((lds[i] + lds[NW + i]) + lds[2 * NW + i]) + lds[3 * NW + i];
+#ifdef ENERF_MLP_TIMING
+    MLP_PH(10);
+    if (lane == 0)
+        for (int k = 0; k < 11; k++) atomicAdd(&g_mlp_phase[k], ph[k]);
+    if (threadIdx.x == 0) atomicAdd(&g_mlp_phase[15], 1ull);
+#endif
 }
 
 struct ReduceJob {
@@ -1207,3 +1283,13 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
 }
 
 }  // extern "C"
+
+#ifdef ENERF_MLP_TIMING
+extern "C" int enerf_debug_mlp_phases(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_phase), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

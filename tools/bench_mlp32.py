@@ -58,6 +58,31 @@ def main():
         macs = 32 * 64 + (nh - 1) * 64 * 64 + 64 * out
         print(f"{name:34s} B={B}: inference {t_inf:6.1f} us | train fwd {t_fwd:6.1f} us | bwd (act+w+reduce) {t_bwd:6.1f} us"
               f" | fwd {2 * macs * B / t_fwd / 1e6:6.1f} TFLOP/s, bwd {4 * macs * B / t_bwd / 1e6:6.1f} TFLOP/s")
+        if hasattr(lib, "enerf_debug_mlp_phases"):      # built with ENERF_DEFINES=-DENERF_MLP_TIMING
+            import ctypes
+
+            def phases(title, call, names, reps=20):
+                arr = (ctypes.c_ulonglong * 16)()
+                lib.enerf_debug_mlp_phases(arr, 1)
+                for _ in range(reps):
+                    call()
+                torch.cuda.synchronize()
+                lib.enerf_debug_mlp_phases(arr, 0)
+                v = [float(x) for x in arr]
+                nwg, tot = v[15] / reps, sum(v[:len(names)])
+                print(f"   {title}: {nwg:.0f} workgroups, s_memtime ticks per wave and share")
+                for k, nm in enumerate(names):
+                    print(f"     {nm:20s} {v[k] / reps / nwg / 4:10.0f}  {100 * v[k] / tot:5.1f} %")
+
+            phases("training forward", lambda: lib.enerf_mlp32_forward(X.data_ptr(), W.data_ptr(), B, 32, out, nh, 0, 6,
+                                                                       fb.data_ptr(), Y.data_ptr(), xl, 0, None, s),
+                   ["weights -> LDS", "fragments", "x + layer 1", "hidden", "out + stores", "exit"])
+            phases("fused backward", lambda: lib.enerf_mlp32_backward(dY.data_ptr(), X.data_ptr(), W.data_ptr(),
+                                                                      fb.data_ptr(), B, 32, out, nh, 0, bb.data_ptr(),
+                                                                      dX.data_ptr(), dW.data_ptr(), xl, 0, None, 0, None,
+                                                                      None, 0, s),
+                   ["set-up / loop", "issue loads", "out dgrad (+wait)", "dWout", "hidden dgrad", "hidden wgrad", "X tile",
+                    "dW0 (+wait X)", "input dgrad + dX", "acc -> LDS", "partial store"])
         L.prof.reset(); L.prof.enable(True)
     print("kernel split via rocprofv3 --kernel-trace --stats")
 
