@@ -70,6 +70,8 @@ def parse():
                     help="extra steps timed with HIP-graph replay after the main (eager) timed region; 0 = skip")
     ap.add_argument("--comm-bf16", action="store_true",
                     help="N > 1: all-reduce the hash-table gradient in bf16 (opt-in; fp32 is the default and the headline)")
+    ap.add_argument("--prefetch-at", choices=("forward", "mlp_backward"), default=None,
+                    help="tuning: where the next batch's march is released on the side stream (default: the harness's)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
@@ -241,6 +243,8 @@ def main():
         args.probe_steps = 0
         args.graph_leg_steps = 0
     harness.prefetch = not args.no_prefetch
+    if args.prefetch_at:
+        harness.prefetch_at = args.prefetch_at
     if args.comm_bf16:
         harness.comm_dtype = torch.bfloat16
     parallel.broadcast_state(model)

@@ -154,7 +154,7 @@ __device__ __forceinline__ void stage_segments(float* wl, const WSrc& w, uint32_
     const int sc = w0_col(c0, w.nerf_perm);
     float v0[N0], v[3][NHID];
 #pragma unroll
-    for (uint32_t k = 0; k < N0; k++) v0[k] = sc < 0 ? 0.0f : w.seg[0][(r0 + k * R0) * w.w0_cols + sc];
+    for (uint32_t k = 0; k < N0; k++) v0[k] = w.seg[0][(r0 + k * R0) * w.w0_cols + (sc < 0 ? 0 : sc)];
     uint32_t cnt[3];
     {
         uint32_t base = HID * IN;
@@ -164,15 +164,16 @@ __device__ __forceinline__ void stage_segments(float* wl, const WSrc& w, uint32_
             base += cnt[m - 1];
 #pragma unroll
             for (uint32_t k = 0; k < NHID; k++) {
-                const uint32_t r = rh + k * RH;
-                v[m - 1][k] = r * HID < cnt[m - 1] ? w.seg[m][r * HID + c] : 0.0f;
+                // rows past the end of the output layer re-read its last row: branch-free, discarded below
+                const uint32_t r = rh + k * RH, rc = r * HID < cnt[m - 1] ? r : cnt[m - 1] / HID - 1;
+                v[m - 1][k] = cnt[m - 1] ? w.seg[m][rc * HID + c] : 0.0f;
             }
         }
     }
 #pragma unroll
     for (uint32_t k = 0; k < N0; k++) {
         const uint32_t r = r0 + k * R0;
-        wl[ROT ? r * IN + ((c0 + r) & (IN - 1)) : r * IN + c0] = v0[k];
+        wl[ROT ? r * IN + ((c0 + r) & (IN - 1)) : r * IN + c0] = sc < 0 ? 0.0f : v0[k];
     }
     uint32_t row0 = 0;                            // rows of the 64-wide matrices, numbered through
 #pragma unroll
@@ -710,7 +711,93 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
     const uint32_t nreal = valid_tiles(W, B, ntiles);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wid;
     const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    // Everything a tile reads from global memory lives in the same registers from tile to tile: each group is
+    // requested for the wave's NEXT tile at the point where the current tile has used it for the last time, so a whole
+    // tile of work hides its latency and no extra registers are held.  The loads are plain (the compiler counts them:
+    // no s_waitcnt vmcnt(0) anywhere in the loop) and branch-free (clamped addresses, the selection happens at use).
+    float dy_raw[KPO], ys_raw[KPO], ds_raw = 0.0f, h0_raw = 0.0f;
+    f32x16 fwl[NH][2];
+    float4 xr0, xr1, xr2, xr3;                         // (named: as an array the compiler parks them in LDS)
+    auto request_out = [&](uint32_t t) {               // dL/dY and the last hidden layer's activations of tile t
+        const size_t sn = (size_t)t * 32 + j;
+        const size_t sc = sn < B ? sn : (size_t)B - 1;
+#pragma unroll
+        for (int p = 0; p < KPO; p++) {
+            const uint32_t o = (uint32_t)(p + KPO * h), oc = o < out_dim ? o : out_dim - 1;
+#ifdef ENERF_MLP_NOLOAD
+            dy_raw[p] = (float)(t & 3);
+            ys_raw[p] = 0.5f;
+#else
+            dy_raw[p] = dys.dY[sc * dys.stride + oc];
+            ys_raw[p] = dys.y_sig ? dys.y_sig[sc * dys.y_sig_stride + oc] : 0.0f;
+#endif
+        }
+        if (dys.dsigma) {
+            ds_raw = dys.dsigma[sc];
+            h0_raw = dys.h0[sc * dys.h0_stride];
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+#ifdef ENERF_MLP_NOLOAD
+            fwl[NH - 1][ib] = (f32x16)((float)(t & 7) - 3.0f);
+#else
+            load_tile_fb(fb + ((size_t)(NH - 1) * Bp + sn) * HID, ib, h, fwl[NH - 1][ib]);
+#endif
+        }
+    };
+    auto request_hidden = [&](uint32_t t, int l) {     // activations of hidden layer l of tile t
+        const size_t sn = (size_t)t * 32 + j;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+#ifdef ENERF_MLP_NOLOAD
+            fwl[l][ib] = (f32x16)((float)(t & 7) - 3.0f);
+#else
+            load_tile_fb(fb + ((size_t)l * Bp + sn) * HID, ib, h, fwl[l][ib]);
+#endif
+        }
+    };
+    auto x_addr = [&](uint32_t t, int q) -> const float4* {
+        const size_t t0 = (size_t)t * 32;
+        if (XL == 0) {
+            // rows past the end of the batch: any finite row does (their activation gradients are zero)
+            const size_t row = t0 + 8 * q + (lane >> 3), rc = row < B ? row : (size_t)B - 1;
+            return reinterpret_cast<const float4*>(X + rc * IN + 4 * (lane & 7));
+        }
+        const int f = q * 256 + lane * 4, lv = f >> 6, off = f & 63;
+        return reinterpret_cast<const float4*>(X + ((size_t)lv * Bp + t0) * 2 + off);
+    };
+    auto request_x = [&](uint32_t t) {                 // the tile's inputs, 1 KB per instruction
+        xr0 = *x_addr(t, 0);
+        xr1 = *x_addr(t, 1);
+        xr2 = *x_addr(t, 2);
+        xr3 = *x_addr(t, 3);
+    };
+    auto x_piece_to_lds = [&](int q, const float4& v) {
+        if (XL == 0) {
+            *reinterpret_cast<float4*>(xt + 256 * q + 4 * lane) = v;
+        } else {
+            const int f = q * 256 + lane * 4, lv = f >> 6, off = f & 63;
+            *reinterpret_cast<float2*>(xt + lv * XT_LD + off) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(xt + lv * XT_LD + off + 2) = make_float2(v.z, v.w);
+        }
+    };
+    auto x_to_lds = [&]() {
+        x_piece_to_lds(0, xr0);
+        x_piece_to_lds(1, xr1);
+        x_piece_to_lds(2, xr2);
+        x_piece_to_lds(3, xr3);
+    };
+    {
+        // (requests are never conditional: a branch around them would make the compiler copy the loaded registers, and
+        // so wait for them, on the spot -- a wave without a further tile re-requests a tile it is allowed to read)
+        const uint32_t t0 = gw < ntiles ? gw : ntiles - 1;
+        request_out(t0);
+#pragma unroll
+        for (int l = NH - 2; l >= 0; l--) request_hidden(t0, l);
+        request_x(t0);
+    }
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const uint32_t tnext = tile + nw < nreal ? tile + nw : tile;      // the wave's next real tile (or this one again)
         const size_t s0 = (size_t)tile * 32;
         const size_t s = s0 + j;
         const bool valid = s < B;
@@ -736,43 +823,17 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
             }
             continue;
         }
-        if (XL == 0) {
-            // the row-major X tile goes straight from global memory into LDS (global_load_lds: no registers, nothing
-            // to wait for until the weight gradient of the first layer at the end of the tile): 4 x 1 KB, linear
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const size_t row = s0 + 8 * q + (lane >> 3);
-                if (row < B)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(X + row * IN + 4 * (lane & 7)),
-                        (__attribute__((address_space(3))) void*)(xt + 256 * q), 16, 0, 0);
-                else
-                    *reinterpret_cast<float4*>(xt + 256 * q + 4 * lane) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
         // ---- output layer
         float dy[KPO];
 #pragma unroll
         for (int p = 0; p < KPO; p++) {
             const uint32_t o = (uint32_t)(p + KPO * h);
-#ifdef ENERF_MLP_NOLOAD
-            dy[p] = (float)(tile & 3);
-#else
-            dy[p] = (valid && o < out_dim) ? load_dy(dys, s, o) : 0.0f;
-#endif
+            float gq = dy_raw[p];                      // load_dy's arithmetic on the values requested a tile ago
+            if (dys.y_sig) gq = (gq * (1.0f - ys_raw[p])) * ys_raw[p];
+            if (dys.dsigma && o == 0) gq = ds_raw * expf(fminf(fmaxf(h0_raw, -15.0f), 15.0f));
+            dy[p] = (valid && o < out_dim) ? gq : 0.0f;
         }
-        // every forward-activation tile of this sample tile is requested up front: with one wave per SIMD the
-        // loads of the deeper layers travel while the output layer computes
-        f32x16 g[2], fwl[NH][2];
-#pragma unroll
-        for (int l = NH - 1; l >= 0; l--)
-#pragma unroll
-#ifdef ENERF_MLP_NOLOAD
-            for (int ib = 0; ib < 2; ib++) fwl[l][ib] = (f32x16)((float)(tile & 7) - 3.0f);
-#else
-            for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + s) * HID, ib, h, fwl[l][ib]);
-#endif
-        MLP_PH(1);      // loads of the tile issued
+        f32x16 g[2];
         f32x16(&fw)[2] = fwl[NH - 1];
         wave_lds_fence();
 #pragma unroll
@@ -786,14 +847,27 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
 #pragma unroll
             for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(g[ib][q], fw[ib][q], act);
         }
+        request_out(tnext);
         wave_lds_fence();
         MLP_PH(2);      // output layer dgrad (waits for dY and the last layer's activations)
         // dWout[o][i] += dY[o][s] * fb_last[i][s]
-#pragma unroll 4
-        for (int p = 0; p < 16; p++) {
-            const float a = (uint32_t)j < 2u * KPO ? dyt[j * T_LD + 2 * p + h] : 0.0f;
-            awo[0] = mma(a, ft[0][j * T_LD + 2 * p + h], awo[0]);
-            awo[1] = mma(a, ft[1][j * T_LD + 2 * p + h], awo[1]);
+        // (operands of four contraction steps are read from LDS before their MFMAs are issued: left to itself the
+        // compiler alternates one read, one wait, one MFMA, and the matrix pipe idles for an LDS latency each time)
+#pragma unroll 1
+        for (int p4 = 0; p4 < 16; p4 += 4) {
+            float a[4], b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int c = j * T_LD + 2 * (p4 + u) + h;
+                a[u] = (uint32_t)j < 2u * KPO ? dyt[c] : 0.0f;
+                b0[u] = ft[0][c];
+                b1[u] = ft[1][c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                awo[0] = mma(a[u], b0[u], awo[0]);
+                awo[1] = mma(a[u], b1[u], awo[1]);
+            }
         }
         wave_lds_fence();
         tile_to_lds(ga[0], j, h, g[0]);
@@ -819,49 +893,56 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
             tile_to_lds(ft[1], j, h, fw[1]);
             wave_lds_fence();
             // dWh[l-1][o][i] += G_l[o][s] * fb[l-1][i][s]
-#pragma unroll 4
-            for (int p = 0; p < 16; p++) {
-                const float a0 = ga[0][j * T_LD + 2 * p + h], a1 = ga[1][j * T_LD + 2 * p + h];
-                const float b0 = ft[0][j * T_LD + 2 * p + h], b1 = ft[1][j * T_LD + 2 * p + h];
-                awh[l - 1][0][0] = mma(a0, b0, awh[l - 1][0][0]);
-                awh[l - 1][0][1] = mma(a0, b1, awh[l - 1][0][1]);
-                awh[l - 1][1][0] = mma(a1, b0, awh[l - 1][1][0]);
-                awh[l - 1][1][1] = mma(a1, b1, awh[l - 1][1][1]);
+#pragma unroll 1
+            for (int p4 = 0; p4 < 16; p4 += 4) {
+                float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int c = j * T_LD + 2 * (p4 + u) + h;
+                    a0[u] = ga[0][c]; a1[u] = ga[1][c];
+                    b0[u] = ft[0][c]; b1[u] = ft[1][c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    awh[l - 1][0][0] = mma(a0[u], b0[u], awh[l - 1][0][0]);
+                    awh[l - 1][0][1] = mma(a0[u], b1[u], awh[l - 1][0][1]);
+                    awh[l - 1][1][0] = mma(a1[u], b0[u], awh[l - 1][1][0]);
+                    awh[l - 1][1][1] = mma(a1[u], b1[u], awh[l - 1][1][1]);
+                }
             }
 #pragma unroll
             for (int ib = 0; ib < 2; ib++)
 #pragma unroll
                 for (int q = 0; q < 16; q++) g[ib][q] = act_bwd(n[ib][q], fw[ib][q], act);
+            request_hidden(tnext, l - 1);
             wave_lds_fence();
             tile_to_lds(ga[0], j, h, g[0]);
             tile_to_lds(ga[1], j, h, g[1]);
         }
         MLP_PH(5);      // hidden wgrad + activation mask
         // ---- input layer
-        if (XL == 1) {
-            // (measured: neither 16 dword-wide global_load_lds at the top of the tile nor issuing these four loads
-            // early beats loading here)
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int f = t * 256 + lane * 4, lv = f >> 6, off = f & 63;
-                const float4 v = *reinterpret_cast<const float4*>(X + ((size_t)lv * Bp + s0) * 2 + off);
-                *reinterpret_cast<float2*>(xt + lv * XT_LD + off) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2*>(xt + lv * XT_LD + off + 2) = make_float2(v.z, v.w);
-            }
-        }
         MLP_PH(6);      // X tile (level-major)
-        // the first layer's weight gradient goes before its input gradient: the wait for the X tile (vmcnt) would
-        // otherwise also wait for the dX stores just issued
-        if (XL == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the X tile has landed in LDS
+        wave_lds_fence();
+        x_to_lds();
+        request_x(tnext);
         wave_lds_fence();
         // dW0[o][i] += G_0[o][s] * X[s][i]
-#pragma unroll 4
-        for (int p = 0; p < 16; p++) {
-            float xin;
-            if (XL == 0) xin = xt[(2 * p + h) * IN + j];
-            else xin = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
-            aw0[0] = mma(ga[0][j * T_LD + 2 * p + h], xin, aw0[0]);
-            aw0[1] = mma(ga[1][j * T_LD + 2 * p + h], xin, aw0[1]);
+#pragma unroll 1
+        for (int p4 = 0; p4 < 16; p4 += 4) {
+            float xin[4], a0[4], a1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int p = p4 + u;
+                if (XL == 0) xin[u] = xt[(2 * p + h) * IN + j];
+                else xin[u] = xt[(j >> 1) * XT_LD + 2 * (2 * p + h) + (j & 1)];
+                a0[u] = ga[0][j * T_LD + 2 * p + h];
+                a1[u] = ga[1][j * T_LD + 2 * p + h];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                aw0[0] = mma(a0[u], xin[u], aw0[0]);
+                aw0[1] = mma(a1[u], xin[u], aw0[1]);
+            }
         }
         MLP_PH(7);      // dW0
         if (dX) {

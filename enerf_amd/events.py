@@ -154,11 +154,13 @@ def train_step_events(model, data, opt, criterion=None, bg_color=None):
     return loss, delta
 
 
-def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None, defer_table=False):
+def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None, defer_table=False,
+                             after_mlp_backward=None):
     """The event-only step with the two renders driven without autograd (fused_render.render_train_raw /
     backward_raw): only the loss itself -- a few elementwise ops on two [N,3] images -- goes through autograd, and its
     gradient is handed to the renders' closed backward.  Same values as train_step_events + loss.backward()
-    (nerf/utils.py:482-546); leaves the gradients in p.grad and returns (loss, delta)."""
+    (nerf/utils.py:482-546); leaves the gradients in p.grad and returns (loss, delta).  `after_forward()` is called
+    once both forwards are queued, `after_mlp_backward()` once the second render's MLP backward kernels are."""
     from . import fused_network as fnet
     from . import fused_render as fr
     B = data["images"].shape[0]
@@ -187,7 +189,7 @@ def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None
     g_emb, dw1 = fr.backward_raw(ctx1, g_image=g1, raw=True, defer_table=total)
     if g_emb is not None:
         emb.grad = g_emb                                # the second backward adds straight into it ...
-    g_emb2, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True, defer_table=total)
+    g_emb2, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True, defer_table=total, after_mlp=after_mlp_backward)
     if g_emb2 is not None:                              # ... unless it could not (then it returns its own buffer)
         emb.grad.add_(g_emb2)
     dw1 += dw2

@@ -152,7 +152,7 @@ def unpack_weight_grads(dw, out_c):
             dw[o[3]:o[4]].view(64, 64), dw[o[4]:].view(out_c, 64))
 
 
-def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, defer_table=0):
+def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, defer_table=0, after_mlp=None):
     """Gradients of (embeddings, ws0, ws1, wc0, wc1, wc2) given d(sigma) [B] and d(rgb) [B,out] (contiguous fp32).
     `sigma_scale` multiplies d(sigma) on the fly (the renderer's density_scale).  The embedding gradient is None when
     it was added straight into the parameter's .grad (`owner`: the caller drives this backward itself, outside autograd,
@@ -191,6 +191,8 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
         lib.enerf_mlp32_defer_reduce(0)
         if sv.get("valid_rows") is not None:
             lib.enerf_mlp32_valid_rows(None)
+    if after_mlp is not None:
+        after_mlp()                          # both MLP backward kernels are queued; the table's backward follows
     param, emb = sv["param"], sv["emb"]
     target = _ge.param_grad_target(param, torch.float32, owner=owner)
     direct = target is not None

@@ -302,7 +302,8 @@ def render_train_raw(model, rays_o, rays_d, bg_color=1, perturb=True, dt_gamma=0
     return out_image, ctx
 
 
-def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, raw=False, defer_table=0):
+def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, raw=False, defer_table=0,
+                 after_mlp=None):
     """Backward half.  Either g_image = d loss / d image [N,3], or target [N,3] for loss = mean((image - target)^2) *
     upstream (gradient and, with loss_out, value formed inside the composite backward).  -> the gradients of
     fused_network.network_params(model) (raw=True: (embedding gradient, flat dW), see fused_network.nerf_backward);
@@ -328,11 +329,11 @@ def backward_raw(ctx, g_image=None, target=None, upstream=1.0, loss_out=None, ra
                                                   ctx["deltas"], ctx["rays"], ctx["weights_sum"], ctx["image"], M, N,
                                                   g_sigmas, g_rgbs, None)
         return fnet.nerf_backward(ctx["sv"], g_sigmas, g_rgbs, sigma_scale=ctx["scale"], raw=raw, owner=True,
-                                  defer_table=defer_table)
+                                  defer_table=defer_table, after_mlp=after_mlp)
 
 
 def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_gamma=0, max_steps=1024, upstream=1.0,
-                   after_forward=None, loss_out=None, raw=False, defer_table=False):
+                   after_forward=None, loss_out=None, raw=False, defer_table=False, after_mlp_backward=None):
     """Forward AND backward of a training render under loss = mean((image - target)^2) * upstream, without autograd:
     -> (image [N,3], gradients of fused_network.network_params(model) in that order; the first is None when the
     embedding gradient was added straight into the parameter's .grad).
@@ -340,7 +341,8 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
     For loops whose loss is the reference's default (nerf/utils.py:628, MSE): the loss gradient and the blend's
     d/d(weights_sum) are formed inside the composite backward kernel, which also zero-fills what it does not write;
     depth is not computed.  What is skipped relative to render_train + autograd: the engine round trip, its
-    AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued;
+    AccumulateGrad nodes, ~18 elementwise / fill launches.  `after_forward()` is called once the forward is queued,
+    `after_mlp_backward()` once both MLP backward kernels are (the hash table's backward and the optimizer follow);
     `loss_out` (a zeroed device scalar) receives the loss value from the backward kernel itself; raw=True returns the
     gradients as (embedding gradient, flat MLP dW accumulator) -- see fused_network.nerf_backward."""
     out_image, ctx = render_train_raw(model, rays_o, rays_d, bg_color, perturb, dt_gamma, max_steps,
@@ -348,4 +350,4 @@ def train_step_mse(model, rays_o, rays_d, target, bg_color=1, perturb=True, dt_g
     if after_forward is not None:
         after_forward()                         # e.g. prefetch_march of the next batch on a side stream
     return out_image, backward_raw(ctx, target=target, upstream=upstream, loss_out=loss_out, raw=raw,
-                                   defer_table=ctx["M"] if defer_table else 0)
+                                   defer_table=ctx["M"] if defer_table else 0, after_mlp=after_mlp_backward)

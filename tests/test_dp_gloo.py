@@ -163,10 +163,11 @@ def test_comm_tuning_slowest_rank_decides(tmp_path):
     assert a["timings"] == b["timings"] and set(a["timings"]) == {1, 2, 8}
     assert a["chosen"] == b["chosen"] == 2
     assert a["timings"][1] >= 19.0 and a["timings"][8] >= 19.0 and a["timings"][2] < 15.0       # ms per step
-    # warm-up + 3 candidates, two windows of the sharded tail, then two windows (march placement) with what was chosen
-    assert [c for _, c, _ in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 + [2] * 12
-    assert [m for _, _, m in a["seen"]] == ["allreduce"] * 12 + ["sharded"] * 6 + ["allreduce"] * 6
-    assert [i for i, _, _ in a["seen"]] == list(range(24))
+    # warm-up + 3 candidates, two windows of the sharded tail, then three windows (march placement) with what was chosen
+    assert [c for _, c, _ in a["seen"]] == [1] * 6 + [2] * 3 + [8] * 3 + [2] * 15
+    assert [m for _, _, m in a["seen"]] == ["allreduce"] * 12 + ["sharded"] * 6 + ["allreduce"] * 9
+    assert [i for i, _, _ in a["seen"]] == list(range(27))
+    assert set(a["tuned"]["prefetch_at_ms_per_step"]) == {"forward", "mlp_backward", "collectives"}
     assert a["mode"] == b["mode"] == "allreduce" and a["tuned"]["sharded_ms_per_step"] == b["tuned"]["sharded_ms_per_step"] >= 11.0
 
 

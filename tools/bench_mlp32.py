@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--unfused-backward", action="store_true")
     ap.add_argument("--fwd-blocks", type=int, default=0)
     ap.add_argument("--bwd-blocks", type=int, default=0)
+    ap.add_argument("--all-shapes", action="store_true")
     a = ap.parse_args()
     if a.unfused_backward:
         L.lib().enerf_debug_mlp32_fused_backward(0)
@@ -41,7 +42,10 @@ def main():
     B, Bp, dev = a.B, pad32(a.B), "cuda"
     lib = L.lib()
     s = L.stream_handle()
-    for name, nh, out, xl in (("sigma 32-64-16 (level-major x)", 1, 16, 1), ("color 32-64-64-3", 2, 3, 0)):
+    cfgs = (("sigma 32-64-16 (level-major x)", 1, 16, 1), ("color 32-64-64-3", 2, 3, 0))
+    if a.all_shapes:
+        cfgs = tuple((f"nh={nh} out={out} xl={xl}", nh, out, xl) for nh in (1, 2, 3) for out in (3, 16) for xl in (0, 1))
+    for name, nh, out, xl in cfgs:
         nw = 64 * 32 + (nh - 1) * 64 * 64 + out * 64
         W = (torch.rand(nw, device=dev) - 0.5) * 0.3
         X = torch.rand(16, Bp, 2, device=dev) if xl else torch.rand(B, 32, device=dev)
@@ -83,7 +87,6 @@ def main():
                                                                       None, 0, s),
                    ["set-up / loop", "issue loads", "out dgrad (+wait)", "dWout", "hidden dgrad", "hidden wgrad", "X tile",
                     "dW0 (+wait X)", "input dgrad + dX", "acc -> LDS", "partial store"])
-        L.prof.reset(); L.prof.enable(True)
     print("kernel split via rocprofv3 --kernel-trace --stats")
 
 
