@@ -320,7 +320,12 @@ def main():
         harness.global_step = 0
         model.iter_density = 0
     # warm-up runs with the same timing hooks as the timed region, so their events exist before the clock starts
-    _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
+    # the timed region carries the event timing of the roofline kernel only (two kernel-attached events per launch);
+    # the table's backward is timed in the probe steps after the region when there are any (its event pair costs
+    # ~10 us per step: measured 0.424 -> 0.416 ms), inside the region otherwise
+    probe_ok = args.probe_steps > 0 and args.net == "linear" and args.mode == "rgb" and not args.graphs
+    timed_families = None if args.prof_all else (("grid_fwd",) if probe_ok else ("grid_fwd", "grid_bwd"))
+    _lib.prof.enable(True, only=timed_families)
     for i in range(args.warmup):
         one_step(i)
     sync()
@@ -330,7 +335,7 @@ def main():
     _lib.prof.reset()
     # live hipEvent timing of the roofline kernel (and its backward) over the timed region; the other kernel families
     # are in profiles/ (rocprofv3) -- timing all of them costs ~25 event records per step, 5 % of a 1 ms step
-    _lib.prof.enable(True, only=None if args.prof_all else ("grid_fwd", "grid_bwd"))
+    _lib.prof.enable(True, only=timed_families)
     sync()
 
     # ray samples of the timed steps: the march's scan pass keeps a running total on the device
@@ -433,7 +438,7 @@ def main():
     # density-grid update in between (its sigma-only sweep is a different launch shape).  Timing every family costs
     # ~5 % of a step, which is why the timed region above only times the grid kernels.
     roofline_mfma = None
-    if args.probe_steps > 0 and args.net == "linear" and args.mode == "rgb" and not args.graphs:
+    if probe_ok:
         keep_interval = harness.update_interval
         harness.update_interval = 10 ** 9
         try:
@@ -441,7 +446,8 @@ def main():
             one_step(base)
             sync()
             _lib.prof.reset()
-            _lib.prof.enable(True, only=("ffmlp_fwd", "ffmlp_bwd"))
+            _lib.prof.enable(True, only=("ffmlp_fwd", "ffmlp_bwd", "grid_bwd"))
+            bwd_before = (gb.STATS["bwd_points"], gb.STATS["bwd_calls"])
             before = marched_total(reset=False)
             for i in range(base + 1, base + 1 + args.probe_steps):
                 one_step(i)
@@ -450,6 +456,18 @@ def main():
             probe_samples = (marched_total(reset=False) - before) / args.probe_steps      # (one march is always ahead)
             fwd_ms, nf = _lib.prof.read("ffmlp_fwd")
             bwd_ms, nb = _lib.prof.read("ffmlp_bwd")
+            gb_ms, gb_n = _lib.prof.read("grid_bwd")
+            gb_calls = gb.STATS["bwd_calls"] - bwd_before[1]
+            if roofline is not None and gb_n and gb_calls and "grid_bwd" not in kernels:
+                ptsb = (gb.STATS["bwd_points"] - bwd_before[0]) / gb_calls
+                kernels["grid_bwd"] = {"avg_ms": gb_ms / gb_n, "launches": int(gb_n), "timed_in": "probe steps"}
+                roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / (gb_ms / gb_n * 1e-3) / 1e9
+                roofline["grid_encode_backward_scope"] = (
+                    ("binning pass (k_grid_bwd_bin) only: on one GPU the tile sums run inside the optimizer's pass over "
+                     "the table (k_grid_tile_adam, profiles/r02_step_kernels_steady.txt)"
+                     if harness.fuse_table_adam and world == 1 else
+                     "binning pass + tile pass (k_grid_bwd_bin + k_grid_bwd_tile)")
+                    + f"; hipEvent-timed over the {args.probe_steps} probe steps after the timed region")
             if nf and nb:
                 per_step_ms = (fwd_ms + bwd_ms) / args.probe_steps
                 tf = probe_samples * MLP_LINEAR_FLOP_STEP / (per_step_ms * 1e-3) / 1e12
