@@ -410,21 +410,23 @@ template <typename T, int D, int C>
 __device__ __forceinline__ bool load_sample(uint32_t b, bool valid, const T* __restrict__ grad,
                                             const float* __restrict__ inputs, uint32_t level, uint32_t B, uint32_t L,
                                             int grad_layout, float in_add, float in_mul, float (&in)[D], float (&g)[C]) {
+    // every load is issued before anything is tested (clamped index, selections afterwards): tested one coordinate at
+    // a time, each load waited for the previous one -- four memory latencies in a row at the head of both backward
+    // kernels
+    const uint32_t bc = b < B ? b : B - 1u;
+    const uint32_t Bp = (B + 31u) & ~31u;
+    float raw[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) raw[d] = inputs[(size_t)bc * D + d];
+    const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(
+        grad)[grad_layout == 0 ? (size_t)level * B + bc : grad_layout == 1 ? (size_t)bc * L + level : (size_t)level * Bp + bc];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        in[d] = valid ? (inputs[(size_t)b * D + d] + in_add) * in_mul : 0.0f;
+        in[d] = valid ? (raw[d] + in_add) * in_mul : 0.0f;
         valid = valid && !(in[d] < 0 || in[d] > 1);   // out-of-range points contribute nothing
     }
-    if (valid) {
-        const uint32_t Bp = (B + 31u) & ~31u;
-        const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(
-            grad)[grad_layout == 0 ? (size_t)level * B + b : grad_layout == 1 ? (size_t)b * L + level : (size_t)level * Bp + b];
 #pragma unroll
-        for (int c = 0; c < C; c++) g[c] = to_f(gv.v[c]);
-    } else {
-#pragma unroll
-        for (int c = 0; c < C; c++) g[c] = 0.0f;
-    }
+    for (int c = 0; c < C; c++) g[c] = valid ? to_f(gv.v[c]) : 0.0f;
     return valid;
 }
 
