@@ -844,16 +844,26 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
         const size_t base = ((size_t)off0 + row0) * C;          // level offsets are multiples of 8 rows: 16-byte aligned
         // the tile's p / m / v (and dense gradient) are requested first: they travel while the records are summed
         constexpr int F = kTileElems / (4 * kTileThreads);
+        // (no branch per piece: a short last tile re-requests its last piece, and the dense gradient is one
+        // workgroup-uniform branch of its own -- conditional loads make the compiler wait between the pieces)
         float4 p4[F], m4[F], v4[F], d4[F];
+        const uint32_t last4 = nrows * C - 4u;                  // nrows is a multiple of 8
 #pragma unroll
         for (int f = 0; f < F; f++) {
-            const uint32_t i = (threadIdx.x + f * kTileThreads) * 4;
-            if (i < nrows * C) {
-                p4[f] = *reinterpret_cast<const float4*>(P + base + i);
-                m4[f] = *reinterpret_cast<const float4*>(M + base + i);
-                v4[f] = *reinterpret_cast<const float4*>(V + base + i);
-                d4[f] = dense ? *reinterpret_cast<const float4*>(G + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t i = (threadIdx.x + f * kTileThreads) * 4, ic = i < nrows * C ? i : last4;
+            p4[f] = *reinterpret_cast<const float4*>(P + base + ic);
+            m4[f] = *reinterpret_cast<const float4*>(M + base + ic);
+            v4[f] = *reinterpret_cast<const float4*>(V + base + ic);
+        }
+        if (dense) {
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const uint32_t i = (threadIdx.x + f * kTileThreads) * 4, ic = i < nrows * C ? i : last4;
+                d4[f] = *reinterpret_cast<const float4*>(G + base + ic);
             }
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; f++) d4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (binned) {
             const uint32_t cap = region / plan.bins;
@@ -870,23 +880,36 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                 const uint32_t n = s_n[rep < 64 ? rep : 63];
                 const uint32_t list = tile * plan.replicas + rep;
                 const uint32_t* r = recs + ((size_t)level * region + (size_t)list * cap) * (1 + C);
-                for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kTileThreads * U) {
-                    uint32_t loc[U];
-                    float val[U][C];
+                if (n == 0) continue;
+                // U records per thread and round; the next round's records are requested before this round's are
+                // added, so a round costs max(memory latency, LDS adds) instead of their sum
+                uint32_t loc[U], nloc[U];
+                float val[U][C], nval[U][C];
+                auto fetch = [&](uint32_t i0, uint32_t (&lo)[U], float (&va)[U][C]) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         const uint32_t i = i0 + u * kTileThreads;
                         const uint32_t ic = i < n ? i : n - 1;
-                        loc[u] = reinterpret_cast<const uint16_t*>(r)[ic];
+                        lo[u] = reinterpret_cast<const uint16_t*>(r)[ic];
 #pragma unroll
-                        for (int c = 0; c < C; c++) val[u][c] = __uint_as_float(r[(size_t)(1 + c) * cap + ic]);
+                        for (int c = 0; c < C; c++) va[u][c] = __uint_as_float(r[(size_t)(1 + c) * cap + ic]);
                     }
+                };
+                fetch(threadIdx.x, loc, val);
+                for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kTileThreads * U) {
+                    fetch(i0 + kTileThreads * U, nloc, nval);           // (past the end: the last record again, unused)
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         if (i0 + u * kTileThreads < n) {
 #pragma unroll
                             for (int c = 0; c < C; c++) atomicAdd(acc + loc[u] * C + c, (double)val[u][c]);
                         }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        loc[u] = nloc[u];
+#pragma unroll
+                        for (int c = 0; c < C; c++) val[u][c] = nval[u][c];
                     }
                 }
             }
