@@ -8,6 +8,8 @@ Every kernel is the library's; what the node removes is the autograd / dispatche
 nodes, a dozen elementwise launches), which is what bounds a 4096-ray step once the kernels are fast.  Values are those
 of the op-by-op route; `tests/test_gpu_training.py` compares the two.
 """
+import contextlib
+
 import torch
 from torch.autograd import Function
 
@@ -57,7 +59,7 @@ def occupied_box_flag(model):
 
 
 def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps,
-                background=False, defer=False):
+                background=False, defer=False, launch_stream=None):
     """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
     Returns the sample buffers; a data-parallel harness runs it for the NEXT batch while the gradient all-reduce of
     the current step is in flight (TrainHarness.prefetch_march).
@@ -68,38 +70,52 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     its total comes back through pinned memory and the write pass goes into buffers of exactly the cropped size
     (same rows, same `rays` / `counter`: the drop rule still sees min(cropped size, N * max_steps)).  With `defer` the
     read-back is left to finish_march(): a stage issued ahead of its step has long finished by then, so the wait is
-    free and the cold window runs the same launch sequence as the budgeted steady state."""
+    free and the cold window runs the same launch sequence as the budgeted steady state.
+
+    `launch_stream`: the kernels are issued on that stream (ordered after everything queued so far on the current
+    one) while every buffer is allocated HERE, from the current stream's pool: the consumer is the current stream,
+    which waits for the stage's event before it reads and frees in its own order -- nothing has to be
+    `record_stream`-ed, and no buffer's release puts an event record (a barrier packet, ~15 us of idle queue) between
+    two kernels of the training step."""
     N = rays_o.shape[0]
     dev = rays_o.device
+    budgeted = not (force_all_rays or mean_count <= 0)
     nears = torch.empty(N, dtype=torch.float32, device=dev)
     fars = torch.empty(N, dtype=torch.float32, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    if budgeted:
+        M = mean_count + (128 - mean_count % 128)            # raymarching.py:186-189 (align = 128)
+        # budgeted buffers: the write pass zero-fills the rows no ray writes, so no torch.zeros passes over them
+        xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
     bufs = model._buffers                            # (nn.Module.__getattr__ is a slow path)
     bitfield = bufs["density_bitfield"]
-    _rb.near_far_from_aabb(rays_o, rays_d, bufs["aabb_train"], N, model.min_near, nears, fars)
-    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
     box = occupied_box_flag(model)
-    if force_all_rays or mean_count <= 0:
-        _rb.march_rays_train_count(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
-                                   model.cascade, model.grid_size, nears, fars, rays, counter, perturb,
-                                   box | (2 if background else 0))
-        total = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        total.copy_(counter, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
-        pre["pending"] = (done, total, rays_o, rays_d, perturb, dt_gamma, max_steps)
-        if not defer:
-            finish_march(model, pre)
-        return pre
-    M = mean_count + (128 - mean_count % 128)                # raymarching.py:186-189 (align = 128)
-    # budgeted buffers: the write pass zero-fills the rows no ray writes, so no torch.zeros passes over them
-    xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-    dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
-    deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
-    _rb.march_rays_train_ex(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
-                            model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
-                            perturb, box | (3 if background else 1))
-    pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
+    if launch_stream is not None:
+        launch_stream.wait_stream(torch.cuda.current_stream())
+    with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
+        _rb.near_far_from_aabb(rays_o, rays_d, bufs["aabb_train"], N, model.min_near, nears, fars)
+        if not budgeted:
+            _rb.march_rays_train_count(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
+                                       model.cascade, model.grid_size, nears, fars, rays, counter, perturb,
+                                       box | (2 if background else 0))
+            total = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            total.copy_(counter, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            pre["pending"] = (done, total, rays_o, rays_d, perturb, dt_gamma, max_steps)
+        else:
+            _rb.march_rays_train_ex(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
+                                    model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                                    perturb, box | (3 if background else 1))
+            pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
+        if launch_stream is not None:
+            pre["ready"] = torch.cuda.Event()
+            pre["ready"].record(launch_stream)
+    if not budgeted and not defer:
+        finish_march(model, pre)
     return pre
 
 
@@ -214,12 +230,8 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
         pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
                           float(dt_gamma), int(max_steps), defer=True)
     else:
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
-            pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
-                              float(dt_gamma), int(max_steps), background=background, defer=True)
-            pre["ready"] = torch.cuda.Event()
-            pre["ready"].record(stream)
+        pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
+                          float(dt_gamma), int(max_steps), background=background, defer=True, launch_stream=stream)
     pre["slot"] = getattr(model, "last_counter_slot", None)
     stash[key] = pre                                 # (an event step stashes both of its renders)
 
@@ -250,12 +262,8 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
         stash.clear()                                # marched for rays that are not coming: drop, march afresh
         return None
     ready = pre.pop("ready", None)
-    if ready is not None:                       # marched on a side stream: order this stream after it, and tell the
-        cur = torch.cuda.current_stream()       # caching allocator that the buffers now live here as well
-        cur.wait_event(ready)
-        for t in pre.values():
-            if isinstance(t, torch.Tensor):
-                t.record_stream(cur)
+    if ready is not None:                       # marched on a side stream, into buffers of this stream's pool (see
+        torch.cuda.current_stream().wait_event(ready)      # march_stage): order this stream after it, nothing else
     return finish_march(model, pre)              # unbudgeted stage: the write pass runs here, sized from the count
 
 
