@@ -72,6 +72,8 @@ def parse():
                     help="N > 1: all-reduce the hash-table gradient in bf16 (opt-in; fp32 is the default and the headline)")
     ap.add_argument("--prefetch-at", choices=("forward", "mlp_backward"), default=None,
                     help="tuning: where the next batch's march is released on the side stream (default: the harness's)")
+    ap.add_argument("--no-live-timing", action="store_true",
+                    help="tuning: no hipEvent timing inside the timed region (the line then carries no `roofline`)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
@@ -325,6 +327,8 @@ def main():
     # ~10 us per step: measured 0.424 -> 0.416 ms), inside the region otherwise
     probe_ok = args.probe_steps > 0 and args.net == "linear" and args.mode == "rgb" and not args.graphs
     timed_families = None if args.prof_all else (("grid_fwd",) if probe_ok else ("grid_fwd", "grid_bwd"))
+    if args.no_live_timing:
+        timed_families = ()
     _lib.prof.enable(True, only=timed_families)
     for i in range(args.warmup):
         one_step(i)
@@ -359,22 +363,34 @@ def main():
     t0 = time.perf_counter()
     # (graph mode counts per step: a capture inside the timed region runs warm-up marches that are not steps)
     per_step = torch.zeros((), dtype=torch.int64, device=device) if args.verify_samples or args.graphs else None
-    # one event per step boundary (no synchronisation): splits the window into the steps that ran before the first
-    # sample budget existed ("cold": the reference's first 16 steps) and after ("steady")
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    cold = []
-    marks[0].record()
+    # events at the borders between runs of like steps (no synchronisation): "cold" = before the first sample budget
+    # existed (the reference's first 16 steps), "steady", and the steps that start with update_extra_state.  Not one
+    # event per step: an event record is a barrier packet, ~8 us of idle queue per step at this step length.
+    def step_class(i):
+        gs = harness.global_step
+        if gs % harness.update_interval == 0:
+            return "with_update_extra_state"
+        return "cold" if model.mean_count <= 0 else "steady"
+
+    runs = []                                   # [class, steps, start event, end event]
     for i in range(args.warmup, args.warmup + args.steps):
-        cold.append(model.mean_count <= 0 and harness.global_step % harness.update_interval != 0
-                    or (harness.global_step % harness.update_interval == 0 and harness.global_step < harness.update_interval))
+        cls = step_class(i)
+        if not runs or runs[-1][0] != cls:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            if runs:
+                runs[-1][3] = ev
+            runs.append([cls, 0, ev, None])
+        runs[-1][1] += 1
         one_step(i)
-        marks[i - args.warmup + 1].record()
         if per_step is not None:      # the per-step bookkeeping the running total replaces (one tiny launch per render)
             slot = getattr(model, "rendered_counter_slot", None)
             slot = (model.local_step - 1) % 16 if slot is None else slot
             per_step.add_(model.step_counter[slot, 0])
             if args.mode == "events":
                 per_step.add_(model.step_counter[(slot - 1) % 16, 0])
+    runs[-1][3] = torch.cuda.Event(enable_timing=True)
+    runs[-1][3].record()
     t_enqueued = time.perf_counter()
     sync()
     t1 = time.perf_counter()
@@ -385,19 +401,11 @@ def main():
         if per_step is not None:
             assert int(per_step.item()) == int(samples_acc.item()), (int(per_step.item()), int(samples_acc.item()))
     _lib.prof.enable(False)
-    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
-    updates = [(args.warmup + k) % harness.update_interval == 0 for k in range(args.steps)]
-
-    def _mean(sel):
-        v = [t for t, ok in zip(step_ms, sel) if ok]
-        return (sum(v) / len(v), len(v)) if v else (None, 0)
-
     split = {}
-    for name, sel in (("cold", [c and not u for c, u in zip(cold, updates)]),
-                      ("steady", [not c and not u for c, u in zip(cold, updates)]),
-                      ("with_update_extra_state", updates)):
-        ms, n = _mean(sel)
-        split[name] = {"ms_per_step": ms, "steps": n}
+    for name in ("cold", "steady", "with_update_extra_state"):
+        sel = [r for r in runs if r[0] == name]
+        n = sum(r[1] for r in sel)
+        split[name] = {"ms_per_step": sum(r[2].elapsed_time(r[3]) for r in sel) / n if n else None, "steps": n}
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)

@@ -100,6 +100,84 @@ __global__ void __launch_bounds__(256) k_event_pair_rays(
     if (!(ok1 && ok2)) atomicAdd(outside, 1);                        // interp1d(bounds_error=True) would raise
 }
 
+
+// ---- event loss, forward and gradient in one launch (nerf/utils.py:499-516 with C_thres != -1) ------------------------
+// Per ray: (luma of) the two renders -> lin-log / log intensities -> delta = p2 - p1 -> (delta - pol * C)^2, mean over
+// rays x channels.  Writes delta, d loss / d image1, d loss / d image2 and the loss (one workgroup, fixed summation
+// order).  The arithmetic follows events.py (= utils/event_utils.py:23-66) operation by operation.
+struct EventLossCfg {
+    uint32_t use_luma, linlog;
+    float c_thres, log_thres, upstream;
+};
+__device__ __forceinline__ float ev_luma(const float* rgb) {
+    // torch.sum(rgb * factors, axis=-1): ((r*w0 + g*w1) + b*w2)
+    return (rgb[0] * 0.299f + rgb[1] * 0.587f) + rgb[2] * 0.114f;
+}
+// intensity p(l) and dp/dl for l in image units (the reference scales by 255 first)
+__device__ __forceinline__ void ev_intensity(float l, const EventLossCfg& c, float& p, float& dp) {
+    const float x = l * 255.0f;
+    if (c.linlog) {
+        const float slope = (float)(2.995732273553991 / 20.0);          // np.log(20) / 20, rounded to fp32 by torch
+        if (x < 20.0f) { p = slope * x; dp = slope * 255.0f; }
+        else { p = logf(x); dp = (1.0f / x) * 255.0f; }
+    } else {
+        if (x > c.log_thres) { p = logf(x); dp = (1.0f / x) * 255.0f; }
+        else { p = logf(c.log_thres); dp = 0.0f; }
+    }
+}
+__global__ void __launch_bounds__(1024) k_event_loss(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                     const float* __restrict__ pols, uint32_t N, EventLossCfg c,
+                                                     float* __restrict__ g1, float* __restrict__ g2,
+                                                     float* __restrict__ delta, float* __restrict__ loss) {
+    __shared__ double red[1024];
+    const uint32_t ch = c.use_luma ? 1u : 3u;
+    const float inv_count = 1.0f / (float)(N * ch);
+    double acc = 0.0;
+    for (uint32_t r = threadIdx.x; r < N; r += 1024u) {
+        const float* a = img1 + (size_t)r * 3;
+        const float* b = img2 + (size_t)r * 3;
+        const float target = pols[r] * c.c_thres;
+        float ga[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+        if (c.use_luma) {
+            float p1, d1, p2, d2;
+            ev_intensity(ev_luma(a), c, p1, d1);
+            // without lin-log the reference evaluates the second term on the FIRST luma (nerf/utils.py:500): delta = 0
+            ev_intensity(c.linlog ? ev_luma(b) : ev_luma(a), c, p2, d2);
+            const float dl = p2 - p1, res = dl - target;
+            delta[r] = dl;
+            acc += (double)(res * res);
+            const float gd = c.upstream * (2.0f * res * inv_count);
+            const float w[3] = {0.299f, 0.587f, 0.114f};
+            for (int k = 0; k < 3; k++) {
+                if (c.linlog) { ga[k] = -gd * d1 * w[k]; gb[k] = gd * d2 * w[k]; }
+                else ga[k] = (gd * d2 - gd * d1) * w[k];
+            }
+        } else {
+            for (int k = 0; k < 3; k++) {
+                float p1, d1, p2, d2;
+                ev_intensity(a[k], c, p1, d1);
+                ev_intensity(b[k], c, p2, d2);
+                const float dl = p2 - p1, res = dl - target;
+                delta[(size_t)r * 3 + k] = dl;
+                acc += (double)(res * res);
+                const float gd = c.upstream * (2.0f * res * inv_count);
+                ga[k] = -gd * d1;
+                gb[k] = gd * d2;
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            g1[(size_t)r * 3 + k] = ga[k];
+            g2[(size_t)r * 3 + k] = gb[k];
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) loss[0] = (float)(red[0] * (double)inv_count) * c.upstream;
+}
 }  // namespace
 
 extern "C" int enerf_event_pair_rays(const float* events, const uint8_t* no_successor, const int64_t* num_successor,
@@ -116,5 +194,19 @@ extern "C" int enerf_event_pair_rays(const float* events, const uint8_t* no_succ
         events, no_successor, num_successor, pol_cumsum, N, start_draw, u_end, M, acc_max_num_evs, knots, rot, rotvec,
         tcoef, K, in, rays_o1, rays_d1, rays_o2, rays_d2, pols, start_out, end_out, (int*)outside_track);
     ENERF_LAUNCH_CHECK("event_pair_rays");
+    return 0;
+}
+
+extern "C" int enerf_event_loss_fwd_bwd(const float* image1, const float* image2, const float* pols, uint32_t N,
+                                        uint32_t use_luma, uint32_t linlog, float C_thres, float log_thres, float upstream,
+                                        float* grad_image1, float* grad_image2, float* delta, float* loss,
+                                        enerf_stream_t stream) {
+    if (N == 0) return 0;
+    if (!image1 || !image2 || !pols || !grad_image1 || !grad_image2 || !delta)
+        ENERF_BADARG("event_loss_fwd_bwd: images, pols, gradients and delta are required");
+    if (C_thres == -1.0f) ENERF_BADARG("event_loss_fwd_bwd: the normalised loss (C_thres == -1) is not fused");
+    const EventLossCfg c = {use_luma, linlog, C_thres, log_thres, upstream};
+    k_event_loss<<<1, 1024, 0, (hipStream_t)stream>>>(image1, image2, pols, N, c, grad_image1, grad_image2, delta, loss);
+    ENERF_LAUNCH_CHECK("event_loss_fwd_bwd");
     return 0;
 }

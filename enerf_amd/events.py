@@ -126,6 +126,34 @@ def event_loss(image1, image2, pols, opt):
     return loss, delta
 
 
+def event_loss_with_grads(image1, image2, pols, opt):
+    """-> (loss, delta, d loss / d image1, d loss / d image2).  On the device, fp32, C_thres != -1: one launch
+    (enerf_event_loss_fwd_bwd, csrc/event_pairs.hip) in place of the ~50 elementwise / reduction launches of
+    event_loss + autograd; anything else goes through those."""
+    fused = (image1.is_cuda and opt.C_thres != -1 and image1.dtype == image2.dtype == pols.dtype == torch.float32
+             and image1.shape == image2.shape and image1.shape[-1] == 3 and pols.numel() * 3 == image1.numel())
+    if fused:
+        from . import _lib as L
+        a, b, p = image1.detach().contiguous(), image2.detach().contiguous(), pols.contiguous()
+        n = p.numel()
+        g1, g2 = torch.empty_like(a), torch.empty_like(b)
+        delta = torch.empty(*a.shape[:-1], 1 if opt.use_luma else 3, dtype=torch.float32, device=a.device)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        L.check(L.lib().enerf_event_loss_fwd_bwd(a.data_ptr(), b.data_ptr(), p.data_ptr(), n, int(bool(opt.use_luma)),
+                                                 int(bool(opt.linlog)), float(opt.C_thres), float(opt.log_thres), 1.0,
+                                                 g1.data_ptr(), g2.data_ptr(), delta.data_ptr(), loss.data_ptr(),
+                                                 L.stream_handle()), "event_loss_fwd_bwd")
+        return loss, delta, g1, g2
+    a = image1.detach().requires_grad_(True)
+    b = image2.detach().requires_grad_(True)
+    with torch.enable_grad():
+        loss, delta = event_loss(a, b, pols, opt)
+        g1, g2 = torch.autograd.grad(loss, [a, b], allow_unused=True)
+    g1 = torch.zeros_like(a) if g1 is None else g1
+    g2 = torch.zeros_like(b) if g2 is None else g2
+    return loss.detach(), delta.detach(), g1, g2
+
+
 def train_step_events(model, data, opt, criterion=None, bg_color=None):
     """One event training step's forward: two renders (+ optional frame render) -> loss.  nerf/utils.py:482-546.
     `bg_color` [B,1,C] replaces the step's random background draw (tests)."""
@@ -172,11 +200,7 @@ def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None
     img2, ctx2 = fr.render_train_raw(model, data["rays_evs_o2"], data["rays_evs_d2"], bg, True, **kw)
     if after_forward is not None:
         after_forward()                                 # e.g. the next step's two marches on a side stream
-    a = img1.view(*shape, 3).requires_grad_(True)
-    b = img2.view(*shape, 3).requires_grad_(True)
-    with torch.enable_grad():
-        loss, delta = event_loss(a, b, data["pols"], opt)
-        g1, g2 = torch.autograd.grad(loss, [a, b])
+    loss, delta, g1, g2 = event_loss_with_grads(img1.view(*shape, 3), img2.view(*shape, 3), data["pols"], opt)
     params = fnet.network_params(model)
     emb = params[0]
     keep = emb.grad if defer_table else None            # (deferred flush: the dense buffer is kept, and kept clean)

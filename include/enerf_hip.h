@@ -454,6 +454,16 @@ int enerf_event_pair_rays(const float* events, const uint8_t* no_successor, cons
                           float* rays_o1, float* rays_d1, float* rays_o2, float* rays_d2, float* pols,
                           int64_t* start_out, int64_t* end_out, int32_t* outside_track, enerf_stream_t stream);
 
+/* The event loss of Trainer.train_step_events (nerf/utils.py:499-516, C_thres != -1) and its gradient with respect to
+ * the two rendered images, one launch: image1 / image2 [N,3] fp32, pols [N] -> delta [N,1] (use_luma) or [N,3],
+ * grad_image1 / grad_image2 [N,3] (d (upstream * loss) / d image), loss [1] (may be NULL).  (utils/event_utils.py:23-66:
+ * BT.601 luma, lin-log with threshold 20 on the 0..255 scale, or log(max(., log_thres)); without lin-log and with luma
+ * the reference evaluates both terms on the first image -- kept.)  Replaces ~50 elementwise / reduction launches of
+ * the autograd route per step. */
+int enerf_event_loss_fwd_bwd(const float* image1, const float* image2, const float* pols, uint32_t N, uint32_t use_luma,
+                             uint32_t linlog, float C_thres, float log_thres, float upstream, float* grad_image1,
+                             float* grad_image2, float* delta, float* loss, enerf_stream_t stream);
+
 /* One fused Adam update (torch.optim.Adam semantics, no weight decay / amsgrad) of a contiguous fp32 tensor:
  * reads p, g, m, v once and writes p, m, v (and g = 0 when zero_grad != 0).  `step` counts from 1. */
 int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,

@@ -576,3 +576,31 @@ def test_padding_rows_of_the_sample_budget_are_skipped_without_changing_anything
         assert torch.equal(i1, i0) and abs(l1 - l0) <= 1e-6 * abs(l0)       # (the loss is summed with float atomics)
         for n in g0:
             assert float((g1[n] - g0[n]).abs().max()) <= 1e-6 * float(g0[n].abs().max()) + 1e-12, (budget, n)
+
+
+@pytest.mark.parametrize("use_luma,linlog", [(True, True), (False, True), (True, False), (False, False)])
+def test_fused_event_loss_matches_autograd(use_luma, linlog):
+    """enerf_event_loss_fwd_bwd (one launch) against events.event_loss + torch.autograd on the same images: loss, delta
+    and both image gradients, all four (use_luma, linlog) variants of nerf/utils.py:499-516, intensities on both sides
+    of the lin-log threshold (20 / 255) and of log_thres."""
+    from enerf_amd.events import EventOptions, event_loss, event_loss_with_grads
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n = 4096
+    a = torch.rand(1, n, 3, device=DEV, generator=g) ** 3           # plenty of values below 20 / 255
+    b = (a + 0.05 * torch.randn(1, n, 3, device=DEV, generator=g)).clamp(1e-4, 1.0)
+    a = a.clamp(1e-4, 1.0)
+    a[0, :7] = 1e-12                                                  # below log_thres * / 255 (log branch: clamped)
+    pols = torch.randint(-3, 4, (1, n), device=DEV, generator=g).float()
+    opt = EventOptions(C_thres=0.2, use_luma=use_luma, linlog=linlog, event_only=True)
+    loss, delta, g1, g2 = event_loss_with_grads(a, b, pols, opt)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref_loss, ref_delta = event_loss(ar, br, pols, opt)
+    r1, r2 = torch.autograd.grad(ref_loss, [ar, br], allow_unused=True)
+    r1 = torch.zeros_like(a) if r1 is None else r1
+    r2 = torch.zeros_like(b) if r2 is None else r2
+    assert delta.shape == ref_delta.shape
+    assert float((delta - ref_delta).abs().max()) <= 1e-6 * max(float(ref_delta.abs().max()), 1.0)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-6 * abs(float(ref_loss)) + 1e-12
+    for got, want in ((g1, r1), (g2, r2)):
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-12
