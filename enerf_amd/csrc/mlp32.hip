@@ -20,6 +20,7 @@
 // out_layout 2 (gridencoder.hip), so the encoding never has to be transposed into rows: a wavefront reads / writes
 // 256 contiguous bytes per level.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "common.h"
 #include "sh_basis.h"
@@ -1054,6 +1055,9 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob
 }
 
 static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
+static bool g_signal_armed = false;      // enerf_mlp32_signal_next_reduce
+static bool g_signal_recorded = false;
+static hipEvent_t g_signal_event = nullptr;
 static bool g_defer_next = false;        // one-shot: set by enerf_mlp32_defer_reduce
 static bool g_have_pending = false;
 static ReduceJob g_pending;
@@ -1305,15 +1309,41 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     if (defer) {
         g_pending = ReduceJob{partial, wgrid, NW, dW};
         g_have_pending = true;
-    } else if (g_have_pending) {
-        g_have_pending = false;
-        k_mlp32_reduce_w2<<<div_up(g_pending.NW, 64) + div_up(NW, 64), 1024, 0, s>>>(g_pending,
-                                                                                     ReduceJob{partial, wgrid, NW, dW});
     } else {
-        k_mlp32_reduce_w<<<div_up(NW, 64), 1024, 0, s>>>(partial, wgrid, NW, dW);
+        // enerf_mlp32_signal_next_reduce: the reduce launch carries the signal event as its stop event -- a
+        // kernel-attached completion signal costs the stream nothing, where an event record after the launch is a
+        // packet of its own that the next kernel waits for (tools/launch_chain.hip: +0 against +3 us per kernel)
+        hipEvent_t sig = nullptr;
+        if (g_signal_armed) {
+            g_signal_armed = false;
+            if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming) != hipSuccess)
+                g_signal_event = nullptr;
+            sig = g_signal_event;
+            g_signal_recorded = sig != nullptr;
+        }
+        if (g_have_pending) {
+            g_have_pending = false;
+            hipExtLaunchKernelGGL(k_mlp32_reduce_w2, dim3(div_up(g_pending.NW, 64) + div_up(NW, 64)), dim3(1024), 0, s,
+                                  nullptr, sig, 0, g_pending, ReduceJob{partial, wgrid, NW, dW});
+        } else {
+            hipExtLaunchKernelGGL(k_mlp32_reduce_w, dim3(div_up(NW, 64)), dim3(1024), 0, s, nullptr, sig, 0, partial,
+                                  wgrid, NW, dW);
+        }
     }
     ENERF_LAUNCH_CHECK("mlp32_backward");
     return 0;
+}
+
+int enerf_mlp32_signal_next_reduce(int on) {
+    g_signal_armed = on != 0;
+    if (on) g_signal_recorded = false;
+    return 0;
+}
+
+int enerf_stream_wait_mlp32_signal(enerf_stream_t stream) {
+    if (!g_signal_recorded || !g_signal_event)
+        ENERF_BADARG("stream_wait_mlp32_signal: no reduce launch has carried the signal since it was armed");
+    return check_hip(hipStreamWaitEvent((hipStream_t)stream, g_signal_event, 0), "stream_wait_mlp32_signal");
 }
 
 int enerf_mlp32_defer_reduce(int on) {

@@ -175,6 +175,8 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
     dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
     if sv.get("valid_rows") is not None:     # the forward skipped the budget's padding rows: so must the backward
         lib.enerf_mlp32_valid_rows(sv["valid_rows"].data_ptr())
+    if after_mlp is not None:                # its side stream waits for the reduce launch's own completion signal
+        lib.enerf_mlp32_signal_next_reduce(1)
     try:
         lib.enerf_mlp32_defer_reduce(1)      # the colour net's dW partial sums are reduced by the sigma net's launch
         L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, 31, 1, 1,
@@ -189,10 +191,13 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
                 "mlp32_backward_p(sigma)")
     finally:
         lib.enerf_mlp32_defer_reduce(0)
+        lib.enerf_mlp32_signal_next_reduce(0)
         if sv.get("valid_rows") is not None:
             lib.enerf_mlp32_valid_rows(None)
     if after_mlp is not None:
-        after_mlp()                          # both MLP backward kernels are queued; the table's backward follows
+        # both MLP backward kernels and their reduce launch are queued (the latter carries the signal armed above: see
+        # enerf_stream_wait_mlp32_signal); the table's backward follows
+        after_mlp(signalled=True)
     param, emb = sv["param"], sv["emb"]
     target = _ge.param_grad_target(param, torch.float32, owner=owner)
     direct = target is not None

@@ -13,6 +13,7 @@ import contextlib
 import torch
 from torch.autograd import Function
 
+from . import _lib as L
 from . import fused_network as fnet
 from . import raymarching as _rm
 from .backends import _raymarching as _rb
@@ -59,7 +60,7 @@ def occupied_box_flag(model):
 
 
 def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps,
-                background=False, defer=False, launch_stream=None):
+                background=False, defer=False, launch_stream=None, after_signal=False):
     """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
     Returns the sample buffers; a data-parallel harness runs it for the NEXT batch while the gradient all-reduce of
     the current step is in flight (TrainHarness.prefetch_march).
@@ -94,7 +95,14 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
     box = occupied_box_flag(model)
     if launch_stream is not None:
-        launch_stream.wait_stream(torch.cuda.current_stream())
+        if after_signal == "ordered":
+            pass        # a stage issued just before on the same launch stream has waited already
+        elif after_signal:
+            # the current stream's last launch (the MLP backward's reduce) carries a completion signal: waiting for it
+            # orders the stage after everything queued so far without an event record in the current stream
+            L.check(L.lib().enerf_stream_wait_mlp32_signal(launch_stream.cuda_stream), "stream_wait_mlp32_signal")
+        else:
+            launch_stream.wait_stream(torch.cuda.current_stream())
     with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
         _rb.near_far_from_aabb(rays_o, rays_d, bufs["aabb_train"], N, model.min_near, nears, fars)
         if not budgeted:
@@ -205,7 +213,8 @@ def _next_counter(model):
     return counter
 
 
-def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None, background=True):
+def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None, background=True,
+                   after_signal=False):
     """Run the parameter-independent stage of the NEXT training render now (e.g. under a gradient all-reduce).  The
     result is picked up by the next render_train call on the same ray tensors; anything that changes what the stage
     reads (update_extra_state: bitfield, sample budget) must not happen in between -- the caller's responsibility.
@@ -231,7 +240,8 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
                           float(dt_gamma), int(max_steps), defer=True)
     else:
         pre = march_stage(model, rays_o, rays_d, _next_counter(model), _budget(model), bool(perturb), False,
-                          float(dt_gamma), int(max_steps), background=background, defer=True, launch_stream=stream)
+                          float(dt_gamma), int(max_steps), background=background, defer=True, launch_stream=stream,
+                          after_signal=after_signal)
     pre["slot"] = getattr(model, "last_counter_slot", None)
     stash[key] = pre                                 # (an event step stashes both of its renders)
 

@@ -208,9 +208,13 @@ class TrainHarness:
         if self._side is None:
             self._side = torch.cuda.Stream()
 
-        def issue(background=True):
-            for ro, rd in next_rays:
-                fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side, background=background)
+        def issue(background=True, signalled=False):
+            # signalled: called right after the MLP backward's reduce launch, which carries a completion signal
+            # (fused_network.nerf_backward) -- the side stream waits for that instead of an event record here.
+            # (the second march of an event step is ordered behind the first on the side stream: no wait of its own)
+            for k, (ro, rd) in enumerate(next_rays):
+                fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side, background=background,
+                                            after_signal=(True if k == 0 else "ordered") if signalled else False)
         return issue
 
     def _manual_fwd_bwd(self, rays_o, rays_d, target, dt_gamma=0, max_steps=1024, after_forward=None, raw=False,

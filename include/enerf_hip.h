@@ -423,6 +423,12 @@ int enerf_debug_mlp32_fused_backward(int on);
  * back to back: one reduce launch and one launch gap less per step).  The pending sums live in their own workspace;
  * nothing is written to the first call's dW until the second call. */
 int enerf_mlp32_defer_reduce(int on);
+/* Cross-stream hand-over without an event record in the launching stream: once armed (on = 1), the next weight-gradient
+ * reduce launch of enerf_mlp32_backward[_p] carries a completion signal; enerf_stream_wait_mlp32_signal makes `stream`
+ * wait for that launch (and, the launching stream being in order, for everything queued before it).  Error if no
+ * launch has carried the signal since it was armed. */
+int enerf_mlp32_signal_next_reduce(int on);
+int enerf_stream_wait_mlp32_signal(enerf_stream_t stream);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);

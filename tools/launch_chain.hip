@@ -48,9 +48,14 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (uint32_t work : {200u, 4000u, 20000u}) {
-        for (int mode = 0; mode < 3; mode++) {
-            // mode 0: plain stream order; 1: any-order launches + counters (no set-up); 2: same with 2 us of set-up
+    hipEvent_t evs[16];
+    for (int k = 0; k < 16; k++) hipEventCreate(&evs[k]);
+    for (uint32_t work : {200u, 4000u}) {
+        for (int mode = 0; mode < 6; mode++) {
+            if (mode == 1 || mode == 2) continue;      // (any-order + counters: measured once, 6x slower)
+            // mode 0: plain stream order; 1: any-order launches + counters (no set-up); 2: same with 2 us of set-up;
+            // 3: every kernel carries a stop event (hipExtLaunchKernelGGL); 4: hipEventRecord after every kernel;
+            // 5: start + stop events on every kernel
             float best = 1e30f;
             for (int rep = 0; rep < 3; rep++) {
                 hipMemsetAsync(cnt, 0, sizeof(uint32_t) * chain * (iters + 8), s);
@@ -59,7 +64,15 @@ int main() {
                 for (uint32_t it = 0; it < iters; it++)
                     for (uint32_t k = 0; k < chain; k++) {
                         const uint32_t idx = it * chain + k;
-                        if (mode == 0) {
+                        if (mode == 3 || mode == 5) {
+                            hipExtLaunchKernelGGL(k_stage, dim3(nwg), dim3(256), 0, s, mode == 5 ? evs[2 * k] : nullptr,
+                                                  evs[2 * k + 1], 0, buf, work, (const uint32_t*)nullptr, 0u,
+                                                  (uint32_t*)nullptr, 8u);
+                        } else if (mode == 4) {
+                            hipLaunchKernelGGL(k_stage, dim3(nwg), dim3(256), 0, s, buf, work, (const uint32_t*)nullptr, 0u,
+                                               (uint32_t*)nullptr, 8u);
+                            hipEventRecord(evs[2 * k + 1], s);
+                        } else if (mode == 0) {
                             hipLaunchKernelGGL(k_stage, dim3(nwg), dim3(256), 0, s, buf, work, (const uint32_t*)nullptr, 0u,
                                                (uint32_t*)nullptr, 8u);
                         } else {
