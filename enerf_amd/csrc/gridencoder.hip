@@ -996,6 +996,8 @@ int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H, float in_add,
     return 0;
 }
 
+__global__ void k_prof_mark() {}
+
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
                const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s,
@@ -1004,10 +1006,15 @@ int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* out
     const uint32_t nblocks = fwd_blocks(nchunks, L);
 #define ENERF_GF(CC)                                                                                               \
     do {                                                                                                           \
-        if (ev_start)                                                                                              \
-            hipExtLaunchKernelGGL((k_grid_fwd<T, D, CC>), dim3(nblocks), dim3(kPtsPerBlock), 0, s, ev_start,       \
+        if (ev_start) {                                                                                            \
+            /* the interval starts at the end of a one-wavefront marker launched right before: two stop events,     \
+               which cost the stream nothing, where a start event on the kernel itself costs it ~10 us of idle    \
+               queue around the launch (tools/launch_chain.hip; the marker's end is the kernel's dispatch) */     \
+            hipExtLaunchKernelGGL(k_prof_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);                     \
+            hipExtLaunchKernelGGL((k_grid_fwd<T, D, CC>), dim3(nblocks), dim3(kPtsPerBlock), 0, s, nullptr,        \
                                   ev_stop, 0, inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, gridtype,     \
                                   layout, nchunks);                                                                \
+        }                                                                                                          \
         else                                                                                                       \
             k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc,  \
                                                                   dy_dx, gridtype, layout, nchunks);               \
