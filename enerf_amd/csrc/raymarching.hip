@@ -782,12 +782,14 @@ __global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ ra
 // report ray-samples/s without a bookkeeping launch per step
 __device__ unsigned long long g_train_samples = 0ull;
 
-__global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* counter, uint32_t N) {
+// `fresh`: the counter is taken as (0, 0) whatever it holds -- the caller's counter.zero_() without its launch
+__global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* counter, uint32_t N, uint32_t fresh) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const int lane = lane_id();
     const int wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = (uint32_t)counter[0];
+    const uint32_t c0 = fresh ? 0u : (uint32_t)counter[0];
+    if (threadIdx.x == 0) carry_s = c0;
     __syncthreads();
     for (uint32_t base = 0; base < N; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -807,9 +809,9 @@ __global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* cou
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        g_train_samples += (unsigned long long)(carry_s - (uint32_t)counter[0]);
+        g_train_samples += (unsigned long long)(carry_s - c0);
         counter[0] = (int32_t)carry_s;
-        counter[1] += (int32_t)N;
+        counter[1] = (fresh ? 0 : counter[1]) + (int32_t)N;
     }
 }
 
@@ -844,10 +846,11 @@ __global__ void __launch_bounds__(1024) k_march_scan_tile_sums(const int32_t* __
 
 // tile_sums[ntiles] -> exclusive offsets (in place, counter[0] at entry included); counter += (sum, N)
 __global__ void __launch_bounds__(1024) k_march_scan_tiles(uint32_t* tile_sums, uint32_t ntiles, int32_t* counter,
-                                                           uint32_t N) {
+                                                           uint32_t N, uint32_t fresh) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = (uint32_t)counter[0];
+    const uint32_t c0 = fresh ? 0u : (uint32_t)counter[0];
+    if (threadIdx.x == 0) carry_s = c0;
     __syncthreads();
     for (uint32_t base = 0; base < ntiles; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -861,9 +864,9 @@ __global__ void __launch_bounds__(1024) k_march_scan_tiles(uint32_t* tile_sums, 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        g_train_samples += (unsigned long long)(carry_s - (uint32_t)counter[0]);
+        g_train_samples += (unsigned long long)(carry_s - c0);
         counter[0] = (int32_t)carry_s;
-        counter[1] += (int32_t)N;
+        counter[1] = (fresh ? 0 : counter[1]) + (int32_t)N;
     }
 }
 
@@ -1581,7 +1584,7 @@ static inline bool march_uses_lattice(float dt_gamma, uint32_t max_steps, uint32
 static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                              const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
-                             bool use_box, hipStream_t s) {
+                             bool use_box, bool fresh_counter, hipStream_t s) {
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
@@ -1608,13 +1611,13 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                                                    fars, rays, perturb);
     }
     if (N <= 16384u) {
-        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N);
+        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N, fresh_counter ? 1u : 0u);
     } else {
         const uint32_t ntiles = div_up(N, 1024);
         uint32_t* tiles = (uint32_t*)workspace(WS_SCAN, (size_t)ntiles * sizeof(uint32_t));
         if (!tiles) return ENERF_E_NOMEM;
         k_march_scan_tile_sums<<<ntiles, 1024, 0, s>>>(rays, N, tiles);
-        k_march_scan_tiles<<<1, 1024, 0, s>>>(tiles, ntiles, counter, N);
+        k_march_scan_tiles<<<1, 1024, 0, s>>>(tiles, ntiles, counter, N, fresh_counter ? 1u : 0u);
         k_march_scan_apply<<<ntiles, 1024, 0, s>>>(rays, N, tiles);
     }
     return 0;
@@ -1664,7 +1667,8 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
-                               perturb, (zero_unwritten & 2u) != 0, (zero_unwritten & 4u) != 0, s);
+                               perturb, (zero_unwritten & 2u) != 0, (zero_unwritten & 4u) != 0, (zero_unwritten & 8u) != 0,
+                               s);
     if (rc) return rc;
     rc = march_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                            rays, counter, perturb, zero_unwritten & 1u, s);
@@ -1683,7 +1687,7 @@ int enerf_march_rays_train_count(const float* rays_o, const float* rays_d, const
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     const int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
-                                     perturb, (flags & 2u) != 0, (flags & 4u) != 0, s);
+                                     perturb, (flags & 2u) != 0, (flags & 4u) != 0, (flags & 8u) != 0, s);
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("march_rays_train_count");
     return 0;

@@ -108,7 +108,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
         if not budgeted:
             _rb.march_rays_train_count(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
                                        model.cascade, model.grid_size, nears, fars, rays, counter, perturb,
-                                       box | (2 if background else 0))
+                                       box | (2 if background else 0) | 8)
             total = torch.empty(2, dtype=torch.int32, pin_memory=True)
             total.copy_(counter, non_blocking=True)
             done = torch.cuda.Event()
@@ -117,7 +117,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
         else:
             _rb.march_rays_train_ex(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
                                     model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
-                                    perturb, box | (3 if background else 1))
+                                    perturb, box | (3 if background else 1) | 8)
             pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
         if launch_stream is not None:
             pre["ready"] = torch.cuda.Event()
@@ -203,13 +203,15 @@ def _budget(model):
 
 
 def _next_counter(model):
+    """The render's slot of the step-counter ring (raymarching.py:197-199).  Not zeroed here: march_stage tells the
+    marcher to start from (0, 0) (flag bit 3) -- a fill launch per step in the middle of the training stream, ~14 us of
+    it with the idle queue around it, for eight bytes."""
     # graph replay needs the counter at a fixed address; the harness copies it into the step_counter ring afterwards
     counter = getattr(model, "graph_counter", None)
     if counter is None:
         model.last_counter_slot = model.local_step % 16
         counter = model._buffers["step_counter"][model.last_counter_slot]
         model.local_step += 1
-    counter.zero_()
     return counter
 
 

@@ -128,7 +128,8 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
  * exactly enerf_march_rays_train.  `zero_unwritten` is a flag word: bit 0 as above; bit 1 says the batch is being
  * prepared ahead of its step on a side stream: the count pass then runs with one wavefront per SIMD (rays in turn) so
  * that it leaves the registers of the chip to the step it runs beside; bit 2: test rays against the occupied cells'
- * bounding box first (enerf_occupied_box_update).  Same rows, same counts, bit for bit. */
+ * bounding box first (enerf_occupied_box_update); bit 3 (value 8): `counter` is taken as (0, 0) whatever it holds --
+ * the wrapper's counter.zero_() (raymarching.py:198) without its launch.  Same rows, same counts, bit for bit. */
 int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                               float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                               const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
@@ -151,7 +152,7 @@ int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float
  * `align`).  The count pass already knows the total on the device:
  *   _count: near/far -> per-ray sample counts -> deterministic scan: rays[n] = (n, offset, count), counter[0] += sum,
  *           counter[1] += N.  Nothing is written to sample buffers.  flags bit 1 = background launch (see _ex),
- *           bit 2 = use the occupied box (enerf_occupied_box_update).
+ *           bit 2 = use the occupied box (enerf_occupied_box_update), bit 3 = counter starts from (0, 0).
  *   _write: the write pass of the SAME batch (same rays / nears / fars / grid / perturb; the fixed-step marcher keeps a
  *           per-process chunk log between the two calls, so no other training march may run in between) into buffers of
  *           M rows; `M` is also the M of the reference's drop rule (`offset + count >= M`: the ray writes nothing).

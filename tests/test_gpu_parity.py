@@ -824,3 +824,29 @@ def test_inference_batch_mult_gives_identical_image(scenes):
         m.infer_batch_mult = 8
         b = m.render(ro, rd, staged=False, bg_color=None, perturb=False)
     assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
+
+
+@pytest.mark.gpu
+def test_march_count_fresh_counter_flag_equals_a_zeroed_counter():
+    """Flag bit 3 of the count / _ex entry points: the counter is taken as (0, 0) whatever it holds -- same rays, same
+    counter as zeroing it first (the reference wrapper's counter.zero_(), raymarching.py:198), for the one-workgroup
+    scan and the tiled one (N > 16384)."""
+    from enerf_amd.backends import _raymarching as rb
+    from enerf_amd import raymarching, scene
+    bound, C, H = 2, 2, 128
+    bits = raymarching.packbits(scene.density_grid(bound, "cuda"), 0.01)
+    for n in (4096, 20000):
+        g = torch.Generator(device="cuda").manual_seed(n)
+        (ro, rd), _ = scene.training_batch(0, n, "cuda", generator=g)
+        aabb = torch.tensor([-bound] * 3 + [bound] * 3, dtype=torch.float32, device="cuda")
+        nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+        out = []
+        for fresh in (False, True):
+            rays = torch.full((n, 3), -7, dtype=torch.int32, device="cuda")
+            counter = torch.zeros(2, dtype=torch.int32, device="cuda") if not fresh else \
+                torch.tensor([123456, 77], dtype=torch.int32, device="cuda")
+            rb.march_rays_train_count(ro, rd, bits, bound, 0.0, 1024, n, C, H, nears, fars, rays, counter, 1,
+                                      8 if fresh else 0)
+            out.append((rays.clone(), counter.clone()))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        assert int(out[0][1][1]) == n and int(out[0][1][0]) > 0
