@@ -71,7 +71,8 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
     its total comes back through pinned memory and the write pass goes into buffers of exactly the cropped size
     (same rows, same `rays` / `counter`: the drop rule still sees min(cropped size, N * max_steps)).  With `defer` the
     read-back is left to finish_march(): a stage issued ahead of its step has long finished by then, so the wait is
-    free and the cold window runs the same launch sequence as the budgeted steady state.
+    free and the cold window runs the same launch sequence as the budgeted steady state -- write pass included, into
+    rows reserved from the previous render's count (kept when the count that comes back fits).
 
     `launch_stream`: the kernels are issued on that stream (ordered after everything queued so far on the current
     one) while every buffer is allocated HERE, from the current stream's pool: the consumer is the current stream,
@@ -90,6 +91,17 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
         xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
         dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
         deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    spec_rows = 0
+    if not budgeted and defer and not force_all_rays:
+        # no budget yet, but the previous render's count is known: its rows + 1/8 are reserved here and the write pass
+        # follows the count pass on the same stream, unseen by the host; finish_march() keeps the result when the count
+        # it reads back fits (consecutive batches differ by a few per cent) and repeats the write pass when not
+        last = int(getattr(model, "_cold_rows", 0))
+        if last > 0:
+            spec_rows = min(last + last // 8 + (128 - (last + last // 8) % 128), N * max_steps)
+            xyzs = torch.empty(spec_rows, 3, dtype=torch.float32, device=dev)
+            dirs = torch.empty(spec_rows, 3, dtype=torch.float32, device=dev)
+            deltas = torch.empty(spec_rows, 2, dtype=torch.float32, device=dev)
     bufs = model._buffers                            # (nn.Module.__getattr__ is a slow path)
     bitfield = bufs["density_bitfield"]
     pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
@@ -114,6 +126,11 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
             done = torch.cuda.Event()
             done.record()
             pre["pending"] = (done, total, rays_o, rays_d, perturb, dt_gamma, max_steps)
+            if spec_rows:
+                _rb.march_rays_train_write(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N, model.cascade,
+                                           model.grid_size, spec_rows, nears, fars, xyzs, dirs, deltas, rays, counter,
+                                           perturb, 1)
+                pre["speculative"] = (spec_rows, xyzs, dirs, deltas)
         else:
             _rb.march_rays_train_ex(rays_o, rays_d, bitfield, model.bound, dt_gamma, max_steps, N,
                                     model.cascade, model.grid_size, M, nears, fars, xyzs, dirs, deltas, rays, counter,
@@ -139,6 +156,13 @@ def finish_march(model, pre):
     dev = rays_o.device
     m = int(total[0])
     M = min(m + (128 - m % 128), N * max_steps)              # the reference's crop of its N * max_steps buffers
+    model._cold_rows = M
+    spec = pre.pop("speculative", None)
+    if spec is not None and M <= spec[0] and m < N * max_steps:
+        # the write pass already ran behind the count pass into buffers at least this large: the rows are the same
+        # (nothing is dropped below N * max_steps samples, rows past the count are zero-filled either way)
+        pre.update(xyzs=spec[1][:M], dirs=spec[2][:M], deltas=spec[3][:M], M=M)
+        return pre
     xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
     deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
