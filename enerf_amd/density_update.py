@@ -32,7 +32,7 @@ def _sigmas(model, xyzs):
 
 
 @torch.no_grad()
-def update(model, decay=0.95):
+def update(model, decay=0.95, split=False):
     """One update_extra_state: density grid EMA, bitfield, mean_density, mean_count, counters reset."""
     lib = L.lib()
     stream = L.stream_handle()
@@ -50,18 +50,43 @@ def update(model, decay=0.95):
     sigmas = _sigmas(model, xyzs).contiguous()
     stats = torch.empty(2, dtype=torch.float64, device=dev)
     total_step = min(16, int(model.local_step))
+    model.local_step = 0                       # renders queued from here on take slots 0.. of the restarted ring
     L.check(lib.enerf_density_grid_update(indices.data_ptr(), sigmas.data_ptr(), P // C, C, H,
                                           float(model.density_scale * 0.003383), float(decay),
                                           float(model.density_thresh), model.density_grid.data_ptr(),
                                           model.density_bitfield.data_ptr(), model.step_counter.data_ptr(), total_step,
                                           stats.data_ptr(), stream), "density_grid_update")
     _rm.BITFIELD_EPOCH[0] += 1                                        # the bitfield was rewritten behind torch's back
-    mean, counted = stats.tolist()                                    # the update's only host synchronisation
-    model.mean_density = mean
     model.iter_density += 1
+    if not split:
+        _finish(model, stats.tolist(), total_step)                    # the update's only host synchronisation
+        return None
+    # split: the 16 bytes travel to pinned memory behind the update's kernels; the caller queues whatever does not need
+    # them (the step's near/far and march count pass read the new bitfield, not the budget) and then calls update_end
+    host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+    host.copy_(stats, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return (done, host, stats, total_step)
+
+
+def _finish(model, values, total_step):
+    mean, counted = values
+    model.mean_density = mean
     if total_step > 0:
         model.mean_count = int(counted / total_step)
-    model.local_step = 0
+
+
+def update_begin(model, decay=0.95):
+    """update() up to its read-back: everything is queued, nothing is waited for.  -> handle for update_end."""
+    return update(model, decay, split=True)
+
+
+def update_end(model, handle):
+    """Wait for the update's 16 bytes and set mean_density / mean_count."""
+    done, host, _stats, total_step = handle
+    done.synchronize()
+    _finish(model, host.tolist(), total_step)
 
 
 @torch.no_grad()

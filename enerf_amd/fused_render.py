@@ -272,6 +272,50 @@ def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=10
     stash[key] = pre                                 # (an event step stashes both of its renders)
 
 
+def premarch_count(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024):
+    """near/far + the marcher's count pass and scan for the coming training render, on the current stream, before the
+    sample budget is known on the host: TrainHarness queues it between density_update.update_begin and update_end, so
+    the device has work while the host waits for the update's read-back (neither pass reads the budget: rays, counter
+    and chunk log do not depend on M).  The render picks the stage up and runs the write pass with the budget it then
+    has -- the same launches as march_rays_train_ex, in the same order."""
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    N, dev = rays_o.shape[0], rays_o.device
+    key = (rays_o.data_ptr(), rays_d.data_ptr(), N, bool(perturb), float(dt_gamma), int(max_steps))
+    nears = torch.empty(N, dtype=torch.float32, device=dev)
+    fars = torch.empty(N, dtype=torch.float32, device=dev)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    counter = _next_counter(model)
+    bufs = model._buffers
+    _rb.near_far_from_aabb(rays_o, rays_d, bufs["aabb_train"], N, model.min_near, nears, fars)
+    _rb.march_rays_train_count(rays_o, rays_d, bufs["density_bitfield"], model.bound, float(dt_gamma), int(max_steps), N,
+                               model.cascade, model.grid_size, nears, fars, rays, counter, bool(perturb),
+                               occupied_box_flag(model) | 8)
+    model._premarched = {key: dict(nears=nears, fars=fars, rays=rays, counter=counter,
+                                   counted=(rays_o, rays_d, bool(perturb), float(dt_gamma), int(max_steps)),
+                                   slot=getattr(model, "last_counter_slot", None))}
+
+
+def _finish_counted(model, pre):
+    """Write pass of a premarch_count stage, with the budget the host has by now (march_stage's budgeted branch)."""
+    rays_o, rays_d, perturb, dt_gamma, max_steps = pre.pop("counted")
+    mean_count = _budget(model)
+    N, dev = rays_o.shape[0], rays_o.device
+    if mean_count <= 0:                         # no budget after all (first window): the reference's crop of N * max_steps
+        m = int(pre["counter"][0].item())
+        M = min(m + (128 - m % 128), N * max_steps)
+    else:
+        M = mean_count + (128 - mean_count % 128)
+    xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    deltas = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    _rb.march_rays_train_write(rays_o, rays_d, model._buffers["density_bitfield"], model.bound, dt_gamma, max_steps, N,
+                               model.cascade, model.grid_size, M, pre["nears"], pre["fars"], xyzs, dirs, deltas,
+                               pre["rays"], pre["counter"], perturb, 1)
+    pre.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=M)
+    return pre
+
+
 def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_gamma, max_steps):
     """-> depth [N], image [N,3] (+ the step counter bookkeeping of run_cuda)."""
     pre = _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps)
@@ -297,6 +341,8 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
     if pre is None:
         stash.clear()                                # marched for rays that are not coming: drop, march afresh
         return None
+    if "counted" in pre:
+        return _finish_counted(model, pre)
     ready = pre.pop("ready", None)
     if ready is not None:                       # marched on a side stream, into buffers of this stream's pool (see
         torch.cuda.current_stream().wait_event(ready)      # march_stage): order this stream after it, nothing else

@@ -141,3 +141,16 @@ class NeRFRenderer(nn.Module):
             density_update.update(self, decay)
         else:
             density_update.update_torch(self, decay)
+
+    def update_extra_state_begin(self, decay=0.95):
+        """update_extra_state with its read-back left open: -> handle for update_extra_state_end, or None when the
+        update ran to the end (no device-side pass for this model).  In between the caller may queue whatever does not
+        read mean_density / mean_count."""
+        if self.cuda_ray and density_update.supported(self):
+            return density_update.update_begin(self, decay)
+        self.update_extra_state(decay)
+        return None
+
+    def update_extra_state_end(self, handle):
+        if handle is not None:
+            density_update.update_end(self, handle)

@@ -37,6 +37,7 @@ class TrainHarness:
         self.prefetch = True          # data parallel: march the next batch underneath the gradient all-reduce
         self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
         self.fuse_table_adam = True   # one GPU: the table gradient's tile sums feed Adam straight from LDS
+        self.overlap_update = True    # update steps: the render's count pass is queued before the update's read-back
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         enc = getattr(model, "encoder", None)
         table = getattr(enc, "embeddings", None)
@@ -66,13 +67,26 @@ class TrainHarness:
         if self.use_graphs:
             model.sample_budget_quantum = 8192
 
-    def maybe_update_extra_state(self):
+    def maybe_update_extra_state(self, coming_render=None):
+        """`coming_render` = (rays_o, rays_d) of the render this step starts with, when it will take the fused path with
+        default march settings: its near/far + count pass are queued before the update's read-back is waited for
+        (fused_render.premarch_count), so the device works while the host waits."""
         m = self.model
         if m.cuda_ray and self.global_step % self.update_interval == 0:
-            m.update_extra_state()
+            begin = getattr(m, "update_extra_state_begin", None)
+            if begin is None or coming_render is None or not self.overlap_update or self.use_graphs:
+                m.update_extra_state()
+                handle = None
+            else:
+                handle = begin()
             if self._syn is not None:
                 m.density_grid.copy_(self._syn[0])
                 m.density_bitfield.copy_(self._syn[1])
+            if handle is not None:
+                from . import fused_render
+                m._premarched = None                    # (anything marched against the old bitfield is void)
+                fused_render.premarch_count(m, *coming_render)
+                m.update_extra_state_end(handle)
             self._agree_on_budget()
 
     def _agree_on_budget(self):
@@ -532,7 +546,11 @@ class TrainHarness:
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
         if not self.model.training:                 # Module.train() walks every submodule: 40 us of a 900 us step
             self.model.train()
-        self.maybe_update_extra_state()
+        coming = None
+        if (self.global_step % self.update_interval == 0 and self.overlap_update and not render_kw and not self.fp16
+                and self._manual_ok(rays_o, rays_d, target, render_kw)):
+            coming = (rays_o, rays_d)
+        self.maybe_update_extra_state(coming)
         self.global_step += 1
         if self._graphable(rays_o, rays_d):
             m = self.model

@@ -604,3 +604,33 @@ def test_fused_event_loss_matches_autograd(use_luma, linlog):
     for got, want in ((g1, r1), (g2, r2)):
         assert torch.isfinite(got).all()
         assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-12
+
+
+def test_update_step_count_pass_queued_before_the_read_back_changes_nothing():
+    """TrainHarness.overlap_update: on steps that start with update_extra_state the render's near/far + count pass are
+    queued before the update's 16-byte read-back is waited for (density_update.update_begin / premarch_count /
+    update_end) and the write pass follows with the budget.  Same launches in the same order on the device as the plain
+    sequence: counters, budgets and bitfield must be identical over 40 steps (three updates, learned occupancy so that
+    the bitfield really changes), losses and parameters equal to run-to-run rounding."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 4096, 2)
+    runs = []
+    for overlap in (False, True):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="learned")
+        h.overlap_update = overlap
+        losses, budgets = [], []
+        for i in range(40):
+            nxt = data[(i + 1) % len(data)]
+            losses.append(h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1])).clone())
+            budgets.append(int(model.mean_count))
+        runs.append((torch.stack(losses).cpu(), model.step_counter.clone().cpu(), budgets, model.density_bitfield.clone(),
+                     {n: p.detach().clone() for n, p in model.named_parameters()}, int(model.local_step)))
+    (l0, c0, b0, f0, p0, s0), (l1, c1, b1, f1, p1, s1) = runs
+    assert b0 == b1 and s0 == s1 and torch.equal(c0, c1) and torch.equal(f0, f1)        # every integer state: exact
+    # (the float state is not bit-reproducible from run to run -- the smallest table levels are summed with atomics)
+    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 5e-4
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().mean()) <= 1e-3 * float(p0[n].abs().mean()), n
