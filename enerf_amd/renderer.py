@@ -31,7 +31,7 @@ class NeRFRenderer(nn.Module):
         super().__init__()
         self.bound, self.cuda_ray, self.bg_radius = bound, cuda_ray, bg_radius
         self.density_scale, self.density_thresh, self.min_near = density_scale, density_thresh, min_near
-        self.cascade = 1 + math.ceil(math.log2(bound))            # occupancy levels: cubes of half-width 1, 2, 4, ... >= bound
+        self.cascade = 1 + int(math.ceil(math.log2(bound)))       # occupancy levels: cubes of half-width 1, 2, 4, ... >= bound
         cube = torch.tensor([-bound] * 3 + [bound] * 3, dtype=torch.float32)
         self.register_buffer("aabb_train", cube)
         self.register_buffer("aabb_infer", cube.clone())
@@ -47,8 +47,8 @@ class NeRFRenderer(nn.Module):
 
     def reset_extra_state(self):
         if self.cuda_ray:
-            self.density_grid.zero_()
-            self.step_counter.zero_()
+            for state in (self.density_grid, self.step_counter):
+                state.zero_()
             self._zero_counters()
 
     # what a network provides
@@ -69,11 +69,11 @@ class NeRFRenderer(nn.Module):
             return self.run_cuda(rays_o, rays_d, **kwargs)
         if not staged:
             return self.run(rays_o, rays_d, **kwargs)
-        B, N = rays_o.shape[:2]
-        depth = torch.empty(B, N, device=rays_o.device)
-        image = torch.empty(B, N, self.out_dim_color, device=rays_o.device)
-        for b in range(B):
-            for a in range(0, N, max_ray_batch):
+        n_img, n_rays = rays_o.shape[0], rays_o.shape[1]
+        depth = torch.empty(n_img, n_rays, device=rays_o.device)
+        image = torch.empty(n_img, n_rays, self.out_dim_color, device=rays_o.device)
+        for b in range(n_img):
+            for a in range(0, n_rays, max_ray_batch):
                 part = self.run(rays_o[b:b + 1, a:a + max_ray_batch], rays_d[b:b + 1, a:a + max_ray_batch], **kwargs)
                 depth[b:b + 1, a:a + max_ray_batch] = part["depth"]
                 image[b:b + 1, a:a + max_ray_batch] = part["image"]
@@ -85,8 +85,7 @@ class NeRFRenderer(nn.Module):
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
                  **kwargs):
         lead = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
+        rays_o, rays_d = (t.contiguous().view(-1, 3) for t in (rays_o, rays_d))
         if self.bg_radius > 0:
             bg = self.background(raymarching.polar_from_ray(rays_o, rays_d, self.bg_radius), rays_d)
         else:
@@ -110,14 +109,14 @@ class NeRFRenderer(nn.Module):
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
         row = self.step_counter[self.local_step % 16]
         row.zero_()
-        self.local_step += 1
+        self.local_step = self.local_step + 1
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(
             rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, row,
             self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
-        sigmas, rgbs = self(xyzs, dirs)
+        sigmas, rgbs = self(xyzs, dirs)                # (the network's forward: density and colour of every sample)
         weights_sum, depth, image = raymarching.composite_rays_train(self.density_scale * sigmas, rgbs, deltas, rays)
         image = image + (1 - weights_sum).unsqueeze(-1) * bg
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        depth = (depth - nears).clamp_(min=0) / (fars - nears)
         return depth, image
 
     # ---------------------------------------------------------------------------------------- occupancy maintenance
