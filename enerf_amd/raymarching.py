@@ -29,7 +29,7 @@ class _near_far_from_aabb(Function):
         rays_o = _f32c(_dev(rays_o)).view(-1, 3)
         rays_d = _f32c(_dev(rays_d)).view(-1, 3)
         aabb = _f32c(_dev(aabb))
-        N = rays_o.shape[0]
+        N = len(rays_o)
         nears = torch.empty(N, dtype=torch.float32, device=rays_o.device)
         fars = torch.empty(N, dtype=torch.float32, device=rays_o.device)
         _backend.near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)
@@ -45,7 +45,7 @@ class _polar_from_ray(Function):
         """rays [N,3] x2 -> (theta, phi) in [-1,1]^2 on the background sphere   (raymarching.py:52-80)"""
         rays_o = _f32c(_dev(rays_o)).view(-1, 3)
         rays_d = _f32c(_dev(rays_d)).view(-1, 3)
-        N = rays_o.shape[0]
+        N = len(rays_o)
         coords = torch.empty(N, 2, dtype=torch.float32, device=rays_o.device)
         _backend.polar_from_ray(rays_o, rays_d, radius, N, coords)
         return coords
@@ -59,8 +59,8 @@ class _morton3D(Function):
     def forward(ctx, coords):
         """coords [N,3] int32 in [0,128) -> indices [N] int32   (raymarching.py:83-104)"""
         coords = _dev(coords).int().contiguous()
-        N = coords.shape[0]
-        indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+        N = len(coords)
+        indices = coords.new_empty(N)
         _backend.morton3D(coords, N, indices)
         return indices
 
@@ -73,8 +73,8 @@ class _morton3D_invert(Function):
     def forward(ctx, indices):
         """indices [N] -> coords [N,3] int32   (raymarching.py:106-126)"""
         indices = _dev(indices).int().contiguous()
-        N = indices.shape[0]
-        coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+        N = len(indices)
+        coords = indices.new_empty(N, 3)
         _backend.morton3D_invert(indices, N, coords)
         return coords
 
@@ -95,7 +95,7 @@ class _packbits(Function):
         C, H3 = grid.shape[0], grid.shape[1]
         N = C * H3 // 8
         if bitfield is None:
-            bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+            bitfield = grid.new_empty(N, dtype=torch.uint8)
         _backend.packbits(grid, N, thresh, bitfield)
         BITFIELD_EPOCH[0] += 1
         return bitfield
@@ -122,7 +122,7 @@ class _march_rays_train(Function):
         nears = _f32c(_dev(nears))
         fars = _f32c(_dev(fars))
 
-        N = rays_o.shape[0]
+        N = len(rays_o)
         M = N * max_steps
         if not force_all_rays and mean_count > 0:
             if align > 0:
@@ -176,8 +176,7 @@ class _composite_rays_train(Function):
         M, N = ctx.dims
         grad_weights_sum = _f32c(grad_weights_sum)
         grad_image = _f32c(grad_image)
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
+        grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
         _backend.composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum,
                                                image, M, N, grad_sigmas, grad_rgbs)
         return grad_sigmas, grad_rgbs, None, None
