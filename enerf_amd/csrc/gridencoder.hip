@@ -494,7 +494,7 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 // (tools/lds_atomic_rate.hip); the sums are rounded to fp32 once, when the tile is added into the table.  A level smaller than `min_tiles`
 // tiles keeps several replica lists per tile (filled by different workgroups, flushed with a few atomics) so that
 // its records do not pile up on one CU.  Everything that depends on the table geometry is derived from `offsets`
-// on the device.  Levels with more than kMaxBins lists (tables beyond 2^24 rows per level) stay with the atomic kernel.
+// on the device.  Levels with more than kMaxBins lists (tables beyond 2^20 rows per level) stay with the atomic kernel.
 // 64-KiB tiles (8192 fp64 accumulators), two tile workgroups per CU: against 128-KiB tiles with one workgroup per CU the
 // tile kernels gain ~8 % (finer-grained last round, two workgroups' phases interleave) at no cost to the binning pass
 #ifndef ENERF_TILE_ELEMS
@@ -503,7 +503,7 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 constexpr uint32_t kTileElems = ENERF_TILE_ELEMS;
 constexpr uint32_t kTileThreads = ENERF_TILE_ELEMS / 16;
 constexpr uint32_t kTilesPerCu = 16384 / ENERF_TILE_ELEMS;     // resident tile workgroups per CU
-constexpr uint32_t kMaxBins = 1024;          // record lists per level
+constexpr uint32_t kMaxBins = 256;           // record lists per level (256: the binning pass keeps 3 workgroups per CU)
 struct BinPlan {
     uint32_t tiles, replicas, bins;          // bins = tiles * replicas (0: level not binned)
 };
