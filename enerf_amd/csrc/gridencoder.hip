@@ -37,7 +37,7 @@ namespace {
 constexpr int kMaxLevels = 32;
 constexpr int kPtsPerBlock = 256;
 // points per workgroup of the backward's binning pass (its LDS staging area grows with PTS * 2^D * (1 + C))
-// measured at C = 2, 133 k samples: 256 -> 66 us, 512 -> 61 us, 1024 -> 79 us
+// measured at C = 2, 133 k samples: 256 -> 66 us, 512 -> 61 us, 1024 -> 79 us (round 2, three workgroups per CU: 384 -> +9 us)
 constexpr int bin_pts(int C) { return C <= 4 ? 512 : 256; }
 
 struct LevelTab {
