@@ -45,6 +45,8 @@ SIGNATURES = {
                                   _int, _f32, _f32, _vp],
     "enerf_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp,
                                    _u32, _int, _int, _f32, _f32, _vp],
+    "enerf_grid_encode_forward_sweep": [_vp, _vp, _vp, _u32, _u32, _f32, ctypes.c_uint64, _u32, _u32, _f32, _u32, _u32, _int, _f32,
+                                        _f32, _vp],
     "enerf_grid_encode_backward_ex": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _int, _vp, _vp,
                                    _u32, _int, _int, _f32, _f32, _u32, _u32, _vp],
     "enerf_grid_records_discard": [_vp],

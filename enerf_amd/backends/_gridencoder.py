@@ -55,3 +55,17 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
                                                   int(gridtype), dt, int(layout), affine[0], affine[1],
                                                   1 if defer else 0, int(reserve), L.stream_handle()),
             "grid_encode_backward")
+
+
+def grid_encode_forward_sweep(embeddings, offsets, outputs, n_cascades, grid_size, bound, seed, C, L_, S, H, gridtype,
+                              layout, affine):
+    """grid_encode_forward over a full density-grid sweep's query points, generated inside the kernel
+    (include/enerf_hip.h: enerf_grid_encode_forward_sweep).  fp32 tables, D = 3."""
+    import ctypes
+    B = int(n_cascades) * int(grid_size) ** 3
+    STATS["fwd_points"] += B
+    STATS["fwd_calls"] += 1
+    L.check(L.lib().enerf_grid_encode_forward_sweep(
+        embeddings.data_ptr(), offsets.data_ptr(), outputs.data_ptr(), int(n_cascades), int(grid_size), float(bound),
+        ctypes.c_uint64(int(seed)), int(C), int(L_), float(S), int(H), int(gridtype), int(layout), float(affine[0]),
+        float(affine[1]), L.stream_handle()), "grid_encode_forward_sweep")

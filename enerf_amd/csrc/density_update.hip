@@ -17,21 +17,13 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "sweep_points.h"
 
 using namespace enerf;
 
 namespace {
 
-__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-__device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
-    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
-}
+__device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) { return sweep_morton3(x, y, z); }
 __device__ __forceinline__ uint32_t compact_bits(uint32_t x) {
     x = x & 0x49249249;
     x = (x | (x >> 2)) & 0xc30c30c3;
@@ -39,37 +31,6 @@ __device__ __forceinline__ uint32_t compact_bits(uint32_t x) {
     x = (x | (x >> 8)) & 0xff0000ff;
     x = (x | (x >> 16)) & 0x0000ffff;
     return x;
-}
-
-// counter-based generator: four independent 32-bit words per (seed, counter) -- splitmix64 finaliser, two rounds
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-    return z ^ (z >> 31);
-}
-struct Rand4 {
-    uint32_t w[4];
-};
-__device__ __forceinline__ Rand4 rand4(uint64_t seed, uint64_t counter) {
-    const uint64_t a = mix64(seed + 0x9e3779b97f4a7c15ULL * (2 * counter + 1));
-    const uint64_t b = mix64(a + 0x9e3779b97f4a7c15ULL * (2 * counter + 2) + seed);
-    return Rand4{{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)}};
-}
-__device__ __forceinline__ float unit_float(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }   // [0, 1)
-
-struct Cascades {
-    float span[8];      // bound_c - half_grid_size
-    float half[8];      // half_grid_size = bound_c / H
-};
-
-// query position of cell (x, y, z) of cascade `cas`: 2 * c / (H - 1) - 1, scaled to the cascade, jittered inside the cell
-__device__ __forceinline__ void cell_position(const Cascades& cs, uint32_t cas, uint32_t H, uint32_t x, uint32_t y,
-                                              uint32_t z, const Rand4& r, float* out) {
-    const float inv = 1.0f / (float)(H - 1);
-    const float span = cs.span[cas], half = cs.half[cas];
-    out[0] = (2.0f * (float)x * inv - 1.0f) * span + (unit_float(r.w[0]) * 2.0f - 1.0f) * half;
-    out[1] = (2.0f * (float)y * inv - 1.0f) * span + (unit_float(r.w[1]) * 2.0f - 1.0f) * half;
-    out[2] = (2.0f * (float)z * inv - 1.0f) * span + (unit_float(r.w[2]) * 2.0f - 1.0f) * half;
 }
 
 // ---- full sweep: thread per (cascade, cell), x fastest so that consecutive query points are x-neighbours
@@ -185,13 +146,21 @@ __global__ void __launch_bounds__(256) k_cells_from_keys(Cascades cs, uint32_t P
 }
 
 // ---- update: scatter, EMA + mean, packbits
+// indices == nullptr: the points are those of the full sweep in its own order (sweep_points.h): cell from p
 __global__ void __launch_bounds__(256) k_tmp_scatter(const int32_t* __restrict__ indices, const float* __restrict__ sigmas,
                                                      uint32_t n_per_cas, uint32_t P, uint32_t H3, float scale,
-                                                     float* __restrict__ tmp) {
+                                                     float* __restrict__ tmp, uint32_t H, uint32_t logH) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const uint32_t cas = p / n_per_cas;
-    tmp[(size_t)cas * H3 + (uint32_t)indices[p]] = sigmas[p] * scale;       // duplicates: some writer wins, as in torch
+    uint32_t idx;
+    if (indices) {
+        idx = (uint32_t)indices[p];
+    } else {
+        const uint32_t cell = p - cas * n_per_cas;
+        idx = morton3(cell & (H - 1), (cell >> logH) & (H - 1), cell >> (2 * logH));
+    }
+    tmp[(size_t)cas * H3 + idx] = sigmas[p] * scale;                        // duplicates: some writer wins, as in torch
 }
 
 __device__ __forceinline__ float ema1(float g, float t, float decay, float& acc) {
@@ -271,18 +240,6 @@ __global__ void __launch_bounds__(256) k_mark_untrained(const float* __restrict_
 }
 
 bool grid_shape_ok(uint32_t C, uint32_t H) { return C >= 1 && C <= 8 && H >= 16 && H <= 512 && (H & (H - 1)) == 0; }
-
-Cascades make_cascades(uint32_t C, uint32_t H, float bound) {
-    Cascades cs;
-    for (uint32_t c = 0; c < 8; c++) {
-        // renderer.py:498-501  bound = min(2 ** cas, self.bound); half_grid_size = bound / self.grid_size
-        const double b = fmin((double)(1u << c), (double)bound);
-        const double half = b / (double)H;
-        cs.span[c] = c < C ? (float)(b - half) : 0.0f;
-        cs.half[c] = c < C ? (float)half : 0.0f;
-    }
-    return cs;
-}
 
 uint32_t log2u(uint32_t v) {
     uint32_t l = 0;
@@ -371,7 +328,8 @@ int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint3
     if (!e) e = check_hip(hipMemsetAsync(tmp, 0xFF, cells * 4, s), "density_grid_update: memset");   // NaN: "not evaluated"
     if (e) return e;
     const uint32_t P = n_per_cascade * C;
-    if (P) k_tmp_scatter<<<div_up(P, 256), 256, 0, s>>>(indices, sigmas, n_per_cascade, P, H3, sigma_scale, tmp);
+    if (!indices && n_per_cascade != H3) ENERF_BADARG("density_grid_update: indices may be NULL for a full sweep only");
+    if (P) k_tmp_scatter<<<div_up(P, 256), 256, 0, s>>>(indices, sigmas, n_per_cascade, P, H3, sigma_scale, tmp, H, log2u(H));
     k_ema_mean<<<2048, 256, 0, s>>>(density_grid, tmp, (uint32_t)(cells / 4), decay, sum);
     const uint32_t nbytes = (uint32_t)(cells / 8);
     k_packbits_mean<<<div_up(nbytes, 256), 256, 0, s>>>(density_grid, nbytes, sum, 1.0 / (double)cells, density_thresh,

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "sweep_points.h"
 
 using namespace enerf;
 
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
                                                            const int32_t* __restrict__ offsets, T* __restrict__ outputs,
                                                            uint32_t B, uint32_t L, LevelTab tab, bool calc_grad_inputs,
                                                            T* __restrict__ dy_dx, uint32_t gridtype, int out_layout,
-                                                           uint32_t nchunks) {
+                                                           uint32_t nchunks, SweepGen gen) {
     uint32_t level, chunk;
     if (!decode_block_fwd(nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
@@ -234,9 +235,21 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
 
     float in[D];
     bool oob = false;
+    float raw[D];
+    if (D == 3 && gen.enabled) {
+        // a full density-grid sweep: point b is generated (sweep_points.h), there is no input array -- every level's
+        // workgroups would otherwise read the same 12 bytes per point again
+        float q[3];
+        sweep_point(gen, b, q);
+#pragma unroll
+        for (int d = 0; d < D; d++) raw[d] = q[d < 3 ? d : 0];
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; d++) raw[d] = inputs[(size_t)b * D + d];
+    }
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        in[d] = (inputs[(size_t)b * D + d] + tab.in_add) * tab.in_mul;
+        in[d] = (raw[d] + tab.in_add) * tab.in_mul;
         oob |= (in[d] < 0 || in[d] > 1);
     }
     Feat<T, C>* out = reinterpret_cast<Feat<T, C>*>(outputs) +
@@ -1001,7 +1014,7 @@ __global__ void k_prof_mark() {}
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
                const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s,
-               hipEvent_t ev_start, hipEvent_t ev_stop) {
+               hipEvent_t ev_start, hipEvent_t ev_stop, const SweepGen& gen = SweepGen{}) {
     const uint32_t nchunks = div_up(layout == 2 ? ((B + 31u) & ~31u) : B, kPtsPerBlock);
     const uint32_t nblocks = fwd_blocks(nchunks, L);
 #define ENERF_GF(CC)                                                                                               \
@@ -1013,11 +1026,11 @@ int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* out
             hipExtLaunchKernelGGL(k_prof_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);                     \
             hipExtLaunchKernelGGL((k_grid_fwd<T, D, CC>), dim3(nblocks), dim3(kPtsPerBlock), 0, s, nullptr,        \
                                   ev_stop, 0, inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, gridtype,     \
-                                  layout, nchunks);                                                                \
+                                  layout, nchunks, gen);                                                                \
         }                                                                                                          \
         else                                                                                                       \
             k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc,  \
-                                                                  dy_dx, gridtype, layout, nchunks);               \
+                                                                  dy_dx, gridtype, layout, nchunks, gen);               \
     } while (0)
     switch (C) {
         case 1: ENERF_GF(1); break;
@@ -1157,6 +1170,32 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
     }
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("grid_encode_forward");
+    return 0;
+}
+
+int enerf_grid_encode_forward_sweep(const void* embeddings, const int32_t* offsets, void* outputs, uint32_t n_cascades,
+                                    uint32_t grid_size, float bound, uint64_t seed, uint32_t C, uint32_t L, float S,
+                                    uint32_t H, uint32_t gridtype, int out_layout, float in_add, float in_mul,
+                                    enerf_stream_t stream) {
+    if (n_cascades < 1 || n_cascades > 8 || grid_size < 16 || grid_size > 512 || (grid_size & (grid_size - 1)) != 0)
+        ENERF_BADARG("grid_encode_forward_sweep: cascades=%u grid_size=%u", n_cascades, grid_size);
+    LevelTab tab;
+    if (fill_level_tab(tab, L, S, H, in_add, in_mul)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
+    if (out_layout < 0 || out_layout > 2) ENERF_BADARG("GridEncoding: out_layout must be 0, 1 or 2, got %d", out_layout);
+    SweepGen gen;
+    gen.cs = make_cascades(n_cascades, grid_size, bound);
+    gen.seed = seed;
+    gen.H = grid_size;
+    gen.logH = 0;
+    while ((1u << gen.logH) < grid_size) gen.logH++;
+    gen.enabled = 1;
+    const uint32_t B = n_cascades << (3 * gen.logH);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(ENERF_K_GRID_FWD, s, true);
+    const int rc = launch_fwd<float, 3>(nullptr, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, false,
+                                        (float*)nullptr, gridtype, out_layout, s, prof.start(), prof.stop(), gen);
+    if (rc) return rc;
+    ENERF_LAUNCH_CHECK("grid_encode_forward_sweep");
     return 0;
 }
 

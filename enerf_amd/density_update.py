@@ -10,6 +10,7 @@ from . import fused_network
 from . import raymarching as _rm
 
 ENABLED = True
+SWEEP_IN_KERNEL = True     # full sweeps: query points generated inside the grid kernel (False: written out first)
 _GOLDEN = 0x9E3779B97F4A7C15
 _CHUNK = 1 << 21          # density() batch for networks outside the fused fp32 path
 
@@ -41,17 +42,24 @@ def update(model, decay=0.95, split=False):
     full = model.iter_density < 16                                    # renderer.py:484
     N = H ** 3 // 4                                                   # renderer.py:515
     P = C * H ** 3 if full else C * 2 * N
-    indices = torch.empty(P, dtype=torch.int32, device=dev)
-    xyzs = torch.empty(P, 3, dtype=torch.float32, device=dev)
     seed = ((torch.initial_seed() + 1) * _GOLDEN + int(model.iter_density) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
-    L.check(lib.enerf_density_grid_cells(None if full else model.density_grid.data_ptr(), C, H, float(model.bound), N,
-                                         ctypes.c_uint64(seed), indices.data_ptr(), xyzs.data_ptr(), stream),
-            "density_grid_cells")
-    sigmas = _sigmas(model, xyzs).contiguous()
+    probe = model.density_grid.new_empty(1, 3)
+    if full and SWEEP_IN_KERNEL and fused_network.supported(model, probe, probe):
+        # full sweep through the fused fp32 network: the grid kernel generates the query points itself (the same points
+        # enerf_density_grid_cells would write: csrc/sweep_points.h), the update takes them in the sweep's own order
+        indices = None
+        sigmas = fused_network.density_sigma_sweep(model, C, H, seed)
+    else:
+        indices = torch.empty(P, dtype=torch.int32, device=dev)
+        xyzs = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        L.check(lib.enerf_density_grid_cells(None if full else model.density_grid.data_ptr(), C, H, float(model.bound), N,
+                                             ctypes.c_uint64(seed), indices.data_ptr(), xyzs.data_ptr(), stream),
+                "density_grid_cells")
+        sigmas = _sigmas(model, xyzs).contiguous()
     stats = torch.empty(2, dtype=torch.float64, device=dev)
     total_step = min(16, int(model.local_step))
     model.local_step = 0                       # renders queued from here on take slots 0.. of the restarted ring
-    L.check(lib.enerf_density_grid_update(indices.data_ptr(), sigmas.data_ptr(), P // C, C, H,
+    L.check(lib.enerf_density_grid_update(None if indices is None else indices.data_ptr(), sigmas.data_ptr(), P // C, C, H,
                                           float(model.density_scale * 0.003383), float(decay),
                                           float(model.density_thresh), model.density_grid.data_ptr(),
                                           model.density_bitfield.data_ptr(), model.step_counter.data_ptr(), total_step,

@@ -260,6 +260,26 @@ def forward_into(net, x, d, sigma_out, rgb_out):
     nerf_forward(x, d, network_cfg(net), False, params[0], encoder_offsets(net), *params[1:], out=(sigma_out, rgb_out))
 
 
+def density_sigma_sweep(net, n_cascades, grid_size, seed):
+    """density_sigma at the query points of a full density-grid sweep (one jittered point per cell of every cascade,
+    x fastest: csrc/sweep_points.h), which the grid kernel generates itself -- no position array is written or read.
+    -> sigma [n_cascades * grid_size^3], in the sweep's order."""
+    enc = net.encoder
+    B = int(n_cascades) * int(grid_size) ** 3
+    dev = enc.embeddings.device
+    sigma = torch.empty(B, dtype=torch.float32, device=dev)
+    Bp = pad32(B)
+    S = float(np.log2(enc.per_level_scale))
+    feats = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
+    _gb.grid_encode_forward_sweep(enc.embeddings.detach().contiguous(), enc.offsets, feats, n_cascades, grid_size,
+                                  net.bound, seed, 2, 16, S, enc.base_resolution, enc.gridtype_id, 2,
+                                  (float(net.bound), float(np.float32(1.0) / np.float32(2 * net.bound))))
+    seg = _segments(net.sigma_net[0].weight, None, None, net.sigma_net[1].weight)
+    L.check(L.lib().enerf_mlp32_forward_p(feats.data_ptr(), seg, 32, 0, B, 32, 16, 1, 0, 6, None, None, 1, 0,
+                                          sigma.data_ptr(), None, L.stream_handle()), "mlp32_forward_p(sigma only)")
+    return sigma
+
+
 def density_sigma(net, x):
     """sigma [N] only (no geo_feat, no autograd): what update_extra_state needs from density() for its 2 M cell
     samples per cascade -- the sigma MLP writes exp(column 0) and nothing else."""

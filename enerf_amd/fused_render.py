@@ -59,6 +59,22 @@ def occupied_box_flag(model):
     return 4
 
 
+class _Stage(dict):
+    """A march stage's buffers.  When its kernels were issued on a launch stream, the buffers (allocated from the
+    consumer stream's pool, see march_stage) must not be recycled before that stream is done with them: a stage that
+    is consumed hands its "ready" event to the consumer, which waits for it; one that is dropped unconsumed -- the
+    rays never came, the bitfield changed, the model was deleted -- makes the current stream wait here, before its
+    tensors go back to the pool."""
+
+    def __del__(self):
+        ready = self.get("ready")
+        if ready is not None:
+            try:
+                torch.cuda.current_stream().wait_event(ready)
+            except Exception:           # interpreter shutdown
+                pass
+
+
 def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_rays, dt_gamma, max_steps,
                 background=False, defer=False, launch_stream=None, after_signal=False):
     """near_far_from_aabb + march_rays_train: everything of a training render that does not read the parameters.
@@ -104,7 +120,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
             deltas = torch.empty(spec_rows, 2, dtype=torch.float32, device=dev)
     bufs = model._buffers                            # (nn.Module.__getattr__ is a slow path)
     bitfield = bufs["density_bitfield"]
-    pre = dict(nears=nears, fars=fars, rays=rays, counter=counter)
+    pre = _Stage(nears=nears, fars=fars, rays=rays, counter=counter)
     box = occupied_box_flag(model)
     if launch_stream is not None:
         if after_signal == "ordered":

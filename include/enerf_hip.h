@@ -106,7 +106,7 @@ int enerf_mark_untrained_grid(const float* poses, uint32_t n_poses, uint32_t pos
  * mean = mean(clamp(density_grid, 0)); bitfield = packbits(density_grid, min(mean, density_thresh)).
  * stats (device, 2 doubles) receives {mean, sum of step_counter[0:total_step][0]} -- the one read-back of the update
  * (mean_density, mean_count).  step_counter: int32 [16,2] (may be NULL when total_step == 0). */
-int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint32_t n_per_cascade, uint32_t C, uint32_t H,
+int enerf_density_grid_update(const int32_t* indices /* NULL: the full sweep's own order */, const float* sigmas, uint32_t n_per_cascade, uint32_t C, uint32_t H,
                               float sigma_scale, float decay, float density_thresh, float* density_grid,
                               uint8_t* bitfield, const int32_t* step_counter, uint32_t total_step, double* stats,
                               enerf_stream_t stream);
@@ -283,6 +283,16 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
                                uint32_t H, int calc_grad_inputs, const void* dy_dx, void* grad_inputs,
                                uint32_t gridtype, int dtype, int grad_layout, float in_add, float in_mul,
                                enerf_stream_t stream);
+
+/* grid_encode_forward over the query points of a full density-grid sweep (NeRFRenderer.update_extra_state,
+ * nerf/renderer.py:484-512: one uniformly drawn point inside every cell of every cascade, x fastest) WITHOUT an input
+ * array: point b = (cascade b / grid_size^3, cell b % grid_size^3) is generated inside the kernel from `seed` -- the
+ * same points, bit for bit, as enerf_density_grid_cells(density_grid = NULL, ..., seed) writes out (csrc/sweep_points.h).
+ * fp32 tables, D = 3; outputs as enerf_grid_encode_forward with B = n_cascades * grid_size^3. */
+int enerf_grid_encode_forward_sweep(const void* embeddings, const int32_t* offsets, void* outputs, uint32_t n_cascades,
+                                    uint32_t grid_size, float bound, uint64_t seed, uint32_t C, uint32_t L, float S,
+                                    uint32_t H, uint32_t gridtype, int out_layout, float in_add, float in_mul,
+                                    enerf_stream_t stream);
 
 /* Deferred flush: the table gradient's only consumer in training is the optimizer (main_nerf.py:211, Adam), which streams
  * over the whole table anyway.  With flags bit 0 set, enerf_grid_encode_backward_ex leaves the binned levels' record

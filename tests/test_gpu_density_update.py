@@ -206,3 +206,51 @@ def test_mark_untrained_grid_native_vs_oracle_and_torch_route(monkeypatch):
     assert 0.02 < frac < 0.98                                   # the cameras see part of the volume, not all of it
     assert np.mean((grids[0] == -1) != want) < 2e-4
     assert np.mean((grids[0] == -1) != (grids[1] == -1)) < 2e-4
+
+
+@pytest.mark.gpu
+def test_sweep_points_generated_inside_the_grid_kernel_equal_the_written_ones():
+    """enerf_grid_encode_forward_sweep (query points generated in the kernel, csrc/sweep_points.h) against
+    enerf_density_grid_cells + enerf_grid_encode_forward on the same seed: bit-identical features, and the whole update
+    (density grid, bitfield, budget) identical with density_update.SWEEP_IN_KERNEL on and off."""
+    import ctypes
+    import numpy as np
+    from enerf_amd import _lib as L, density_update, fused_network
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.backends import _gridencoder as gb
+    torch.manual_seed(3)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).cuda()
+    enc = model.encoder
+    C, H = int(model.cascade), int(model.grid_size)
+    P, seed = C * H ** 3, 0x1234567890ABCDEF
+    idx = torch.empty(P, dtype=torch.int32, device="cuda")
+    xyz = torch.empty(P, 3, dtype=torch.float32, device="cuda")
+    L.check(L.lib().enerf_density_grid_cells(None, C, H, float(model.bound), H ** 3 // 4, ctypes.c_uint64(seed),
+                                             idx.data_ptr(), xyz.data_ptr(), L.stream_handle()), "cells")
+    S = float(np.log2(enc.per_level_scale))
+    aff = (float(model.bound), float(np.float32(1.0) / np.float32(2 * model.bound)))
+    Pp = (P + 31) // 32 * 32
+    a = torch.zeros(16, Pp, 2, device="cuda")
+    gb.grid_encode_forward(xyz, enc.embeddings.detach(), enc.offsets, a, P, 3, 2, 16, S, enc.base_resolution, False, a,
+                           enc.gridtype_id, layout=2, affine=aff)
+    b = torch.zeros(16, Pp, 2, device="cuda")
+    L.check(L.lib().enerf_grid_encode_forward_sweep(enc.embeddings.detach().data_ptr(), enc.offsets.data_ptr(),
+                                                    b.data_ptr(), C, H, float(model.bound), ctypes.c_uint64(seed), 2, 16, S,
+                                                    int(enc.base_resolution), int(enc.gridtype_id), 2, aff[0], aff[1],
+                                                    L.stream_handle()), "sweep")
+    assert torch.equal(a, b)
+    states = []
+    for in_kernel in (False, True):
+        torch.manual_seed(3)
+        m = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).cuda()
+        m.local_step = 5
+        m.step_counter[:5, 0] = torch.tensor([100, 200, 300, 400, 500], dtype=torch.int32)
+        density_update.SWEEP_IN_KERNEL = in_kernel
+        try:
+            m.update_extra_state()
+            m.update_extra_state()
+        finally:
+            density_update.SWEEP_IN_KERNEL = True
+        states.append((m.density_grid.clone(), m.density_bitfield.clone(), m.mean_density, m.mean_count))
+    assert torch.equal(states[0][0], states[1][0]) and torch.equal(states[0][1], states[1][1])
+    assert states[0][2:] == states[1][2:]
