@@ -126,8 +126,39 @@ def lib():
         l.enerf_last_error.argtypes = []
         l.enerf_workspace_generation.restype = _c.c_uint64
         l.enerf_workspace_generation.argtypes = []
+        if os.environ.get("ENERF_TRACE_CALLS"):
+            l = _TracedLib(l, os.environ["ENERF_TRACE_CALLS"])
         _lib = l
     return _lib
+
+
+class _TracedLib:
+    """Debugging aid (ENERF_TRACE_CALLS=<file>): every entry point writes its name to the file before it runs and the
+    device is drained after it, so that after a memory access fault (which aborts the process) the file names the call
+    whose kernels faulted."""
+
+    def __init__(self, inner, path):
+        self._inner = inner
+        self._fd = os.open(path, os.O_CREAT | os.O_WRONLY | os.O_TRUNC, 0o644)
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._inner, name)
+            if not name.startswith("enerf_") or name in ("enerf_last_error", "enerf_workspace_generation"):
+                return raw
+            tag = (name + " " * 80)[:80].encode()
+
+            def fn(*a, _raw=raw, _tag=tag):
+                import torch
+                os.pwrite(self._fd, _tag, 0)
+                rc = _raw(*a)
+                torch.cuda.synchronize()
+                os.pwrite(self._fd, (b"done " + _tag)[:80], 0)
+                return rc
+            self._cache[name] = fn
+        return fn
 
 
 def check(rc, what):
