@@ -52,6 +52,7 @@ SIGNATURES = {
     "enerf_grid_records_discard": [_vp],
     "enerf_mlp32_signal_next_reduce": [_int],
     "enerf_stream_wait_mlp32_signal": [_vp],
+    "enerf_debug_workspace_ordering": [_int],
     "enerf_mlp32_valid_rows": [_vp],
     "enerf_grid_adam_from_records_ex": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp],

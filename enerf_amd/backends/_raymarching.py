@@ -6,41 +6,6 @@ from .. import _lib as L
 STATS = {"infer_samples": 0, "infer_calls": 0}
 
 
-# The marcher's scratch (chunk log, scan tiles, compaction counters, occupied box) is one set of library workspaces per
-# device.  A stage issued ahead on a side stream (fused_render.march_stage) may still be running when another stream --
-# an evaluation render between two training steps, a cold-window write pass -- launches marcher kernels of its own: that
-# stream first waits for the side stage's event.  (Without it: a corrupted chunk log, replayed by the write pass into
-# out-of-bounds rows -- a memory access fault once in a few hundred trainings.)
-_SIDE_STAGE = {}         # device index -> [launch stream handle, event, handles of the streams that have waited]
-
-
-def note_side_stage(stream, event):
-    import torch
-    _SIDE_STAGE[torch.cuda.current_device()] = [stream.cuda_stream, event, set()]
-
-
-def side_stage_waited(stream_handle, event):
-    """`stream_handle` has been made to wait for `event`: if that is the latest side stage's, it need not wait again."""
-    import torch
-    ent = _SIDE_STAGE.get(torch.cuda.current_device())
-    if ent is not None and ent[1] is event:
-        ent[2].add(stream_handle)
-
-
-def _after_side_stage():
-    if not _SIDE_STAGE:
-        return
-    import torch
-    ent = _SIDE_STAGE.get(torch.cuda.current_device())
-    if ent is None:
-        return
-    cur = torch.cuda.current_stream()
-    h = cur.cuda_stream
-    if h != ent[0] and h not in ent[2]:
-        cur.wait_event(ent[1])
-        ent[2].add(h)
-
-
 def _f32(t, name):
     import torch
     L.check_cuda(t, name)
@@ -95,7 +60,6 @@ def packbits(grid, N, density_thresh, bitfield):
 
 def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                      rays, counter, perturb):
-    _after_side_stage()
     L.check(L.lib().enerf_march_rays_train(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
                                            float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
                                            int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
@@ -107,7 +71,6 @@ def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, 
 def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                         rays, counter, perturb, zero_unwritten):
     """march_rays_train into possibly uninitialised xyzs / dirs / deltas (include/enerf_hip.h)."""
-    _after_side_stage()
     L.check(L.lib().enerf_march_rays_train_ex(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
                                               float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
                                               int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
@@ -118,7 +81,6 @@ def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, 
 
 def occupied_box_update(grid, C, H, bound):
     """(Re)compute the library's bounding box of the occupied cells of `grid` (include/enerf_hip.h)."""
-    _after_side_stage()
     L.check(L.lib().enerf_occupied_box_update(_u8(grid, "grid"), int(C), int(H), float(bound), L.stream_handle()),
             "occupied_box_update")
 
@@ -126,7 +88,6 @@ def occupied_box_update(grid, C, H, bound):
 def march_rays_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter, perturb,
                            flags=0):
     """Count + scan half of march_rays_train: fills rays / counter, writes no samples (include/enerf_hip.h)."""
-    _after_side_stage()
     L.check(L.lib().enerf_march_rays_train_count(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
                                                  float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
                                                  _f32(nears, "nears"), _f32(fars, "fars"), _i32(rays, "rays"),
@@ -137,7 +98,6 @@ def march_rays_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, 
 def march_rays_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                            rays, counter, perturb, zero_unwritten):
     """Write half of march_rays_train for the batch last counted (include/enerf_hip.h)."""
-    _after_side_stage()
     L.check(L.lib().enerf_march_rays_train_write(_f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _u8(grid, "grid"),
                                                  float(bound), float(dt_gamma), int(max_steps), int(N), int(C), int(H),
                                                  int(M), _f32(nears, "nears"), _f32(fars, "fars"), _f32(xyzs, "xyzs"),
@@ -225,7 +185,6 @@ def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, de
 def march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
                   fars, xyzs, dirs, deltas, perturb):
     """march_rays into uninitialised buffers: unfilled slots and alignment rows are zeroed by the kernel."""
-    _after_side_stage()
     STATS["infer_samples"] += int(n_alive) * int(n_step)
     STATS["infer_calls"] += 1
     L.check(L.lib().enerf_march_rays_ex(int(n_alive), int(n_step), _i32(rays_alive, "rays_alive"),
@@ -238,7 +197,6 @@ def march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt
 
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
                fars, xyzs, dirs, deltas, perturb):
-    _after_side_stage()
     STATS["infer_samples"] += int(n_alive) * int(n_step)
     STATS["infer_calls"] += 1
     L.check(L.lib().enerf_march_rays(int(n_alive), int(n_step), _i32(rays_alive, "rays_alive"),
@@ -258,7 +216,6 @@ def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, we
 
 
 def compact_rays(n_alive, rays_alive, rays_alive_old, rays_t, rays_t_old, alive_counter):
-    _after_side_stage()
     L.check(L.lib().enerf_compact_rays(int(n_alive), _i32(rays_alive, "rays_alive"),
                                        _i32(rays_alive_old, "rays_alive_old"), _f32(rays_t, "rays_t"),
                                        _f32(rays_t_old, "rays_t_old"), _i32(alive_counter, "alive_counter"),

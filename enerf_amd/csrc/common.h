@@ -52,6 +52,11 @@ struct ProfScope {
 void* workspace(int slot, size_t bytes);
 uint64_t workspace_generation();    // bumped whenever a slot is re-allocated (its old pointer dies)
 uint32_t num_cus();                    // compute units of the current device (256 when it cannot be asked)
+// The workspaces of one kernel family are shared by every stream of the device.  An entry point that is about to use
+// them on stream `s` calls this first: if the family's previous user was another stream, `s` is made to wait for
+// everything queued on that stream so far (an event recorded there now).  Costs nothing while one stream keeps the
+// family to itself.  `family`: 0 = the marcher (chunk log, scan tiles, compaction counters, occupied box).
+int workspace_family_enter(int family, hipStream_t s);
 enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_AABB = 7, WS_SLOTS = 8 };
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }

@@ -278,6 +278,7 @@ int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, 
     const size_t o_counts = 0, o_cas = o_counts + align256((size_t)nblocks * 4), o_list = o_cas + 256,
                  o_keys = o_list + align256((size_t)C * H3 * 4), o_sorted = o_keys + align256((size_t)P * 4),
                  o_sort = o_sorted + align256((size_t)P * 4), total = o_sort + align256(sort_bytes);
+    if (int ew = workspace_family_enter(1, s)) return ew;
     char* ws = (char*)workspace(WS_DENSITY, total);
     if (!ws) return ENERF_E_NOMEM;
     uint32_t* block_counts = (uint32_t*)(ws + o_counts);
@@ -320,6 +321,7 @@ int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint3
     hipStream_t s = (hipStream_t)stream;
     const uint32_t H3 = H * H * H;
     const size_t cells = (size_t)C * H3;
+    if (int ew = workspace_family_enter(1, s)) return ew;
     char* ws = (char*)workspace(WS_DENSITY, 256 + cells * 4);
     if (!ws) return ENERF_E_NOMEM;
     double* sum = (double*)ws;

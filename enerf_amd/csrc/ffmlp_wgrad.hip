@@ -189,6 +189,7 @@ int ffmlp_wgrad_launch(int dtype, const void* dY, const void* X, const void* fb,
     const uint32_t NWn = HID * (input_dim + HID * (num_layers - 1) + OUT);
     uint32_t wgrid = div_up(B / 32, 4);
     if (wgrid > 256u) wgrid = 256u;
+    if (int ew = enerf::workspace_family_enter(1, s)) return ew;
     float* partial = (float*)workspace(WS_FFMLP, sizeof(float) * (size_t)wgrid * NWn);
     if (!partial) return ENERF_E_NOMEM;
     if (dtype == ENERF_BF16) {

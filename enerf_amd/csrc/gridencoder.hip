@@ -1085,6 +1085,7 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
         region = g_pending.region;                    // later calls of the session append to the same lists
     }
     if (binned) {
+        if (int ew = workspace_family_enter(1, s)) return ew;
         recs = (uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C));
         cursors = bin_cursors();
         overflow = overflow_counter();
@@ -1280,6 +1281,7 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
     if (!cursors || !overflow) return ENERF_E_NOMEM;
     uint32_t* other = g_overflow + ((g_session + 1u) & 1u);
     const uint32_t region = g_pending.region;
+    if (int ew = workspace_family_enter(1, s)) return ew;
     const uint32_t* recs = region ? (const uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C))
                                   : nullptr;
     const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;

@@ -1260,6 +1260,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     // call's reduce launch
     const bool defer = g_defer_next && !g_have_pending;
     g_defer_next = false;
+    if (int ew = workspace_family_enter(1, s)) return ew;
     float* partial = (float*)workspace(defer ? WS_MLP32_DEFER : WS_FFMLP,
                                        part_bytes + (fused_dy ? sizeof(float) * (size_t)B * out_dim : 0));
     if (!partial) return ENERF_E_NOMEM;

@@ -1585,6 +1585,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                              const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
                              bool use_box, bool fresh_counter, hipStream_t s) {
+    if (int e = workspace_family_enter(0, s)) return e;
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
@@ -1628,6 +1629,7 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                              const float* fars, float* xyzs, float* dirs, float* deltas, const int32_t* rays,
                              const int32_t* counter, uint32_t perturb, uint32_t zero_unwritten, hipStream_t s) {
+    if (int e = workspace_family_enter(0, s)) return e;
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
         char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
@@ -1825,6 +1827,7 @@ static uint32_t g_march_wave_min_steps = 16u;
 int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float bound, enerf_stream_t stream) {
     if (!grid || C == 0 || H < 2 || (H * H * H) % 8 != 0) ENERF_BADARG("occupied_box_update: bad C=%u H=%u", C, H);
     hipStream_t s = (hipStream_t)stream;
+    if (int e = workspace_family_enter(0, s)) return e;
     int* keys = (int*)workspace(WS_AABB, 6 * sizeof(int));
     if (!keys) return ENERF_E_NOMEM;
     (void)hipMemsetAsync(keys, 0x7f, 6 * sizeof(int), s);
@@ -1916,6 +1919,7 @@ int enerf_compact_rays(uint32_t n_alive, int32_t* rays_alive, const int32_t* ray
                        const float* rays_t_old, int32_t* alive_counter, enerf_stream_t stream) {
     if (n_alive == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (int e0 = workspace_family_enter(0, s)) return e0;
     const uint32_t nb = div_up(n_alive, kCompactBlock);
     // slot layout: [0] = alive_counter value at entry (snapshot), [1..nb] = block counts / offsets
     uint32_t* ws = (uint32_t*)workspace(WS_COMPACT, sizeof(uint32_t) * (nb + 1));

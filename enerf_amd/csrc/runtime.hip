@@ -58,6 +58,38 @@ uint64_t workspace_generation() {
     return g_ws_generation;
 }
 
+static bool g_ws_ordering = true;      // enerf_debug_workspace_ordering
+
+int workspace_family_enter(int family, hipStream_t s) {
+    constexpr int kFamilies = 2;
+    if (!g_ws_ordering) return 0;
+    static hipStream_t last[kMaxDevices][kFamilies] = {};
+    static bool used[kMaxDevices][kFamilies] = {};
+    static hipEvent_t ev[kMaxDevices][kFamilies] = {};
+    if (family < 0 || family >= kFamilies) return 0;
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);
+    // (a stream under graph capture cannot wait for an event of a stream outside the capture; captures start from a
+    // drained device -- torch.cuda.graph synchronises first -- so there is nothing in flight to wait for)
+    if (used[dev][family] && last[dev][family] != s && capturing == hipStreamCaptureStatusNone) {
+        if (!ev[dev][family] && hipEventCreateWithFlags(&ev[dev][family], hipEventDisableTiming) != hipSuccess) {
+            ev[dev][family] = nullptr;
+            set_error("workspace_family_enter: hipEventCreate failed");
+            return ENERF_E_NOMEM;
+        }
+        if (hipEventRecord(ev[dev][family], last[dev][family]) != hipSuccess ||
+            hipStreamWaitEvent(s, ev[dev][family], 0) != hipSuccess) {
+            set_error("workspace_family_enter: could not order stream after the family's previous user");
+            return ENERF_E_NOMEM;
+        }
+    }
+    used[dev][family] = true;
+    last[dev][family] = s;
+    return 0;
+}
+
 uint32_t num_cus() {
     static uint32_t n[kMaxDevices] = {};
     const int dev = current_device();
@@ -118,6 +150,11 @@ ProfScope::~ProfScope() {
 }  // namespace enerf
 
 extern "C" {
+
+int enerf_debug_workspace_ordering(int on) {
+    enerf::g_ws_ordering = on != 0;
+    return 0;
+}
 
 const char* enerf_last_error(void) { return enerf::g_err; }
 int enerf_abi_version(void) { return 1; }

@@ -155,7 +155,6 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
         if launch_stream is not None:
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(launch_stream)
-            _rb.note_side_stage(launch_stream, pre["ready"])      # (the marcher's workspaces are shared: see there)
     if not budgeted and not defer:
         finish_march(model, pre)
     return pre
@@ -362,9 +361,7 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
         return _finish_counted(model, pre)
     ready = pre.pop("ready", None)
     if ready is not None:                       # marched on a side stream, into buffers of this stream's pool (see
-        cur = torch.cuda.current_stream()       # march_stage): order this stream after it, nothing else
-        cur.wait_event(ready)
-        _rb.side_stage_waited(cur.cuda_stream, ready)
+        torch.cuda.current_stream().wait_event(ready)      # march_stage): order this stream after it, nothing else
     return finish_march(model, pre)              # unbudgeted stage: the write pass runs here, sized from the count
 
 

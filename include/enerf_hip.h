@@ -447,6 +447,9 @@ int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
 int enerf_debug_march_wave_max_rays(uint32_t n);
 /* test / measurement aid: 0 switches off the occupied-box test (below) globally */
 int enerf_debug_march_clip(int on);
+/* Testing aid: 0 switches off the cross-stream ordering of the library's shared workspaces (a stream that is about to
+ * use a kernel family's scratch waits for the family's previous user when that was another stream); 1 = default. */
+int enerf_debug_workspace_ordering(int on);
 /* tuning aid: workgroups of the background training march (enerf_march_rays_train_ex flag bit 1); 0 = one per CU */
 int enerf_debug_march_bg_blocks(uint32_t n);
 /* tuning aid: workgroup caps of the mlp32 forward and fused-backward grids (0 = built-in defaults) */

@@ -850,3 +850,49 @@ def test_march_count_fresh_counter_flag_equals_a_zeroed_counter():
             out.append((rays.clone(), counter.clone()))
         assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
         assert int(out[0][1][1]) == n and int(out[0][1][0]) > 0
+
+
+@pytest.mark.gpu
+def test_marcher_workspaces_are_ordered_between_streams():
+    """The marcher's chunk log / scan / box workspaces are one set per device.  A training stage issued ahead on a side
+    stream (fused_render.prefetch_march) and a march of other rays launched right behind it on the current stream (an
+    evaluation render between two training steps) must not run on the same log at once: the library orders the second
+    stream after the first (csrc/runtime.hip: workspace_family_enter).  200 rounds of exactly that, each compared bit
+    for bit with the stage marched on its own.  (Unordered, a corrupted log is replayed into out-of-bounds rows: the
+    memory access fault a 500-training run hit.)"""
+    from enerf_amd import fused_render, raymarching, scene
+    from enerf_amd.backends import _raymarching as rb
+    from enerf_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).cuda()
+    model.density_bitfield.copy_(raymarching.packbits(scene.density_grid(2, "cuda"), 0.01))
+    model.mean_count = 140000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    (ro, rd), _ = scene.training_batch(0, 4096, "cuda", generator=g)
+    (ro2, rd2), _ = scene.training_batch(1, 16384, "cuda", generator=g)
+    ro, rd, ro2, rd2 = (t.contiguous().view(-1, 3) for t in (ro, rd, ro2, rd2))
+    aabb = model.aabb_train
+    C, H = int(model.cascade), int(model.grid_size)
+
+    def stage_alone():
+        model._premarched = None
+        fused_render.prefetch_march(model, ro, rd, perturb=True)
+        pre = fused_render._take_premarched(model, ro, rd, True, 0, 1024)
+        torch.cuda.synchronize()
+        return {k: pre[k].clone() for k in ("rays", "xyzs", "dirs", "deltas")}, pre["counter"].clone()
+
+    want, want_counter = stage_alone()
+    side = torch.cuda.Stream()
+    nears2, fars2 = raymarching.near_far_from_aabb(ro2, rd2, aabb, 0.2)
+    for _ in range(200):
+        model._premarched = None
+        fused_render.prefetch_march(model, ro, rd, perturb=True, stream=side)
+        rays2 = torch.empty(16384, 3, dtype=torch.int32, device="cuda")
+        counter2 = torch.zeros(2, dtype=torch.int32, device="cuda")
+        rb.march_rays_train_count(ro2, rd2, model.density_bitfield, model.bound, 0.0, 1024, 16384, C, H, nears2, fars2,
+                                  rays2, counter2, 1, 8)
+        pre = fused_render._take_premarched(model, ro, rd, True, 0, 1024)
+        torch.cuda.synchronize()
+        assert torch.equal(pre["counter"], want_counter)
+        for k in want:
+            assert torch.equal(pre[k], want[k]), k
