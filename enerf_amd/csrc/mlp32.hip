@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s = (size_t)tile * 32 + j;
         const bool valid = s < B;
-        if (tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
+        if (!SIG && tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
         float dir0 = 0.0f, dir1 = 0.0f, dir2 = 0.0f;            // requested now, used after the MFMAs
         if (SH && valid) {
             dir0 = sh_dirs[s * 3]; dir1 = sh_dirs[s * 3 + 1]; dir2 = sh_dirs[s * 3 + 2];
@@ -357,6 +357,12 @@ __global__ void __launch_bounds__(256) k_mlp32_fwd(const float* __restrict__ X, 
             a[ob] = (f32x16)(0.0f);
 #pragma unroll
             for (int p = 0; p < 16; p++) a[ob] = mma(w0[ob][p], x[p], a[ob]);
+        }
+        // density-only sweeps (SIG: ~100 tiles per wavefront): the first layer has taken x, the same registers receive
+        // the wave's next tile now, and the rest of this tile hides the latency
+        if (SIG && tile + nw < ntiles) load_x<XL>(X, tile + nw, j, h, B, Bp, x);
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++) {
 #pragma unroll
             for (int q = 0; q < 16; q++) a[ob][q] = act_fwd(a[ob][q], act);
             if (TRAIN) store_tile_fb(fb + s * HID, ob, h, a[ob]);
