@@ -8,7 +8,7 @@ B = the reference's structure over the same HIP entry points: run_cuda op by op 
 
 Same model seed, same batches, the occupancy grid learned by update_extra_state itself.  Reports held-out PSNR
 (16 K pixels never trained on) for several seeds of each; writes a JSON summary.
-python tools/psnr_ab.py [steps] [seeds] [out.json]"""
+python tools/psnr_ab.py [steps] [seeds] [out.json] [first_seed]"""
 import json
 import math
 import os
@@ -28,6 +28,7 @@ from test_gpu_training import _batches  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 out_path = sys.argv[3] if len(sys.argv) > 3 else None
+first_seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 data = _batches(32, 4096, 2, seed=5)
 held = _batches(1, 16384, 2, seed=77)[0]
 
@@ -64,7 +65,7 @@ def run(route, seed):
 
 
 rows = []
-for seed in range(seeds):
+for seed in range(first_seed, first_seed + seeds):
     for route in ("A", "B"):
         r = run(route, seed)
         rows.append(r)
