@@ -192,7 +192,9 @@ __device__ __forceinline__ bool decode_block_fwd(uint32_t nchunks, uint32_t L, u
 }
 inline uint32_t fwd_blocks(uint32_t nchunks, uint32_t L) { return 8u * div_up(nchunks, kGroupXcds) * div_up(L, kGroups); }
 
-// backward (atomic-rate bound, placement irrelevant): XCD k takes level k, then k+8
+// backward: XCD k takes level k, then k+8.  (The binning pass too: its lists' partial lines meet in one XCD's L2 --
+// dealt over all eight XCDs it takes 75 us instead of 66; pairing the k-th finest with the k-th coarsest level, to
+// even out the 23..37 us a level costs, changed nothing in the training step.)
 __device__ __forceinline__ bool decode_block(uint32_t nchunks, uint32_t L, uint32_t& level, uint32_t& chunk) {
     const uint32_t bid = blockIdx.x;
     const uint32_t xcd = bid & 7u;
@@ -465,6 +467,19 @@ __device__ __forceinline__ void corner_contrib(const float (&pos)[D], const floa
     }
 }
 
+// lane i reads lane i + O of its own 16-lane row (DPP row_shl; 0.0 where that lane lies beyond the row)
+template <int O>
+__device__ __forceinline__ float row_down(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 | O, 0xf, 0xf, true));
+}
+// one step of the in-row suffix sums: v[k] += (take ? v[k] of lane + O : 0) -- as v + take * t, so that the lane
+// exchange folds into the multiply-add (v_fmac_f32 with a DPP operand) instead of a move, an add and a select
+template <int O, int N>
+__device__ __forceinline__ void run_step(float (&v)[N], float takef) {
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = fmaf(takef, row_down<O>(v[k]), v[k]);
+}
+
 template <int D, int C>
 __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint32_t (&pos_grid)[D],
                                                float (&v)[(1 << D) * C]) {
@@ -485,13 +500,32 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
         const unsigned long long cont = same_mask >> 1;                 // bit i: lane i+1 continues lane i's run
         const unsigned long long stop = ~cont >> lane;                  // first zero of cont at or above my lane
         const int end = lane + (stop ? __builtin_ctzll(stop) : 64 - lane) + 1;   // one past my run's last lane
-        for (int o = 1; o < 64; o <<= 1) {
-            const bool take = lane + o < end;
-            if (__ballot(take) == 0ull) break;
+        // The run's sum lands in its head lane in two stages, neither of which goes through the LDS crossbar
+        // (16 ds_bpermute per doubling step kept the CU's one LDS pipe busy for a third of the binning pass):
+        // 1. suffix sums inside each 16-lane row with DPP row shifts: lane i ends up with the sum over
+        //    [i, min(run end, row end));
+        // 2. a run that continues into the next rows picks up those rows' first lanes (which hold the run's share of
+        //    their row), read with v_readlane -- three rows at most.
+        constexpr int N = (1 << D) * C;
+        if (__ballot(lane + 1 < end) != 0ull) {
+            run_step<1, N>(v, lane + 1 < end ? 1.0f : 0.0f);
+            if (__ballot(lane + 2 < end) != 0ull) {
+                run_step<2, N>(v, lane + 2 < end ? 1.0f : 0.0f);
+                if (__ballot(lane + 4 < end) != 0ull) {
+                    run_step<4, N>(v, lane + 4 < end ? 1.0f : 0.0f);
+                    if (__ballot(lane + 8 < end) != 0ull) run_step<8, N>(v, lane + 8 < end ? 1.0f : 0.0f);
+                }
+            }
+        }
 #pragma unroll
-            for (int k = 0; k < (1 << D) * C; k++) {
-                const float t = __shfl_down(v[k], o, 64);
-                if (take) v[k] += t;
+        for (int r = 1; r < 4; r++) {
+            if ((same_mask >> (16 * r)) & 1ull) {                      // lane 16 r continues a run of the row before
+                const float addf = (lane < 16 * r && 16 * r < end) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const float part = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 16 * r));
+                    v[k] = fmaf(addf, part, v[k]);
+                }
             }
         }
     }
@@ -584,7 +618,11 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     constexpr uint32_t R = kTileElems / C;
     constexpr uint32_t NREC = PTS << D;
     __shared__ uint32_t s_ofs[kMaxBins];         // records per list, then exclusive offset of the list in the staging area
-    __shared__ uint32_t s_gbase[kMaxBins];       // first global slot reserved in the list
+    // where the staging area's record j of list t goes, in words from the level's first record: s_at[t] + j, valid
+    // below s_end[t] (= the list's first word + its capacity); both are made once per list, so that the copy-out does
+    // no multiplication and no 64-bit arithmetic per record
+    __shared__ uint32_t s_at[kMaxBins];
+    __shared__ uint32_t s_end[kMaxBins];
     __shared__ uint32_t s_key[NREC];             // row within tile | list << 16
     __shared__ float s_val[C][NREC];
     __shared__ uint32_t s_wave[PTS / 64 + 1];
@@ -637,7 +675,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     if (head) {
 #pragma unroll
         for (int idx = 0; idx < (1 << D); idx++) {
-            bin[idx] = (cr[idx] / R) * plan.replicas + replica;      // R is a power of two
+            bin[idx] = __umul24(cr[idx] / R, plan.replicas) + replica;      // (R is a power of two; both factors < 2^24)
             rank[idx] = atomicAdd(&s_ofs[bin[idx]], 1u);
         }
     }
@@ -666,8 +704,11 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
         if (t < plan.bins) {
             const uint32_t n = s_ofs[t];
             s_ofs[t] = before;
+            const uint32_t first = t * cap * (1u + C);        // (< 2^32 words: a level's region is far smaller)
+            const uint32_t got = n ? atomicAdd(&cursors[level * kMaxBins + t], n) : 0u;
+            s_at[t] = first + got - before;
+            s_end[t] = first + cap;
             before += n;
-            if (n) s_gbase[t] = atomicAdd(&cursors[level * kMaxBins + t], n);
         }
     }
     __syncthreads();
@@ -687,14 +728,13 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     uint32_t* lrecs = recs + (size_t)level * region * (1 + C);
     for (uint32_t j = threadIdx.x; j < total; j += PTS) {
         const uint32_t key = s_key[j], list = key >> 16, loc = key & 0xffffu;
-        const uint32_t slot = s_gbase[list] + (j - s_ofs[list]);
-        if (slot < cap) {
-            // record = 16-bit row within the tile (first half of the list's index plane) + C value planes
-            uint32_t* lbase = lrecs + (size_t)list * cap * (1 + C);
-            reinterpret_cast<uint16_t*>(lbase)[slot] = (uint16_t)loc;
-            uint32_t* r = lbase + slot;
+        const uint32_t w = s_at[list] + j, e = s_end[list];   // word of the record's slot in plane 0; the list's limit
+        if (w < e) {
+            // record = 16-bit row within the tile (first half of the list's index plane) + C value planes:
+            // list word f = e - cap, slot = w - f -> index plane entry 2 f + slot = f + w, value plane c at w + (1 + c) cap
+            reinterpret_cast<uint16_t*>(lrecs)[(e - cap) + w] = (uint16_t)loc;
 #pragma unroll
-            for (int c = 0; c < C; c++) r[(size_t)(1 + c) * cap] = __float_as_uint(s_val[c][j]);
+            for (int c = 0; c < C; c++) lrecs[w + (1u + c) * cap] = __float_as_uint(s_val[c][j]);
         } else {
             float gg[C];
 #pragma unroll
