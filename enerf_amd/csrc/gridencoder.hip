@@ -472,8 +472,8 @@ template <int O>
 __device__ __forceinline__ float row_down(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 | O, 0xf, 0xf, true));
 }
-// one step of the in-row suffix sums: v[k] += (take ? v[k] of lane + O : 0) -- as v + take * t, so that the lane
-// exchange folds into the multiply-add (v_fmac_f32 with a DPP operand) instead of a move, an add and a select
+// one step of the in-row suffix sums: v[k] += (take ? v[k] of lane + O : 0) -- as v + take * t: a DPP move per value
+// and one packed multiply-add per pair of values (v_pk_fma_f32), no select
 template <int O, int N>
 __device__ __forceinline__ void run_step(float (&v)[N], float takef) {
 #pragma unroll
