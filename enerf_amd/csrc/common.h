@@ -64,30 +64,51 @@ __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a +
 // ---- wave-level primitives (wave64) ----------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
+// Inclusive scans of a wavefront with DPP lane exchanges (no LDS crossbar, no per-step select): Hillis-Steele steps
+// 1, 2, 4, 8 inside each 16-lane row (row_shr; a lane without a source keeps the operation's identity), then the row
+// totals: lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15, row mask 0xA), lane 31 into rows 2 and 3 (row_bcast31,
+// row mask 0xC).  All 64 lanes must be active.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ int dpp_take(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ float dpp_take(float identity, float v) {
+    return __int_as_float(dpp_take<CTRL, ROWS>(__float_as_int(identity), __float_as_int(v)));
+}
+__device__ __forceinline__ float wave_incl_scan_add(float v, int) {
+    v += dpp_take<0x111>(0.0f, v);
+    v += dpp_take<0x112>(0.0f, v);
+    v += dpp_take<0x114>(0.0f, v);
+    v += dpp_take<0x118>(0.0f, v);
+    v += dpp_take<0x142, 0xa>(0.0f, v);
+    v += dpp_take<0x143, 0xc>(0.0f, v);
     return v;
 }
-__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float u = __shfl_up(v, o, 64);
-        if (lane >= o) v *= u;
-    }
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int) {
+    v *= dpp_take<0x111>(1.0f, v);
+    v *= dpp_take<0x112>(1.0f, v);
+    v *= dpp_take<0x114>(1.0f, v);
+    v *= dpp_take<0x118>(1.0f, v);
+    v *= dpp_take<0x142, 0xa>(1.0f, v);
+    v *= dpp_take<0x143, 0xc>(1.0f, v);
     return v;
 }
-__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t u = (uint32_t)__shfl_up((int)v, o, 64);
-        if (lane >= o) v += u;
-    }
-    return v;
+__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t x, int) {
+    int v = (int)x;
+    v += dpp_take<0x111>(0, v);
+    v += dpp_take<0x112>(0, v);
+    v += dpp_take<0x114>(0, v);
+    v += dpp_take<0x118>(0, v);
+    v += dpp_take<0x142, 0xa>(0, v);
+    v += dpp_take<0x143, 0xc>(0, v);
+    return (uint32_t)v;
 }
-__device__ __forceinline__ float wave_bcast(float v, int src) { return __shfl(v, src, 64); }
+// value of the lane below (wave_shr:1); lane 0 gets `first`
+__device__ __forceinline__ float wave_prev(float v, float first) { return dpp_take<0x138>(first, v); }
+// a lane's value in every lane (v_readlane: `src` is wave-uniform)
+__device__ __forceinline__ float wave_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
 }  // namespace enerf

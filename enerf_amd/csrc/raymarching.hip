@@ -917,8 +917,7 @@ __device__ __forceinline__ void comp_chunk(bool active, float sigma, float dl0, 
     const float alpha = active ? 1.0f - __expf(-sigma * dl0) : 0.0f;
     const float om = 1.0f - alpha;
     const float P = wave_incl_scan_mul(om, lane);  // prod_{j<=i} (1 - alpha_j) within the chunk
-    float Pex = __shfl_up(P, 1, 64);
-    if (lane == 0) Pex = 1.0f;
+    const float Pex = wave_prev(P, 1.0f);
     w = alpha * (k.T * Pex);
     T_post = k.T * P;
     const float tt = k.t + wave_incl_scan_add(active ? dl1 : 0.0f, lane);
