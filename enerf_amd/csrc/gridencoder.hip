@@ -487,10 +487,10 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
     bool same = lane > 0 && valid;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const uint32_t prev = (uint32_t)__shfl_up((int)pos_grid[d], 1, 64);
+        const uint32_t prev = (uint32_t)dpp_take<0x138>(0, (int)pos_grid[d]);      // lane - 1 (wave_shr:1)
         same = same && (prev == pos_grid[d]);
     }
-    const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
+    const bool prev_valid = dpp_take<0x138>(0, (int)valid) != 0;
     same = same && prev_valid;
     const unsigned long long same_mask = __ballot(same);
     bool head = valid;
@@ -688,12 +688,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
         const uint32_t t = threadIdx.x * per + k;
         if (t < plan.bins) mine += s_ofs[t];
     }
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += u;
-    }
+    const uint32_t incl = wave_incl_scan_add_u32(mine, lane);
     if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
     __syncthreads();
     uint32_t before = incl - mine;

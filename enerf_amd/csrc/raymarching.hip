@@ -1032,8 +1032,8 @@ __global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
             const float d = mse.out_image[(size_t)ray * 3 + lane_id()] - mse.target[(size_t)ray * 3 + lane_id()];
             e = d * d;
         }
-        e += __shfl_down(e, 2, 64);
-        e += __shfl_down(e, 1, 64);
+        e += dpp_take<0x102>(0.0f, e);                        // lanes 0..2 -> lane 0 (row_shl 2, 1)
+        e += dpp_take<0x101>(0.0f, e);
         if (lane_id() == 0) s_err[threadIdx.x >> 6] = e;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1161,8 +1161,8 @@ __global__ void __launch_bounds__(1024) k_composite_train_fwd_bwd_mse(
             const float d = (lane == 0 ? o0 : lane == 1 ? o1 : o2) - mse.target[(size_t)index * 3 + lane];
             e = d * d;
         }
-        e += __shfl_down(e, 2, 64);
-        e += __shfl_down(e, 1, 64);
+        e += dpp_take<0x102>(0.0f, e);                        // lanes 0..2 -> lane 0 (row_shl 2, 1)
+        e += dpp_take<0x101>(0.0f, e);
         if (lane == 0) s_err[threadIdx.x >> 6] = e;
         __syncthreads();
         if (threadIdx.x == 0) {
