@@ -163,6 +163,9 @@ __global__ void __launch_bounds__(256) k_tmp_scatter(const int32_t* __restrict__
     tmp[(size_t)cas * H3 + idx] = sigmas[p] * scale;                        // duplicates: some writer wins, as in torch
 }
 
+// partial sums of the grid's mean: kSumSlots doubles, one per 128-byte line
+constexpr uint32_t kSumSlots = 16, kSumStride = 16, kSumBytes = kSumSlots * kSumStride * 8;
+
 __device__ __forceinline__ float ema1(float g, float t, float decay, float& acc) {
     if (g >= 0.0f && t >= 0.0f) g = fmaxf(g * decay, t);          // `tmp` untouched = NaN bit pattern: never >= 0
     acc += fmaxf(g, 0.0f);
@@ -183,7 +186,10 @@ __global__ void __launch_bounds__(256) k_ema_mean(float* __restrict__ grid, cons
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sum, (double)((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])));
+    // (2048 fp64 atomics on one address queue up for ~12 ns each -- 25 us of a 33 us kernel: sixteen addresses on
+    // sixteen lines instead, added up in a fixed order by the reader)
+    if (threadIdx.x == 0)
+        atomicAdd(sum + (blockIdx.x % kSumSlots) * kSumStride, (double)((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])));
 }
 
 __global__ void __launch_bounds__(256) k_packbits_mean(const float* __restrict__ grid, uint32_t nbytes,
@@ -191,7 +197,9 @@ __global__ void __launch_bounds__(256) k_packbits_mean(const float* __restrict__
                                                        float density_thresh, uint8_t* __restrict__ bitfield,
                                                        const int32_t* __restrict__ step_counter, uint32_t total_step,
                                                        double* __restrict__ stats) {
-    const float mean = (float)(*sum * inv_total);
+    double total = 0.0;
+    for (uint32_t k = 0; k < kSumSlots; k++) total += sum[k * kSumStride];
+    const float mean = (float)(total * inv_total);
     const float thresh = fminf(mean, density_thresh);
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n == 0) {
@@ -322,11 +330,11 @@ int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint3
     const uint32_t H3 = H * H * H;
     const size_t cells = (size_t)C * H3;
     if (int ew = workspace_family_enter(1, s)) return ew;
-    char* ws = (char*)workspace(WS_DENSITY, 256 + cells * 4);
+    char* ws = (char*)workspace(WS_DENSITY, kSumBytes + cells * 4);
     if (!ws) return ENERF_E_NOMEM;
     double* sum = (double*)ws;
-    float* tmp = (float*)(ws + 256);
-    int e = check_hip(hipMemsetAsync(sum, 0, 8, s), "density_grid_update: memset");
+    float* tmp = (float*)(ws + kSumBytes);
+    int e = check_hip(hipMemsetAsync(sum, 0, kSumBytes, s), "density_grid_update: memset");
     if (!e) e = check_hip(hipMemsetAsync(tmp, 0xFF, cells * 4, s), "density_grid_update: memset");   // NaN: "not evaluated"
     if (e) return e;
     const uint32_t P = n_per_cascade * C;
