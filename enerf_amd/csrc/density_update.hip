@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(256) k_tmp_scatter(const int32_t* __restrict__
 // partial sums of the grid's mean: kSumSlots doubles, one per 128-byte line
 constexpr uint32_t kSumSlots = 16, kSumStride = 16, kSumBytes = kSumSlots * kSumStride * 8;
 
+__global__ void k_zero_sums(double* __restrict__ sum) { sum[threadIdx.x] = 0.0; }
+
 __device__ __forceinline__ float ema1(float g, float t, float decay, float& acc) {
     if (g >= 0.0f && t >= 0.0f) g = fmaxf(g * decay, t);          // `tmp` untouched = NaN bit pattern: never >= 0
     acc += fmaxf(g, 0.0f);
@@ -334,8 +336,10 @@ int enerf_density_grid_update(const int32_t* indices, const float* sigmas, uint3
     if (!ws) return ENERF_E_NOMEM;
     double* sum = (double*)ws;
     float* tmp = (float*)(ws + kSumBytes);
-    int e = check_hip(hipMemsetAsync(sum, 0, kSumBytes, s), "density_grid_update: memset");
-    if (!e) e = check_hip(hipMemsetAsync(tmp, 0xFF, cells * 4, s), "density_grid_update: memset");   // NaN: "not evaluated"
+    // (cleared by a launch of our own: a 2 KiB hipMemsetAsync takes a fill kernel of the runtime's that nothing else in
+    // the step uses, and its first use in a process cost the first update 15-23 ms on a fresh box)
+    k_zero_sums<<<1, kSumSlots * kSumStride, 0, s>>>(sum);
+    int e = check_hip(hipMemsetAsync(tmp, 0xFF, cells * 4, s), "density_grid_update: memset");   // NaN: "not evaluated"
     if (e) return e;
     const uint32_t P = n_per_cascade * C;
     if (!indices && n_per_cascade != H3) ENERF_BADARG("density_grid_update: indices may be NULL for a full sweep only");
