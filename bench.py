@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)   # 125 ms timed: one scheduling hiccup no longer moves the figure
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--global-rays", type=int, default=0,
+                    help="strong scaling: this many rays per step over ALL ranks (BASELINE configs[3]: 65536 over 8 GPUs "
+                         "= 8192 per rank); overrides --rays, the line says \"scaling\": \"strong\"")
     ap.add_argument("--bound", type=int, default=3)
     ap.add_argument("--mode", choices=["rgb", "events"], default="rgb")
     ap.add_argument("--render-frames", type=int, default=2, help="full 640x480 inference frames timed after training")
@@ -213,6 +216,10 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    if args.global_rays:
+        if args.global_rays % world:
+            raise SystemExit(f"--global-rays {args.global_rays} does not divide over {world} ranks")
+        args.rays = args.global_rays // world
     # one process per GPU, pinned to its own block of host cores (launch thread + autograd thread + HIP runtime threads)
     full_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     if full_affinity is not None and not args.no_pin and len(full_affinity) >= 16:
@@ -619,11 +626,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_rays else "weak",
             "vs_baseline": None,
             "dtype": "f16-autocast" if args.fp16 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: shakeCarpet1-shaped train step, bound={args.bound}, hashgrid "
+            "config": {"workload": (f"BASELINE configs[3]: {args.global_rays} rays/step ray-sharded over {world} rank(s), "
+                                    if args.global_rays else "BASELINE configs[1]: ") +
+                                   f"shakeCarpet1-shaped train step, bound={args.bound}, hashgrid "
                                    f"L16 F2 T2^19 + HIP march_rays_train, {'nn.Linear MLPs fp32' if args.net == 'linear' else 'FFMLP bf16'}, {args.rays} rays/GPU, "
                                    f"mode={args.mode}",
                        "rays_per_gpu": args.rays, "global_rays": world * args.rays,

@@ -1,0 +1,117 @@
+"""Checkpoints in the reference's format (row f4): the dict `Trainer.save_checkpoint` writes and `Trainer.load_checkpoint`
+reads (nerf/utils.py:1295-1351, 1353-1415):
+
+    {'epoch', 'global_step', 'stats', ['mean_count', 'mean_density' when cuda_ray],
+     ['optimizer', 'lr_scheduler', 'scaler' when full], 'model': state_dict}
+
+so that a run trained by the reference resumes on this path and the other way round.  The model's module / parameter /
+buffer names are the reference's (tests/golden/ref_state_dict_schema.json); what needs care is the optimizer:
+`FusedAdam` keeps `step` as a Python int and only the hyper-parameters it uses, `torch.optim.Adam` keeps `step` as a
+float32 tensor and a dozen per-group flags that its `step()` reads -- the file always holds the torch form.
+"""
+import torch
+
+# per-group keys torch.optim.Adam's step() reads (torch 2.x); written with Adam's defaults when the optimizer here does
+# not carry them, so that `torch.optim.Adam.load_state_dict` + `step()` work on a file written from FusedAdam
+_TORCH_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                                  differentiable=False, fused=None, decoupled_weight_decay=False)
+
+
+def _optimizer_state_for_file(opt):
+    sd = opt.state_dict()
+    state = {}
+    for k, st in sd["state"].items():
+        st = dict(st)
+        if "step" in st and not torch.is_tensor(st["step"]):
+            st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+        state[k] = st
+    groups = []
+    for g in sd["param_groups"]:
+        g = dict(g)
+        for k, v in _TORCH_ADAM_GROUP_DEFAULTS.items():
+            g.setdefault(k, v)
+        groups.append(g)
+    return {"state": state, "param_groups": groups}
+
+
+def _load_optimizer_state(opt, sd):
+    from .optim import FusedAdam
+    opt.load_state_dict(sd)
+    if isinstance(opt, FusedAdam):
+        for st in opt.state.values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = int(round(float(st["step"])))
+        opt._group_of = None
+
+
+def checkpoint_dict(harness, full=False):
+    """The reference's checkpoint dict for `harness` (a TrainHarness, or anything with .model, .opt, .global_step)."""
+    m = harness.model
+    state = {"epoch": int(getattr(harness, "epoch", 1)), "global_step": int(harness.global_step),
+             "stats": getattr(harness, "stats", None) or {"loss": [], "valid_loss": [], "results": [],
+                                                          "checkpoints": [], "best_result": None}}
+    if m.cuda_ray:
+        state["mean_count"] = int(m.mean_count)
+        state["mean_density"] = float(m.mean_density)
+    if full:
+        gather = getattr(harness, "gather_sharded_optimizer_state", None)
+        if gather is not None and getattr(harness, "comm_mode", None) == "sharded":
+            gather()                      # the sharded data-parallel tail keeps 1/N of the table's moments per rank
+        state["optimizer"] = _optimizer_state_for_file(harness.opt)
+        sched = getattr(harness, "lr_scheduler", None)
+        if sched is not None:
+            state["lr_scheduler"] = sched.state_dict()
+        scaler = getattr(harness, "scaler", None)
+        state["scaler"] = scaler.state_dict() if scaler is not None else {}
+    state["model"] = m.state_dict()
+    return state
+
+
+def save_checkpoint(harness, path, full=False):
+    torch.save(checkpoint_dict(harness, full=full), path)
+    return path
+
+
+def load_checkpoint(harness, checkpoint, model_only=False, map_location=None):
+    """`checkpoint`: a path / file object, or an already loaded dict.  Mirrors Trainer.load_checkpoint: a bare
+    state_dict is accepted; the model loads non-strictly and the (missing, unexpected) key lists are returned; the
+    sample budget and mean density follow when the model marches on the occupancy grid; optimizer / scheduler / scaler
+    are restored when present and wanted."""
+    m = harness.model
+    if not isinstance(checkpoint, dict):
+        dev = map_location or next(m.parameters()).device
+        checkpoint = torch.load(checkpoint, map_location=dev, weights_only=False)
+    if "model" not in checkpoint:
+        m.load_state_dict(checkpoint)
+        return [], []
+    missing, unexpected = m.load_state_dict(checkpoint["model"], strict=False)
+    if m.cuda_ray:
+        if "mean_count" in checkpoint:
+            m.mean_count = checkpoint["mean_count"]
+        if "mean_density" in checkpoint:
+            m.mean_density = checkpoint["mean_density"]
+        # what was marched ahead, and the library's box of occupied cells, belong to the old bitfield
+        m._premarched = None
+        from . import raymarching
+        epoch = getattr(raymarching, "BITFIELD_EPOCH", None)
+        if epoch is not None:
+            epoch[0] += 1
+    if model_only:
+        return list(missing), list(unexpected)
+    if "stats" in checkpoint:
+        harness.stats = checkpoint["stats"]
+    if "epoch" in checkpoint:
+        harness.epoch = checkpoint["epoch"]
+    if "global_step" in checkpoint:
+        harness.global_step = checkpoint["global_step"]
+    if getattr(harness, "opt", None) is not None and "optimizer" in checkpoint:
+        _load_optimizer_state(harness.opt, checkpoint["optimizer"])
+        if hasattr(harness, "_cleared_grad"):
+            harness._cleared_grad = None
+    sched = getattr(harness, "lr_scheduler", None)
+    if sched is not None and "lr_scheduler" in checkpoint:
+        sched.load_state_dict(checkpoint["lr_scheduler"])
+    scaler = getattr(harness, "scaler", None)
+    if scaler is not None and checkpoint.get("scaler"):
+        scaler.load_state_dict(checkpoint["scaler"])
+    return list(missing), list(unexpected)

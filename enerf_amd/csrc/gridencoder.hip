@@ -1103,8 +1103,14 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
                int layout, hipStream_t s, uint32_t flags = 0, uint32_t reserve_B = 0) {
     const uint32_t nchunks = div_up(B, kPtsPerBlock);
     const uint32_t nblocks = 8u * nchunks * div_up(L, 8u);
-    // fp32 tables and enough samples: the binned path (the atomic kernel then only sees levels it cannot bin)
-    const bool binned = std::is_same<T, float>::value && B >= g_binned_min_batch;
+    // fp32 tables and enough samples: the binned path (the atomic kernel then only sees levels it cannot bin).  A
+    // deferred session (several backward calls, one flush by k_grid_tile_adam) is decided ONCE, from the step's total
+    // (reserve_B): a call that joins an open session is binned whatever its own B -- tile_adam reads the dense buffer
+    // only for the levels it does not bin, so a call routed through the atomics in mid-session would be lost
+    const bool session_open = g_pending.region != 0;
+    const uint32_t decide_B = ((flags & 1u) != 0 && reserve_B > B) ? reserve_B : B;
+    const bool binned = std::is_same<T, float>::value &&
+                        (session_open ? (flags & 1u) != 0 : decide_B >= g_binned_min_batch);
     const bool defer = binned && (flags & 1u) != 0;
     uint32_t* recs = nullptr;
     uint32_t* cursors = nullptr;

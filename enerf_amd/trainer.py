@@ -35,6 +35,9 @@ class TrainHarness:
         if model.cuda_ray and occupancy == "synthetic":
             self._syn = scene.install_occupancy(model)
         self.prefetch = True          # data parallel: march the next batch underneath the gradient all-reduce
+        self.perturb = True           # training renders jitter their rays (nerf/utils.py:605 `perturb=True`); tests of
+        #                               shard-vs-whole-batch equality switch it off: the jitter is seeded by the ray's
+        #                               index in ITS batch (raymarching.cu:349-350)
         self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
         self.fuse_table_adam = True   # one GPU: the table gradient's tile sums feed Adam straight from LDS
         self.overlap_update = True    # update steps: the render's count pass is queued before the update's read-back
@@ -61,11 +64,35 @@ class TrainHarness:
         # half nn.Linear GEMMs, fp32 marching / compositing.  The fused fp32 paths stand aside under autocast.
         self.fp16 = bool(fp16)
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if self.fp16 else None
+        # what Trainer keeps beside the model and lands in its checkpoints (nerf/utils.py:381-389,1300-1304)
+        self.epoch = 1
+        self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
+        self.lr_scheduler = None      # set_lr_scheduler(): stepped after every optimizer step (main_nerf.py:212,214)
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
         self._graph_generation = 0
         if self.use_graphs:
             model.sample_budget_quantum = 8192
+
+    def set_lr_scheduler(self, factory):
+        """`factory(optimizer) -> scheduler`, as the reference's Trainer takes it (main_nerf.py:212: LambdaLR with
+        0.1 ** min(iter / iters, 1)); stepped once after every optimizer step (`scheduler_update_every_step=True`).
+        Every optimizer route of the harness reads `param_groups[...]['lr']` at launch time, the fused table pass
+        (FusedAdam.step_grid_table) included, so the schedule reaches all of them."""
+        self.lr_scheduler = factory(self.opt)
+        self.opt._opt_called = True       # the harness calls step_now / step_grid_table, not the wrapped step()
+        return self.lr_scheduler
+
+    def save_checkpoint(self, path, full=False):
+        """The reference's checkpoint dict (nerf/utils.py:1295-1351) -> `path`."""
+        from .checkpoint import save_checkpoint
+        return save_checkpoint(self, path, full=full)
+
+    def load_checkpoint(self, checkpoint, model_only=False):
+        """Resume from a checkpoint in the reference's format (nerf/utils.py:1353-1415), whoever wrote it."""
+        from .checkpoint import load_checkpoint
+        self._graphs.clear()
+        return load_checkpoint(self, checkpoint, model_only=model_only)
 
     def maybe_update_extra_state(self, coming_render=None):
         """`coming_render` = (rays_o, rays_d) of the render this step starts with, when it will take the fused path with
@@ -85,7 +112,7 @@ class TrainHarness:
             if handle is not None:
                 from . import fused_render
                 m._premarched = None                    # (anything marched against the old bitfield is void)
-                fused_render.premarch_count(m, *coming_render)
+                fused_render.premarch_count(m, *coming_render, perturb=self.perturb)
                 m.update_extra_state_end(handle)
             self._agree_on_budget()
 
@@ -164,6 +191,10 @@ class TrainHarness:
         m = self.model
         for dst, src in zip(st["in"], inputs):
             dst.copy_(src)
+        # the captured count pass clips rays against the library's occupied-cell box, which only host code refreshes
+        # (fused_render.occupied_box_flag): update_extra_state may have rewritten the bitfield since the capture
+        from . import fused_render
+        fused_render.occupied_box_flag(m)
         st["graph"].replay()
         for p, g in st["grads"]:
             p.grad = g
@@ -196,7 +227,7 @@ class TrainHarness:
             from . import fused_render
             ro, rd = next_rays
             if fused_render.supported(m, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1, 0):
-                fused_render.prefetch_march(m, ro, rd, perturb=True)
+                fused_render.prefetch_march(m, ro, rd, perturb=self.perturb)
         self.avg.finish()
 
     def _manual_ok(self, rays_o, rays_d, target, render_kw):
@@ -227,7 +258,7 @@ class TrainHarness:
             # (fused_network.nerf_backward) -- the side stream waits for that instead of an event record here.
             # (the second march of an event step is ordered behind the first on the side stream: no wait of its own)
             for k, (ro, rd) in enumerate(next_rays):
-                fused_render.prefetch_march(m, ro, rd, perturb=True, stream=self._side, background=background,
+                fused_render.prefetch_march(m, ro, rd, perturb=self.perturb, stream=self._side, background=background,
                                             after_signal=(True if k == 0 else "ordered") if signalled else False)
         return issue
 
@@ -260,7 +291,7 @@ class TrainHarness:
             loss = self._loss_ring[slot]
         if defer_table and emb.grad is None:        # the dense part of the gradient (levels too small to bin) needs a home
             emb.grad = torch.zeros_like(emb)
-        image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, True, dt_gamma, max_steps,
+        image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, self.perturb, dt_gamma, max_steps,
                                                    after_forward=after_forward, loss_out=loss, raw=raw,
                                                    defer_table=defer_table, after_mlp_backward=after_mlp_backward)
         if raw:
@@ -544,6 +575,12 @@ class TrainHarness:
 
     def step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
+        loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        return loss
+
+    def _step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
         if not self.model.training:                 # Module.train() walks every submodule: 40 us of a 900 us step
             self.model.train()
         coming = None
@@ -560,13 +597,13 @@ class TrainHarness:
                 self._graphs[key] = self._capture(
                     (rays_o, rays_d, target),
                     lambda ro, rd, tg: torch.nn.functional.mse_loss(
-                        m.render(ro, rd, staged=False, bg_color=None, perturb=True, **render_kw)["image"], tg),
+                        m.render(ro, rd, staged=False, bg_color=None, perturb=self.perturb, **render_kw)["image"], tg),
                     (lambda ro, rd, tg: self._manual_fwd_bwd(ro, rd, tg, **render_kw)) if manual else None)
             return self._replay(self._graphs[key], (rays_o, rays_d, target), 1)
         if self.fp16:
             self.opt.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.float16):
-                out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=True, **render_kw)
+                out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=self.perturb, **render_kw)
                 loss = torch.nn.functional.mse_loss(out["image"], target)
             self.scaler.scale(loss).backward()
             self.scaler.unscale_(self.opt)
@@ -577,7 +614,7 @@ class TrainHarness:
         if self._manual_ok(rays_o, rays_d, target, render_kw):
             return self._step_rgb_manual(rays_o, rays_d, target, next_rays, **render_kw)
         self.opt.zero_grad(set_to_none=True)
-        out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=True, **render_kw)
+        out = self.model.render(rays_o, rays_d, staged=False, bg_color=None, perturb=self.perturb, **render_kw)
         loss = torch.nn.functional.mse_loss(out["image"], target)
         loss.backward()
         self._reduce_grads(next_rays)
@@ -586,6 +623,12 @@ class TrainHarness:
 
     def step_events(self, data, opt, next_data=None):
         """One event training step: two renders sharing one backward (nerf/utils.py:482-573)."""
+        loss = self._step_events(data, opt, next_data)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        return loss
+
+    def _step_events(self, data, opt, next_data=None):
         from .events import train_step_events
         if not self.model.training:
             self.model.train()
@@ -599,6 +642,18 @@ class TrainHarness:
                 self._graphs[key] = self._capture(
                     inputs, lambda *ts: train_step_events(self.model, dict(zip(names, ts)), opt)[0])
             return self._replay(self._graphs[key], inputs, 2)
+        if self.fp16:
+            # the shipped configs' fp16 = True around the event step (nerf/utils.py:964-975): autocast + GradScaler
+            self.opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss, _ = train_step_events(self.model, data, opt)
+            self.scaler.scale(loss).backward()
+            self.scaler.unscale_(self.opt)
+            if self.avg is not None:
+                self.avg()
+            self.scaler.step(self.opt)
+            self.scaler.update()
+            return loss.detach()
         if self._events_manual_ok(data, opt):
             from .events import train_step_events_manual
             side = None

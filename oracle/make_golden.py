@@ -391,6 +391,84 @@ def gold_state_dict_schema():
     print("  wrote ref_state_dict_schema.json", {k: len(v) for k, v in schema.items()})
 
 
+def gold_config0():
+    """BASELINE configs[0]: configs/spiral1 shape on the PyTorch sampler -- nerf/network.py with frequency encodings for
+    position and direction (encoding.py:5-43,54-55), cuda_ray off, 256 rays x 512 stratified samples, out_dim_color 1,
+    bound 3, lr 0.005 (configs/spiral1/spiral1_enerf.txt), NeRFRenderer.run (nerf/renderer.py:150-278) + MSE + backward +
+    Adam(betas=(0.9, 0.99), eps=1e-15) (main_nerf.py:211) for three steps, jitter on (torch's host generator, re-seeded
+    per step).  Stored: rays, targets, the first step's image, the three losses, and a few parameters after the steps."""
+    from nerf.network import NeRFNetwork
+    model = NeRFNetwork(encoding="frequency", encoding_dir="frequency", bound=3, cuda_ray=False, out_dim_color=1)
+    det_fill_(list(model.parameters()), 91, -0.25, 0.25)
+    opt = torch.optim.Adam(model.get_params(0.005), betas=(0.9, 0.99), eps=1e-15)
+    o, d = _rays(256, 92, 3)
+    target = torch.rand(1, 256, 1, generator=torch.Generator().manual_seed(93))
+    model.train()
+    losses, image0 = [], None
+    for it in range(3):
+        torch.manual_seed(500 + it)
+        opt.zero_grad(set_to_none=True)
+        out = model.render(o, d, staged=False, bg_color=None, perturb=True, num_steps=512, upsample_steps=0,
+                           out_dim_color=1)
+        loss = torch.nn.functional.mse_loss(out["image"], target)
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+        if it == 0:
+            image0, depth0 = out["image"].detach().clone(), out["depth"].detach().clone()
+    sd = model.state_dict()
+    save("ref_config0_steps", rays_o=o, rays_d=d, target=target, image0=image0, depth0=depth0,
+         losses=torch.stack(losses), in_dim=np.int64(model.in_dim), in_dim_dir=np.int64(model.in_dim_dir),
+         **{"p_" + k.replace(".", "_"): v for k, v in sd.items() if k.endswith(".weight")})
+
+
+def gold_checkpoint():
+    """A checkpoint written by the reference's own Trainer.save_checkpoint(full=True) (nerf/utils.py:1295-1351) for a
+    small model (frequency encodings: no hash table; cuda_ray on, so the dict carries mean_count / mean_density and the
+    state_dict the occupancy buffers), with a LambdaLR schedule as main_nerf.py:212 builds it, after three optimizer
+    steps; then one more step on the reference side, whose result a resumed run must reproduce.  Stored: the .pth
+    itself (gzip: the 8 MB density grid is almost all zeros) and the after-resume parameters."""
+    import gzip
+    import io
+    import tempfile
+    from nerf.network import NeRFNetwork
+    from nerf.utils import Trainer
+    model = NeRFNetwork(encoding="frequency", encoding_dir="frequency", bound=1, cuda_ray=True, out_dim_color=3)
+    det_fill_(list(model.parameters()), 95, -0.25, 0.25)
+    g = torch.Generator().manual_seed(96)
+    idx = torch.randint(0, model.density_grid.numel(), (500,), generator=g)
+    model.density_grid.view(-1)[idx] = torch.rand(500, generator=g) * 20
+    model.density_bitfield.view(-1)[idx // 8] = 255
+    model.step_counter[:3] = torch.tensor([[1200, 64], [1100, 64], [1300, 64]], dtype=torch.int32)
+    model.mean_count, model.mean_density, model.iter_density, model.local_step = 1200, 0.37, 3, 3
+    t = Trainer.__new__(Trainer)
+    t.name, t.model, t.ema, t.epoch, t.global_step, t.max_keep_ckpt = "ngp", model, None, 2, 3, 2
+    t.stats = {"loss": [0.5, 0.25], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
+    t.optimizer = torch.optim.Adam(model.get_params(0.01), betas=(0.9, 0.99), eps=1e-15)
+    t.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(t.optimizer, lambda it: 0.1 ** min(it / 10, 1))
+    t.scaler = torch.cuda.amp.GradScaler(enabled=False)
+    x, d = pts(64, 97), pts(64, 98)
+
+    def step():
+        t.optimizer.zero_grad(set_to_none=True)
+        sigma, color = model(x, d)
+        (sigma.mean() + (color ** 2).mean()).backward()
+        t.optimizer.step()
+        t.lr_scheduler.step()
+    for _ in range(3):
+        step()
+    with tempfile.TemporaryDirectory() as tmp:
+        t.ckpt_path = tmp
+        t.save_checkpoint(name="ngp_ep0002", full=True, remove_old=False)
+        raw = open(os.path.join(tmp, "ngp_ep0002.pth"), "rb").read()
+    with gzip.open(os.path.join(OUT, "ref_checkpoint_freq.pth.gz"), "wb", compresslevel=9) as f:
+        f.write(raw)
+    print(f"  wrote ref_checkpoint_freq.pth.gz ({len(raw)} B raw)")
+    step()
+    save("ref_checkpoint_resumed", x=x, d=d, lr_after=np.float64(t.optimizer.param_groups[0]["lr"]),
+         **{"p_" + k.replace(".", "_"): v for k, v in model.state_dict().items() if k.endswith(".weight")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -402,7 +480,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_binding_signatures, gold_state_dict_schema]
+            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

@@ -71,8 +71,21 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
         orig_loss = events.event_loss
         mp.setattr(events, "event_loss", lambda a, b, p, o: (out.update(im1=a.detach().clone(), im2=b.detach().clone()),
                                                              orig_loss(a, b, p, o))[1])
+        # every nn.Linear call's input X and output gradient dY (both renders): the weight gradient is dY^T X summed
+        # over ~2 x 130 k samples; its fp64 reduction and the sum of the terms' magnitudes bound what fp32 summation in
+        # ANY order may differ by (see below)
+        terms = {}
+        hooks = []
+        for net_name in ("sigma_net", "color_net"):
+            for li, layer in enumerate(getattr(ref, net_name)):
+                def fwd_hook(mod, inp, outp, key=f"{net_name}.{li}.weight"):
+                    x = inp[0].detach()
+                    outp.register_hook(lambda g, key=key, x=x: terms.setdefault(key, []).append((x, g.detach())))
+                hooks.append(layer.register_forward_hook(fwd_hook))
         loss_ref, _ = events.train_step_events(ref, data, opt, bg_color=bg)
         loss_ref.backward()
+        for h_ in hooks:
+            h_.remove()
         grads_ref = {n: p.grad.clone() for n, p in ref.named_parameters()}
         counter_ref = ref.step_counter.clone()
 
@@ -98,14 +111,31 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
     assert_close(got["images"][0].view(-1, 3), out["im1"].view(-1, 3), rtol=1e-4, atol=2e-5)
     assert_close(got["images"][1].view(-1, 3), out["im2"].view(-1, 3), rtol=1e-4, atol=2e-5)
     assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
-    # gradients: sums over 2 x ~130 k samples accumulated in fp32 in different orders on the two sides (the MLP weight
-    # gradients cancel to ~1e-6 from terms ~100x larger); the 192-ray end-to-end test holds 2e-4 of the largest entry,
-    # rounding noise grows like sqrt(#terms): sqrt(2 * 4096 / 192) ~ 6.5x
+    # MLP weight gradients: dW = sum over 2 x ~130 k samples of dY_i x_i^T, whose terms cancel to ~1 % of their
+    # magnitudes.  The oracle side's own per-sample terms are reduced in fp64 here (G64) together with the sum of their
+    # magnitudes (A): a correct fp32 accumulation in any order stays within a few eps32 x A of G64, so the bar is
+    # north_star's 1e-4 relative plus 32 eps32 x A per entry -- no longer a fraction of the tensor's largest entry.
+    eps32 = float(np.finfo(np.float32).eps)
+    worst = {}
     for n, p in model.named_parameters():
         r = grads_ref[n]
-        tol = 1.5e-3 * float(r.abs().max()) + 1e-9
-        err = float((p.grad.cpu() - r).abs().max())
-        assert err < tol, (n, err, float(r.abs().max()))
+        got_g = p.grad.cpu()
+        if n in terms:
+            assert len(terms[n]) == 2, (n, len(terms[n]))                  # two renders
+            g64 = sum(dy.double().t() @ x.double() for x, dy in terms[n])
+            mag = sum(dy.double().abs().t() @ x.double().abs() for x, dy in terms[n])
+            assert float((g64 - r.double()).abs().max()) <= 64 * eps32 * float(mag.max())     # (the hooks saw the real terms)
+            excess = (got_g.double() - g64).abs() - 1e-4 * g64.abs()
+            worst[n] = float((excess / mag.clamp(min=1e-30)).max()) / eps32
+            assert bool((excess <= 32 * eps32 * mag + 1e-12).all()), (n, worst[n])
+        else:
+            # the table: per row a sum over the few hundred (coarse levels) to a handful (fine levels) of samples in its
+            # cells, accumulated by fp32 atomics in an arbitrary order on the oracle side, in fp64 per tile here
+            tol = 2e-4 * float(r.abs().max()) + 1e-9
+            err = float((got_g - r).abs().max())
+            worst[n] = err / float(r.abs().max())
+            assert err < tol, (n, err, float(r.abs().max()))
+    print("configs[2] gradient bars used (MLP: excess over 1e-4 rel in units of eps32 x sum|terms|; table: / max):", worst)
     assert float(grads_ref["encoder.embeddings"].abs().max()) > 0
 
 

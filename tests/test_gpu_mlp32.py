@@ -222,7 +222,9 @@ def test_grid_table_adam_from_records_equals_backward_then_adam():
     from enerf_amd.gridencoder import GridEncoder
     from enerf_amd.optim import FusedAdam
     torch.manual_seed(0)
-    for sizes in ((70000,), (40000, 52000), (3000,)):
+    # (9000, 30000) / (30000, 9000): one call of the session below the binning threshold (16384) -- the session is
+    # decided once, from the step's total, and every call that joins it is binned
+    for sizes in ((70000,), (40000, 52000), (3000,), (9000, 30000), (30000, 9000)):
         encs = [GridEncoder(desired_resolution=2048 * 2).to("cuda") for _ in range(2)]
         encs[1].embeddings.data.copy_(encs[0].embeddings.data)
         opts = [FusedAdam([{"params": [e.embeddings], "lr": 1e-2}], betas=(0.9, 0.99), eps=1e-15) for e in encs]
