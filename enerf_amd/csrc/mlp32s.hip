@@ -1,0 +1,644 @@
+// mlp32s.hip -- the fused fp32 MLP of mlp32.hip on the bf16 matrix pipe at fp32 accuracy (split operands).
+// Its own translation unit because it is compiled with -amdgpu-mfma-vgpr-form: every MFMA result here is post-processed
+// by VALU code at once (activation, hi / lo split, repacking of a flipped tile), and in the default AGPR form each of
+// those elements costs a v_accvgpr_read first (a third of the tile loop's instructions).  The long-lived weight-gradient
+// accumulators spill to AGPRs on their own where the arch VGPRs run out.
+#include <hip/hip_runtime.h>
+
+#include "mlp32_common.h"
+
+namespace enerf_mlp32 {
+
+// ================================================================== split-bf16 kernels ("x3")
+// The same networks on the bf16 matrix pipe, at fp32 accuracy: every fp32 operand v is carried as hi + lo with
+// hi = bf16(v) and lo = bf16(v - hi) (both round-to-nearest: |v - hi - lo| <= 2^-17 |v|), and a product a * b as the
+// three bf16 MFMA terms a.hi b.hi + a.hi b.lo + a.lo b.hi accumulated in fp32 (bf16 x bf16 is exact in fp32; the
+// dropped a.lo b.lo is <= 2^-18 |a b|): ~2^-16 relative per product, against the 1e-4 the path has to hold, for 3/16 of
+// the fp32 MFMA's pipe time (v_mfma_f32_32x32x16_bf16: 16 contraction steps per 32 cycles, v_mfma_f32_32x32x2_f32: 2
+// per 64).  enerf_mlp32_precision(0) brings the bit-exact fp32 kernels above back.
+//
+// Layouts are those of the fp32 kernels with the contraction index grouped in eights: lane (j, h) of an A / B operand
+// holds 8 consecutive contraction steps; K-step t of a D tile consumes accumulator registers 8t .. 8t+7, i.e. neurons
+// nrow(8t + e, h) -- the weight fragments are gathered in that order, so one layer's D tile is still the next layer's
+// B operand as it stands (split into hi / lo on the way).
+//
+// Weight gradients contract over SAMPLES, which a D tile keeps on the lanes.  Instead of passing every tile through LDS
+// (the fp32 kernel above) the tile is flipped by the matrix pipe itself: used as the A operand (row = sample) against a
+// 0/1 selection matrix, D[sample][neuron] comes back with the NEURON on the lanes and the samples in the registers
+// (order nrow(q, h), the same for both operands of the weight-gradient product, which is all that matters) -- exact,
+// since the operands are bf16 values times 1.0, and four MFMAs per 32 x 32 tile (hi and lo).  The backward therefore
+// uses LDS only for the staged weights and its final per-workgroup sums, and no wavefront-level fences at all.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct Frag {
+    bf16x8 hi, lo;
+};
+
+__device__ __forceinline__ f32x16 mmab(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma3(const Frag& a, const Frag& b, f32x16 c) {
+    c = mmab(a.lo, b.hi, c);
+    c = mmab(a.hi, b.lo, c);
+    return mmab(a.hi, b.hi, c);
+}
+__device__ __forceinline__ Frag split8(const float (&v)[8]) {
+    i32x4 rh, rl;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const f32x2 f = {v[2 * p], v[2 * p + 1]};
+        const bf16x2 h2 = __builtin_convertvector(f, bf16x2);              // v_cvt_pk_bf16_f32 (RNE)
+        const f32x2 rest = f - __builtin_convertvector(h2, f32x2);         // exact in fp32
+        const bf16x2 l2 = __builtin_convertvector(rest, bf16x2);
+        rh[p] = __builtin_bit_cast(int, h2);
+        rl[p] = __builtin_bit_cast(int, l2);
+    }
+    Frag r;
+    r.hi = __builtin_bit_cast(bf16x8, rh);
+    r.lo = __builtin_bit_cast(bf16x8, rl);
+    return r;
+}
+// accumulator registers 8t .. 8t+7 of a D tile as the operand of K-step t
+__device__ __forceinline__ void split_tile(const f32x16& a, Frag (&f)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = a[8 * t + e];
+        f[t] = split8(v);
+    }
+}
+// registers of a tile whose values ARE bf16 numbers (a flipped tile) -> operand halves, exactly
+__device__ __forceinline__ bf16x8 exact8(const f32x16& d, int t) {
+    i32x4 r;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const f32x2 f = {d[8 * t + 2 * p], d[8 * t + 2 * p + 1]};
+        r[p] = __builtin_bit_cast(int, __builtin_convertvector(f, bf16x2));
+    }
+    return __builtin_bit_cast(bf16x8, r);
+}
+// selection matrices B[k][c] of the flips, as B operands of lane (c, h): k = 8h + e
+//   kind 0: k == c            (an operand in natural order: dL/dY, outputs 8h + e)
+//   kind 1: nrow(e, h) == c   (registers 0..7 of a D tile: neurons 0..15 of its block)
+//   kind 2: 16 + nrow(e, h) == c   (registers 8..15: neurons 16..31)
+__device__ __forceinline__ bf16x8 selector(int c, int h, int kind) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = kind == 0 ? 8 * h + e : nrow(e, h) + (kind == 2 ? 16 : 0);
+        f[e] = k == c ? (__bf16)1.0f : (__bf16)0.0f;
+    }
+    return f;
+}
+// D tile (as its two K-step operands) -> the same 32 x 32 block with the neuron on the lanes: lane (c, h) gets
+// T[c][sample nrow(q, h)], q = 0..15, again as two K-step operands (contraction over samples)
+__device__ __forceinline__ void flip_tile(const Frag (&f)[2], bf16x8 selA, bf16x8 selB, Frag (&out)[2]) {
+    f32x16 dh = (f32x16)(0.0f), dl = (f32x16)(0.0f);
+    dh = mmab(f[0].hi, selA, dh);
+    dl = mmab(f[0].lo, selA, dl);
+    dh = mmab(f[1].hi, selB, dh);
+    dl = mmab(f[1].lo, selB, dl);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        out[t].hi = exact8(dh, t);
+        out[t].lo = exact8(dl, t);
+    }
+}
+__device__ __forceinline__ void flip_natural(const Frag& f, bf16x8 selN, Frag (&out)[2]) {
+    f32x16 dh = (f32x16)(0.0f), dl = (f32x16)(0.0f);
+    dh = mmab(f.hi, selN, dh);
+    dl = mmab(f.lo, selN, dl);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        out[t].hi = exact8(dh, t);
+        out[t].lo = exact8(dl, t);
+    }
+}
+
+template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false>
+__global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X, WSrc W,
+                                                    float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
+                                                    uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
+                                                    float* __restrict__ y0_exp, const float* __restrict__ sh_dirs = nullptr,
+                                                    ShNorm4 nrm = ShNorm4{}) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    const uint32_t Bp = (B + 31u) & ~31u;
+    float x[16];
+    {
+        const uint32_t tile0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (tile0 < Bp / 32) load_x<XL>(X, tile0, j, h, B, Bp, x);
+    }
+    stage_rot(wl, W, NH, out_dim);
+
+    Frag w0[2][2], wh[NH > 1 ? NH - 1 : 1][2][2][2], wo[2][2];
+    float wsig[2][16];                                    // SIG: the output row as fp32 (VALU dot product)
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = wl[rot(32 * ob + j, kmap<XL>(8 * t + e, h), IN)];
+            w0[ob][t] = split8(v);
+        }
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        v[e] = wl[HID * IN + rot(l * HID + 32 * ob + j, 32 * ib + nrow(8 * t + e, h), HID)];
+                    wh[l][ob][ib][t] = split8(v);
+                }
+    {
+        const float* w64 = wl + HID * IN;
+        const uint32_t r0 = (NH - 1) * HID;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+            if (SIG) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) wsig[ib][q] = w64[rot(r0, 32 * ib + nrow(q, h), HID)];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        v[e] = (uint32_t)j < out_dim ? w64[rot(r0 + j, 32 * ib + nrow(8 * t + e, h), HID)] : 0.0f;
+                    wo[ib][t] = split8(v);
+                }
+            }
+        }
+    }
+
+    // ReLU as a signed-integer max on the bit pattern against a wave-uniform limit (0: negative floats, -0.0 and negative
+    // NaNs are negative integers -> +0.0, everything else unchanged; INT_MIN: no activation): one v_max_i32 per element
+    const int relu_lim = act == 0 ? 0 : (int)0x80000000;
+    const uint32_t ntiles = valid_tiles(W, B, Bp / 32);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const size_t s = (size_t)tile * 32 + j;
+        const bool valid = s < B;
+        if (!SIG && tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
+        float dir0 = 0.0f, dir1 = 0.0f, dir2 = 0.0f;
+        if (SH && valid) {
+            dir0 = sh_dirs[s * 3]; dir1 = sh_dirs[s * 3 + 1]; dir2 = sh_dirs[s * 3 + 2];
+        }
+        Frag xf[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = x[8 * t + e];
+            xf[t] = split8(v);
+        }
+        if (SIG && tile + nw < ntiles) load_x<XL>(X, tile + nw, j, h, B, Bp, x);
+        f32x16 a[2];
+        Frag af[2][2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++) {
+            a[ob] = (f32x16)(0.0f);
+#pragma unroll
+            for (int t = 0; t < 2; t++) a[ob] = mma3(w0[ob][t], xf[t], a[ob]);
+#pragma unroll
+            for (int q = 0; q < 16; q++) a[ob][q] = __int_as_float(max(__float_as_int(a[ob][q]), relu_lim));
+            if (TRAIN) store_tile_fb(fb + s * HID, ob, h, a[ob]);
+            if (!SIG || NH > 1) split_tile(a[ob], af[ob]);
+        }
+#pragma unroll
+        for (int l = 1; l < NH; l++) {
+            f32x16 n[2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {
+                n[ob] = (f32x16)(0.0f);
+#pragma unroll
+                for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) n[ob] = mma3(wh[l - 1][ob][ib][t], af[ib][t], n[ob]);
+#pragma unroll
+                for (int q = 0; q < 16; q++) n[ob][q] = __int_as_float(max(__float_as_int(n[ob][q]), relu_lim));
+                if (TRAIN) store_tile_fb(fb + ((size_t)l * Bp + s) * HID, ob, h, n[ob]);
+            }
+            a[0] = n[0];
+            a[1] = n[1];
+            if (!SIG || l < NH - 1) {
+                split_tile(a[0], af[0]);
+                split_tile(a[1], af[1]);
+            }
+        }
+        if (SIG) {
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                p0 = fmaf(wsig[0][q], a[0][q], p0);
+                p1 = fmaf(wsig[1][q], a[1][q], p1);
+            }
+            float p = p0 + p1;
+            p += __shfl_xor(p, 32, 64);
+            if (valid && h == 0) y0_exp[s] = expf(p);
+            continue;
+        }
+        f32x16 o = (f32x16)(0.0f);
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) o = mma3(wo[ib][t], af[ib][t], o);
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const uint32_t r = (uint32_t)nrow(q, h);
+                if (Y && r < out_dim) Y[s * y_stride + r] = out_act_fwd(o[q], out_act);
+                if (r == 0 && y0_exp) y0_exp[s] = expf(o[q]);
+            }
+            if (SH) {
+                float sh[16];
+                sh4(dir0, dir1, dir2, nrm, sh);
+                const uint32_t m = 0u - (uint32_t)h;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    v[e] = __uint_as_float((__float_as_uint(sh[e]) & ~m) | (__float_as_uint(sh[8 + e]) & m));
+                float* dst = Y + s * y_stride + 16 + 8 * h;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+}
+
+// dgrad + wgrad of a net with one or two hidden layers and out_dim <= 16, one kernel, no LDS traffic for the tiles.
+// Two hidden layers: the weight operands (14 fragments, 112 registers) would push the wavefront past its 512 registers,
+// so they are kept in LDS in operand order (hi and lo: 64 lanes x 16 B each, one conflict-free ds_read_b128 per half) and
+// read where they are used; one hidden layer keeps them in registers.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+template <int NH, int XL>
+__global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* __restrict__ X, WSrc W,
+                                                    const float* __restrict__ fb, float* __restrict__ dX,
+                                                    float* __restrict__ partial, uint32_t B, uint32_t out_dim,
+                                                    uint32_t act) {
+    constexpr uint32_t NW_MAX = HID * IN + (NH - 1) * HID * HID + 16 * HID;
+    constexpr bool WL = NH > 1;                                        // weight operands from LDS
+    constexpr int NFRAG = 2 + 4 + 8 * (NH - 1);
+    static_assert(NW_MAX * 4 + NFRAG * 2048 <= 4 * NW_MAX * 4, "operand region must fit beside the staged weights");
+    __shared__ __attribute__((aligned(16))) float lds[4 * NW_MAX];      // staged weights (+ operands), then the four waves' dW sums
+    float* wl = lds;
+    const uint32_t NW = blob_size(NH, out_dim);
+    stage(wl, W, NW);
+    const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    const int wid = threadIdx.x >> 6;
+    const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
+    const uint32_t Bp = (B + 31u) & ~31u;
+    u32x4v* fr = reinterpret_cast<u32x4v*>(lds + NW_MAX);
+    auto put = [&](int f, const Frag& w) {                             // built by every wave, stored by wave f % 4
+        if ((f & 3) == wid) {
+            fr[(2 * f) * 64 + lane] = __builtin_bit_cast(u32x4v, w.hi);
+            fr[(2 * f + 1) * 64 + lane] = __builtin_bit_cast(u32x4v, w.lo);
+        }
+    };
+    auto get = [&](int f) -> Frag {
+        Frag w;
+        w.hi = __builtin_bit_cast(bf16x8, fr[(2 * f) * 64 + lane]);
+        w.lo = __builtin_bit_cast(bf16x8, fr[(2 * f + 1) * 64 + lane]);
+        return w;
+    };
+
+    Frag woT[2], whT[NH > 1 ? NH - 1 : 1][2][2][2], wiT[2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t o = (uint32_t)(8 * h + e);
+            v[e] = o < out_dim ? wout[o * HID + 32 * ib + j] : 0.0f;
+        }
+        woT[ib] = split8(v);
+        if (WL) put(ib, woT[ib]);
+    }
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = wl[(32 * ob + nrow(8 * t + e, h)) * IN + j];
+            wiT[ob][t] = split8(v);
+            if (WL) put(2 + 2 * ob + t, wiT[ob][t]);
+        }
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        v[e] = wl[HID * IN + l * HID * HID + (32 * ob + nrow(8 * t + e, h)) * HID + 32 * ib + j];
+                    whT[l][ib][ob][t] = split8(v);
+                    if (WL) put(6 + ((l * 2 + ib) * 2 + ob) * 2 + t, whT[l][ib][ob][t]);
+                }
+    if (WL) __syncthreads();
+    auto WO = [&](int ib) -> Frag { return WL ? get(ib) : woT[ib]; };
+    auto WI = [&](int ob, int t) -> Frag { return WL ? get(2 + 2 * ob + t) : wiT[ob][t]; };
+    auto WH = [&](int l, int ib, int ob, int t) -> Frag {
+        return WL ? get(6 + ((l * 2 + ib) * 2 + ob) * 2 + t) : whT[l][ib][ob][t];
+    };
+    const bf16x8 selN = selector(j, h, 0), selA = selector(j, h, 1), selB = selector(j, h, 2);
+
+    f32x16 aw0[2], awh[NH > 1 ? NH - 1 : 1][2][2], awo[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        aw0[a] = (f32x16)(0.0f);
+        awo[a] = (f32x16)(0.0f);
+#pragma unroll
+        for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) awh[l][a][b] = (f32x16)(0.0f);
+    }
+
+    const uint32_t ntiles = Bp / 32;
+    const uint32_t nreal = valid_tiles(W, B, ntiles);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    // as in the fp32 kernel: everything a tile reads from global memory is requested for the wave's NEXT tile where the
+    // current tile has used it for the last time, branch-free, into the same registers
+    float dy_raw[8], ys_raw[8], ds_raw = 0.0f, h0_raw = 0.0f;
+    f32x16 fwl[NH][2];
+    float xT[16];                                      // X^T: lane (input column j, h) holds samples nrow(q, h)
+    auto request_out = [&](uint32_t t) {
+        const size_t sn = (size_t)t * 32 + j;
+        const size_t sc = sn < B ? sn : (size_t)B - 1;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t o = (uint32_t)(8 * h + e), oc = o < out_dim ? o : out_dim - 1;
+            dy_raw[e] = dys.dY[sc * dys.stride + oc];
+            ys_raw[e] = dys.y_sig ? dys.y_sig[sc * dys.y_sig_stride + oc] : 0.0f;
+        }
+        if (dys.dsigma) {
+            ds_raw = dys.dsigma[sc];
+            h0_raw = dys.h0[sc * dys.h0_stride];
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)(NH - 1) * Bp + sn) * HID, ib, h, fwl[NH - 1][ib]);
+    };
+    auto request_hidden = [&](uint32_t t, int l) {
+        const size_t sn = (size_t)t * 32 + j;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + sn) * HID, ib, h, fwl[l][ib]);
+    };
+    auto request_x = [&](uint32_t t) {
+        const size_t t0 = (size_t)t * 32;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const size_t row = t0 + nrow(q, h);
+            if (XL == 0) {
+                const size_t rc = row < B ? row : (size_t)B - 1;
+                xT[q] = X[rc * IN + j];
+            } else {
+                xT[q] = X[((size_t)(j >> 1) * Bp + row) * 2 + (j & 1)];     // pad rows of a level-major X hold zeros
+            }
+        }
+    };
+    {
+        const uint32_t t0 = gw < ntiles ? gw : ntiles - 1;
+        request_out(t0);
+#pragma unroll
+        for (int l = NH - 2; l >= 0; l--) request_hidden(t0, l);
+        request_x(t0);
+    }
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const uint32_t tnext = tile + nw < nreal ? tile + nw : tile;
+        const size_t s0 = (size_t)tile * 32;
+        const size_t s = s0 + j;
+        const bool valid = s < B;
+        if (WL) asm volatile("" ::: "memory");        // the operand reads stay in the loop (hoisted, they are 112 registers)
+        if (tile >= nreal) {
+            if (dX) {
+                if (XL == 0) {
+                    if (valid) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++)
+                            *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const size_t lv = (size_t)(4 * gq + 2 * h);
+                        *reinterpret_cast<float2*>(dX + (lv * Bp + s) * 2) = make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(dX + ((lv + 1) * Bp + s) * 2) = make_float2(0.f, 0.f);
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- output layer
+        Frag dyf;
+        {
+            float dy[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t o = (uint32_t)(8 * h + e);
+                float gq = dy_raw[e];
+                if (dys.y_sig) gq = (gq * (1.0f - ys_raw[e])) * ys_raw[e];
+                if (dys.dsigma && o == 0) gq = ds_raw * expf(fminf(fmaxf(h0_raw, -15.0f), 15.0f));
+                dy[e] = (valid && o < out_dim) ? gq : 0.0f;
+            }
+            dyf = split8(dy);
+        }
+        f32x16 g[2];
+        Frag ft[2][2], gf[2][2], gT[2][2];             // [block][K-step]: flipped activations, gradients, flipped gradients
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+            g[ib] = mma3(WO(ib), dyf, (f32x16)(0.0f));
+            if (act == 0) {                            // (wave-uniform: a scalar branch, not a select per element)
+#pragma unroll
+                for (int q = 0; q < 16; q++) g[ib][q] = fwl[NH - 1][ib][q] > 0.0f ? g[ib][q] : 0.0f;
+            }
+            Frag ff[2];
+            split_tile(fwl[NH - 1][ib], ff);
+            flip_tile(ff, selA, selB, ft[ib]);
+        }
+        request_out(tnext);
+        {
+            // dWout[o][i] += dY[o][s] * fb_last[i][s]
+            Frag dyT[2];
+            flip_natural(dyf, selN, dyT);
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) awo[nb] = mma3(dyT[t], ft[nb][t], awo[nb]);
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+            split_tile(g[ib], gf[ib]);
+            flip_tile(gf[ib], selA, selB, gT[ib]);
+        }
+        // ---- hidden layers
+#pragma unroll
+        for (int jj = 1; jj < NH; jj++) {
+            const int l = NH - jj;
+            f32x16 n[2];
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                n[ib] = (f32x16)(0.0f);
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) n[ib] = mma3(WH(l - 1, ib, ob, t), gf[ob][t], n[ib]);
+            }
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                Frag ff[2];
+                split_tile(fwl[l - 1][ib], ff);
+                flip_tile(ff, selA, selB, ft[ib]);
+            }
+            // dWh[l-1][o][i] += G_l[o][s] * fb[l-1][i][s]
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) awh[l - 1][ob][nb] = mma3(gT[ob][t], ft[nb][t], awh[l - 1][ob][nb]);
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) g[ib][q] = (act != 0 || fwl[l - 1][ib][q] > 0.0f) ? n[ib][q] : 0.0f;
+            request_hidden(tnext, l - 1);
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                split_tile(g[ib], gf[ib]);
+                flip_tile(gf[ib], selA, selB, gT[ib]);
+            }
+        }
+        // ---- input layer: dW0[o][i] += G_0[o][s] * X[s][i]
+        {
+            Frag xf[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int q = 8 * t + e;
+                    v[e] = (XL == 0 && s0 + nrow(q, h) >= B) ? 0.0f : xT[q];
+                }
+                xf[t] = split8(v);
+            }
+            request_x(tnext);
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) aw0[ob] = mma3(gT[ob][t], xf[t], aw0[ob]);
+        }
+        if (dX) {
+            f32x16 d = (f32x16)(0.0f);
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) d = mma3(WI(ob, t), gf[ob][t], d);
+            if (XL == 0) {
+                if (valid) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        *reinterpret_cast<float4*>(dX + s * IN + 8 * gq + 4 * h) =
+                            make_float4(d[4 * gq], d[4 * gq + 1], d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const size_t lv = (size_t)(4 * gq + 2 * h);
+                    *reinterpret_cast<float2*>(dX + (lv * Bp + s) * 2) = make_float2(d[4 * gq], d[4 * gq + 1]);
+                    *reinterpret_cast<float2*>(dX + ((lv + 1) * Bp + s) * 2) = make_float2(d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            }
+        }
+    }
+
+    // per-workgroup sums, as in the fp32 kernel: the four waves write their accumulators into regions of their own, the
+    // sums are taken in wave order on the way out (deterministic)
+    __syncthreads();
+    float* red = lds + (size_t)wid * NW;
+    auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t o = (uint32_t)(32 * ob + nrow(q, h));
+            if (o < nrows) red[base + o * ld + 32 * nb + j] = a[q];
+        }
+    };
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID);
+#pragma unroll
+    for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID);
+#pragma unroll
+    for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim);
+    __syncthreads();
+    float* dst = partial + (size_t)blockIdx.x * NW;
+    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x)
+        dst[i] = ((lds[i] + lds[NW + i]) + lds[2 * NW + i]) + lds[3 * NW + i];
+}
+
+void mlp32s_launch_fwd(uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X, const WSrc& W,
+                       float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
+                       uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s) {
+#define S_FWD(NHV, TR, XLV, SIGV, SHV)                                                                                 \
+    k_mlp32s_fwd<NHV, TR, XLV, SIGV, SHV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, \
+                                                                 sh_dirs, nrm)
+#define S_FWD_XL(NHV, TR)                              \
+    do {                                               \
+        if (x_layout == 0) S_FWD(NHV, TR, 0, false, false); \
+        else S_FWD(NHV, TR, 1, false, false);          \
+    } while (0)
+#define S_FWD_TR(NHV)                 \
+    do {                              \
+        if (train) S_FWD_XL(NHV, true); \
+        else S_FWD_XL(NHV, false);    \
+    } while (0)
+    const ShNorm4 nrm = sh_dirs ? make_sh_norm4() : ShNorm4{};
+    if (sh_dirs) {
+        if (train) S_FWD(1, true, 1, false, true);
+        else S_FWD(1, false, 1, false, true);
+    } else if (sigma_only) {
+        S_FWD(1, false, 1, true, false);
+    } else if (num_hidden == 1) {
+        S_FWD_TR(1);
+    } else if (num_hidden == 2) {
+        S_FWD_TR(2);
+    } else {
+        S_FWD_TR(3);
+    }
+#undef S_FWD_TR
+#undef S_FWD_XL
+#undef S_FWD
+}
+
+void mlp32s_launch_bwd(uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X, const WSrc& W,
+                       const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim, uint32_t act,
+                       uint32_t grid, hipStream_t s) {
+#define S_BWD(NHV, XLV) k_mlp32s_bwd<NHV, XLV><<<grid, 256, 0, s>>>(dys, X, W, fb, dX, partial, B, out_dim, act)
+    if (num_hidden == 1) {
+        if (x_layout == 0) S_BWD(1, 0);
+        else S_BWD(1, 1);
+    } else {
+        if (x_layout == 0) S_BWD(2, 0);
+        else S_BWD(2, 1);
+    }
+#undef S_BWD
+}
+
+}  // namespace enerf_mlp32

@@ -426,6 +426,14 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
                          uint32_t x_layout, uint32_t dy_stride, const float* y_sigmoid, uint32_t y_sigmoid_stride,
                          const float* dsigma, const float* h0, uint32_t h0_stride, enerf_stream_t stream);
 
+/* Arithmetic of the enerf_mlp32_* kernels (the nn.Linear nets of nerf/network.py:40-77 are fp32):
+ *   0  v_mfma_f32_32x32x2_f32: every dot product an fp32 fmaf chain, bit-comparable with an fp32 GEMM;
+ *   1  (default) split-bf16: every fp32 operand as bf16 hi + lo, three bf16 MFMA products per fp32 product (hi*hi +
+ *      hi*lo + lo*hi), fp32 accumulation: ~2^-16 relative per product, inside the path's 1e-4, at 3/16 of the fp32
+ *      MFMA's pipe time.  Applies to forward, dgrad and wgrad (the fused backward; nets with three hidden layers or
+ *      more than 16 outputs keep mode 0 in the backward).
+ * Returns the previous mode (NOT a status); a negative `mode` only queries. */
+int enerf_mlp32_precision(int mode);
 /* Testing aid: 1 (default) lets enerf_mlp32_backward use its fused dgrad + wgrad kernel (num_hidden <= 2; `bb` is then
  * not written), 0 forces the separate dgrad / wgrad kernels. */
 int enerf_debug_mlp32_fused_backward(int on);

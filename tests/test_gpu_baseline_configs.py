@@ -113,10 +113,22 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
     assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
     # MLP weight gradients: dW = sum over 2 x ~130 k samples of dY_i x_i^T, whose terms cancel to ~1 % of their
     # magnitudes.  The oracle side's own per-sample terms are reduced in fp64 here (G64) together with the sum of their
-    # magnitudes (A): a correct fp32 accumulation in any order stays within a few eps32 x A of G64, so the bar is
-    # north_star's 1e-4 relative plus 32 eps32 x A per entry -- no longer a fraction of the tensor's largest entry.
+    # magnitudes (A) and the largest single term (T): a correct fp32 evaluation stays within a few eps32 x A of G64
+    # (summation order) plus a few whole terms (a ReLU whose pre-activation is within an ulp of zero opens on one side
+    # and not on the other: with 2 x 130 k x 64 hidden units per layer a handful always are).  The bar per entry is
+    # north_star's 1e-4 relative + 64 eps32 x A + 4 T -- no longer a fraction of the tensor's largest entry.
     eps32 = float(np.finfo(np.float32).eps)
     worst = {}
+
+    def largest_term(pairs):
+        out = None
+        for x, dy in pairs:
+            x, dy = x.to(DEV).abs(), dy.to(DEV).abs()
+            for k in range(0, x.shape[0], 8192):
+                m = (dy[k:k + 8192, :, None] * x[k:k + 8192, None, :]).amax(0)
+                out = m if out is None else torch.maximum(out, m)
+        return out.double().cpu()
+
     for n, p in model.named_parameters():
         r = grads_ref[n]
         got_g = p.grad.cpu()
@@ -124,10 +136,13 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
             assert len(terms[n]) == 2, (n, len(terms[n]))                  # two renders
             g64 = sum(dy.double().t() @ x.double() for x, dy in terms[n])
             mag = sum(dy.double().abs().t() @ x.double().abs() for x, dy in terms[n])
+            top = largest_term(terms[n])
             assert float((g64 - r.double()).abs().max()) <= 64 * eps32 * float(mag.max())     # (the hooks saw the real terms)
-            excess = (got_g.double() - g64).abs() - 1e-4 * g64.abs()
-            worst[n] = float((excess / mag.clamp(min=1e-30)).max()) / eps32
-            assert bool((excess <= 32 * eps32 * mag + 1e-12).all()), (n, worst[n])
+            err = (got_g.double() - g64).abs()
+            bar = 1e-4 * g64.abs() + 64 * eps32 * mag + 4 * top + 1e-12
+            worst[n] = {"err/bar": float((err / bar).max()), "bar/max|G|": float(bar.max() / g64.abs().max()),
+                        "err/max|G|": float(err.max() / g64.abs().max())}
+            assert bool((err <= bar).all()), (n, worst[n])
         else:
             # the table: per row a sum over the few hundred (coarse levels) to a handful (fine levels) of samples in its
             # cells, accumulated by fp32 atomics in an arbitrary order on the oracle side, in fp64 per tile here
@@ -135,7 +150,7 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
             err = float((got_g - r).abs().max())
             worst[n] = err / float(r.abs().max())
             assert err < tol, (n, err, float(r.abs().max()))
-    print("configs[2] gradient bars used (MLP: excess over 1e-4 rel in units of eps32 x sum|terms|; table: / max):", worst)
+    print("configs[2] gradient bars (MLP: per-entry error / bar, and both relative to the largest entry; table: / max):", worst)
     assert float(grads_ref["encoder.embeddings"].abs().max()) > 0
 
 

@@ -1,10 +1,25 @@
-"""Fused fp32 MLP (v_mfma_f32_32x32x2_f32) vs the plain nn.Linear / ReLU stack it replaces: 1e-4 rel (fp32)."""
+"""Fused fp32 MLP vs the plain nn.Linear / ReLU stack it replaces, in both of its arithmetic modes
+(enerf_mlp32_precision): "fp32" = v_mfma_f32_32x32x2_f32, every dot product an fp32 fmaf chain -- the bars below are
+fp32 round-off (2e-6 of the output scale on the forward); "split-bf16" (the default of the product) = operands as bf16
+hi + lo, three bf16 MFMA products per fp32 product -- the same bars times 8, i.e. 1.6e-5 on the forward, all inside the
+path's 1e-4."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+@pytest.fixture(autouse=True, params=["split-bf16", "fp32"])
+def precision(request):
+    """Runs every test of this file in both arithmetic modes; the value is the factor on the fp32 round-off bars."""
+    from enerf_amd import _lib
+    mode = 1 if request.param == "split-bf16" else 0
+    prev = _lib.lib().enerf_mlp32_precision(mode)
+    assert _lib.lib().enerf_mlp32_precision(-1) == mode
+    yield 8.0 if mode == 1 else 1.0
+    _lib.lib().enerf_mlp32_precision(prev)
 
 
 def _ref(x, ws):
@@ -18,7 +33,8 @@ def _ref(x, ws):
 
 @pytest.mark.parametrize("dims,B", [((32, 64, 16), 4096), ((31, 64, 64, 3), 5000), ((32, 64, 64, 64, 32), 96),
                                     ((20, 64, 1), 33)])
-def test_fused_mlp_forward_backward(dims, B):
+def test_fused_mlp_forward_backward(dims, B, precision):
+    k = precision
     from enerf_amd.fused_mlp import fused_mlp, supported
     torch.manual_seed(len(dims) * 7 + B)
     ws = [(torch.rand(dims[k + 1], dims[k], device=DEV) * 2 - 1) * (3.0 / dims[k]) ** 0.5 for k in range(len(dims) - 1)]
@@ -34,11 +50,22 @@ def test_fused_mlp_forward_backward(dims, B):
     # fp64 reference of the same stack
     yr = _ref(xb.double(), [w.double() for w in wb])
     (yr * g.double()).sum().backward()
-    sc = float(yr.abs().max())
-    assert float((y.double() - yr).abs().max()) < 2e-6 * max(sc, 1.0)
-    assert float((xa.grad.double() - xb.grad).abs().max()) < 1e-5 * float(xb.grad.abs().max())
+    sc = float(yr.detach().abs().max())
+    assert float((y.double() - yr).abs().max()) < k * 2e-6 * max(sc, 1.0)
+    # a hidden unit whose fp64 pre-activation lies within the forward error of zero may sit on the other side of the
+    # ReLU on the device: that sample's input gradient and one term of each weight gradient legitimately differ
+    with torch.no_grad():
+        h, kink = xb.double(), torch.zeros(B, dtype=torch.bool, device=DEV)
+        for w in wb[:-1]:
+            pre = h @ w.double().t()
+            kink |= ((pre.abs() < k * 2e-6 * max(float(pre.abs().max()), 1.0)) & (pre != 0)).any(dim=1)
+            h = torch.relu(pre)
+    n_kink = int(kink.sum())
+    assert n_kink <= k * (2 + B // 500)
+    ok = ~kink
+    assert float((xa.grad.double() - xb.grad)[ok].abs().max()) < k * 1e-5 * float(xb.grad.abs().max())
     for a, b in zip(wa, wb):
-        assert float((a.grad.double() - b.grad).abs().max()) < 2e-5 * float(b.grad.abs().max())
+        assert float((a.grad.double() - b.grad).abs().max()) < (k * 2e-5 + 2e-3 * n_kink) * float(b.grad.abs().max())
     # inference path (no grad) gives the same values
     with torch.no_grad():
         y2 = fused_mlp(x, ws)
@@ -46,11 +73,12 @@ def test_fused_mlp_forward_backward(dims, B):
 
 
 @pytest.mark.parametrize("B", [1, 31, 4097, 70000])
-def test_level_major_encoder_into_fused_mlp(B):
+def test_level_major_encoder_into_fused_mlp(B, precision):
     """Grid encoder (out_layout 2, [16,Bp,2]) -> fused MLP (x_layout 1) -> and back: same values / gradients as the
     row-major route, bit for bit on the encoding and to fp32 round-off through the MLP."""
     from enerf_amd.fused_mlp import fused_mlp, pad32
     from enerf_amd.gridencoder import GridEncoder
+    k = precision
     torch.manual_seed(B)
     enc = GridEncoder(desired_resolution=4096).to(DEV)
     enc.embeddings.data.uniform_(-1, 1)
@@ -80,27 +108,27 @@ def test_level_major_encoder_into_fused_mlp(B):
     y1, ge1, gx1, gw1 = run(True)
     y0, ge0, gx0, gw0 = run(False)
     sc = max(float(y0.abs().max()), 1.0)
-    assert float((y1 - y0).abs().max()) < 2e-6 * sc
+    assert float((y1 - y0).abs().max()) < k * 2e-6 * sc
     # fp64 statement of the MLP on the exact encoder output
     pre = feats_rows.double() @ ws[0].double().t()
     h = torch.relu(pre) @ ws[1].double().t()
-    assert float((y1.double() - h).abs().max()) < 2e-6 * sc
+    assert float((y1.double() - h).abs().max()) < k * 2e-6 * sc
     # The two layouts sum the first layer in different orders, so a pre-activation within round-off of zero may
     # take the other side of the ReLU kink; such a sample legitimately changes its own gradients (8 rows per level
     # of the embedding gradient, its input gradient, one term of each weight gradient).
-    kink = ((pre.abs() < 2e-6) & (pre != 0)).any(dim=1)      # exact zeros (out-of-range point) are not kinks
+    kink = ((pre.abs() < k * 2e-6) & (pre != 0)).any(dim=1)      # exact zeros (out-of-range point) are not kinks
     n_kink = int(kink.sum())
-    assert n_kink <= 3 + B // 1000
-    bad_rows = ((ge1 - ge0).abs().max(dim=1).values > 2e-5 * float(ge0.abs().max()) + 1e-12).sum()
+    assert n_kink <= (3 + B // 1000) * k
+    bad_rows = ((ge1 - ge0).abs().max(dim=1).values > k * 2e-5 * float(ge0.abs().max()) + 1e-12).sum()
     assert int(bad_rows) <= 128 * n_kink
     ok = ~kink
-    assert float((gx1[ok] - gx0[ok]).abs().max()) <= 2e-5 * float(gx0.abs().max()) + 1e-12
+    assert float((gx1[ok] - gx0[ok]).abs().max()) <= k * 2e-5 * float(gx0.abs().max()) + 1e-12
     for a, b in zip(gw1, gw0):
-        assert float((a - b).abs().max()) <= (2e-5 + 1e-3 * n_kink) * float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= (k * 2e-5 + 1e-3 * n_kink) * float(b.abs().max()) + 1e-12
 
 
 @pytest.mark.parametrize("N", [1, 4096, 70001])
-def test_fused_network_node_matches_unfused_route(monkeypatch, N):
+def test_fused_network_node_matches_unfused_route(monkeypatch, N, precision):
     """enerf_amd.fused_network (one autograd node for grid -> sigma MLP -> trunc_exp / SH -> colour MLP -> sigmoid)
     against the op-by-op route of network.py, which itself is pinned against the nn.Linear loop below."""
     from enerf_amd import fused_network as fn
@@ -127,10 +155,10 @@ def test_fused_network_node_matches_unfused_route(monkeypatch, N):
     assert len(calls) == 1
     s0, c0, g0 = run(False)
     assert len(calls) == 1
-    assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-6)).max()) < 2e-5
-    assert float((c1 - c0).abs().max()) < 2e-6
+    assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-6)).max()) < precision * 2e-5
+    assert float((c1 - c0).abs().max()) < precision * 2e-6
     for n in g0:
-        tol = 5e-4 if N > 10000 else 5e-5          # a ReLU kink flipped by the summation order moves one sample's terms
+        tol = (5e-4 if N > 10000 else 5e-5) * (2 if precision > 1 else 1)          # a ReLU kink flipped by the summation order moves one sample's terms
         assert float((g1[n] - g0[n]).abs().max()) <= tol * float(g0[n].abs().max()) + 1e-9, n
     # accumulation straight into an existing .grad gives the same embedding gradient
     m.zero_grad()
@@ -139,13 +167,13 @@ def test_fused_network_node_matches_unfused_route(monkeypatch, N):
     s, c = m(x, d)
     ((s * gs).sum() + (c * gc).sum()).backward()
     ref = g1["encoder.embeddings"]
-    assert float((m.encoder.embeddings.grad - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9
+    assert float((m.encoder.embeddings.grad - ref).abs().max()) <= precision * 2e-5 * float(ref.abs().max()) + 1e-9
     with torch.no_grad():
         s2, c2 = m(x, d)
     assert torch.equal(s2, s1) and torch.equal(c2, c1)
 
 
-def test_network_uses_fused_path_and_matches_linear_loop(monkeypatch):
+def test_network_uses_fused_path_and_matches_linear_loop(monkeypatch, precision):
     from enerf_amd import fused_mlp as fm
     from enerf_amd import fused_network as fn
     from enerf_amd.network import NeRFNetwork
@@ -170,7 +198,13 @@ def test_network_uses_fused_path_and_matches_linear_loop(monkeypatch):
     assert float(((s1 - s2).abs() / s2.abs().clamp(min=1e-6)).max()) < 1e-4
     assert float((c1 - c2).abs().max()) < 1e-5
     for n, p in m.named_parameters():
-        assert float((p.grad - g1[n]).abs().max()) <= 2e-4 * float(p.grad.abs().max()) + 1e-7, n
+        # split-bf16: ~10x the forward error of the fp32 chains, so a few more hidden units of the 4096 x 192 sit on the
+        # other side of their ReLU than in the nn.Linear loop; each moves one row of a weight gradient by one sample's term
+        err, top = (p.grad - g1[n]).abs(), float(p.grad.abs().max())
+        if precision == 1:
+            assert float(err.max()) <= 2e-4 * top + 1e-7, n
+        else:
+            assert float(err.max()) <= 4e-3 * top + 1e-7 and float((err > 2e-4 * top).float().mean()) <= 0.05, n
 
 
 def test_fused_adam_matches_torch_adam():
@@ -196,7 +230,7 @@ def test_fused_adam_matches_torch_adam():
             assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
 
 
-def test_density_sigma_only_path_matches_density():
+def test_density_sigma_only_path_matches_density(precision):
     """fused_network.density_sigma (update_extra_state's evaluator: sigma MLP writes exp(column 0) only) vs
     NeRFNetwork.density on the same points."""
     from enerf_amd import fused_network as fn
@@ -209,7 +243,8 @@ def test_density_sigma_only_path_matches_density():
         ref = m.density(x)["sigma"]
         got = fn.density_sigma(m, x)
     assert got.shape == ref.shape
-    assert float(((got - ref).abs() / ref.abs().clamp(min=1e-6)).max()) < 2e-5
+    # (both sides run the same kernels' arithmetic mode; the sigma-only variant sums its output row on the VALU in fp32)
+    assert float(((got - ref).abs() / ref.abs().clamp(min=1e-6)).max()) < (2e-5 if precision == 1 else 1e-4)
 
 
 def test_grid_table_adam_from_records_equals_backward_then_adam():
