@@ -61,8 +61,11 @@ def parse():
     ap.add_argument("--net", choices=["linear", "ff"], default="linear",
                     help="linear = nerf/network.py (BASELINE configs[1-3]); ff = nerf/network_ff.py FFMLP bf16 (configs[4])")
     ap.add_argument("--fp16", action="store_true",
-                    help="the shipped configs' fp16 = True variant: autocast(float16) + GradScaler, half hash table "
-                         "(588 B/point); op-by-op autograd route (reported as dtype f16-autocast; not the headline)")
+                    help="the shipped configs' fp16 = True regime on its MI355X route: the closed-form step with the "
+                         "networks on bf16 operands (fp32 accumulation, fp32 table, no loss scaling); dtype bf16-amp")
+    ap.add_argument("--fp16-autocast", action="store_true",
+                    help="fp16 = True taken literally: autocast(float16) + GradScaler, half hash table (588 B/point), "
+                         "op-by-op autograd route (dtype f16-autocast)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
                          "timing behind `roofline` only sees the launches that stay eager)")
@@ -247,8 +250,9 @@ def main():
         from enerf_amd import frame
         frame.FRAME_ENABLED = False
         model.infer_batch_mult = 8
-    harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs, fp16=args.fp16)
-    if args.fp16:
+    harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs,
+                           fp16="autocast" if args.fp16_autocast else args.fp16)
+    if args.fp16 or args.fp16_autocast:
         args.probe_steps = 0
         args.graph_leg_steps = 0
     harness.prefetch = not args.no_prefetch
@@ -628,7 +632,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.global_rays else "weak",
             "vs_baseline": None,
-            "dtype": "f16-autocast" if args.fp16 else "f32",
+            "dtype": "f16-autocast" if args.fp16_autocast else ("bf16-amp" if args.fp16 else ("bf16" if args.net == "ff" else "f32")),
             "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[3]: {args.global_rays} rays/step ray-sharded over {world} rank(s), "
                                     if args.global_rays else "BASELINE configs[1]: ") +

@@ -828,7 +828,8 @@ static bool g_have_pending = false;
 static ReduceJob g_pending;
 
 bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
-int g_precision = 1;                // enerf_mlp32_precision: 0 = fp32 MFMA (bit-exact fmaf chains), 1 = split-bf16 (x3)
+int g_precision = 1;                // enerf_mlp32_precision: 0 = fp32 MFMA (bit-exact fmaf chains), 1 = split-bf16 (x3),
+                                    // 2 = bf16 operands (the FFMLP nets' arithmetic: one product, 16-bit roundings)
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
 uint32_t g_fwd_blocks = 0;          // 0: default cap of the forward grid
@@ -851,10 +852,13 @@ int enerf_mlp32_valid_rows(const int32_t* device_count) {
 
 // Arithmetic of the mlp32 kernels: 0 = v_mfma_f32_32x32x2_f32 (every dot product an fp32 fmaf chain, bit-comparable
 // with an fp32 GEMM), 1 (default) = split-bf16: operands carried as bf16 hi + lo, three bf16 MFMA products per fp32
-// product, fp32 accumulation (~2^-16 relative per product).  Returns the previous mode; mode < 0 only queries.
+// product, fp32 accumulation (~2^-16 relative per product), 2 = bf16 operands: inputs, weights and every layer's
+// activations / activation gradients rounded to bf16, one product, fp32 accumulation, outputs rounded to bf16 -- the
+// arithmetic of the FFMLP nets (ffmlp.hip) on fp32 buffers, for the fused training step of nerf/network_ff.py.
+// Returns the previous mode; mode < 0 only queries.
 int enerf_mlp32_precision(int mode) {
     const int prev = g_precision;
-    if (mode == 0 || mode == 1) g_precision = mode;
+    if (mode >= 0 && mode <= 2) g_precision = mode;
     return prev;
 }
 
@@ -898,8 +902,8 @@ static int segs_ok(const void* const* seg, uint32_t num_hidden, uint32_t w0_cols
         set_error("%s: a weight segment pointer is missing", what);
         return ENERF_E_BADARG;
     }
-    if ((nerf_perm && w0_cols != 31) || (!nerf_perm && w0_cols != IN)) {
-        set_error("%s: first-layer rows are 32 floats, or 31 with the NeRF colour permutation", what);
+    if ((nerf_perm && w0_cols != 31 && w0_cols != IN) || (!nerf_perm && w0_cols != IN)) {
+        set_error("%s: first-layer rows are 32 floats, or 31 / 32 with the NeRF colour permutation", what);
         return ENERF_E_BADARG;
     }
     return 0;
@@ -910,8 +914,10 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
                               uint32_t x_layout, uint32_t y_stride, float* y0_exp, const float* sh_dirs,
                               enerf_stream_t stream) {
     if (B == 0) return 0;
-    if (sh_dirs && !(num_hidden == 1 && x_layout == 1 && Y && out_dim <= 16 && (y_stride == 0 ? out_dim : y_stride) >= 32))
-        ENERF_BADARG("mlp32_forward_sh: needs one hidden layer, level-major input, out_dim <= 16 and rows of >= 32 floats");
+    if (sh_dirs && !((num_hidden == 1 || (num_hidden == 2 && g_precision != 0)) && x_layout == 1 && Y && out_dim <= 16 &&
+                     (y_stride == 0 ? out_dim : y_stride) >= 32))
+        ENERF_BADARG("mlp32_forward_sh: needs one hidden layer (two in the bf16 modes), level-major input, out_dim <= 16 "
+                     "and rows of >= 32 floats");
     if (in_dim != IN) ENERF_BADARG("mlp32: in_dim must be 32 (pad the input), got %u", in_dim);
     if (out_dim == 0 || out_dim > 32) ENERF_BADARG("mlp32: out_dim must be in [1, 32], got %u", out_dim);
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
@@ -940,8 +946,8 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
         }                                                     \
     } while (0)
     const bool sigma_only = num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1;
-    if (g_precision == 1) {
-        mlp32s_launch_fwd(num_hidden, fb != nullptr, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
+    if (g_precision != 0) {
+        mlp32s_launch_fwd(g_precision == 1 ? 3 : 1, num_hidden, fb != nullptr, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
                           output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s);
     } else if (sh_dirs) {
         const ShNorm4 nrm = make_sh_norm4();
@@ -1025,7 +1031,13 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
     const size_t lds = sizeof(float) * NW;
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
-    const bool fused = g_fused_bwd && num_hidden <= 2;
+    // the split / bf16 kernels: one or two hidden layers in either mode, three (the FFMLP colour net, row-major input) with
+    // bf16 operands
+    const bool split_bwd = g_fused_bwd && g_precision != 0 && out_dim <= 16 &&
+                           (num_hidden <= 2 || (g_precision == 2 && num_hidden == 3 && x_layout == 0));
+    if (g_precision == 2 && !split_bwd)
+        ENERF_BADARG("mlp32_backward: bf16 operands (precision 2) need out_dim <= 16 and at most three hidden layers");
+    const bool fused = split_bwd || (g_fused_bwd && num_hidden <= 2);
     if (!fused && W.valid_rows)
         ENERF_BADARG("mlp32_backward: enerf_mlp32_valid_rows needs the fused backward (num_hidden <= 2)");
     const uint32_t grid = pgrid(B, 1024);
@@ -1074,9 +1086,9 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         else if (out_dim <= 16) MLP32_BF(NHV, 8, XLV); \
         else MLP32_BF(NHV, 16, XLV);             \
     } while (0)
-    if (fused && g_precision == 1 && out_dim <= 16) {
+    if (split_bwd) {
         (void)bb;
-        mlp32s_launch_bwd(num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation, wgrid, s);
+        mlp32s_launch_bwd(g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation, wgrid, s);
     } else if (fused) {
         (void)bb;
         if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }

@@ -33,42 +33,56 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-struct Frag {
+// P = 3: hi + lo (fp32 operands, three products); P = 1: hi only -- the operand IS a bf16 number (the FFMLP nets of
+// nerf/network_ff.py: 16-bit weights, activations rounded to 16 bits between layers, fp32 accumulation), one product.
+template <int P>
+struct FragT {
     bf16x8 hi, lo;
+};
+template <>
+struct FragT<1> {
+    bf16x8 hi;
 };
 
 __device__ __forceinline__ f32x16 mmab(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x16 mma3(const Frag& a, const Frag& b, f32x16 c) {
+__device__ __forceinline__ f32x16 mmap(const FragT<3>& a, const FragT<3>& b, f32x16 c) {
     c = mmab(a.lo, b.hi, c);
     c = mmab(a.hi, b.lo, c);
     return mmab(a.hi, b.hi, c);
 }
-__device__ __forceinline__ Frag split8(const float (&v)[8]) {
+__device__ __forceinline__ f32x16 mmap(const FragT<1>& a, const FragT<1>& b, f32x16 c) { return mmab(a.hi, b.hi, c); }
+
+__device__ __forceinline__ float bf16r(float x) { return (float)(__bf16)x; }      // round to nearest bf16, back to fp32
+
+template <int P>
+__device__ __forceinline__ FragT<P> split8(const float (&v)[8]) {
     i32x4 rh, rl;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const f32x2 f = {v[2 * p], v[2 * p + 1]};
         const bf16x2 h2 = __builtin_convertvector(f, bf16x2);              // v_cvt_pk_bf16_f32 (RNE)
-        const f32x2 rest = f - __builtin_convertvector(h2, f32x2);         // exact in fp32
-        const bf16x2 l2 = __builtin_convertvector(rest, bf16x2);
         rh[p] = __builtin_bit_cast(int, h2);
-        rl[p] = __builtin_bit_cast(int, l2);
+        if (P == 3) {
+            const f32x2 rest = f - __builtin_convertvector(h2, f32x2);     // exact in fp32
+            rl[p] = __builtin_bit_cast(int, __builtin_convertvector(rest, bf16x2));
+        }
     }
-    Frag r;
+    FragT<P> r;
     r.hi = __builtin_bit_cast(bf16x8, rh);
-    r.lo = __builtin_bit_cast(bf16x8, rl);
+    if constexpr (P == 3) r.lo = __builtin_bit_cast(bf16x8, rl);
     return r;
 }
 // accumulator registers 8t .. 8t+7 of a D tile as the operand of K-step t
-__device__ __forceinline__ void split_tile(const f32x16& a, Frag (&f)[2]) {
+template <int P>
+__device__ __forceinline__ void split_tile(const f32x16& a, FragT<P> (&f)[2]) {
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = a[8 * t + e];
-        f[t] = split8(v);
+        f[t] = split8<P>(v);
     }
 }
 // registers of a tile whose values ARE bf16 numbers (a flipped tile) -> operand halves, exactly
@@ -96,30 +110,34 @@ __device__ __forceinline__ bf16x8 selector(int c, int h, int kind) {
 }
 // D tile (as its two K-step operands) -> the same 32 x 32 block with the neuron on the lanes: lane (c, h) gets
 // T[c][sample nrow(q, h)], q = 0..15, again as two K-step operands (contraction over samples)
-__device__ __forceinline__ void flip_tile(const Frag (&f)[2], bf16x8 selA, bf16x8 selB, Frag (&out)[2]) {
-    f32x16 dh = (f32x16)(0.0f), dl = (f32x16)(0.0f);
+template <int P>
+__device__ __forceinline__ void flip_tile(const FragT<P> (&f)[2], bf16x8 selA, bf16x8 selB, FragT<P> (&out)[2]) {
+    f32x16 dh = (f32x16)(0.0f);
     dh = mmab(f[0].hi, selA, dh);
-    dl = mmab(f[0].lo, selA, dl);
     dh = mmab(f[1].hi, selB, dh);
-    dl = mmab(f[1].lo, selB, dl);
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        out[t].hi = exact8(dh, t);
-        out[t].lo = exact8(dl, t);
+    for (int t = 0; t < 2; t++) out[t].hi = exact8(dh, t);
+    if constexpr (P == 3) {
+        f32x16 dl = (f32x16)(0.0f);
+        dl = mmab(f[0].lo, selA, dl);
+        dl = mmab(f[1].lo, selB, dl);
+#pragma unroll
+        for (int t = 0; t < 2; t++) out[t].lo = exact8(dl, t);
     }
 }
-__device__ __forceinline__ void flip_natural(const Frag& f, bf16x8 selN, Frag (&out)[2]) {
-    f32x16 dh = (f32x16)(0.0f), dl = (f32x16)(0.0f);
-    dh = mmab(f.hi, selN, dh);
-    dl = mmab(f.lo, selN, dl);
+template <int P>
+__device__ __forceinline__ void flip_natural(const FragT<P>& f, bf16x8 selN, FragT<P> (&out)[2]) {
+    f32x16 dh = mmab(f.hi, selN, (f32x16)(0.0f));
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        out[t].hi = exact8(dh, t);
-        out[t].lo = exact8(dl, t);
+    for (int t = 0; t < 2; t++) out[t].hi = exact8(dh, t);
+    if constexpr (P == 3) {
+        f32x16 dl = mmab(f.lo, selN, (f32x16)(0.0f));
+#pragma unroll
+        for (int t = 0; t < 2; t++) out[t].lo = exact8(dl, t);
     }
 }
 
-template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false>
+template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false, int P = 3>
 __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X, WSrc W,
                                                     float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
                                                     uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
@@ -135,6 +153,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
     }
     stage_rot(wl, W, NH, out_dim);
 
+    typedef FragT<P> Frag;
     Frag w0[2][2], wh[NH > 1 ? NH - 1 : 1][2][2][2], wo[2][2];
     float wsig[2][16];                                    // SIG: the output row as fp32 (VALU dot product)
 #pragma unroll
@@ -144,7 +163,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = wl[rot(32 * ob + j, kmap<XL>(8 * t + e, h), IN)];
-            w0[ob][t] = split8(v);
+            w0[ob][t] = split8<P>(v);
         }
 #pragma unroll
     for (int l = 0; l < NH - 1; l++)
@@ -158,7 +177,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
 #pragma unroll
                     for (int e = 0; e < 8; e++)
                         v[e] = wl[HID * IN + rot(l * HID + 32 * ob + j, 32 * ib + nrow(8 * t + e, h), HID)];
-                    wh[l][ob][ib][t] = split8(v);
+                    wh[l][ob][ib][t] = split8<P>(v);
                 }
     {
         const float* w64 = wl + HID * IN;
@@ -175,7 +194,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
 #pragma unroll
                     for (int e = 0; e < 8; e++)
                         v[e] = (uint32_t)j < out_dim ? w64[rot(r0 + j, 32 * ib + nrow(8 * t + e, h), HID)] : 0.0f;
-                    wo[ib][t] = split8(v);
+                    wo[ib][t] = split8<P>(v);
                 }
             }
         }
@@ -201,7 +220,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = x[8 * t + e];
-            xf[t] = split8(v);
+            xf[t] = split8<P>(v);
         }
         if (SIG && tile + nw < ntiles) load_x<XL>(X, tile + nw, j, h, B, Bp, x);
         f32x16 a[2];
@@ -210,7 +229,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
         for (int ob = 0; ob < 2; ob++) {
             a[ob] = (f32x16)(0.0f);
 #pragma unroll
-            for (int t = 0; t < 2; t++) a[ob] = mma3(w0[ob][t], xf[t], a[ob]);
+            for (int t = 0; t < 2; t++) a[ob] = mmap(w0[ob][t], xf[t], a[ob]);
 #pragma unroll
             for (int q = 0; q < 16; q++) a[ob][q] = __int_as_float(max(__float_as_int(a[ob][q]), relu_lim));
             if (TRAIN) store_tile_fb(fb + s * HID, ob, h, a[ob]);
@@ -225,7 +244,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
 #pragma unroll
                 for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-                    for (int t = 0; t < 2; t++) n[ob] = mma3(wh[l - 1][ob][ib][t], af[ib][t], n[ob]);
+                    for (int t = 0; t < 2; t++) n[ob] = mmap(wh[l - 1][ob][ib][t], af[ib][t], n[ob]);
 #pragma unroll
                 for (int q = 0; q < 16; q++) n[ob][q] = __int_as_float(max(__float_as_int(n[ob][q]), relu_lim));
                 if (TRAIN) store_tile_fb(fb + ((size_t)l * Bp + s) * HID, ob, h, n[ob]);
@@ -253,13 +272,19 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
 #pragma unroll
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) o = mma3(wo[ib][t], af[ib][t], o);
+            for (int t = 0; t < 2; t++) o = mmap(wo[ib][t], af[ib][t], o);
         if (valid) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t r = (uint32_t)nrow(q, h);
-                if (Y && r < out_dim) Y[s * y_stride + r] = out_act_fwd(o[q], out_act);
-                if (r == 0 && y0_exp) y0_exp[s] = expf(o[q]);
+                // P == 1: the net's outputs are 16-bit numbers, and so is whatever an elementwise op makes of them
+                // (torch evaluates exp / sigmoid of a bf16 tensor in fp32 and rounds once)
+                const float ov = P == 1 ? bf16r(o[q]) : o[q];
+                if (Y && r < out_dim) {
+                    const float yv = out_act_fwd(ov, out_act);
+                    Y[s * y_stride + r] = (P == 1 && out_act != 6) ? bf16r(yv) : yv;
+                }
+                if (r == 0 && y0_exp) y0_exp[s] = P == 1 ? bf16r(expf(ov)) : expf(ov);
             }
             if (SH) {
                 float sh[16];
@@ -277,12 +302,12 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
     }
 }
 
-// dgrad + wgrad of a net with one or two hidden layers and out_dim <= 16, one kernel, no LDS traffic for the tiles.
+// dgrad + wgrad of a net with one to three hidden layers and out_dim <= 16, one kernel, no LDS traffic for the tiles.
 // Two hidden layers: the weight operands (14 fragments, 112 registers) would push the wavefront past its 512 registers,
 // so they are kept in LDS in operand order (hi and lo: 64 lanes x 16 B each, one conflict-free ds_read_b128 per half) and
 // read where they are used; one hidden layer keeps them in registers.
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-template <int NH, int XL>
+template <int NH, int XL, int P = 3>
 __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* __restrict__ X, WSrc W,
                                                     const float* __restrict__ fb, float* __restrict__ dX,
                                                     float* __restrict__ partial, uint32_t B, uint32_t out_dim,
@@ -290,8 +315,13 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
     constexpr uint32_t NW_MAX = HID * IN + (NH - 1) * HID * HID + 16 * HID;
     constexpr bool WL = NH > 1;                                        // weight operands from LDS
     constexpr int NFRAG = 2 + 4 + 8 * (NH - 1);
-    static_assert(NW_MAX * 4 + NFRAG * 2048 <= 4 * NW_MAX * 4, "operand region must fit beside the staged weights");
-    __shared__ __attribute__((aligned(16))) float lds[4 * NW_MAX];      // staged weights (+ operands), then the four waves' dW sums
+    constexpr int FRQ = P == 3 ? 2 : 1;                                // 64 x 16 B pieces per operand (hi, lo)
+    // the final sums: four regions (one per wave) where they fit, two otherwise (three hidden layers: 4 x 44 KiB would
+    // not), see the end of the kernel
+    constexpr int NRED = NH > 2 ? 2 : 4;
+    static_assert(NW_MAX * 4 + NFRAG * FRQ * 1024 <= NRED * NW_MAX * 4, "operand region must fit beside the staged weights");
+    typedef FragT<P> Frag;
+    __shared__ __attribute__((aligned(16))) float lds[NRED * NW_MAX];   // staged weights (+ operands), then the waves' dW sums
     float* wl = lds;
     const uint32_t NW = blob_size(NH, out_dim);
     stage(wl, W, NW);
@@ -302,14 +332,14 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
     u32x4v* fr = reinterpret_cast<u32x4v*>(lds + NW_MAX);
     auto put = [&](int f, const Frag& w) {                             // built by every wave, stored by wave f % 4
         if ((f & 3) == wid) {
-            fr[(2 * f) * 64 + lane] = __builtin_bit_cast(u32x4v, w.hi);
-            fr[(2 * f + 1) * 64 + lane] = __builtin_bit_cast(u32x4v, w.lo);
+            fr[(FRQ * f) * 64 + lane] = __builtin_bit_cast(u32x4v, w.hi);
+            if constexpr (P == 3) fr[(FRQ * f + 1) * 64 + lane] = __builtin_bit_cast(u32x4v, w.lo);
         }
     };
     auto get = [&](int f) -> Frag {
         Frag w;
-        w.hi = __builtin_bit_cast(bf16x8, fr[(2 * f) * 64 + lane]);
-        w.lo = __builtin_bit_cast(bf16x8, fr[(2 * f + 1) * 64 + lane]);
+        w.hi = __builtin_bit_cast(bf16x8, fr[(FRQ * f) * 64 + lane]);
+        if constexpr (P == 3) w.lo = __builtin_bit_cast(bf16x8, fr[(FRQ * f + 1) * 64 + lane]);
         return w;
     };
 
@@ -322,7 +352,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             const uint32_t o = (uint32_t)(8 * h + e);
             v[e] = o < out_dim ? wout[o * HID + 32 * ib + j] : 0.0f;
         }
-        woT[ib] = split8(v);
+        woT[ib] = split8<P>(v);
         if (WL) put(ib, woT[ib]);
     }
 #pragma unroll
@@ -332,7 +362,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = wl[(32 * ob + nrow(8 * t + e, h)) * IN + j];
-            wiT[ob][t] = split8(v);
+            wiT[ob][t] = split8<P>(v);
             if (WL) put(2 + 2 * ob + t, wiT[ob][t]);
         }
 #pragma unroll
@@ -347,7 +377,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
 #pragma unroll
                     for (int e = 0; e < 8; e++)
                         v[e] = wl[HID * IN + l * HID * HID + (32 * ob + nrow(8 * t + e, h)) * HID + 32 * ib + j];
-                    whT[l][ib][ob][t] = split8(v);
+                    whT[l][ib][ob][t] = split8<P>(v);
                     if (WL) put(6 + ((l * 2 + ib) * 2 + ob) * 2 + t, whT[l][ib][ob][t]);
                 }
     if (WL) __syncthreads();
@@ -456,35 +486,35 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
                 if (dys.dsigma && o == 0) gq = ds_raw * expf(fminf(fmaxf(h0_raw, -15.0f), 15.0f));
                 dy[e] = (valid && o < out_dim) ? gq : 0.0f;
             }
-            dyf = split8(dy);
+            dyf = split8<P>(dy);
         }
         f32x16 g[2];
         Frag ft[2][2], gf[2][2], gT[2][2];             // [block][K-step]: flipped activations, gradients, flipped gradients
 #pragma unroll
         for (int ib = 0; ib < 2; ib++) {
-            g[ib] = mma3(WO(ib), dyf, (f32x16)(0.0f));
+            g[ib] = mmap(WO(ib), dyf, (f32x16)(0.0f));
             if (act == 0) {                            // (wave-uniform: a scalar branch, not a select per element)
 #pragma unroll
                 for (int q = 0; q < 16; q++) g[ib][q] = fwl[NH - 1][ib][q] > 0.0f ? g[ib][q] : 0.0f;
             }
             Frag ff[2];
-            split_tile(fwl[NH - 1][ib], ff);
-            flip_tile(ff, selA, selB, ft[ib]);
+            split_tile<P>(fwl[NH - 1][ib], ff);
+            flip_tile<P>(ff, selA, selB, ft[ib]);
         }
         request_out(tnext);
         {
             // dWout[o][i] += dY[o][s] * fb_last[i][s]
             Frag dyT[2];
-            flip_natural(dyf, selN, dyT);
+            flip_natural<P>(dyf, selN, dyT);
 #pragma unroll
             for (int nb = 0; nb < 2; nb++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) awo[nb] = mma3(dyT[t], ft[nb][t], awo[nb]);
+                for (int t = 0; t < 2; t++) awo[nb] = mmap(dyT[t], ft[nb][t], awo[nb]);
         }
 #pragma unroll
         for (int ib = 0; ib < 2; ib++) {
-            split_tile(g[ib], gf[ib]);
-            flip_tile(gf[ib], selA, selB, gT[ib]);
+            split_tile<P>(g[ib], gf[ib]);
+            flip_tile<P>(gf[ib], selA, selB, gT[ib]);
         }
         // ---- hidden layers
 #pragma unroll
@@ -497,13 +527,13 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
 #pragma unroll
                 for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-                    for (int t = 0; t < 2; t++) n[ib] = mma3(WH(l - 1, ib, ob, t), gf[ob][t], n[ib]);
+                    for (int t = 0; t < 2; t++) n[ib] = mmap(WH(l - 1, ib, ob, t), gf[ob][t], n[ib]);
             }
 #pragma unroll
             for (int ib = 0; ib < 2; ib++) {
                 Frag ff[2];
-                split_tile(fwl[l - 1][ib], ff);
-                flip_tile(ff, selA, selB, ft[ib]);
+                split_tile<P>(fwl[l - 1][ib], ff);
+                flip_tile<P>(ff, selA, selB, ft[ib]);
             }
             // dWh[l-1][o][i] += G_l[o][s] * fb[l-1][i][s]
 #pragma unroll
@@ -511,7 +541,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
 #pragma unroll
                 for (int nb = 0; nb < 2; nb++)
 #pragma unroll
-                    for (int t = 0; t < 2; t++) awh[l - 1][ob][nb] = mma3(gT[ob][t], ft[nb][t], awh[l - 1][ob][nb]);
+                    for (int t = 0; t < 2; t++) awh[l - 1][ob][nb] = mmap(gT[ob][t], ft[nb][t], awh[l - 1][ob][nb]);
 #pragma unroll
             for (int ib = 0; ib < 2; ib++)
 #pragma unroll
@@ -519,8 +549,8 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             request_hidden(tnext, l - 1);
 #pragma unroll
             for (int ib = 0; ib < 2; ib++) {
-                split_tile(g[ib], gf[ib]);
-                flip_tile(gf[ib], selA, selB, gT[ib]);
+                split_tile<P>(g[ib], gf[ib]);
+                flip_tile<P>(gf[ib], selA, selB, gT[ib]);
             }
         }
         // ---- input layer: dW0[o][i] += G_0[o][s] * X[s][i]
@@ -534,20 +564,20 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
                     const int q = 8 * t + e;
                     v[e] = (XL == 0 && s0 + nrow(q, h) >= B) ? 0.0f : xT[q];
                 }
-                xf[t] = split8(v);
+                xf[t] = split8<P>(v);
             }
             request_x(tnext);
 #pragma unroll
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) aw0[ob] = mma3(gT[ob][t], xf[t], aw0[ob]);
+                for (int t = 0; t < 2; t++) aw0[ob] = mmap(gT[ob][t], xf[t], aw0[ob]);
         }
         if (dX) {
             f32x16 d = (f32x16)(0.0f);
 #pragma unroll
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) d = mma3(WI(ob, t), gf[ob][t], d);
+                for (int t = 0; t < 2; t++) d = mmap(WI(ob, t), gf[ob][t], d);
             if (XL == 0) {
                 if (valid) {
 #pragma unroll
@@ -566,55 +596,80 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
         }
     }
 
-    // per-workgroup sums, as in the fp32 kernel: the four waves write their accumulators into regions of their own, the
-    // sums are taken in wave order on the way out (deterministic)
+    // per-workgroup sums, as in the fp32 kernel: the waves write their accumulators into regions of their own and the
+    // sums are taken in a fixed order on the way out (deterministic).  NRED == 4: one region per wave, ((w0 + w1) + w2) +
+    // w3.  NRED == 2: waves 0 / 1 write, waves 2 / 3 add into the same regions, (w0 + w2) + (w1 + w3).
     __syncthreads();
-    float* red = lds + (size_t)wid * NW;
-    auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows) {
+    float* red = lds + (size_t)(wid % NRED) * NW;
+    auto flush = [&](const f32x16& a, uint32_t base, int ld, int ob, int nb, uint32_t nrows, bool add) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const uint32_t o = (uint32_t)(32 * ob + nrow(q, h));
-            if (o < nrows) red[base + o * ld + 32 * nb + j] = a[q];
+            if (o < nrows) {
+                float* p = red + base + o * ld + 32 * nb + j;
+                *p = add ? *p + a[q] : a[q];
+            }
         }
     };
+    auto flush_all = [&](bool add) {
 #pragma unroll
-    for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID);
+        for (int ob = 0; ob < 2; ob++) flush(aw0[ob], 0, IN, ob, 0, HID, add);
 #pragma unroll
-    for (int l = 0; l < NH - 1; l++)
+        for (int l = 0; l < NH - 1; l++)
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++)
+            for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-            for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID);
+                for (int nb = 0; nb < 2; nb++) flush(awh[l][ob][nb], HID * IN + l * HID * HID, HID, ob, nb, HID, add);
 #pragma unroll
-    for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim);
-    __syncthreads();
+        for (int nb = 0; nb < 2; nb++) flush(awo[nb], HID * IN + (NH - 1) * HID * HID, HID, 0, nb, out_dim, add);
+    };
     float* dst = partial + (size_t)blockIdx.x * NW;
-    for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x)
-        dst[i] = ((lds[i] + lds[NW + i]) + lds[2 * NW + i]) + lds[3 * NW + i];
+    if (NRED == 4) {
+        flush_all(false);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x)
+            dst[i] = ((lds[i] + lds[NW + i]) + lds[2 * NW + i]) + lds[3 * NW + i];
+    } else {
+        if (wid < 2) flush_all(false);
+        __syncthreads();
+        if (wid >= 2) flush_all(true);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = lds[i] + lds[NW + i];
+    }
 }
 
-void mlp32s_launch_fwd(uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X, const WSrc& W,
-                       float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
+void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
+                       const WSrc& W, float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
                        uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s) {
-#define S_FWD(NHV, TR, XLV, SIGV, SHV)                                                                                 \
-    k_mlp32s_fwd<NHV, TR, XLV, SIGV, SHV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, \
-                                                                 sh_dirs, nrm)
-#define S_FWD_XL(NHV, TR)                              \
-    do {                                               \
-        if (x_layout == 0) S_FWD(NHV, TR, 0, false, false); \
-        else S_FWD(NHV, TR, 1, false, false);          \
+#define S_FWD(NHV, TR, XLV, SIGV, SHV, PV)                                                                                  \
+    k_mlp32s_fwd<NHV, TR, XLV, SIGV, SHV, PV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, \
+                                                                     sh_dirs, nrm)
+#define S_FWD_P(NHV, TR, XLV, SIGV, SHV)                 \
+    do {                                                 \
+        if (prec == 3) S_FWD(NHV, TR, XLV, SIGV, SHV, 3); \
+        else S_FWD(NHV, TR, XLV, SIGV, SHV, 1);          \
     } while (0)
-#define S_FWD_TR(NHV)                 \
-    do {                              \
+#define S_FWD_XL(NHV, TR)                                   \
+    do {                                                    \
+        if (x_layout == 0) S_FWD_P(NHV, TR, 0, false, false); \
+        else S_FWD_P(NHV, TR, 1, false, false);             \
+    } while (0)
+#define S_FWD_TR(NHV)                   \
+    do {                                \
         if (train) S_FWD_XL(NHV, true); \
-        else S_FWD_XL(NHV, false);    \
+        else S_FWD_XL(NHV, false);      \
     } while (0)
     const ShNorm4 nrm = sh_dirs ? make_sh_norm4() : ShNorm4{};
-    if (sh_dirs) {
-        if (train) S_FWD(1, true, 1, false, true);
-        else S_FWD(1, false, 1, false, true);
+    if (sh_dirs) {                       // level-major input, the SH encoding into columns 16..31 of the output rows
+        if (num_hidden == 1) {
+            if (train) S_FWD_P(1, true, 1, false, true);
+            else S_FWD_P(1, false, 1, false, true);
+        } else {
+            if (train) S_FWD_P(2, true, 1, false, true);
+            else S_FWD_P(2, false, 1, false, true);
+        }
     } else if (sigma_only) {
-        S_FWD(1, false, 1, true, false);
+        S_FWD_P(1, false, 1, true, false);
     } else if (num_hidden == 1) {
         S_FWD_TR(1);
     } else if (num_hidden == 2) {
@@ -624,20 +679,29 @@ void mlp32s_launch_fwd(uint32_t num_hidden, bool train, uint32_t x_layout, bool 
     }
 #undef S_FWD_TR
 #undef S_FWD_XL
+#undef S_FWD_P
 #undef S_FWD
 }
 
-void mlp32s_launch_bwd(uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X, const WSrc& W,
-                       const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim, uint32_t act,
-                       uint32_t grid, hipStream_t s) {
-#define S_BWD(NHV, XLV) k_mlp32s_bwd<NHV, XLV><<<grid, 256, 0, s>>>(dys, X, W, fb, dX, partial, B, out_dim, act)
+void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
+                       const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
+                       uint32_t act, uint32_t grid, hipStream_t s) {
+#define S_BWD(NHV, XLV, PV) k_mlp32s_bwd<NHV, XLV, PV><<<grid, 256, 0, s>>>(dys, X, W, fb, dX, partial, B, out_dim, act)
+#define S_BWD_P(NHV, XLV)                  \
+    do {                                   \
+        if (prec == 3) S_BWD(NHV, XLV, 3); \
+        else S_BWD(NHV, XLV, 1);           \
+    } while (0)
     if (num_hidden == 1) {
-        if (x_layout == 0) S_BWD(1, 0);
-        else S_BWD(1, 1);
-    } else {
-        if (x_layout == 0) S_BWD(2, 0);
-        else S_BWD(2, 1);
+        if (x_layout == 0) S_BWD_P(1, 0);
+        else S_BWD_P(1, 1);
+    } else if (num_hidden == 2) {
+        if (x_layout == 0) S_BWD_P(2, 0);
+        else S_BWD_P(2, 1);
+    } else {                                 // three hidden layers: the FFMLP colour net (row-major input), P == 1 only
+        S_BWD(3, 0, 1);
     }
+#undef S_BWD_P
 #undef S_BWD
 }
 

@@ -217,6 +217,7 @@ def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None
     if g_emb2 is not None:                              # ... unless it could not (then it returns its own buffer)
         emb.grad.add_(g_emb2)
     dw1 += dw2
-    for p, g in zip(params[1:], fnet.unpack_weight_grads(dw1, params[-1].shape[0])):
+    kind = ctx1["sv"]["kind"]
+    for p, g in zip(params[1:], fnet.unpack_weight_grads(dw1, ctx1["sv"]["out_c"], kind)):
         p.grad = g.view_as(p)
     return loss.detach(), delta

@@ -192,7 +192,7 @@ def finish_march(model, pre):
 class _FusedRenderTrain(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, model, bg_color, counter, mean_count, perturb, force_all_rays, dt_gamma,
-                max_steps, pre, embeddings, ws0, ws1, wc0, wc1, wc2):
+                max_steps, pre, embeddings, *weights):
         N = rays_o.shape[0]
         dev = rays_o.device
         if pre is None:
@@ -200,9 +200,9 @@ class _FusedRenderTrain(Function):
         nears, fars, xyzs, dirs, deltas, rays, M = (pre[k] for k in ("nears", "fars", "xyzs", "dirs", "deltas", "rays",
                                                                      "M"))
 
-        train = any(p.requires_grad for p in (embeddings, ws0, ws1, wc0, wc1, wc2))
+        train = any(p.requires_grad for p in (embeddings,) + weights)
         sigma, rgb, sv = fnet.nerf_forward(xyzs, dirs, fnet.network_cfg(model), train, embeddings, fnet.encoder_offsets(model),
-                                           ws0, ws1, wc0, wc1, wc2)
+                                           *weights)
         scale = float(model.density_scale)
         sigmas = sigma if scale == 1.0 else sigma * scale
         weights_sum = torch.empty(N, dtype=torch.float32, device=dev)

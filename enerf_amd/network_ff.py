@@ -7,7 +7,7 @@ stores out_dim_color (3) so `render(staged=True)` also works.
 """
 import torch
 
-from . import fused_network_ff
+from . import fused_network, fused_network_ff
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .ffmlp import FFMLP
@@ -21,6 +21,7 @@ class NeRFNetwork(NeRFRenderer):
         super().__init__(bound, **kwargs)
         assert out_dim_color == 3, "the fully-fused colour net has 3 outputs (network_ff.py:44-49)"
         self.out_dim_color = 3
+        self.disable_view_direction = disable_view_direction
         self.num_layers = num_layers
         self.hidden_dim = hidden_dim
         self.geo_feat_dim = geo_feat_dim
@@ -43,6 +44,10 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d):
         if fused_network_ff.supported(self, x, d):
             return fused_network_ff.forward(self, x, d)           # inference: grid encode + one MFMA kernel
+        if fused_network.supported(self, x, d):
+            # training: one autograd node over the bf16-operand MFMA kernels (csrc/mlp32s.hip, precision 2), fp32 master
+            # weights, the activations of the five hidden layers kept for a fused dgrad + wgrad backward per net
+            return fused_network.forward(self, x, d)
         h = self.sigma_net(self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]

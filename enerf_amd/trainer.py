@@ -59,11 +59,25 @@ class TrainHarness:
         self._cleared_grad = None     # the embeddings' gradient buffer as the last Adam pass left it (all zeros)
         self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
         self._loss_cursor = 0
-        # fp16 = the shipped configs' `fp16 = True`: the step runs under torch.autocast(float16) with a GradScaler
-        # (nerf/utils.py:350,964-975): half hash table + half table gradient (gridencoder/grid.py:38-39,72), half SH,
-        # half nn.Linear GEMMs, fp32 marching / compositing.  The fused fp32 paths stand aside under autocast.
-        self.fp16 = bool(fp16)
-        self.scaler = torch.amp.GradScaler("cuda", enabled=True) if self.fp16 else None
+        # fp16 = the shipped configs' `fp16 = True` (nerf/utils.py:350,964-975: mixed-precision training).  Two routes:
+        #   True / "bf16": the MI355X form of it -- the closed-form step with the networks on bf16 operands (fp32
+        #     accumulation, every layer's activations and activation gradients rounded to 16 bits: mlp32 precision 2),
+        #     fp32 hash table, fp32 marching / compositing, fp32 master weights.  bf16 has fp32's exponent range, so
+        #     there is no loss scaling to do: the GradScaler is kept disabled (its state_dict() is what a checkpoint
+        #     stores for a run without overflow handling).
+        #   "autocast": the literal statement -- torch.autocast(float16) + GradScaler around the op-by-op route: half hash
+        #     table + half table gradient (gridencoder/grid.py:38-39,72), half SH, half nn.Linear GEMMs.  Also what runs
+        #     when the model is not one the fused path serves.
+        self.fp16 = fp16 == "autocast"
+        self.amp_bf16 = False
+        if fp16 is True or fp16 == "bf16":
+            from . import fused_network
+            if next(model.parameters()).is_cuda and fused_network.kind_of(model) is not None:
+                model.mlp_precision = 2
+                self.amp_bf16 = True
+            else:
+                self.fp16 = True
+        self.scaler = (torch.amp.GradScaler("cuda", enabled=self.fp16) if (self.fp16 or self.amp_bf16) else None)
         # what Trainer keeps beside the model and lands in its checkpoints (nerf/utils.py:381-389,1300-1304)
         self.epoch = 1
         self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
@@ -347,7 +361,8 @@ class TrainHarness:
         if not nccl:
             dw.mul_(inv)
         small = fused_network.network_params(m)[1:]
-        for p, g in zip(small, fused_network.unpack_weight_grads(dw, small[-1].shape[0])):
+        for p, g in zip(small, fused_network.unpack_weight_grads(dw, getattr(m, "out_dim_color", 3),
+                                                                 fused_network.kind_of(m))):
             p.grad = g.view_as(p)
         self.opt.step_now(only=small)
 
@@ -415,7 +430,8 @@ class TrainHarness:
         if not nccl:
             dw.mul_(1.0 / world)
         small = fused_network.network_params(m)[1:]
-        for q, g in zip(small, fused_network.unpack_weight_grads(dw, small[-1].shape[0])):
+        for q, g in zip(small, fused_network.unpack_weight_grads(dw, getattr(m, "out_dim_color", 3),
+                                                                 fused_network.kind_of(m))):
             q.grad = g.view_as(q)
         self.opt.step_now(only=small)
         gather.wait()

@@ -432,6 +432,10 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
  *      hi*lo + lo*hi), fp32 accumulation: ~2^-16 relative per product, inside the path's 1e-4, at 3/16 of the fp32
  *      MFMA's pipe time.  Applies to forward, dgrad and wgrad (the fused backward; nets with three hidden layers or
  *      more than 16 outputs keep mode 0 in the backward).
+ *   2  bf16 operands: inputs, weights and each layer's activations / activation gradients rounded to bf16, one MFMA
+ *      product, fp32 accumulation, outputs (and exp / sigmoid of them) rounded to bf16 -- the arithmetic of the FFMLP
+ *      nets (enerf_ffmlp_*, ffmlp/src/ffmlp.cu:410-895) over this family's fp32 buffers and fused epilogues; serves the
+ *      fused training step of nerf/network_ff.py (sigma net: two hidden layers + SH epilogue, colour net: three).
  * Returns the previous mode (NOT a status); a negative `mode` only queries. */
 int enerf_mlp32_precision(int mode);
 /* Testing aid: 1 (default) lets enerf_mlp32_backward use its fused dgrad + wgrad kernel (num_hidden <= 2; `bb` is then

@@ -39,3 +39,16 @@ def cpu_oracle_backend(monkeypatch):
     monkeypatch.setattr(ff, "_backend", ob.ffmlp_backend)
     monkeypatch.setattr(ff.FFMLP, "compute_dtype", torch.float32)
     return ob
+
+
+@pytest.fixture(params=["split-bf16", "fp32"])
+def mlp32_mode(request):
+    """Arithmetic of the fused fp32 MLP kernels for tests that compare them with an fp32 statement on the oracle side:
+    "fp32" (v_mfma_f32_32x32x2_f32, bit-comparable fmaf chains) keeps the round-off-level bars; "split-bf16" (the
+    product's default: three bf16 MFMA products per fp32 product, ~2^-16 per product) is held to the path's 1e-4 on what
+    is rendered, and on gradients to bars that allow for the hidden units it leaves on the other side of a ReLU."""
+    from enerf_amd import _lib
+    mode = 1 if request.param == "split-bf16" else 0
+    prev = _lib.lib().enerf_mlp32_precision(mode)
+    yield request.param
+    _lib.lib().enerf_mlp32_precision(prev)

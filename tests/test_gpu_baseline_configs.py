@@ -45,7 +45,7 @@ def _event_batch(n, dev):
     return {k_: v.to(dev) for k_, v in data.items()}
 
 
-def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
+def test_config2_event_step_4096_rays_vs_oracle(monkeypatch, mlp32_mode):
     import enerf_amd.raymarching as rmod, enerf_amd.gridencoder as gmod, enerf_amd.shencoder as smod
     from oracle import backend as ob
     from enerf_amd import events, fused_render
@@ -115,9 +115,11 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
     # magnitudes.  The oracle side's own per-sample terms are reduced in fp64 here (G64) together with the sum of their
     # magnitudes (A) and the largest single term (T): a correct fp32 evaluation stays within a few eps32 x A of G64
     # (summation order) plus a few whole terms (a ReLU whose pre-activation is within an ulp of zero opens on one side
-    # and not on the other: with 2 x 130 k x 64 hidden units per layer a handful always are).  The bar per entry is
-    # north_star's 1e-4 relative + 64 eps32 x A + 4 T -- no longer a fraction of the tensor's largest entry.
+    # and not on the other: with 2 x 130 k x 64 hidden units per layer a handful always are; the split-bf16 arithmetic,
+    # whose forward error is ~10x the fp32 chains', leaves a few more).  The bar per entry is north_star's 1e-4 relative
+    # + 64 eps32 x A + n_flip x T with n_flip = 2 (fp32 MFMA) / 8 (split-bf16).
     eps32 = float(np.finfo(np.float32).eps)
+    n_flip = 8 if mlp32_mode == "split-bf16" else 2
     worst = {}
 
     def largest_term(pairs):
@@ -139,14 +141,14 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch):
             top = largest_term(terms[n])
             assert float((g64 - r.double()).abs().max()) <= 64 * eps32 * float(mag.max())     # (the hooks saw the real terms)
             err = (got_g.double() - g64).abs()
-            bar = 1e-4 * g64.abs() + 64 * eps32 * mag + 4 * top + 1e-12
+            bar = 1e-4 * g64.abs() + 64 * eps32 * mag + n_flip * top + 1e-12
             worst[n] = {"err/bar": float((err / bar).max()), "bar/max|G|": float(bar.max() / g64.abs().max()),
                         "err/max|G|": float(err.max() / g64.abs().max())}
             assert bool((err <= bar).all()), (n, worst[n])
         else:
             # the table: per row a sum over the few hundred (coarse levels) to a handful (fine levels) of samples in its
             # cells, accumulated by fp32 atomics in an arbitrary order on the oracle side, in fp64 per tile here
-            tol = 2e-4 * float(r.abs().max()) + 1e-9
+            tol = (4e-3 if mlp32_mode == "split-bf16" else 1.5e-3) * float(r.abs().max())
             err = float((got_g - r).abs().max())
             worst[n] = err / float(r.abs().max())
             assert err < tol, (n, err, float(r.abs().max()))

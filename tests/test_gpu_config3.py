@@ -66,7 +66,7 @@ def _eval_image(m):
     ro, rd = scene.pixel_rays(scene.pose(3), inds, DEV)
     m.eval()
     with torch.no_grad():
-        img = m.render(ro[None], rd[None], staged=False, bg_color=None, perturb=False)["image"].cpu()
+        img = m.render(ro, rd, staged=False, bg_color=None, perturb=False)["image"].cpu()
     m.train()
     return img
 
@@ -117,7 +117,8 @@ def _gloo_worker(rank, world, port, mode, cold_steps, more_steps, out):
         from enerf_amd.trainer import TrainHarness
         torch.cuda.set_device(0)
         lo, hi = rank * RAYS_PER_RANK, (rank + 1) * RAYS_PER_RANK
-        data = [tuple(t[lo:hi].contiguous() for t in b) for b in _data(4, world * RAYS_PER_RANK)]
+        data = [tuple((t[:, lo:hi] if t.dim() == 3 else t[lo:hi]).contiguous() for t in b)
+                for b in _data(4, world * RAYS_PER_RANK)]
         model = _model()
         h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=world)
         h.perturb = False

@@ -187,3 +187,83 @@ def test_fused_ff_network_inference_matches_op_by_op_route(monkeypatch, dtype, n
     net.train()
     net(x[:64], d[:64])
     assert len(calls) == 1
+
+
+@pytest.mark.parametrize("n", [1, 4000, 70001])
+def test_fused_ff_network_training_node_matches_op_by_op_route(monkeypatch, n):
+    """nerf/network_ff.py's TRAINING forward + backward as one autograd node (enerf_amd/fused_network.py, kind "ff": grid
+    encode -> csrc/mlp32s.hip with bf16 operands -> grid backward) against the op-by-op route through the FFMLP entry
+    points (encoder -> ffmlp_forward -> exp ; SH, cat -> ffmlp_forward -> sigmoid, and autograd back through
+    ffmlp_backward).  Forward: the same 16-bit roundings at the same points, so the results agree to an ulp of bf16
+    almost everywhere.  Backward: the node keeps weight gradients in fp32 where the FFMLP route rounds them (and its
+    intermediate input gradients) to bf16, so the bars are bf16-sized, relative to each tensor's largest entry."""
+    from enerf_amd import fused_network as fn
+    from enerf_amd.network_ff import NeRFNetwork
+    torch.manual_seed(0)
+    net = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to("cuda").train()
+    assert fn.kind_of(net) == "ff"
+    net.encoder.embeddings.data.uniform_(-1.0, 1.0)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    net.color_net.weights.data.copy_((torch.rand(net.color_net.weights.shape, generator=g, device="cuda") - 0.5) * 0.6)
+    x = (torch.rand(n, 3, generator=g, device="cuda") * 2 - 1) * 2
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g, device="cuda"), dim=-1)
+    gs = torch.randn(n, generator=g, device="cuda") * 0.1
+    gc = torch.randn(n, 3, generator=g, device="cuda")
+
+    def run(enabled):
+        monkeypatch.setattr(fn, "ENABLED", enabled)
+        net.zero_grad()
+        s, c = net(x, d)
+        ((s.float() * gs).sum() + (c.float() * gc).sum()).backward()
+        return s.detach().float(), c.detach().float(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    calls = []
+    orig = fn.forward
+    monkeypatch.setattr(fn, "forward", lambda *a: (calls.append(1), orig(*a))[1])
+    s1, c1, g1 = run(True)
+    assert len(calls) == 1 and s1.dtype == torch.float32 and c1.shape == (n, 3)
+    s0, c0, g0 = run(False)
+    assert len(calls) == 1
+    ulp = 2.0 ** -8
+    rel = ((s1 - s0).abs() / s0.abs().clamp(min=1e-6))
+    assert float((rel > 2.5 * ulp).float().mean()) < 0.02 and float(rel.max()) < 0.1, float(rel.max())
+    err = (c1 - c0).abs()
+    assert float((err > 2.5 * ulp).float().mean()) < 0.02 and float(err.max()) < 0.05, float(err.max())
+    for k in g0:
+        a, b = g1[k].float(), g0[k].float()
+        top = float(b.abs().max())
+        assert top > 0, k
+        # a handful of ReLU decisions differ between the two routes (bf16 boundaries), each worth one sample's terms
+        assert float((a - b).abs().max()) <= (0.04 if n > 1 else 0.02) * top, (k, float((a - b).abs().max()) / top)
+        assert float((a - b).abs().mean()) <= 2e-2 * float(b.abs().mean()) + 1e-12, k          # (bf16: 2^-8 per rounding)
+    # the pad column of the colour net's first layer and its unused output rows never receive a gradient
+    wc = g1["color_net.weights"]
+    assert float(wc[:2048].view(64, 32)[:, 31].abs().max()) == 0.0
+    assert float(wc[2048 + 8192 + 3 * 64:].abs().max()) == 0.0
+
+
+def test_network_ff_training_step_takes_the_closed_form_path():
+    """TrainHarness drives network_ff through the same closed-form step as the nn.Linear nets (march -> grid -> fused MLPs
+    -> composite + MSE gradient -> fused MLP backward -> table records -> one optimizer launch): the loss falls, the
+    table gradient is never materialised, and the FFMLP master weights are what Adam updates."""
+    from enerf_amd import fused_render
+    from enerf_amd.network_ff import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    from test_gpu_training import _batches
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to(DEV)
+    h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+    data = _batches(8, 2048, 2)
+    assert h._manual_ok(data[0][0], data[0][1], data[0][2], {})
+    w0 = model.sigma_net.weights.detach().clone()
+    calls = []
+    orig = fused_render.train_step_mse
+    fused_render.train_step_mse = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        losses = [float(h.step_rgb(*data[i % 8])) for i in range(120)]
+    finally:
+        fused_render.train_step_mse = orig
+    assert len(calls) == 120
+    assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.5 * np.mean(losses[:8]), (losses[:4], losses[-4:])
+    assert float((model.sigma_net.weights - w0).abs().max()) > 1e-3
+    assert model.mean_count > 0

@@ -780,7 +780,7 @@ def _cpu_model_and_outputs(bound, o, d, bits, train, monkeypatch):
 
 
 @pytest.mark.parametrize("train", [True, False])
-def test_render_end_to_end_vs_cpu_oracle(scenes, monkeypatch, train):
+def test_render_end_to_end_vs_cpu_oracle(scenes, monkeypatch, train, mlp32_mode):
     from enerf_amd.network import NeRFNetwork
     bound = 2
     grid, bits, C = scenes[bound]
@@ -799,8 +799,15 @@ def test_render_end_to_end_vs_cpu_oracle(scenes, monkeypatch, train):
         assert_close(out["depth"], ref["depth"], rtol=1e-4, atol=2e-5)
         for n, p in model.named_parameters():
             r = ref_grads[n]
-            tol = 2e-4 * float(r.abs().max()) + 1e-7
-            assert float((p.grad.cpu() - r).abs().max()) < tol, n
+            top = float(r.abs().max())
+            err = (p.grad.cpu() - r).abs()
+            if mlp32_mode == "fp32":
+                assert float(err.max()) < 2e-4 * top + 1e-7, n
+            else:
+                # ~7 k samples x 192 hidden units at ~1e-5 forward error: a few sit on the other side of their ReLU than
+                # on the oracle route, and each moves its own sample's terms (a handful of entries) by a whole term
+                assert float(err.max()) < 2e-3 * top + 1e-7, n
+                assert float((err > 2e-4 * top + 1e-7).float().mean()) < 0.02, n
     else:
         with torch.no_grad():
             out = model.render(ro, rd, staged=False, bg_color=None, perturb=False)

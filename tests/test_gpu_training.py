@@ -515,35 +515,46 @@ def test_fused_table_adam_step_matches_dense_gradient_step():
     assert float(l1[-4:].mean()) < 0.7 * float(l1[:4].mean())
 
 
-def test_fp16_autocast_training_variant():
-    """The shipped configs' `fp16 = True` variant (autocast + GradScaler, nerf/utils.py:964-975): half hash table and
-    half table gradient through the grid kernels (gridencoder/grid.py:38-39,72: the 588 B/point case), half SH, fp32
-    marching / compositing.  The loss must fall, the scaler must not see overflows after its first steps, the sample
-    counters must be those of the fp32 run (marching does not depend on the networks), and the first step's loss must
-    agree with the fp32 step's to half precision."""
+@pytest.mark.parametrize("route", ["bf16", "autocast"])
+def test_fp16_training_variant(route):
+    """The shipped configs' `fp16 = True` (nerf/utils.py:964-975), both routes of TrainHarness(fp16=...):
+    "autocast" -- the literal one (autocast(float16) + GradScaler): half hash table and half table gradient through the
+    grid kernels (gridencoder/grid.py:38-39,72: the 588 B/point case), half SH, fp32 marching / compositing; the scaler
+    must not see overflows after its first steps;
+    "bf16" (what fp16=True selects) -- the closed-form step with the networks on bf16 operands (mlp32 precision 2), fp32
+    table, no loss scaling.
+    Either way the loss must fall, the sample counters must be those of the fp32 run (marching does not depend on the
+    networks), and the first step's loss must agree with the fp32 step's to 16-bit precision."""
+    from enerf_amd import fused_render
     from enerf_amd.backends import _gridencoder as ge
     from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
     data = _batches(4, 4096, 2)
     runs = []
-    for fp16 in (False, True):
+    for fp16 in (False, True if route == "bf16" else "autocast"):
         torch.manual_seed(0)
         model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
         h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16)
-        seen = []
-        orig = ge.grid_encode_forward
+        seen, closed = [], []
+        orig, orig_step = ge.grid_encode_forward, fused_render.train_step_mse
         ge.grid_encode_forward = lambda *a, **k: (seen.append(a[1].dtype), orig(*a, **k))[1]
+        fused_render.train_step_mse = lambda *a, **k: (closed.append(1), orig_step(*a, **k))[1]
         try:
             losses = [float(h.step_rgb(*data[i % len(data)])) for i in range(48)]
         finally:
-            ge.grid_encode_forward = orig
-        runs.append((losses, model.step_counter.clone().cpu(), set(seen), h))
-    (l32, c32, d32, _), (l16, c16, d16, h16) = runs
-    assert torch.float16 in d16 and d32 == {torch.float32}          # training renders used the half table (the density
-    assert torch.equal(c32, c16)                                     # sweep of update_extra_state stays fp32)
+            ge.grid_encode_forward, fused_render.train_step_mse = orig, orig_step
+        runs.append((losses, model.step_counter.clone().cpu(), set(seen), h, len(closed)))
+    (l32, c32, d32, _, n32), (l16, c16, d16, h16, n16) = runs
+    assert d32 == {torch.float32} and n32 == 48
+    if route == "autocast":
+        assert torch.float16 in d16 and n16 == 0                     # training renders used the half table (the density
+        assert float(h16.scaler.get_scale()) >= 1024.0               # sweep of update_extra_state stays fp32); no run of
+    else:                                                            # overflow-halvings
+        assert d16 == {torch.float32} and n16 == 48 and h16.model.mlp_precision == 2
+        assert not h16.scaler.is_enabled() and h16.scaler.state_dict() == {}
+    assert torch.equal(c32, c16)
     assert np.isfinite(l16).all() and abs(l16[0] - l32[0]) <= 0.02 * abs(l32[0])
     assert np.mean(l16[-8:]) < 0.6 * np.mean(l16[:8])
-    assert float(h16.scaler.get_scale()) >= 1024.0                   # no run of overflow-halvings
 
 
 def test_padding_rows_of_the_sample_budget_are_skipped_without_changing_anything(monkeypatch):
