@@ -41,7 +41,8 @@ MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 MFMA
 MLP_LINEAR_FLOP_FWD = 18688       # nn.Linear nets, sigma 6144 + colour 12544 FLOP/sample forward
 MLP_LINEAR_FLOP_STEP = 56064      # forward + dgrad + wgrad = 3 x forward
 FFMLP_FLOP_FWD = 36864            # FFMLP nets (padded dims), sigma 14336 + colour 22528
-PMC_FILE = "profiles/r02_pmc_hbm_bench.json"
+PMC_FILE = "profiles/r03_pmc_hbm_bench.json"
+TABLE_OPT_BYTES_PER_PARAM = 24     # Adam over the table: p, m, v read + written, 4 B each
 
 
 def parse():
@@ -83,6 +84,8 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
+    ap.add_argument("--other-legs", type=int, default=48,
+                    help="steps of each extra leg (event step of configs[2], network_ff step, fp16=True step); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--cpu-rays", type=int, default=256)
@@ -116,23 +119,48 @@ def build_batches(n_batches, n_rays, device, rank, bound):
 
 
 def pmc_traffic(points_per_launch):
-    """HBM-side bytes per grid_encode_forward launch from the committed rocprofv3 PMC passes (profiles/
-    r01_pmc_hbm_bench.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this very command, averaged over
-    every k_grid_fwd dispatch -- training batches and density-grid updates alike, the same mix `achieved` is
-    averaged over), rescaled by points per launch.  FETCH_SIZE is in KB and, per MI355X_MICROARCH.md (HBM), counts
-    64 B per 128-byte request on gfx950, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).  None if absent."""
+    """HBM-side bytes per grid_encode_forward launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of this very command).  The counters are averaged over EVERY k_grid_fwd dispatch of the profiled
+    process (warm-up, timed region, probe and graph legs), so they are divided by the points per launch of that same
+    population -- `grid_fwd_points_per_launch_all_dispatches`, which the profiled run's own JSON line carries
+    (roofline.lifetime) -- and the resulting bytes per point are rescaled by this run's points per launch.  FETCH_SIZE is in
+    KB and, per MI355X_MICROARCH.md (HBM), counts 64 B per 128-byte request on gfx950, so it is doubled; WRITE_SIZE is
+    taken as is (uncalibrated).  None if absent."""
     try:
         path = os.path.join(ROOT, PMC_FILE)
         if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_bench.json")
+            path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_bench.json")
         with open(path) as f:
             j = json.load(f)
         d = j["k_grid_fwd<float, 3, 2>"]
-        ref_pts = float(j["_meta"]["grid_fwd_points_per_launch"])
+        meta = j["_meta"]
+        ref_pts = float(meta.get("grid_fwd_points_per_launch_all_dispatches") or meta["grid_fwd_points_per_launch"])
         per_point = (2.0 * d["FETCH_SIZE_avg"] + d["WRITE_SIZE_avg"]) * 1024.0 / ref_pts
         return per_point * points_per_launch, os.path.relpath(path, ROOT)
     except Exception:
         return None, None
+
+
+def table_backward_object(points, bin_ms, adam_ms, n_params, fused, where):
+    """One object for "table backward + optimizer" (grid_encode_backward through the Adam update of the table):
+    algorithmic bytes = 1164 B/point x points (the backward's scatter counted once) + 24 B x table
+    parameters (p, m, v read and written), time = binning pass + (fused) k_grid_tile_adam, which does the scatter's
+    summing AND the optimizer -- the scatter bytes belong to that pair, not to the binning pass alone."""
+    out = {"points_per_launch": points, "binning_pass_ms": bin_ms, "timed_in": where,
+           # what the binning pass itself moves: 12 B/point in, 128 B/point of dL/dfeat in, 16 levels x 8 corners x
+           # 10-byte records out
+           "binning_pass_GBs": points * (12 + 128 + 16 * 8 * 10) / (bin_ms * 1e-3) / 1e9,
+           "binning_pass_bytes_per_point": 12 + 128 + 16 * 8 * 10}
+    if fused and adam_ms is not None:
+        bytes_alg = points * GRID_FWD_BYTES_PER_POINT + TABLE_OPT_BYTES_PER_PARAM * n_params
+        t = (bin_ms + adam_ms) * 1e-3
+        out.update({"tile_adam_ms": adam_ms, "algorithmic_bytes": bytes_alg, "achieved": bytes_alg / t / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_alg / t / 1e9 / HBM_PEAK_GBS,
+                    "kernels": "k_grid_bwd_bin + k_grid_tile_adam (record lists -> LDS tile sums -> Adam; the table "
+                               "gradient is never materialised)"})
+    elif not fused:
+        out["kernels"] = "k_grid_bwd_bin + k_grid_bwd_tile (the dense gradient exists: all-reduce, then k_adam_multi)"
+    return out
 
 
 def _cpu_model():
@@ -260,6 +288,7 @@ def main():
         harness.prefetch_at = args.prefetch_at
     if args.comm_bf16:
         harness.comm_dtype = torch.bfloat16
+    n_table_params = int(model.encoder.embeddings.numel())
     parallel.broadcast_state(model)
     batches = build_batches(8, args.rays, device, rank, args.bound)
     ev_opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
@@ -336,7 +365,7 @@ def main():
     # the timed region carries the event timing of the roofline kernel only (two kernel-attached events per launch);
     # the table's backward is timed in the probe steps after the region when there are any (its event pair costs
     # ~10 us per step: measured 0.424 -> 0.416 ms), inside the region otherwise
-    probe_ok = args.probe_steps > 0 and args.net == "linear" and args.mode == "rgb" and not args.graphs
+    probe_ok = args.probe_steps > 0 and args.mode == "rgb" and not args.graphs
     timed_families = None if args.prof_all else (("grid_fwd",) if probe_ok else ("grid_fwd", "grid_bwd"))
     if args.no_live_timing:
         timed_families = ()
@@ -443,15 +472,15 @@ def main():
                     "traffic_source": None if traffic is None else
                     f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run), "
                     f"bytes per point x this run's points per launch",
-                    "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"]}
+                    "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"],
+                    # every grid_encode_forward launch of this process so far (what a whole-process profile averages over)
+                    "lifetime": {"launches": gb.LIFETIME["fwd_calls"],
+                                 "points_per_launch": gb.LIFETIME["fwd_points"] / max(gb.LIFETIME["fwd_calls"], 1)}}
         if "grid_bwd" in kernels and gb.STATS["bwd_calls"]:
             ptsb = gb.STATS["bwd_points"] / gb.STATS["bwd_calls"]
-            roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / \
-                (kernels["grid_bwd"]["avg_ms"] * 1e-3) / 1e9
-            roofline["grid_encode_backward_scope"] = (
-                "binning pass (k_grid_bwd_bin) only: on one GPU the tile sums run inside the optimizer's pass over the "
-                "table (k_grid_tile_adam, profiles/r02_step_kernels_steady.txt)" if harness.fuse_table_adam and world == 1
-                else "binning pass + tile pass (k_grid_bwd_bin + k_grid_bwd_tile)")
+            roofline["table_backward"] = table_backward_object(ptsb, kernels["grid_bwd"]["avg_ms"], None, n_table_params,
+                                                               harness.fuse_table_adam and world == 1,
+                                                               "the timed region")
 
     # ---- MFMA probe (not part of `value`): a few more steps with the MLP kernel families hipEvent-timed as well, no
     # density-grid update in between (its sigma-only sweep is a different launch shape).  Timing every family costs
@@ -465,7 +494,7 @@ def main():
             one_step(base)
             sync()
             _lib.prof.reset()
-            _lib.prof.enable(True, only=("ffmlp_fwd", "ffmlp_bwd", "grid_bwd"))
+            _lib.prof.enable(True, only=("ffmlp_fwd", "ffmlp_bwd", "mlp_reduce", "grid_bwd", "table_adam"))
             bwd_before = (gb.STATS["bwd_points"], gb.STATS["bwd_calls"])
             before = marched_total(reset=False)
             for i in range(base + 1, base + 1 + args.probe_steps):
@@ -475,29 +504,48 @@ def main():
             probe_samples = (marched_total(reset=False) - before) / args.probe_steps      # (one march is always ahead)
             fwd_ms, nf = _lib.prof.read("ffmlp_fwd")
             bwd_ms, nb = _lib.prof.read("ffmlp_bwd")
+            red_ms, _ = _lib.prof.read("mlp_reduce")
+            mode = 2 if (args.net == "ff" or args.fp16) else _lib.lib().enerf_mlp32_precision(-1)
+            if mode != 0:                                 # (split kernels: timed by their own stamps, the reduce launch apart;
+                bwd_ms += red_ms                          # the fp32 MFMA route's interval already spans its reduce)
             gb_ms, gb_n = _lib.prof.read("grid_bwd")
+            ta_ms, ta_n = _lib.prof.read("table_adam")
             gb_calls = gb.STATS["bwd_calls"] - bwd_before[1]
-            if roofline is not None and gb_n and gb_calls and "grid_bwd" not in kernels:
+            if roofline is not None and gb_n and gb_calls:
                 ptsb = (gb.STATS["bwd_points"] - bwd_before[0]) / gb_calls
                 kernels["grid_bwd"] = {"avg_ms": gb_ms / gb_n, "launches": int(gb_n), "timed_in": "probe steps"}
-                roofline["grid_encode_backward_GBs"] = ptsb * GRID_FWD_BYTES_PER_POINT / (gb_ms / gb_n * 1e-3) / 1e9
-                roofline["grid_encode_backward_scope"] = (
-                    ("binning pass (k_grid_bwd_bin) only: on one GPU the tile sums run inside the optimizer's pass over "
-                     "the table (k_grid_tile_adam, profiles/r02_step_kernels_steady.txt)"
-                     if harness.fuse_table_adam and world == 1 else
-                     "binning pass + tile pass (k_grid_bwd_bin + k_grid_bwd_tile)")
-                    + f"; hipEvent-timed over the {args.probe_steps} probe steps after the timed region")
+                if ta_n:
+                    kernels["table_adam"] = {"avg_ms": ta_ms / ta_n, "launches": int(ta_n), "timed_in": "probe steps"}
+                roofline["table_backward"] = table_backward_object(
+                    ptsb, gb_ms / gb_n, ta_ms / ta_n if ta_n else None, n_table_params,
+                    harness.fuse_table_adam and world == 1, f"the {args.probe_steps} probe steps after the timed region")
             if nf and nb:
                 per_step_ms = (fwd_ms + bwd_ms) / args.probe_steps
-                tf = probe_samples * MLP_LINEAR_FLOP_STEP / (per_step_ms * 1e-3) / 1e12
-                roofline_mfma = {"bound": "mfma", "kernel": "mlp32 sigma + colour nets, forward + fused dgrad/wgrad "
-                                 "(v_mfma_f32_32x32x2_f32)", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                 "frac": tf / MFMA_F32_PEAK_TF, "flop_per_sample": MLP_LINEAR_FLOP_STEP,
+                flop_step = MLP_LINEAR_FLOP_STEP if args.net == "linear" else 3 * FFMLP_FLOP_FWD
+                tf = probe_samples * flop_step / (per_step_ms * 1e-3) / 1e12
+                issued = 3.0 if mode == 1 else 1.0          # MFMA products issued per algorithmic fp32 product
+                roofline_mfma = {"bound": "mfma", "kernel": "mlp32 sigma + colour nets, forward + fused dgrad/wgrad ("
+                                 + ("v_mfma_f32_32x32x2_f32: fp32 fmaf chains" if mode == 0 else
+                                    "v_mfma_f32_32x32x16_bf16 on split operands: hi*hi + hi*lo + lo*hi per fp32 product, "
+                                    "fp32 accumulation" if mode == 1 else "v_mfma_f32_32x32x16_bf16, bf16 operands") + ")",
+                                 "achieved": tf, "peak": MFMA_BF16_PEAK_TF if mode == 2 else MFMA_F32_PEAK_TF,
+                                 "unit": "TFLOP/s",
+                                 "frac": tf / (MFMA_BF16_PEAK_TF if mode == 2 else MFMA_F32_PEAK_TF),
+                                 "peak_note": ("bf16 nets: FLOP of the nets against the dense bf16 MFMA peak" if mode == 2 else
+                                               "algorithmic fp32 FLOP of the nn.Linear nets against the dense fp32 MFMA peak "
+                                               "(the speed of light of the reference's arithmetic type)"),
+                                 # the same kernels priced against the pipe they actually run on: flops issued (the
+                                 # flips of the weight-gradient tiles not counted) / dense bf16 peak
+                                 "issued": None if mode != 1 else {
+                                     "products_per_fp32_product": issued, "achieved": tf * issued,
+                                     "peak": MFMA_BF16_PEAK_TF, "frac": tf * issued / MFMA_BF16_PEAK_TF},
+                                 "mlp32_precision": mode, "flop_per_sample": flop_step,
                                  "samples_per_step": probe_samples, "kernel_ms_per_step": per_step_ms,
                                  "forward_ms_per_step": fwd_ms / args.probe_steps,
                                  "backward_ms_per_step": bwd_ms / args.probe_steps,
                                  "launches": int(nf + nb), "steps": args.probe_steps,
-                                 "timing": "hipEvent pairs around each launch (read ~6 % long on 30 us kernels)"}
+                                 "timing": "kernel-attached events (each MLP kernel's own dispatch-to-end, as rocprofv3 reports it) + the "
+                                           "weight-gradient reduce launch between two event packets"}
         finally:
             harness.update_interval = keep_interval
 
@@ -520,6 +568,49 @@ def main():
         graph_replay = {"ms_per_step": tg * 1e3,
                         "rays_per_sec": args.rays * (2 if args.mode == "events" else 1) / tg,
                         "steps": args.graph_leg_steps, "graphs_captured": len(harness._graphs)}
+
+    # ---- other steps (not part of `value`; one GPU): the event step of BASELINE configs[2] (two renders per step, rays
+    # drawn from the event stream) and the training step of nerf/network_ff.py (FFMLP nets), each on a model of its own,
+    # timed like the main region (warm-up, then steps between two synchronisations), so that they are measured by
+    # whoever runs this file and not only quoted in DESIGN.md
+    other_steps = None
+    if world == 1 and args.other_legs > 0 and args.mode == "rgb" and args.net == "linear" and not args.fp16 \
+            and not args.fp16_autocast and not args.graphs:
+        other_steps = {}
+        for tag, net_kind, mode, bound, fp16 in (("events_configs2", "linear", "events", 2, False),
+                                                 ("network_ff_rgb", "ff", "rgb", args.bound, False),
+                                                 ("fp16_true_rgb", "linear", "rgb", args.bound, True)):
+            try:
+                if net_kind == "ff":
+                    from enerf_amd.network_ff import NeRFNetwork as LegNet
+                else:
+                    from enerf_amd.network import NeRFNetwork as LegNet
+                torch.manual_seed(0)
+                m2 = LegNet(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3).to(device)
+                h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16)
+                b2 = batches if bound == args.bound else build_batches(8, args.rays, device, rank, bound)
+
+                def leg_step(i):
+                    if mode == "rgb":
+                        nxt = b2[(i + 1) % len(b2)]
+                        return h2.step_rgb(*b2[i % len(b2)], next_rays=(nxt[0], nxt[1]))
+                    return h2.step_events(event_data(i), ev_opt, next_data=event_data(i + 1))
+                for i in range(20):
+                    leg_step(i)
+                sync()
+                tl0 = time.perf_counter()
+                for i in range(20, 20 + args.other_legs):
+                    leg_step(i)
+                sync()
+                dt = (time.perf_counter() - tl0) / args.other_legs
+                renders = 2 if mode == "events" else 1
+                other_steps[tag] = {"ms_per_step": dt * 1e3, "rays_per_sec": args.rays * renders / dt,
+                                    "steps": args.other_legs, "warmup": 20, "bound": bound, "net": net_kind, "mode": mode,
+                                    "renders_per_step": renders, "fp16": fp16,
+                                    "includes_update_extra_state_steps": args.other_legs // 16}
+                del m2, h2
+            except Exception as e:          # a leg that breaks must not take the headline down with it
+                other_steps[tag] = {"error": repr(e)[:300]}
 
     # ---- render leg (not part of `value`): full 640x480 frame, pixels sharded over the ranks + all_gather of the tiles
     # (SURVEY.md 8e).  msamples_per_sec is the whole job's: samples marched on all ranks / slowest rank's time.
@@ -645,6 +736,11 @@ def main():
             "samples_per_step_per_gpu": total_samples / args.steps / world,
             "render": render,
             "step_split": split,
+            "other_steps": other_steps,
+            # every grid_encode_forward launch of this process (all legs): the population a whole-process counter profile
+            # averages over (tools/profile_round.sh divides its per-dispatch FETCH / WRITE averages by this)
+            "grid_fwd_lifetime": {"launches": gb.LIFETIME["fwd_calls"],
+                                  "points_per_launch": gb.LIFETIME["fwd_points"] / max(gb.LIFETIME["fwd_calls"], 1)},
             "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
             "roofline_mfma": roofline_mfma,
             "roofline_mfma_ffmlp": ffmlp_kernel,

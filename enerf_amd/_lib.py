@@ -222,7 +222,7 @@ class prof:
     """Thin Python face of the enerf_prof_* hooks (used by bench.py)."""
 
     KERNELS = {"grid_fwd": 0, "grid_bwd": 1, "march_train": 2, "composite_fwd": 3, "composite_bwd": 4, "sh_fwd": 5,
-               "ffmlp_fwd": 6, "ffmlp_bwd": 7, "march_infer": 8, "composite_infer": 9}
+               "ffmlp_fwd": 6, "ffmlp_bwd": 7, "march_infer": 8, "composite_infer": 9, "table_adam": 10, "mlp_reduce": 11}
 
     @staticmethod
     def enable(on=True, only=None):

@@ -5,6 +5,9 @@ from .. import _lib as L
 
 # points processed per entry point since the last reset (bench.py: algorithmic bytes = 1164 B/point)
 STATS = {"fwd_points": 0, "fwd_calls": 0, "bwd_points": 0, "bwd_calls": 0}
+# the same forward counts from process start, never reset: the denominator of per-dispatch counter averages taken over a
+# whole profiled process (tools/profile_round.sh)
+LIFETIME = {"fwd_points": 0, "fwd_calls": 0}
 
 
 def _chk(t, name, floating=True):
@@ -24,6 +27,8 @@ def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L_, S, H,
         raise RuntimeError("inputs must be a float32 tensor (gridencoder.cu:437 reads inputs as float*)")
     STATS["fwd_points"] += int(B)
     STATS["fwd_calls"] += 1
+    LIFETIME["fwd_points"] += int(B)
+    LIFETIME["fwd_calls"] += 1
     dt = L.dtype_code(embeddings)
     if outputs.dtype != embeddings.dtype or dy_dx.dtype != embeddings.dtype:
         raise RuntimeError("outputs/dy_dx must have the dtype of embeddings")
@@ -65,6 +70,8 @@ def grid_encode_forward_sweep(embeddings, offsets, outputs, n_cascades, grid_siz
     B = int(n_cascades) * int(grid_size) ** 3
     STATS["fwd_points"] += B
     STATS["fwd_calls"] += 1
+    LIFETIME["fwd_points"] += B
+    LIFETIME["fwd_calls"] += 1
     L.check(L.lib().enerf_grid_encode_forward_sweep(
         embeddings.data_ptr(), offsets.data_ptr(), outputs.data_ptr(), int(n_cascades), int(grid_size), float(bound),
         ctypes.c_uint64(int(seed)), int(C), int(L_), float(S), int(H), int(gridtype), int(layout), float(affine[0]),

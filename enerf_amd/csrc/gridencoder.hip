@@ -1326,6 +1326,7 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
     const uint32_t* recs = region ? (const uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C))
                                   : nullptr;
     const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;
+    ProfScope prof(ENERF_K_TABLE_ADAM, s);
     switch (C) {
         case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;

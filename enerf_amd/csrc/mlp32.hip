@@ -928,7 +928,8 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     if (y_stride == 0) y_stride = out_dim;
     if (y_stride < out_dim) ENERF_BADARG("mlp32: y_stride %u < out_dim %u", y_stride, out_dim);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(ENERF_K_FFMLP_FWD, s);
+    // (the split kernels are timed by their own begin / end stamps; the fp32 MFMA kernels between two event packets)
+    ProfScope prof(ENERF_K_FFMLP_FWD, s, g_precision != 0);
     // two workgroups per CU are resident (the weights sit in ~130-210 registers): one round of them, each wave
     // setting up once, beats four short-lived ones per CU (measured at the 138 k-sample training batch)
     const uint32_t grid = pgrid(B, g_fwd_blocks ? g_fwd_blocks : 512);
@@ -948,7 +949,7 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     const bool sigma_only = num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1;
     if (g_precision != 0) {
         mlp32s_launch_fwd(g_precision == 1 ? 3 : 1, num_hidden, fb != nullptr, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
-                          output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s);
+                          output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop());
     } else if (sh_dirs) {
         const ShNorm4 nrm = make_sh_norm4();
         if (fb)
@@ -1027,7 +1028,6 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     dys.h0 = h0;
     dys.h0_stride = h0_stride ? h0_stride : 1u;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(ENERF_K_FFMLP_BWD, s);
     const uint32_t NW = HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID;
     const size_t lds = sizeof(float) * NW;
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
@@ -1035,6 +1035,9 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     // bf16 operands
     const bool split_bwd = g_fused_bwd && g_precision != 0 && out_dim <= 16 &&
                            (num_hidden <= 2 || (g_precision == 2 && num_hidden == 3 && x_layout == 0));
+    // timing (enerf_prof_*): the split kernel by its own begin / end stamps, the weight-gradient reduce launch as a family
+    // of its own (ENERF_K_MLP_REDUCE); the fp32 MFMA route between two event packets around all of its launches
+    ProfScope prof(ENERF_K_FFMLP_BWD, s, split_bwd);
     if (g_precision == 2 && !split_bwd)
         ENERF_BADARG("mlp32_backward: bf16 operands (precision 2) need out_dim <= 16 and at most three hidden layers");
     const bool fused = split_bwd || (g_fused_bwd && num_hidden <= 2);
@@ -1088,7 +1091,8 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     } while (0)
     if (split_bwd) {
         (void)bb;
-        mlp32s_launch_bwd(g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation, wgrid, s);
+        mlp32s_launch_bwd(g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation,
+                          wgrid, s, prof.start(), prof.stop());
     } else if (fused) {
         (void)bb;
         if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }
@@ -1116,6 +1120,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
             sig = g_signal_event;
             g_signal_recorded = sig != nullptr;
         }
+        ProfScope prof_reduce(ENERF_K_MLP_REDUCE, s);
         if (g_have_pending) {
             g_have_pending = false;
             hipExtLaunchKernelGGL(k_mlp32_reduce_w2, dim3(div_up(g_pending.NW, 64) + div_up(NW, 64)), dim3(1024), 0, s,

@@ -4,6 +4,7 @@
 // those elements costs a v_accvgpr_read first (a third of the tile loop's instructions).  The long-lived weight-gradient
 // accumulators spill to AGPRs on their own where the arch VGPRs run out.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "mlp32_common.h"
 
@@ -638,12 +639,18 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
     }
 }
 
+__global__ void k_mlp32s_mark() {}
+
 void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
                        const WSrc& W, float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
-                       uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s) {
+                       uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s,
+                       hipEvent_t ev_start, hipEvent_t ev_stop) {
+    // timed launches (enerf_prof_*): the interval runs between two kernel-attached stop events -- a one-wavefront marker
+    // right before the kernel, and the kernel itself -- i.e. the kernel's own dispatch-to-end, as for grid_encode_forward
+    if (ev_start) hipExtLaunchKernelGGL(k_mlp32s_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);
 #define S_FWD(NHV, TR, XLV, SIGV, SHV, PV)                                                                                  \
-    k_mlp32s_fwd<NHV, TR, XLV, SIGV, SHV, PV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, \
-                                                                     sh_dirs, nrm)
+    hipExtLaunchKernelGGL((k_mlp32s_fwd<NHV, TR, XLV, SIGV, SHV, PV>), dim3(grid), dim3(256), lds, s, nullptr, ev_stop, 0, X, W, \
+                          fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, sh_dirs, nrm)
 #define S_FWD_P(NHV, TR, XLV, SIGV, SHV)                 \
     do {                                                 \
         if (prec == 3) S_FWD(NHV, TR, XLV, SIGV, SHV, 3); \
@@ -685,8 +692,11 @@ void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
 
 void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
                        const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
-                       uint32_t act, uint32_t grid, hipStream_t s) {
-#define S_BWD(NHV, XLV, PV) k_mlp32s_bwd<NHV, XLV, PV><<<grid, 256, 0, s>>>(dys, X, W, fb, dX, partial, B, out_dim, act)
+                       uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (ev_start) hipExtLaunchKernelGGL(k_mlp32s_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);
+#define S_BWD(NHV, XLV, PV)                                                                                              \
+    hipExtLaunchKernelGGL((k_mlp32s_bwd<NHV, XLV, PV>), dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, dys, X, W, fb, dX, \
+                          partial, B, out_dim, act)
 #define S_BWD_P(NHV, XLV)                  \
     do {                                   \
         if (prec == 3) S_BWD(NHV, XLV, 3); \

@@ -526,7 +526,9 @@ int enerf_debug_grid_bwd_binned(uint32_t min_batch, uint32_t min_tiles);
 #define ENERF_K_FFMLP_BWD 7
 #define ENERF_K_MARCH_INFER 8
 #define ENERF_K_COMPOSITE_INFER 9
-#define ENERF_K_COUNT 10
+#define ENERF_K_TABLE_ADAM 10 /* enerf_grid_adam_from_records[_ex]: table flush + table Adam (+ the small tensors) */
+#define ENERF_K_MLP_REDUCE 11 /* the weight-gradient reduce launch of enerf_mlp32_backward[_p] */
+#define ENERF_K_COUNT 12
 
 /* Measurement aid: samples reserved (counter[0] increments) by all enerf_march_rays_train[_ex] calls of this process
  * since the last reset, kept on the device by the march's own scan pass.  Synchronises `stream`, then reads (total may

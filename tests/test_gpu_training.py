@@ -525,6 +525,7 @@ def test_fp16_training_variant(route):
     table, no loss scaling.
     Either way the loss must fall, the sample counters must be those of the fp32 run (marching does not depend on the
     networks), and the first step's loss must agree with the fp32 step's to 16-bit precision."""
+    import functools
     from enerf_amd import fused_render
     from enerf_amd.backends import _gridencoder as ge
     from enerf_amd.network import NeRFNetwork
@@ -537,7 +538,8 @@ def test_fp16_training_variant(route):
         h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16)
         seen, closed = [], []
         orig, orig_step = ge.grid_encode_forward, fused_render.train_step_mse
-        ge.grid_encode_forward = lambda *a, **k: (seen.append(a[1].dtype), orig(*a, **k))[1]
+        # (functools.wraps: gridencoder._supports_layout reads the backend function's signature)
+        ge.grid_encode_forward = functools.wraps(orig)(lambda *a, **k: (seen.append(a[1].dtype), orig(*a, **k))[1])
         fused_render.train_step_mse = lambda *a, **k: (closed.append(1), orig_step(*a, **k))[1]
         try:
             losses = [float(h.step_rgb(*data[i % len(data)])) for i in range(48)]
