@@ -354,7 +354,10 @@ def main():
                            "sharded_tail_ms_per_step": harness.tuned["sharded_ms_per_step"],
                            "chosen_tail": harness.comm_mode,
                            "prefetch_at_ms_per_step": harness.tuned["prefetch_at_ms_per_step"],
-                           "chosen_prefetch_at": harness.prefetch_at}
+                           "chosen_prefetch_at": harness.prefetch_at,
+                           "native_tail_ms_per_step": harness.tuned.get("native_tail_ms_per_step"),
+                           "torch_distributed_tail_ms_per_step": harness.tuned.get("torch_distributed_tail_ms_per_step"),
+                           "chosen_native_tail": harness.tuned.get("native_tail")}
             if harness.comm_dtype is None:      # reported only: what the opt-in 16-bit wire format would give here
                 comm_tuning["bf16_wire_ms_per_step"] = harness.probe_comm_dtype(one_step, torch.bfloat16)
         # the tuning steps must not change what the timed region holds: back to step 0 of the density-grid schedule
@@ -753,6 +756,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        parallel.native_tail_shutdown()
         dist.destroy_process_group()
 
 

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libenerf_hip.so")
 SOURCES = ["runtime.hip", "raymarching.hip", "gridencoder.hip", "shencoder.hip", "ffmlp.hip", "ffmlp_wgrad.hip",
-           "mlp32.hip", "mlp32s.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip"]
+           "mlp32.hip", "mlp32s.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "dp_tail.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 # Per-file extras.  ffmlp.hip (forward + dgrad) keeps its MFMA accumulators in arch VGPRs: every accumulator is
@@ -73,7 +73,7 @@ def build(force=False, verbose=True):
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in srcs]
     if force or jobs or not os.path.exists(LIB) or any(_mtime(o) > _mtime(LIB) for o in objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB + ".tmp"])
         os.replace(LIB + ".tmp", LIB)
     return LIB
 

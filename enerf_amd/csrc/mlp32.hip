@@ -932,8 +932,13 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     ProfScope prof(ENERF_K_FFMLP_FWD, s, g_precision != 0);
     // two workgroups per CU are resident (the weights sit in ~130-210 registers): one round of them, each wave
     // setting up once, beats four short-lived ones per CU (measured at the 138 k-sample training batch)
-    const uint32_t grid = pgrid(B, g_fwd_blocks ? g_fwd_blocks : 512);
-    const size_t lds = sizeof(float) * (HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID);
+    // (split operands: the weights sit in LDS as operands -- 2 KiB per fragment, hi + lo -- over the staged fp32 copy,
+    // and three workgroups per CU are resident)
+    const bool sigma_only_shape = num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1;
+    const bool lds_operands = g_precision == 1 && !sigma_only_shape;
+    const uint32_t grid = pgrid(B, g_fwd_blocks ? g_fwd_blocks : (lds_operands ? 768 : 512));
+    size_t lds = sizeof(float) * (HID * IN + (num_hidden - 1) * HID * HID + out_dim * HID);
+    if (lds_operands && lds < (size_t)(8 + 8 * (num_hidden - 1)) * 2048) lds = (size_t)(8 + 8 * (num_hidden - 1)) * 2048;
 #define MLP32_FWD2(NHV, TR, XLV) \
     k_mlp32_fwd<NHV, TR, XLV><<<grid, 256, lds, s>>>(X, W, fb, Y, B, out_dim, activation, output_activation, y_stride, y0_exp)
 #define MLP32_FWD(NHV)                                        \

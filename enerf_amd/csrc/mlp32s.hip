@@ -138,8 +138,15 @@ __device__ __forceinline__ void flip_natural(const FragT<P>& f, bf16x8 selN, Fra
     }
 }
 
+// Weight operands of the forward: in registers for the density-only sweeps (SIG: ~100 tiles per wavefront) and for bf16
+// operands; for split operands (P == 3) of a training / rendering batch they are kept in LDS in operand order instead
+// (k_mlp32s_bwd's scheme) -- the 96 / 128 registers they would take hold the kernel at two wavefronts per SIMD, and a
+// 4096-ray batch is ~4160 tiles: over 2048 resident wavefronts that is a third round for 64 of them, over 3072 it is two.
+constexpr bool fwd_weights_in_lds(bool SIG, int P) { return P == 3 && !SIG; }
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
 template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false, int P = 3>
-__global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X, WSrc W,
+__global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp32s_fwd(const float* __restrict__ X, WSrc W,
                                                     float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
                                                     uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
                                                     float* __restrict__ y0_exp, const float* __restrict__ sh_dirs = nullptr,
@@ -155,6 +162,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
     stage_rot(wl, W, NH, out_dim);
 
     typedef FragT<P> Frag;
+    constexpr bool WL = fwd_weights_in_lds(SIG, P);
     Frag w0[2][2], wh[NH > 1 ? NH - 1 : 1][2][2][2], wo[2][2];
     float wsig[2][16];                                    // SIG: the output row as fp32 (VALU dot product)
 #pragma unroll
@@ -201,6 +209,48 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
         }
     }
 
+    // operand order in LDS (over the staged fp32 copy, which nobody reads any more): fragment f, hi then lo, 64 lanes x 16 B
+    u32x4w* fr = reinterpret_cast<u32x4w*>(wl);
+    auto fidx0 = [](int ob, int t) { return 2 * ob + t; };
+    auto fidxh = [](int l, int ob, int ib, int t) { return 4 + ((l * 2 + ob) * 2 + ib) * 2 + t; };
+    auto fidxo = [](int ib, int t) { return 4 + 8 * (NH - 1) + 2 * ib + t; };
+    if (WL) {
+        const int wid = threadIdx.x >> 6;
+        auto put = [&](int f, const Frag& w) {
+            if ((f & 3) == wid) {
+                fr[(2 * f) * 64 + lane] = __builtin_bit_cast(u32x4w, w.hi);
+                if constexpr (P == 3) fr[(2 * f + 1) * 64 + lane] = __builtin_bit_cast(u32x4w, w.lo);
+            }
+        };
+        __syncthreads();                                   // every wave has read what it needs of the staged weights
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) put(fidx0(ob, t), w0[ob][t]);
+#pragma unroll
+        for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) put(fidxh(l, ob, ib, t), wh[l][ob][ib][t]);
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) put(fidxo(ib, t), wo[ib][t]);
+        __syncthreads();
+    }
+    auto get = [&](int f) -> Frag {
+        Frag w;
+        w.hi = __builtin_bit_cast(bf16x8, fr[(2 * f) * 64 + lane]);
+        if constexpr (P == 3) w.lo = __builtin_bit_cast(bf16x8, fr[(2 * f + 1) * 64 + lane]);
+        return w;
+    };
+    auto W0 = [&](int ob, int t) -> Frag { return WL ? get(fidx0(ob, t)) : w0[ob][t]; };
+    auto WH = [&](int l, int ob, int ib, int t) -> Frag { return WL ? get(fidxh(l, ob, ib, t)) : wh[l][ob][ib][t]; };
+    auto WO = [&](int ib, int t) -> Frag { return WL ? get(fidxo(ib, t)) : wo[ib][t]; };
+
     // ReLU as a signed-integer max on the bit pattern against a wave-uniform limit (0: negative floats, -0.0 and negative
     // NaNs are negative integers -> +0.0, everything else unchanged; INT_MIN: no activation): one v_max_i32 per element
     const int relu_lim = act == 0 ? 0 : (int)0x80000000;
@@ -210,6 +260,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const size_t s = (size_t)tile * 32 + j;
         const bool valid = s < B;
+        if (WL) asm volatile("" ::: "memory");             // the operand reads stay inside the loop
         if (!SIG && tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
         float dir0 = 0.0f, dir1 = 0.0f, dir2 = 0.0f;
         if (SH && valid) {
@@ -230,7 +281,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
         for (int ob = 0; ob < 2; ob++) {
             a[ob] = (f32x16)(0.0f);
 #pragma unroll
-            for (int t = 0; t < 2; t++) a[ob] = mmap(w0[ob][t], xf[t], a[ob]);
+            for (int t = 0; t < 2; t++) a[ob] = mmap(W0(ob, t), xf[t], a[ob]);
 #pragma unroll
             for (int q = 0; q < 16; q++) a[ob][q] = __int_as_float(max(__float_as_int(a[ob][q]), relu_lim));
             if (TRAIN) store_tile_fb(fb + s * HID, ob, h, a[ob]);
@@ -245,7 +296,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
 #pragma unroll
                 for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-                    for (int t = 0; t < 2; t++) n[ob] = mmap(wh[l - 1][ob][ib][t], af[ib][t], n[ob]);
+                    for (int t = 0; t < 2; t++) n[ob] = mmap(WH(l - 1, ob, ib, t), af[ib][t], n[ob]);
 #pragma unroll
                 for (int q = 0; q < 16; q++) n[ob][q] = __int_as_float(max(__float_as_int(n[ob][q]), relu_lim));
                 if (TRAIN) store_tile_fb(fb + ((size_t)l * Bp + s) * HID, ob, h, n[ob]);
@@ -273,7 +324,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_fwd(const float* __restrict__ X,
 #pragma unroll
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-            for (int t = 0; t < 2; t++) o = mmap(wo[ib][t], af[ib][t], o);
+            for (int t = 0; t < 2; t++) o = mmap(WO(ib, t), af[ib][t], o);
         if (valid) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {

@@ -50,6 +50,9 @@ class TrainHarness:
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
         self.comm_mode = "allreduce"  # or "sharded": reduce-scatter -> Adam on this rank's slice -> all-gather
         self.comm_dtype = None        # torch.bfloat16: halve the table gradient's bytes on the wire (changes rounding)
+        # the tail through the library's own RCCL communicator (csrc/dp_tail.hip: two C calls per step); None = use it
+        # when parallel.native_tail_init() succeeds (RCCL backend, every rank), False = the torch.distributed tail
+        self.native_tail = None
         # where the next batch's march is released on the side stream: once the "forward" is queued (runs beside the
         # MLP backward), once the MLP backward is ("mlp_backward": runs beside the hash table's backward and the
         # optimizer -- the MFMA kernels, one register-filling wavefront per SIMD, then have the CUs to themselves:
@@ -366,6 +369,60 @@ class TrainHarness:
             p.grad = g.view_as(p)
         self.opt.step_now(only=small)
 
+    def _native_tail_ok(self):
+        want = getattr(self, "native_tail", False)
+        if want is False or getattr(self, "comm_dtype", None) is not None \
+                or not hasattr(getattr(self, "opt", None), "step_now"):
+            return False
+        from . import parallel
+        ok = parallel.native_tail_init()
+        if want is None:
+            self.native_tail = ok
+        return ok
+
+    def _finish_native(self, issue_prefetch=None):
+        """Both data-parallel tails through csrc/dp_tail.hip: enerf_dp_begin queues the collectives (all-reduce of the
+        table gradient in `comm_chunks` pieces, or its reduce-scatter; the flat MLP gradient buffer's all-reduce) on the
+        library's communicator and returns; the next batch's march is issued underneath them; enerf_dp_finish queues Adam
+        per piece / on this rank's slice (+ the all-gather of the updated slices) on the training stream.  Same
+        collectives, same arithmetic and the same order as _finish_distributed / _finish_sharded; what changes is that
+        the host spends two ctypes calls on it instead of a torch.distributed round trip per piece."""
+        import torch.distributed as dist
+        from . import _lib as L
+        from . import fused_network
+        m = self.model
+        g_emb, dw = self._raw_grads
+        self._raw_grads = None
+        emb = m.encoder.embeddings
+        if g_emb is None:
+            g_emb = emb.grad
+        else:
+            emb.grad = g_emb
+        world = dist.get_world_size()
+        n = g_emb.numel()
+        sharded = self.comm_mode == "sharded" and n % world == 0 and (n // world) % 4 == 0
+        st = self.opt.state[emb]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(emb, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(emb, memory_format=torch.preserve_format)
+        st["step"] += 1
+        group = next(g for g in self.opt.param_groups if any(q is emb for q in g["params"]))
+        lib, stream = L.lib(), L.stream_handle()
+        L.check(lib.enerf_dp_begin(1 if sharded else 0, g_emb.data_ptr(), n, max(1, min(16, int(self.comm_chunks))),
+                                   dw.data_ptr(), dw.numel(), stream), "dp_begin")
+        if issue_prefetch is not None:
+            issue_prefetch(background=False)                  # marches while the gradients are on the wire
+        b1, b2 = group["betas"]
+        L.check(lib.enerf_dp_finish(emb.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                    float(group["lr"]), b1, b2, float(group["eps"]), int(st["step"]), stream), "dp_finish")
+        self._cleared_grad = emb.grad
+        small = fused_network.network_params(m)[1:]
+        for q, g in zip(small, fused_network.unpack_weight_grads(dw, getattr(m, "out_dim_color", 3),
+                                                                 fused_network.kind_of(m))):
+            q.grad = g.view_as(q)
+        self.opt.step_now(only=small)
+
     @staticmethod
     def _discard_pending_records():
         """A step that left the table gradient as record lists died before its optimizer pass: empty the lists so that
@@ -528,8 +585,32 @@ class TrainHarness:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             placements[at] = float(dt.item()) / window * 1e3
         self.prefetch_at = min(placements, key=placements.get)
+        # everything above ran on the library's own communicator when it exists; one window on the torch.distributed
+        # tail with the same settings decides between the two (and puts the difference on record)
+        native_ms = python_ms = None
+        if self._native_tail_ok():
+            native_ms = placements[self.prefetch_at]
+            self.native_tail = False
+            if self.comm_mode == "sharded":
+                self.gather_sharded_optimizer_state()
+            for n in range(2):
+                sync()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(window):
+                    step_fn(i)
+                    i += 1
+                sync()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                python_ms = float(dt.item()) / window * 1e3
+            if self.comm_mode == "sharded":
+                self.gather_sharded_optimizer_state()
+            self.native_tail = native_ms <= python_ms
         self.tuned = {"chunks_ms_per_step": dict(timings), "sharded_ms_per_step": sharded_ms,
-                      "mode": self.comm_mode, "prefetch_at_ms_per_step": placements}
+                      "mode": self.comm_mode, "prefetch_at_ms_per_step": placements,
+                      "native_tail_ms_per_step": native_ms, "torch_distributed_tail_ms_per_step": python_ms,
+                      "native_tail": bool(getattr(self, "native_tail", False))}
         return timings
 
     def probe_comm_dtype(self, step_fn, dtype=torch.bfloat16, window=None, first_step=0):
@@ -573,7 +654,10 @@ class TrainHarness:
             self._discard_pending_records()
             raise
         if chunked:
-            tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
+            if self._native_tail_ok():
+                tail = self._finish_native
+            else:
+                tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
             tail(side if late else None)
             return loss
         self._reduce_grads(None if side is not None else next_rays)

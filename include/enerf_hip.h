@@ -506,6 +506,31 @@ int enerf_adam_step_multi(uint32_t count, float* const* p, float* const* g, floa
                           const size_t* n, const float* lr, const uint32_t* step, float beta1, float beta2, float eps,
                           int zero_grad, enerf_stream_t stream);
 
+/* ------------------------------------------------------------------ data-parallel tail (not in the reference,
+ * whose Trainer wraps the model in DistributedDataParallel: nerf/utils.py:353-355)
+ * One process per GPU; rays shard over the ranks, and the step's only exchange is the average of the hash-table gradient
+ * and of the MLP weight gradients before Adam.  The library owns an RCCL communicator and a stream for it: the unique id
+ * is minted on rank 0 (enerf_dp_unique_id: 128 bytes) and handed to every rank's enerf_dp_init by the caller
+ * (e.g. a torch.distributed broadcast).  Per step:
+ *   enerf_dp_begin(mode, table_grad, n, pieces, mlp_grad, n_mlp, stream): queue the collectives behind everything `stream`
+ *     holds so far and return.  mode 0: all-reduce (AVG) of table_grad[0..n) in `pieces` pieces (1..16) ; mode 1:
+ *     reduce-scatter (AVG), this rank keeping slice [rank * n / world, (rank + 1) * n / world) (n must divide, in multiples
+ *     of 4); then the all-reduce (AVG) of mlp_grad[0..n_mlp) (may be NULL).
+ *   enerf_dp_finish(p, m, v, lr, beta1, beta2, eps, step, stream): on `stream`, Adam (torch.optim.Adam's update, as
+ *     enerf_adam_step_multi) on each piece of the table as its collective lands, the gradients cleared by the same pass;
+ *     mode 1: on this rank's slice only, the other slices' gradients cleared and the updated slices all-gathered in place
+ *     into every replica's table.  `stream` ends up waiting for the MLP gradients' all-reduce too: what the caller queues
+ *     next sees averaged mlp_grad and the updated table.
+ * Work queued on `stream` between the two calls runs underneath the collectives. */
+int enerf_dp_unique_id(void* out, size_t bytes);
+int enerf_dp_init(const void* unique_id, size_t bytes, int rank, int world);
+int enerf_dp_world(int* rank, int* world);              /* (-1, 0) before enerf_dp_init */
+int enerf_dp_shutdown(void);
+int enerf_dp_begin(int mode, float* table_grad, size_t n, uint32_t pieces, float* mlp_grad, size_t n_mlp,
+                   enerf_stream_t stream);
+int enerf_dp_finish(float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, uint32_t step,
+                    enerf_stream_t stream);
+
 /* profiling aid: restrict grid_encode_forward/backward to the levels whose bit is set (default all) */
 int enerf_debug_grid_level_mask(uint32_t mask);
 /* Testing / profiling aid: fp32 grid_encode_backward batches of at least `min_batch` samples send the levels spanning

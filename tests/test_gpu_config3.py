@@ -1,9 +1,10 @@
 """BASELINE configs[3] (spiral1-shaped: bound 3, 65 536 rays per step ray-sharded over 8 GPUs = 8192 rays per rank, RCCL
 all-reduce of the hash-grid / MLP gradients) at its PER-RANK shape on the one GPU a test box has:
 
-  * 8192 rays through both data-parallel tails (`_finish_distributed`: chunked all-reduce + Adam per piece;
-    `_finish_sharded`: reduce-scatter -> Adam on the slice -> all-gather) on the real backend (RCCL) with a world of one
-    rank, against the single-process step (which takes the fused record-list optimizer instead);
+  * 8192 rays through both data-parallel tails (chunked all-reduce + Adam per piece; reduce-scatter -> Adam on the slice
+    -> all-gather), each driven natively (`_finish_native`: csrc/dp_tail.hip on the library's own RCCL communicator) and
+    through torch.distributed (`_finish_distributed` / `_finish_sharded`), on the real backend (RCCL) with a world of
+    one rank, against the single-process step (which takes the fused record-list optimizer instead);
   * 2 ranks x 8192 rays (gloo, both ranks on this device) against the single-process 16 384-ray step: per-step sample /
     ray counters add up bit for bit, the losses average to the whole batch's loss, the post-Adam parameters agree and
     an evaluation render of the replicas gives the single-process image.  The jitter of a training march is seeded by
@@ -80,12 +81,19 @@ def _rccl_worker(rank, world, port, out):
     try:
         from enerf_amd.trainer import TrainHarness
         data = _data(4, RAYS_PER_RANK)
-        for tag, dp, mode in (("single", 1, None), ("allreduce", 2, "allreduce"), ("sharded", 2, "sharded")):
+        # every tail twice: through the library's own communicator (csrc/dp_tail.hip, two C calls per step) and through
+        # torch.distributed (one round trip per piece)
+        for tag, dp, mode, native in (("single", 1, None, None), ("allreduce", 2, "allreduce", True),
+                                      ("sharded", 2, "sharded", True), ("allreduce_torch", 2, "allreduce", False),
+                                      ("sharded_torch", 2, "sharded", False)):
             model = _model()
             h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=dp)   # dp = 2: the data-parallel tail runs
             if mode:
                 h.comm_mode = mode
+                h.native_tail = None if native else False
             losses, counters = _run(h, data, 40)
+            if native:
+                assert h.native_tail is True, "the native tail did not come up on RCCL"
             out[tag] = (losses, counters, _params(model), int(model.mean_count))
     finally:
         dist.destroy_process_group()
@@ -100,7 +108,7 @@ def test_configs3_rank_shape_through_both_tails_on_rccl():
     mp.spawn(_rccl_worker, args=(1, _port(), out), nprocs=1, join=True)
     la, ca, pa, ma = out["single"]
     assert ca[:, 1].max() == RAYS_PER_RANK and ma > 0
-    for tag in ("allreduce", "sharded"):
+    for tag in ("allreduce", "sharded", "allreduce_torch", "sharded_torch"):
         lb, cb, pb, mb = out[tag]
         assert np.array_equal(ca, cb) and ma == mb, tag
         assert np.abs(np.array(la) - np.array(lb)).max() <= 1e-4 * np.abs(la).max(), tag

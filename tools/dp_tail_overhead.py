@@ -32,14 +32,18 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1)
     dev = torch.device("cuda", 0)
     batches = bench.build_batches(8, a.rays, dev, 0, a.bound)
-    configs = (("single process", 1, 4, None), ("tail, 1 piece", 2, 1, None), ("tail, 2 pieces", 2, 2, None),
-               ("tail, 4 pieces", 2, 4, None), ("tail, 8 pieces", 2, 8, None),
-               ("tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16))
-    for tag, dp, chunks, dtype in (configs if a.only is None else configs[a.only:a.only + 1]):
+    # (native: csrc/dp_tail.hip on the library's own communicator; torch: torch.distributed, one round trip per piece)
+    configs = (("single process", 1, 4, None, None, "allreduce"),
+               ("torch tail, 1 piece", 2, 1, None, False, "allreduce"), ("torch tail, 4 pieces", 2, 4, None, False, "allreduce"),
+               ("torch tail, 8 pieces", 2, 8, None, False, "allreduce"), ("torch tail, sharded", 2, 4, None, False, "sharded"),
+               ("native tail, 1 piece", 2, 1, None, None, "allreduce"), ("native tail, 4 pieces", 2, 4, None, None, "allreduce"),
+               ("native tail, 8 pieces", 2, 8, None, None, "allreduce"), ("native tail, sharded", 2, 4, None, None, "sharded"),
+               ("torch tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16, False, "allreduce"))
+    for tag, dp, chunks, dtype, native, mode in (configs if a.only is None else configs[a.only:a.only + 1]):
         torch.manual_seed(0)
         model = NeRFNetwork(encoding="hashgrid", bound=a.bound, cuda_ray=True, out_dim_color=3).to(dev)
         h = TrainHarness(model, occupancy="synthetic", world=dp)
-        h.comm_chunks, h.comm_dtype = chunks, dtype
+        h.comm_chunks, h.comm_dtype, h.native_tail, h.comm_mode = chunks, dtype, native, mode
 
         def step(i):
             ro, rd, tg = batches[i % 8]
