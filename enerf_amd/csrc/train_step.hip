@@ -1,0 +1,99 @@
+// train_step.hip -- one closed-form training step as ONE call (host code only: every launch is one of the library's
+// own entry points, in the order the Python harness issues them -- enerf_amd/fused_render.train_step_mse +
+// fused_network.nerf_forward / nerf_backward + FusedAdam.step_grid_table -- so the two routes are bit-identical).
+//
+// Why: with the kernels of a 4096-ray step at ~0.32 ms, the ~28 launches of a step cost the Python harness ~0.4 ms of
+// host time (argument marshalling, tensor checks, dispatcher calls between the launches): the host, not the device,
+// bounds the step -- and under data parallelism it has the collectives to issue as well.  Here the host's share of a
+// step is one struct and one call; what remains on its side is the launches themselves.
+//
+//   render of batch i (its samples were marched by the previous call, on the side stream):
+//     grid_encode_forward -> mlp32 forward (sigma net, + SH columns) -> mlp32 forward (colour net)
+//     -> composite forward + MSE + composite backward (one launch)
+//     -> mlp32 backward (colour net) -> mlp32 backward (sigma net; its reduce launch carries the signal the side stream
+//        waits for) -> [side stream: near_far + march_rays_train of batch i+1] -> grid_encode_backward (record lists)
+//     -> table Adam from the records + the MLP weights' Adam (one launch)
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+using namespace enerf;
+
+extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
+    if (!a) ENERF_BADARG("train_step_mse: null arguments");
+    if (a->struct_bytes != sizeof(enerf_train_step_args))
+        ENERF_BADARG("train_step_mse: struct of %u bytes, this library expects %zu", a->struct_bytes,
+                     sizeof(enerf_train_step_args));
+    if (a->M == 0 || a->N == 0) return 0;
+    enerf_stream_t s = a->stream;
+    const uint32_t M = a->M, N = a->N;
+    const float in_add = a->bound, in_mul = a->inv_two_bound;
+    int prev_prec = -1;
+    if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
+    int rc = 0;
+    bool rows_set = false, defer_set = false, signal_set = false;
+#define STEP(call)            \
+    do {                      \
+        rc = (call);          \
+        if (rc) goto done;    \
+    } while (0)
+    // ---- forward
+    STEP(enerf_grid_encode_forward(a->xyzs, a->embeddings, a->offsets, a->feats, M, 3, 2, 16, a->level_scale_log2,
+                                   a->base_resolution, 0, a->feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
+    if (a->counter) {
+        enerf_mlp32_valid_rows(a->counter);
+        rows_set = true;
+    }
+    STEP(enerf_mlp32_forward_p(a->feats, a->wseg_s, 32, 0, M, 32, 16, a->nh_s, 0, 6, a->fb_s, a->h32, 1, 32, a->sigma,
+                               a->dirs, s));
+    STEP(enerf_mlp32_forward_p(a->h32, a->wseg_c, a->w0_cols_c, 1, M, 32, a->out_c, a->nh_c, 0, 3, a->fb_c, a->rgb, 0, 0,
+                               nullptr, nullptr, s));
+    // ---- compositing forward + loss gradient + compositing backward
+    STEP(enerf_composite_rays_train_fwd_bwd_mse(a->sigma, a->rgb, a->deltas, a->rays, M, N, a->weights_sum, a->image,
+                                                nullptr, 0, a->bg_scalar, a->out_image, a->target, a->grad_scale,
+                                                a->counter, a->g_sigmas, a->g_rgbs, a->loss, s));
+    // ---- MLP backward (the colour net's partial sums wait for the sigma net's reduce launch)
+    if (a->next_rays_o) {
+        enerf_mlp32_signal_next_reduce(1);
+        signal_set = true;
+    }
+    enerf_mlp32_defer_reduce(1);
+    defer_set = true;
+    STEP(enerf_mlp32_backward_p(a->g_rgbs, a->h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, 1, a->fb_c, M, 32, a->out_c,
+                                a->nh_c, 0, nullptr, a->dx32, 0, 0, a->rgb, a->out_c, nullptr, nullptr, 0, s));
+    STEP(enerf_mlp32_backward_p(a->dx32, a->feats, a->wseg_s, a->dwseg_s, 32, 0, 1, a->fb_s, M, 32, 16, a->nh_s, 0, nullptr,
+                                a->dfeat, 1, 32, nullptr, 0, a->g_sigmas, a->h32, 32, s));
+    enerf_mlp32_defer_reduce(0);
+    defer_set = false;
+    if (rows_set) {
+        enerf_mlp32_valid_rows(nullptr);
+        rows_set = false;
+    }
+    // ---- the next batch's march, on the side stream, behind the MLP backward (it reads no parameter)
+    if (a->next_rays_o) {
+        enerf_mlp32_signal_next_reduce(0);
+        signal_set = false;
+        enerf_stream_t ss = a->side_stream;
+        STEP(enerf_stream_wait_mlp32_signal(ss));
+        STEP(enerf_near_far_from_aabb(a->next_rays_o, a->next_rays_d, a->aabb, a->next_N, a->min_near, a->next_nears,
+                                      a->next_fars, ss));
+        STEP(enerf_march_rays_train_ex(a->next_rays_o, a->next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
+                                       a->next_N, a->cascade, a->grid_size, a->next_M, a->next_nears, a->next_fars,
+                                       a->next_xyzs, a->next_dirs, a->next_deltas, a->next_rays, a->next_counter, a->perturb,
+                                       a->march_flags, ss));
+    }
+    // ---- table backward (record lists) and the optimizer
+    STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,
+                                       a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
+                                       ENERF_F32, 2, in_add, in_mul, 1, M, s));
+    STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr,
+                                         a->beta1, a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g,
+                                         a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step, s));
+done:
+#undef STEP
+    if (defer_set) enerf_mlp32_defer_reduce(0);
+    if (signal_set) enerf_mlp32_signal_next_reduce(0);
+    if (rows_set) enerf_mlp32_valid_rows(nullptr);
+    if (prev_prec >= 0) enerf_mlp32_precision(prev_prec);
+    return rc;
+}

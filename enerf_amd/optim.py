@@ -32,6 +32,23 @@ class FusedAdam(torch.optim.Optimizer):
         for the binned levels.  p.grad (dense, zero-initialised, kept across steps) receives what was not binned and
         comes back cleared.  `extra`: up to 8 small fp32 parameters with dense gradients (the MLP weights), updated by
         the same launch.  Same update as step_now on the summed gradient."""
+        extra = [q for q in extra if q.grad is not None]
+        if len(extra) > 8 or any(not (q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
+                                      and q.grad.is_contiguous() and q.grad.dtype == torch.float32) for q in extra):
+            self.step_now(only=extra)                       # (more / other tensors than the launch carries)
+            extra = []
+        group, st, args = self.grid_table_args(p, extra, [q.grad for q in extra])
+        b1, b2 = group["betas"]
+        L.check(L.lib().enerf_grid_adam_from_records_ex(
+            p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), offsets.data_ptr(),
+            offsets.numel() - 1, int(level_dim), float(group["lr"]), b1, b2, float(group["eps"]), st["step"], *args,
+            L.stream_handle()), "grid_adam_from_records")
+
+    def grid_table_args(self, p, extra, extra_grads):
+        """Bookkeeping of one step_grid_table: the step counts of the table `p` and of the `extra` small tensors advance,
+        and -> (the table's param group, its state, the (n_small, p, g, m, v, n, lr, step) host arrays of
+        enerf_grid_adam_from_records_ex).  `extra_grads`: the tensors the small gradients live in (they need not be the
+        parameters' .grad yet: the native step hands out the buffers its backward is about to write)."""
         def state_of(q):
             st = self.state[q]
             if not st:
@@ -46,26 +63,17 @@ class FusedAdam(torch.optim.Optimizer):
             groups = self._group_of = {id(q): g for g in self.param_groups for q in g["params"]}
         group = groups[id(p)]
         st = state_of(p)
-        b1, b2 = group["betas"]
-        extra = [q for q in extra if q.grad is not None]
-        if len(extra) > 8 or any(not (q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
-                                      and q.grad.is_contiguous() and q.grad.dtype == torch.float32) for q in extra):
-            self.step_now(only=extra)                       # (more / other tensors than the launch carries)
-            extra = []
         n = len(extra)
         if n:
             sts = [state_of(q) for q in extra]
             vp, u32, fl = ctypes.c_void_p * n, ctypes.c_uint32 * n, ctypes.c_float * n
-            args = (n, vp(*[q.data_ptr() for q in extra]), vp(*[q.grad.data_ptr() for q in extra]),
+            args = (n, vp(*[q.data_ptr() for q in extra]), vp(*[g.data_ptr() for g in extra_grads]),
                     vp(*[t["exp_avg"].data_ptr() for t in sts]), vp(*[t["exp_avg_sq"].data_ptr() for t in sts]),
                     u32(*[q.numel() for q in extra]), fl(*[float(groups[id(q)]["lr"]) for q in extra]),
                     u32(*[t["step"] for t in sts]))
         else:
             args = (0, None, None, None, None, None, None, None)
-        L.check(L.lib().enerf_grid_adam_from_records_ex(
-            p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), offsets.data_ptr(),
-            offsets.numel() - 1, int(level_dim), float(group["lr"]), b1, b2, float(group["eps"]), st["step"], *args,
-            L.stream_handle()), "grid_adam_from_records")
+        return group, st, args
 
     @torch.no_grad()
     def step_now(self, only=None, ranges=None, zero_grads=False, advance=None):

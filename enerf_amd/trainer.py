@@ -41,6 +41,7 @@ class TrainHarness:
         self.manual_mse = True        # RGB step: closed-form MSE gradient into the fused render node, no autograd engine
         self.fuse_table_adam = True   # one GPU: the table gradient's tile sums feed Adam straight from LDS
         self.overlap_update = True    # update steps: the render's count pass is queued before the update's read-back
+        self.native_step = True       # steady-state RGB steps on one GPU as ONE library call (enerf_train_step_mse)
         self._params = [p for g in self.opt.param_groups for p in g["params"]]
         enc = getattr(model, "encoder", None)
         table = getattr(enc, "embeddings", None)
@@ -301,11 +302,7 @@ class TrainHarness:
         if not self.use_graphs:                     # (a captured graph would always accumulate into the same slot)
             # loss values land in a ring of device scalars, cleared once per lap: no loss kernels, no per-step fill
             # (laps are counted on the ring's own cursor: steps of other kinds in between do not use slots)
-            slot = self._loss_cursor % self._loss_ring.numel()
-            self._loss_cursor += 1
-            if slot == 0:
-                self._loss_ring.zero_()
-            loss = self._loss_ring[slot]
+            loss = self._loss_slot()
         if defer_table and emb.grad is None:        # the dense part of the gradient (levels too small to bin) needs a home
             emb.grad = torch.zeros_like(emb)
         image, grads = fused_render.train_step_mse(m, rays_o, rays_d, target, 1, self.perturb, dt_gamma, max_steps,
@@ -636,7 +633,49 @@ class TrainHarness:
             self.comm_dtype = keep
         return float(dt.item()) / window * 1e3
 
+    def _loss_slot(self):
+        """Loss values land in a ring of device scalars, cleared once per lap: no loss kernels, no per-step fill (laps are
+        counted on the ring's own cursor: steps of other kinds in between do not use slots)."""
+        slot = self._loss_cursor % self._loss_ring.numel()
+        self._loss_cursor += 1
+        if slot == 0:
+            self._loss_ring.zero_()
+        return self._loss_ring[slot]
+
+    def _step_rgb_native(self, rays_o, rays_d, target, next_rays):
+        """The steady-state step as one library call (fused_render.train_step_native -> enerf_train_step_mse): the same
+        launches in the same order as _step_rgb_manual's one-GPU route, issued from C."""
+        from . import fused_render
+        m = self.model
+        emb = m._modules["encoder"]._parameters["embeddings"]
+        if not (self._cleared_grad is not None and emb.grad is self._cleared_grad):
+            emb.grad = None                     # only a buffer the last flush left clean may be added into
+        self._cleared_grad = None
+        nxt = None
+        if (next_rays is not None and all(r is not None for r in next_rays) and self.prefetch
+                and self.global_step % self.update_interval != 0
+                and fused_render.supported(m, next_rays[0].contiguous().view(-1, 3),
+                                           next_rays[1].contiguous().view(-1, 3), 1, 0)):
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            nxt = next_rays
+        loss = self._loss_slot()
+        try:
+            fused_render.train_step_native(m, rays_o, rays_d, target, self.opt, next_rays=nxt, side_stream=self._side,
+                                           loss_out=loss, perturb=self.perturb)
+        except BaseException:
+            self._discard_pending_records()
+            raise
+        self._cleared_grad = emb.grad
+        return loss
+
     def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
+        if (self.native_step and not render_kw and self.avg is None and self.fuse_table_adam and not self.use_graphs
+                and self.prefetch_at == "mlp_backward" and getattr(self.model, "graph_counter", None) is None):
+            from . import fused_render
+            if fused_render.native_step_supported(self.model, rays_o.contiguous().view(-1, 3),
+                                                  rays_d.contiguous().view(-1, 3), self.opt):
+                return self._step_rgb_native(rays_o, rays_d, target, next_rays)
         side = self._side_prefetch(next_rays) if not render_kw else None
         chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")
                    and self.comm_chunks > 0)

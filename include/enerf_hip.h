@@ -426,6 +426,11 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
                          uint32_t x_layout, uint32_t dy_stride, const float* y_sigmoid, uint32_t y_sigmoid_stride,
                          const float* dsigma, const float* h0, uint32_t h0_stride, enerf_stream_t stream);
 
+/* Rows of a training batch that are real: `device_count` points at a device int32 (the march's counter[0]); the
+ * enerf_mlp32_* calls that follow skip the tiles beyond min(*device_count, B) -- the sample budget's padding, which no
+ * ray covers (forward: left unwritten; fused backward: zero input gradients) -- until it is set again; NULL: every row
+ * is real. */
+int enerf_mlp32_valid_rows(const int32_t* device_count);
 /* Arithmetic of the enerf_mlp32_* kernels (the nn.Linear nets of nerf/network.py:40-77 are fp32):
  *   0  v_mfma_f32_32x32x2_f32: every dot product an fp32 fmaf chain, bit-comparable with an fp32 GEMM;
  *   1  (default) split-bf16: every fp32 operand as bf16 hi + lo, three bf16 MFMA products per fp32 product (hi*hi +
@@ -505,6 +510,63 @@ int enerf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
 int enerf_adam_step_multi(uint32_t count, float* const* p, float* const* g, float* const* m, float* const* v,
                           const size_t* n, const float* lr, const uint32_t* step, float beta1, float beta2, float eps,
                           int zero_grad, enerf_stream_t stream);
+
+/* ------------------------------------------------------------------ one training step as one call (not in the reference)
+ * The closed-form RGB step of the nn.Linear / FFMLP networks on one GPU -- render of a batch whose samples have been
+ * marched already, MSE against `target`, backward, the hash table's Adam from the backward's record lists together with
+ * the MLP weights' Adam, and (optionally) near_far + march_rays_train of the NEXT batch on `side_stream` behind the MLP
+ * backward -- issued by the library itself, in the order and with the arguments of the entry points above
+ * (grid_encode_forward, mlp32_forward_p x 2, composite_rays_train_fwd_bwd_mse, mlp32_backward_p x 2, near_far_from_aabb,
+ * march_rays_train_ex, grid_encode_backward_ex(defer), grid_adam_from_records_ex): results are those of the calls made
+ * one by one.  What it removes is the host's work between the launches (nerf/utils.py:575-640 + main_nerf.py:211 run
+ * ~60 framework calls per step).  All pointers are device pointers unless noted; every buffer is the caller's.
+ * Scalar background (bg_scalar), density_scale 1, fp32 table with L = 16, C = 2, D = 3. */
+typedef struct enerf_train_step_args {
+    uint32_t struct_bytes;              /* sizeof(enerf_train_step_args): checked */
+    int mlp_precision;                  /* enerf_mlp32_precision for this call's MLP launches; < 0: leave as is */
+    enerf_stream_t stream, side_stream; /* side_stream only used when next_rays_o != NULL */
+    /* this batch: samples from march_rays_train (M rows budgeted, counter[0] real), N rays */
+    uint32_t N, M;
+    const float *xyzs, *dirs, *deltas;
+    const int32_t *rays, *counter;
+    const float* target;                /* [N,3] */
+    float bg_scalar, grad_scale;        /* d loss / d image = (out_image - target) * grad_scale */
+    float* loss;                        /* device scalar the loss value is added into, or NULL */
+    /* networks */
+    const float* embeddings;            /* == table below */
+    const int32_t* offsets;
+    float level_scale_log2, bound, inv_two_bound;
+    uint32_t base_resolution, gridtype;
+    const float* const* wseg_s;         /* host arrays of 4 device pointers, as enerf_mlp32_forward_p takes them */
+    const float* const* wseg_c;
+    float* const* dwseg_s;              /* where the weight gradients are written (overwrite) */
+    float* const* dwseg_c;
+    uint32_t nh_s, nh_c, w0_cols_c, out_c;
+    /* scratch of the step, all fp32: feats [16,Mp,2], h32 [M,32], fb_s [nh_s,Mp,64], fb_c [nh_c,Mp,64], sigma [M],
+     * rgb [M,out_c], weights_sum [N], image [N,3], out_image [N,3], g_sigmas [M], g_rgbs [M,3], dx32 [M,32],
+     * dfeat [16,Mp,2] (Mp = M rounded up to 32) */
+    float *feats, *h32, *fb_s, *fb_c, *sigma, *rgb, *weights_sum, *image, *out_image, *g_sigmas, *g_rgbs, *dx32, *dfeat;
+    /* next batch's march (next_rays_o == NULL: none) */
+    const float *next_rays_o, *next_rays_d, *aabb;
+    const uint8_t* bitfield;
+    float min_near, dt_gamma;
+    uint32_t next_N, next_M, cascade, grid_size, max_steps, perturb, march_flags;
+    float *next_nears, *next_fars, *next_xyzs, *next_dirs, *next_deltas;
+    int32_t *next_rays, *next_counter;
+    /* optimizer: the table (dense gradient buffer for the levels too small to bin, zero-filled, comes back clean) and up
+     * to 8 small tensors whose gradients the backward has just written through dwseg_* */
+    float *table, *table_grad, *table_m, *table_v;
+    float lr, beta1, beta2, eps;
+    uint32_t table_step, n_small;
+    float* const* small_p;              /* host arrays of n_small entries, as enerf_grid_adam_from_records_ex takes them */
+    const float* const* small_g;
+    float* const* small_m;
+    float* const* small_v;
+    const uint32_t* small_n;
+    const float* small_lr;
+    const uint32_t* small_step;
+} enerf_train_step_args;
+int enerf_train_step_mse(const enerf_train_step_args* args);
 
 /* ------------------------------------------------------------------ data-parallel tail (not in the reference,
  * whose Trainer wraps the model in DistributedDataParallel: nerf/utils.py:353-355)

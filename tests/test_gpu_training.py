@@ -655,3 +655,46 @@ def test_update_step_count_pass_queued_before_the_read_back_changes_nothing():
     assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 2e-2
     for n in p0:
         assert float((p0[n] - p1[n]).abs().mean()) <= 2e-2 * float(p0[n].abs().mean()), n
+
+
+@pytest.mark.parametrize("net", ["linear", "ff"])
+def test_native_step_call_equals_the_python_driven_step(net):
+    """enerf_train_step_mse (csrc/train_step.hip: the steady-state closed-form step as ONE library call, the next batch's
+    march included) issues the same entry points in the same order as the Python-driven step: same sample counters, same
+    loss values, same weights (to the float atomics of the table's smallest levels), for both network families."""
+    from enerf_amd import fused_render
+    from enerf_amd.trainer import TrainHarness
+    if net == "ff":
+        from enerf_amd.network_ff import NeRFNetwork
+    else:
+        from enerf_amd.network import NeRFNetwork
+    data = _batches(4, 4096, 2)
+    runs = {}
+    for native in (True, False):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.native_step = native
+        calls = []
+        orig = fused_render.train_step_native
+        fused_render.train_step_native = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            losses, counters = [], []
+            for i in range(40):
+                nxt = data[(i + 1) % 4]
+                losses.append(float(h.step_rgb(*data[i % 4], next_rays=(nxt[0], nxt[1]))))
+                counters.append(model.step_counter[model.rendered_counter_slot].cpu().clone())
+        finally:
+            fused_render.train_step_native = orig
+        torch.cuda.synchronize()
+        runs[native] = (losses, torch.stack(counters), {n: p.detach().clone() for n, p in model.named_parameters()},
+                        len(calls), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    (la, ca, pa, na, ga), (lb, cb, pb, nb, gb) = runs[True], runs[False]
+    # steps 0..15 have no sample budget (cold window), steps 16 and 32 start with update_extra_state: all of them steady
+    # from the render on, i.e. native from step 16
+    assert na == 24 and nb == 0
+    assert torch.equal(ca, cb)
+    assert np.abs(np.array(la) - np.array(lb)).max() <= 1e-5 * np.abs(lb).max()
+    for n, a in pa.items():
+        assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
+    assert set(ga) == set(gb)
