@@ -100,6 +100,7 @@ SIGNATURES = {
     "enerf_adam_step_multi": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp],
     "enerf_prof_enable_mask": [_u32],
     "enerf_train_step_mse": [_vp],
+    "enerf_debug_step_timing": [_int, _c.POINTER(_c.c_double)],
     "enerf_dp_unique_id": [_vp, _sz],
     "enerf_dp_init": [_vp, _sz, _int, _int],
     "enerf_dp_world": [_c.POINTER(_int), _c.POINTER(_int)],

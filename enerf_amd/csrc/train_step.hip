@@ -15,9 +15,16 @@
 //     -> table Adam from the records + the MLP weights' Adam (one launch)
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include "common.h"
 
 using namespace enerf;
+
+// development aid (enerf_debug_step_timing): host microseconds spent in each call of the step, summed over steps
+static double g_host_us[16];
+static uint64_t g_host_steps = 0;
+static bool g_host_timing = false;
 
 extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     if (!a) ENERF_BADARG("train_step_mse: null arguments");
@@ -32,10 +39,19 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
     bool rows_set = false, defer_set = false, signal_set = false;
-#define STEP(call)            \
-    do {                      \
-        rc = (call);          \
-        if (rc) goto done;    \
+    int slot = 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    if (g_host_timing) g_host_steps++;
+#define STEP(call)                                                                       \
+    do {                                                                                 \
+        rc = (call);                                                                     \
+        if (g_host_timing) {                                                             \
+            const auto t_now = std::chrono::steady_clock::now();                         \
+            g_host_us[slot < 15 ? slot : 15] += std::chrono::duration<double, std::micro>(t_now - t_prev).count(); \
+            t_prev = t_now;                                                              \
+            slot++;                                                                      \
+        }                                                                                \
+        if (rc) goto done;                                                               \
     } while (0)
     // ---- forward
     STEP(enerf_grid_encode_forward(a->xyzs, a->embeddings, a->offsets, a->feats, M, 3, 2, 16, a->level_scale_log2,
@@ -96,4 +112,17 @@ done:
     if (rows_set) enerf_mlp32_valid_rows(nullptr);
     if (prev_prec >= 0) enerf_mlp32_precision(prev_prec);
     return rc;
+}
+
+// development aid: on != 0 starts (and clears) the per-call host timers of enerf_train_step_mse; out (16 doubles, may
+// be NULL) receives the microseconds per call slot, in call order, averaged over the steps since the last start
+extern "C" int enerf_debug_step_timing(int on, double* out) {
+    if (out)
+        for (int k = 0; k < 16; k++) out[k] = g_host_steps ? g_host_us[k] / (double)g_host_steps : 0.0;
+    if (on >= 0) {
+        g_host_timing = on != 0;
+        for (int k = 0; k < 16; k++) g_host_us[k] = 0.0;
+        g_host_steps = 0;
+    }
+    return 0;
 }

@@ -567,6 +567,9 @@ typedef struct enerf_train_step_args {
     const uint32_t* small_step;
 } enerf_train_step_args;
 int enerf_train_step_mse(const enerf_train_step_args* args);
+/* Development aid: host microseconds enerf_train_step_mse spends in each of its calls (in call order, 16 slots, averaged
+ * over the steps since timing was switched on); on >= 0 switches the timers (and clears them), on < 0 only reads. */
+int enerf_debug_step_timing(int on, double* out16);
 
 /* ------------------------------------------------------------------ data-parallel tail (not in the reference,
  * whose Trainer wraps the model in DistributedDataParallel: nerf/utils.py:353-355)

@@ -103,8 +103,10 @@ def test_manual_mse_step_matches_autograd_step(monkeypatch):
     from enerf_amd.trainer import TrainHarness
     data = _batches(4, 2048, 2)
     calls = []
-    orig = fused_render.train_step_mse
+    orig, orig_native = fused_render.train_step_mse, fused_render.train_step_native
     monkeypatch.setattr(fused_render, "train_step_mse", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    # (once the sample budget exists the same launches are issued by the library itself: enerf_train_step_mse)
+    monkeypatch.setattr(fused_render, "train_step_native", lambda *a, **k: (calls.append(1), orig_native(*a, **k))[1])
     runs = []
     for manual in (False, True):
         torch.manual_seed(0)

@@ -12,11 +12,18 @@ import bench  # noqa: E402
 from enerf_amd.network import NeRFNetwork  # noqa: E402
 from enerf_amd.trainer import TrainHarness  # noqa: E402
 
+import argparse
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--rays", type=int, default=4096, help="64: the device is never the limit, what is timed is the host")
+_ap.add_argument("--python-step", action="store_true", help="the Python-driven step instead of enerf_train_step_mse")
+_ap.add_argument("--no-profile", action="store_true")
+_a = _ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(dev)
 h = TrainHarness(model, occupancy="synthetic", world=1)
-batches = bench.build_batches(8, 4096, dev, 0, 3)
+h.native_step = not _a.python_step
+batches = bench.build_batches(8, _a.rays, dev, 0, 3)
 def step(i):
     nxt = batches[(i + 1) % 8]
     return h.step_rgb(*batches[i % 8], next_rays=(nxt[0], nxt[1]))
@@ -36,7 +43,23 @@ for i in range(41, 41 + 15):          # (no update_extra_state inside: steps 41.
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"enqueue {1e3 * (t1 - t0) / 15:.3f} ms/step, drained after {1e3 * (t2 - t0) / 15:.3f} ms/step")
+print(f"rays {_a.rays} native_step {h.native_step}: enqueue {1e3 * (t1 - t0) / 15:.3f} ms/step, drained after "
+      f"{1e3 * (t2 - t0) / 15:.3f} ms/step")
+if h.native_step:
+    import ctypes
+    from enerf_amd import _lib
+    _lib.lib().enerf_debug_step_timing(1, None)
+    for i in range(81, 81 + 14):
+        step(i)
+    torch.cuda.synchronize()
+    arr = (ctypes.c_double * 16)()
+    _lib.lib().enerf_debug_step_timing(0, arr)
+    names = ["grid_fwd", "mlp_fwd_sigma", "mlp_fwd_colour", "composite", "mlp_bwd_colour", "mlp_bwd_sigma(+reduce)",
+             "wait_signal", "near_far", "march", "grid_bwd", "table_adam"]
+    print("host us per call inside enerf_train_step_mse:", {n: round(arr[k], 1) for k, n in enumerate(names)},
+          "sum", round(sum(arr), 1))
+if _a.no_profile:
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 n_prof = 0
