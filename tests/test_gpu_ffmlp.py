@@ -257,12 +257,13 @@ def test_network_ff_training_step_takes_the_closed_form_path():
     assert h._manual_ok(data[0][0], data[0][1], data[0][2], {})
     w0 = model.sigma_net.weights.detach().clone()
     calls = []
-    orig = fused_render.train_step_mse
+    orig, orig_native = fused_render.train_step_mse, fused_render.train_step_native
     fused_render.train_step_mse = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    fused_render.train_step_native = lambda *a, **k: (calls.append(1), orig_native(*a, **k))[1]      # (the same, from C)
     try:
         losses = [float(h.step_rgb(*data[i % 8])) for i in range(120)]
     finally:
-        fused_render.train_step_mse = orig
+        fused_render.train_step_mse, fused_render.train_step_native = orig, orig_native
     assert len(calls) == 120
     assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.5 * np.mean(losses[:8]), (losses[:4], losses[-4:])
     assert float((model.sigma_net.weights - w0).abs().max()) > 1e-3

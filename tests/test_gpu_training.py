@@ -542,11 +542,14 @@ def test_fp16_training_variant(route):
         orig, orig_step = ge.grid_encode_forward, fused_render.train_step_mse
         # (functools.wraps: gridencoder._supports_layout reads the backend function's signature)
         ge.grid_encode_forward = functools.wraps(orig)(lambda *a, **k: (seen.append(a[1].dtype), orig(*a, **k))[1])
+        orig_native = fused_render.train_step_native          # (steady-state steps: the same launches from one C call)
         fused_render.train_step_mse = lambda *a, **k: (closed.append(1), orig_step(*a, **k))[1]
+        fused_render.train_step_native = lambda *a, **k: (closed.append(1), orig_native(*a, **k))[1]
         try:
             losses = [float(h.step_rgb(*data[i % len(data)])) for i in range(48)]
         finally:
             ge.grid_encode_forward, fused_render.train_step_mse = orig, orig_step
+            fused_render.train_step_native = orig_native
         runs.append((losses, model.step_counter.clone().cpu(), set(seen), h, len(closed)))
     (l32, c32, d32, _, n32), (l16, c16, d16, h16, n16) = runs
     assert d32 == {torch.float32} and n32 == 48
