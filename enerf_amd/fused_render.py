@@ -605,6 +605,14 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
         for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"), small[1:]):
             setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
+        # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
+        from .backends import _gridencoder as _gbk
+        _gbk.STATS["fwd_points"] += M
+        _gbk.STATS["fwd_calls"] += 1
+        _gbk.STATS["bwd_points"] += M
+        _gbk.STATS["bwd_calls"] += 1
+        _gbk.LIFETIME["fwd_points"] += M
+        _gbk.LIFETIME["fwd_calls"] += 1
         if nxt is not None:
             nxt["ready"] = torch.cuda.Event()
             nxt["ready"].record(side_stream)
