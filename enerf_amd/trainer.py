@@ -61,7 +61,14 @@ class TrainHarness:
         self.prefetch_at = "mlp_backward"
         self._raw_grads = None
         self._cleared_grad = None     # the embeddings' gradient buffer as the last Adam pass left it (all zeros)
-        self._loss_ring = torch.zeros(64, device=next(model.parameters()).device)
+        dev0 = next(model.parameters()).device
+        if dev0.type == "cuda" and not getattr(TrainHarness, "_pool_primed", False):
+            # once per process: leave one large free block in torch's caching pool.  The first 16 steps size their sample
+            # buffers from each render's own count (a different size every step), and every size the pool cannot serve is
+            # a hipMalloc in the middle of a step -- milliseconds on a fresh process, in a loop whose step is 0.4 ms.
+            torch.empty(2 << 30, dtype=torch.uint8, device=dev0)
+            TrainHarness._pool_primed = True
+        self._loss_ring = torch.zeros(64, device=dev0)
         self._loss_cursor = 0
         # fp16 = the shipped configs' `fp16 = True` (nerf/utils.py:350,964-975: mixed-precision training).  Two routes:
         #   True / "bf16": the MI355X form of it -- the closed-form step with the networks on bf16 operands (fp32

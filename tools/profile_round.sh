@@ -17,12 +17,13 @@ rm -rf /tmp/p_agree; timeout 900 rocprofv3 --kernel-trace --output-format csv -d
 python $R/tools/agree.py $(find /tmp/p_agree -name "*kernel_trace.csv") $OUT/bench_under_trace.log $OUT/${TAG}_hipevent_vs_rocprof.json
 
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/p_$C; timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$C -o c -- $BENCH --render-frames 0 > $OUT/bench_under_$C.log 2>&1
+  rm -rf /tmp/p_$C; timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/p_$C -o c -- $BENCH --render-frames 0 --graph-leg-steps 0 > $OUT/bench_under_$C.log 2>&1
 done
 PTS=$(grep '^{"metric"' $OUT/bench_under_FETCH_SIZE.log | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.readline())['roofline']['points_per_launch'])" 2>/dev/null)
-# the counters are averaged over EVERY k_grid_fwd dispatch of the process: so is this denominator (bench.py: grid_fwd_lifetime)
+# the counters are averaged over EVERY k_grid_fwd dispatch of the process: so is this denominator (bench.py:
+# grid_fwd_lifetime; no graph leg in this command -- a replayed graph launches the kernel without the wrapper that counts)
 PTS_ALL=$(grep '^{"metric"' $OUT/bench_under_FETCH_SIZE.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline())['grid_fwd_lifetime']; print(d['points_per_launch'], d['launches'])" 2>/dev/null)
-python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_bench.json --meta "command=bench.py --no-cpu-baseline --render-frames 0" --meta "grid_fwd_points_per_launch=$PTS" \
+python $R/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_bench.json --meta "command=bench.py --no-cpu-baseline --render-frames 0 --graph-leg-steps 0" --meta "grid_fwd_points_per_launch=$PTS" \
   --meta "grid_fwd_points_per_launch_all_dispatches=${PTS_ALL% *}" --meta "grid_fwd_dispatches_in_process=${PTS_ALL#* }" \
   $(find /tmp/p_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/p_WRITE_SIZE -name "*counter_collection.csv")
 
