@@ -99,6 +99,13 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
                                        a->march_flags, ss));
     }
     // ---- table backward (record lists) and the optimizer
+    if (a->flags & 1u) {
+        // data parallel: the gradient has to exist to be averaged -- the backward's own flush into the dense buffer
+        STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,
+                                           a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
+                                           ENERF_F32, 2, in_add, in_mul, 0, 0, s));
+        goto done;
+    }
     STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,
                                        a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
                                        ENERF_F32, 2, in_add, in_mul, 1, M, s));

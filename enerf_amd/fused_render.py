@@ -488,23 +488,86 @@ class _StepArgs(_ct.Structure):          # enerf_train_step_args (include/enerf_
                 + [(n, _vp) for n in ("table", "table_grad", "table_m", "table_v")]
                 + [(n, _f32c) for n in ("lr", "beta1", "beta2", "eps")]
                 + [("table_step", _u32), ("n_small", _u32)]
-                + [(n, _vp) for n in ("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step")])
+                + [(n, _vp) for n in ("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step")]
+                + [("flags", _u32), ("reserved", _u32)])
 
 
 def native_step_supported(model, rays_o, rays_d, opt):
-    """The one-call step serves the steady state of the closed-form RGB step on one GPU: a sample budget exists (the
-    cold window sizes its buffers from a read-back), unit density scale, the fused optimizer."""
+    """The one-call step serves the steady state of the closed-form RGB step: a sample budget exists (the cold window
+    sizes its buffers from a read-back), unit density scale, the fused optimizer."""
     return (NATIVE_STEP and _budget(model) > 0 and float(model.density_scale) == 1.0
             and hasattr(opt, "grid_table_args") and supported(model, rays_o, rays_d, 1, 0))
 
 
+def _native_ctx(model, N, M, Nn, Mn, dev):
+    """Everything of a native step that does not change from step to step, built once per (rays, sample budget) -- i.e.
+    once per update_extra_state window: the step's scratch buffers, two sets of sample buffers for the march that runs
+    ahead (the step reads one set while the side stream fills the other), the weight / gradient pointer arrays, and the
+    argument struct with its constant fields filled in.  (20 torch.empty calls and ~60 struct fields per step otherwise:
+    most of the host's share of a step once the launches themselves come from C.)"""
+    params = fnet.network_params(model)
+    emb, weights = params[0], params[1:]
+    kind = fnet.kind_of(model)
+    arch = fnet._ARCH[kind]
+    prec = model.__dict__.get("mlp_precision")
+    prec = arch["prec"] if prec is None else int(prec)
+    out_c = weights[-1].shape[0] if kind == "linear" else 3
+    key = (N, M, Nn, Mn, kind, prec, out_c, emb.data_ptr(), tuple(w.data_ptr() for w in weights), dev)
+    ctx = model.__dict__.get("_native_ctx")
+    if ctx is not None and ctx["key"] == key:
+        return ctx
+    import numpy as _np
+    enc = model._modules["encoder"]
+    bufs = model._buffers
+    f32 = dict(dtype=torch.float32, device=dev)
+    Mp = (M + 31) // 32 * 32
+    t = dict(feats=torch.empty(16, Mp, 2, **f32), h32=torch.empty(M, 32, **f32),
+             fb_s=torch.empty(arch["nh_s"], Mp, 64, **f32), fb_c=torch.empty(arch["nh_c"], Mp, 64, **f32),
+             sigma=torch.empty(M, **f32), rgb=torch.empty(M, out_c, **f32), weights_sum=torch.empty(N, **f32),
+             image=torch.empty(N, 3, **f32), out_image=torch.empty(N, 3, **f32), g_sigmas=torch.empty(M, **f32),
+             g_rgbs=torch.empty(M, out_c, **f32), dx32=torch.empty(M, 32, **f32), dfeat=torch.empty(16, Mp, 2, **f32))
+    seg_s, seg_c = fnet._weight_segments(kind, weights)
+    dw, (dseg_s, dseg_c) = fnet._grad_segments(kind, dev, out_c)
+    grads = fnet.unpack_weight_grads(dw, out_c, kind)
+    stages = []
+    if Nn:
+        for _ in range(2):
+            stages.append(dict(nears=torch.empty(Nn, **f32), fars=torch.empty(Nn, **f32),
+                               rays=torch.empty(Nn, 3, dtype=torch.int32, device=dev), xyzs=torch.empty(Mn, 3, **f32),
+                               dirs=torch.empty(Mn, 3, **f32), deltas=torch.empty(Mn, 2, **f32), M=Mn))
+    a = _StepArgs()
+    a.struct_bytes = _ct.sizeof(_StepArgs)
+    a.mlp_precision = -1 if prec is None else prec
+    a.N, a.M = N, M
+    a.bg_scalar, a.grad_scale = 1.0, 2.0 / (3 * N)
+    a.embeddings, a.offsets = emb.data_ptr(), enc._buffers["offsets"].data_ptr()
+    a.level_scale_log2 = float(_np.log2(enc.per_level_scale))
+    a.bound, a.inv_two_bound = float(model.bound), float(_np.float32(1.0) / _np.float32(2 * model.bound))
+    a.base_resolution, a.gridtype = int(enc.base_resolution), int(enc.gridtype_id)
+    a.wseg_s, a.wseg_c = _ct.cast(seg_s, _vp), _ct.cast(seg_c, _vp)
+    a.dwseg_s, a.dwseg_c = _ct.cast(dseg_s, _vp), _ct.cast(dseg_c, _vp)
+    a.nh_s, a.nh_c, a.w0_cols_c, a.out_c = arch["nh_s"], arch["nh_c"], arch["w0c"], out_c
+    for name, buf in t.items():
+        setattr(a, name, buf.data_ptr())
+    a.aabb, a.bitfield = bufs["aabb_train"].data_ptr(), bufs["density_bitfield"].data_ptr()
+    a.min_near = float(model.min_near)
+    a.cascade, a.grid_size = int(model.cascade), int(model.grid_size)
+    a.table = emb.data_ptr()
+    ctx = dict(key=key, t=t, seg=(seg_s, seg_c), dseg=(dseg_s, dseg_c), dw=dw, grads=grads, stages=stages, flip=0, a=a,
+               emb=emb, weights=weights, out_image=t["out_image"], kind=kind, out_c=out_c)
+    model.__dict__["_native_ctx"] = ctx
+    return ctx
+
+
 def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_stream=None, loss_out=None, perturb=True,
-                      dt_gamma=0, max_steps=1024):
+                      dt_gamma=0, max_steps=1024, raw=False):
     """One closed-form RGB step (loss = mean((image - target)^2), white background) through enerf_train_step_mse:
     render of this batch (marched ahead of time when the previous step asked for it) + backward + the optimizer, and the
-    march of `next_rays` = (rays_o, rays_d) on `side_stream` behind the MLP backward.  -> blended image [N,3].
-    Gradients of the MLP weights are left in p.grad (views of one flat buffer), the table's dense gradient buffer comes
-    back clean; the optimizer's step counts advance."""
+    march of `next_rays` = (rays_o, rays_d) on `side_stream` behind the MLP backward.  -> blended image [N,3] (a buffer
+    that the next step of the same shape overwrites).  Gradients of the MLP weights are left in p.grad (views of one flat
+    buffer, likewise reused), the table's dense gradient buffer comes back clean; the optimizer's step counts advance.
+    raw=True (data parallel): the table's gradient is summed into the dense buffer `embeddings.grad` and NO optimizer
+    runs -- -> (image, flat MLP dW buffer); the caller averages both over the ranks and steps the optimizer."""
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     N, dev = rays_o.shape[0], rays_o.device
@@ -517,93 +580,64 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
             pre = march_stage(model, rays_o, rays_d, counter, _budget(model), bool(perturb), False, float(dt_gamma),
                               int(max_steps))
-        xyzs, dirs, deltas, rays, M = (pre[k] for k in ("xyzs", "dirs", "deltas", "rays", "M"))
-        Mp = (M + 31) // 32 * 32
-        params = fnet.network_params(model)
-        emb, weights = params[0], params[1:]
-        kind = fnet.kind_of(model)
-        arch = fnet._ARCH[kind]
-        prec = model.__dict__.get("mlp_precision")
-        prec = arch["prec"] if prec is None else int(prec)
-        out_c = weights[-1].shape[0] if kind == "linear" else 3
-        enc = model._modules["encoder"]
-        f32 = dict(dtype=torch.float32, device=dev)
-        feats = torch.empty(16, Mp, 2, **f32)
-        h32 = torch.empty(M, 32, **f32)
-        fb_s = torch.empty(arch["nh_s"], Mp, 64, **f32)
-        fb_c = torch.empty(arch["nh_c"], Mp, 64, **f32)
-        sigma = torch.empty(M, **f32)
-        rgb = torch.empty(M, out_c, **f32)
-        weights_sum = torch.empty(N, **f32)
-        image = torch.empty(N, 3, **f32)
-        out_image = torch.empty(N, 3, **f32)
-        g_sigmas = torch.empty(M, **f32)
-        g_rgbs = torch.empty(M, out_c, **f32)
-        dx32 = torch.empty(M, 32, **f32)
-        dfeat = torch.empty(16, Mp, 2, **f32)
-        seg_s, seg_c = fnet._weight_segments(kind, weights)
-        dw, (dseg_s, dseg_c) = fnet._grad_segments(kind, dev, out_c)
-        grads = fnet.unpack_weight_grads(dw, out_c, kind)
-        if emb.grad is None:                    # the dense part of the table's gradient (levels too small to bin)
-            emb.grad = torch.zeros_like(emb)
-        group, st, small = opt.grid_table_args(emb, list(weights), list(grads))
-        a = _StepArgs()
-        a.struct_bytes = _ct.sizeof(_StepArgs)
-        a.mlp_precision = -1 if prec is None else prec
-        a.stream = L.stream_handle()
-        a.N, a.M = N, M
-        a.xyzs, a.dirs, a.deltas, a.rays = xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr()
-        a.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
-        a.target = target.contiguous().view(-1, 3).data_ptr()
-        a.bg_scalar, a.grad_scale = 1.0, 2.0 / (3 * N)
-        a.loss = None if loss_out is None else loss_out.data_ptr()
-        a.embeddings, a.offsets = emb.data_ptr(), enc._buffers["offsets"].data_ptr()
-        import numpy as _np
-        a.level_scale_log2 = float(_np.log2(enc.per_level_scale))
-        a.bound, a.inv_two_bound = float(model.bound), float(_np.float32(1.0) / _np.float32(2 * model.bound))
-        a.base_resolution, a.gridtype = int(enc.base_resolution), int(enc.gridtype_id)
-        a.wseg_s, a.wseg_c = _ct.cast(seg_s, _vp), _ct.cast(seg_c, _vp)
-        a.dwseg_s, a.dwseg_c = _ct.cast(dseg_s, _vp), _ct.cast(dseg_c, _vp)
-        a.nh_s, a.nh_c, a.w0_cols_c, a.out_c = arch["nh_s"], arch["nh_c"], arch["w0c"], out_c
-        for name, t in (("feats", feats), ("h32", h32), ("fb_s", fb_s), ("fb_c", fb_c), ("sigma", sigma), ("rgb", rgb),
-                        ("weights_sum", weights_sum), ("image", image), ("out_image", out_image), ("g_sigmas", g_sigmas),
-                        ("g_rgbs", g_rgbs), ("dx32", dx32), ("dfeat", dfeat)):
-            setattr(a, name, t.data_ptr())
-        # the next batch's march: buffers from this stream's pool, kernels on the side stream (march_stage's rules)
-        nxt = None
+        M = pre["M"]
+        nxt_ok = False
+        Nn = Mn = 0
         if next_rays is not None and side_stream is not None:
             no, nd = next_rays[0].contiguous().view(-1, 3), next_rays[1].contiguous().view(-1, 3)
             stash = getattr(model, "_premarched", None)
             if not isinstance(stash, dict):
                 stash = model._premarched = {}
             if not any("pending" in p for p in stash.values()):
+                nxt_ok = True
                 Nn = no.shape[0]
                 mc = _budget(model)
                 Mn = mc + (128 - mc % 128)
-                bufs = model._buffers
-                nxt = _Stage(nears=torch.empty(Nn, **f32), fars=torch.empty(Nn, **f32),
-                             rays=torch.empty(Nn, 3, dtype=torch.int32, device=dev), counter=_next_counter(model),
-                             xyzs=torch.empty(Mn, 3, **f32), dirs=torch.empty(Mn, 3, **f32),
-                             deltas=torch.empty(Mn, 2, **f32), M=Mn)
-                nxt["slot"] = getattr(model, "last_counter_slot", None)
-                a.side_stream = side_stream.cuda_stream
-                a.next_rays_o, a.next_rays_d = no.data_ptr(), nd.data_ptr()
-                a.aabb, a.bitfield = bufs["aabb_train"].data_ptr(), bufs["density_bitfield"].data_ptr()
-                a.min_near, a.dt_gamma = float(model.min_near), float(dt_gamma)
-                a.next_N, a.next_M = Nn, Mn
-                a.cascade, a.grid_size, a.max_steps = int(model.cascade), int(model.grid_size), int(max_steps)
-                a.perturb = 1 if perturb else 0
-                a.march_flags = occupied_box_flag(model) | 3 | 8
-                for name in ("nears", "fars", "xyzs", "dirs", "deltas", "rays", "counter"):
-                    setattr(a, "next_" + name, nxt[name].data_ptr())
-                key = (no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps))
-        a.table, a.table_grad = emb.data_ptr(), emb.grad.data_ptr()
-        a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-        b1, b2 = group["betas"]
-        a.lr, a.beta1, a.beta2, a.eps = float(group["lr"]), b1, b2, float(group["eps"])
-        a.table_step, a.n_small = int(st["step"]), small[0]
-        for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"), small[1:]):
-            setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
+        ctx = _native_ctx(model, N, M, Nn, Mn, dev)
+        a, emb, weights, grads = ctx["a"], ctx["emb"], ctx["weights"], ctx["grads"]
+        if emb.grad is None:                    # the dense part of the table's gradient (levels too small to bin)
+            emb.grad = torch.zeros_like(emb)
+        a.stream = L.stream_handle()
+        a.xyzs, a.dirs, a.deltas = pre["xyzs"].data_ptr(), pre["dirs"].data_ptr(), pre["deltas"].data_ptr()
+        a.rays = pre["rays"].data_ptr()
+        a.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
+        a.target = target.contiguous().view(-1, 3).data_ptr()
+        a.loss = None if loss_out is None else loss_out.data_ptr()
+        a.flags = 1 if raw else 0
+        # the next batch's march: kernels on the side stream, into the buffer set the current batch is NOT using
+        nxt = None
+        a.next_rays_o = None
+        if nxt_ok:
+            st_bufs = ctx["stages"][ctx["flip"]]
+            if any(pre[k] is st_bufs[k] for k in ("xyzs", "rays")):
+                st_bufs = ctx["stages"][ctx["flip"] ^ 1]
+            else:
+                ctx["flip"] ^= 1
+            nxt = _Stage(st_bufs)
+            nxt["counter"] = _next_counter(model)
+            nxt["slot"] = getattr(model, "last_counter_slot", None)
+            a.side_stream = side_stream.cuda_stream
+            a.next_rays_o, a.next_rays_d = no.data_ptr(), nd.data_ptr()
+            a.dt_gamma = float(dt_gamma)
+            a.next_N, a.next_M, a.max_steps = Nn, Mn, int(max_steps)
+            a.perturb = 1 if perturb else 0
+            a.march_flags = occupied_box_flag(model) | 3 | 8
+            for name in ("nears", "fars", "xyzs", "dirs", "deltas", "rays", "counter"):
+                setattr(a, "next_" + name, nxt[name].data_ptr())
+            key = (no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps))
+        a.table_grad = emb.grad.data_ptr()
+        if raw:
+            a.n_small = 0
+        else:
+            group, st, small = opt.grid_table_args(emb, list(weights), list(grads))
+            a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            b1, b2 = group["betas"]
+            a.lr, a.beta1, a.beta2, a.eps = float(group["lr"]), b1, b2, float(group["eps"])
+            a.table_step, a.n_small = int(st["step"]), small[0]
+            ctx["small_args"] = small           # (keeps the host arrays alive across the call)
+            for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"),
+                                 small[1:]):
+                setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
         from .backends import _gridencoder as _gbk
@@ -617,6 +651,11 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             nxt["ready"] = torch.cuda.Event()
             nxt["ready"].record(side_stream)
             stash[key] = nxt
-        for p, g in zip(weights, grads):
-            p.grad = g.view_as(p)
-    return out_image
+        if not raw:
+            views = ctx.get("grad_views")
+            if views is None:
+                views = ctx["grad_views"] = [g.view_as(p) for p, g in zip(weights, grads)]
+            for p, g in zip(weights, views):
+                if p.grad is not g:
+                    p.grad = g
+    return (ctx["out_image"], ctx["dw"]) if raw else ctx["out_image"]

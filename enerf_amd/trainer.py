@@ -649,9 +649,11 @@ class TrainHarness:
             self._loss_ring.zero_()
         return self._loss_ring[slot]
 
-    def _step_rgb_native(self, rays_o, rays_d, target, next_rays):
+    def _step_rgb_native(self, rays_o, rays_d, target, next_rays, data_parallel=False):
         """The steady-state step as one library call (fused_render.train_step_native -> enerf_train_step_mse): the same
-        launches in the same order as _step_rgb_manual's one-GPU route, issued from C."""
+        launches in the same order as _step_rgb_manual's one-GPU route, issued from C.  data_parallel: the call stops
+        after the table's backward (dense gradient, no optimizer) and one of the data-parallel tails takes over -- the
+        native one (two more library calls) when the library has its communicator."""
         from . import fused_render
         m = self.model
         emb = m._modules["encoder"]._parameters["embeddings"]
@@ -668,24 +670,34 @@ class TrainHarness:
             nxt = next_rays
         loss = self._loss_slot()
         try:
-            fused_render.train_step_native(m, rays_o, rays_d, target, self.opt, next_rays=nxt, side_stream=self._side,
-                                           loss_out=loss, perturb=self.perturb)
+            out = fused_render.train_step_native(m, rays_o, rays_d, target, self.opt, next_rays=nxt,
+                                                 side_stream=self._side, loss_out=loss, perturb=self.perturb,
+                                                 raw=data_parallel)
         except BaseException:
             self._discard_pending_records()
             raise
+        if data_parallel:
+            self._raw_grads = (None, out[1])            # (the table's gradient sits in embeddings.grad)
+            if self._native_tail_ok():
+                tail = self._finish_native
+            else:
+                tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
+            tail(None)                                  # the next batch's march is already queued (behind the MLP backward)
+            return loss
         self._cleared_grad = emb.grad
         return loss
 
     def _step_rgb_manual(self, rays_o, rays_d, target, next_rays, **render_kw):
-        if (self.native_step and not render_kw and self.avg is None and self.fuse_table_adam and not self.use_graphs
-                and self.prefetch_at == "mlp_backward" and getattr(self.model, "graph_counter", None) is None):
+        chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")
+                   and self.comm_chunks > 0)
+        if (self.native_step and not render_kw and not self.use_graphs and self.prefetch_at == "mlp_backward"
+                and getattr(self.model, "graph_counter", None) is None
+                and ((self.avg is None and self.fuse_table_adam) or chunked)):
             from . import fused_render
             if fused_render.native_step_supported(self.model, rays_o.contiguous().view(-1, 3),
                                                   rays_d.contiguous().view(-1, 3), self.opt):
-                return self._step_rgb_native(rays_o, rays_d, target, next_rays)
+                return self._step_rgb_native(rays_o, rays_d, target, next_rays, data_parallel=chunked)
         side = self._side_prefetch(next_rays) if not render_kw else None
-        chunked = (self.avg is not None and isinstance(self.avg, GradAverager) and hasattr(self.opt, "step_now")
-                   and self.comm_chunks > 0)
         late = chunked and side is not None and self.prefetch_at == "collectives"
         # one GPU: nobody but Adam reads the table's gradient, so the backward leaves it as record lists and the
         # optimizer's pass over the table sums them tile by tile in LDS (FusedAdam.step_grid_table)

@@ -565,6 +565,10 @@ typedef struct enerf_train_step_args {
     const uint32_t* small_n;
     const float* small_lr;
     const uint32_t* small_step;
+    /* bit 0: data parallel -- the table's gradient is SUMMED INTO the dense buffer table_grad (grid_encode_backward's
+     * own flush, no record lists left behind) and no optimizer runs: the caller averages table_grad and the buffers
+     * behind dwseg_* over the ranks (enerf_dp_begin / enerf_dp_finish) and steps the optimizer itself */
+    uint32_t flags, reserved;
 } enerf_train_step_args;
 int enerf_train_step_mse(const enerf_train_step_args* args);
 /* Development aid: host microseconds enerf_train_step_mse spends in each of its calls (in call order, 16 slots, averaged
