@@ -628,16 +628,21 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
         a.table_grad = emb.grad.data_ptr()
         if raw:
             a.n_small = 0
+            ctx["plan"] = None                  # (a later optimizer-carrying step rebuilds its arrays)
         else:
-            group, st, small = opt.grid_table_args(emb, list(weights), list(grads))
-            a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            b1, b2 = group["betas"]
-            a.lr, a.beta1, a.beta2, a.eps = float(group["lr"]), b1, b2, float(group["eps"])
-            a.table_step, a.n_small = int(st["step"]), small[0]
-            ctx["small_args"] = small           # (keeps the host arrays alive across the call)
-            for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"),
-                                 small[1:]):
-                setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
+            plan = ctx.get("plan")
+            if plan is None or ctx.get("plan_opt") is not opt:
+                # the optimizer's host arrays (pointers, sizes, learning rates, step counts of the MLP weights): built once
+                plan = ctx["plan"] = opt.grid_table_plan(emb, list(weights), list(grads))
+                ctx["plan_opt"] = opt
+                small = plan.arrays
+                st = plan.state
+                a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                a.n_small = small[0]
+                for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"),
+                                     small[1:]):
+                    setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
+            a.lr, a.beta1, a.beta2, a.eps, a.table_step = plan()
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
         from .backends import _gridencoder as _gbk

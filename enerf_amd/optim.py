@@ -75,6 +75,31 @@ class FusedAdam(torch.optim.Optimizer):
             args = (0, None, None, None, None, None, None, None)
         return group, st, args
 
+    def grid_table_plan(self, p, extra, extra_grads):
+        """grid_table_args for a loop that steps the same tensors every time: the host arrays are built ONCE; the returned
+        callable advances the step counts, refreshes the learning rates (a scheduler may have moved them) and -> (lr,
+        beta1, beta2, eps, table step) -- the arrays behind `.arrays` then hold this step's values."""
+        group, st, args = self.grid_table_args(p, extra, extra_grads)
+        for q in [p] + list(extra):                       # (the planning call advanced them once: undo)
+            self.state[q]["step"] -= 1
+        groups = self._group_of
+        sts = [self.state[q] for q in extra]
+        egroups = [groups[id(q)] for q in extra]
+        n, lr_arr, step_arr = args[0], args[6], args[7]
+
+        def advance():
+            st["step"] += 1
+            for k in range(n):
+                t = sts[k]
+                t["step"] += 1
+                step_arr[k] = t["step"]
+                lr_arr[k] = float(egroups[k]["lr"])
+            b1, b2 = group["betas"]
+            return float(group["lr"]), b1, b2, float(group["eps"]), st["step"]
+        advance.arrays = args
+        advance.state = st
+        return advance
+
     @torch.no_grad()
     def step_now(self, only=None, ranges=None, zero_grads=False, advance=None):
         """The update itself.  `step()` is wrapped by torch.optim.Optimizer with profiler / hook plumbing that costs

@@ -17,6 +17,9 @@ _ap = argparse.ArgumentParser()
 _ap.add_argument("--rays", type=int, default=4096, help="64: the device is never the limit, what is timed is the host")
 _ap.add_argument("--python-step", action="store_true", help="the Python-driven step instead of enerf_train_step_mse")
 _ap.add_argument("--no-profile", action="store_true")
+_ap.add_argument("--stub", action="store_true",
+                 help="after the timed runs: the same steps with enerf_train_step_mse replaced by a no-op (nothing reaches the "
+                      "device but the stage hand-over's event packets): what the Python around the one call costs")
 _a = _ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -58,6 +61,20 @@ if h.native_step:
              "wait_signal", "near_far", "march", "grid_bwd", "table_adam"]
     print("host us per call inside enerf_train_step_mse:", {n: round(arr[k], 1) for k, n in enumerate(names)},
           "sum", round(sum(arr), 1))
+if _a.stub and h.native_step:
+    from enerf_amd import _lib
+    real = _lib.lib().enerf_train_step_mse
+    _lib.lib().enerf_train_step_mse = lambda a: 0
+    for i in range(97, 97 + 3):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(100, 100 + 12):      # (steps 100..111: no update_extra_state inside)
+        step(i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    _lib.lib().enerf_train_step_mse = real
+    print(f"Python around a stubbed enerf_train_step_mse: {1e3 * (t1 - t0) / 12:.3f} ms/step")
 if _a.no_profile:
     sys.exit(0)
 pr = cProfile.Profile()
