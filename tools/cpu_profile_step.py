@@ -73,8 +73,15 @@ if _a.stub and h.native_step:
         step(i)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
-    _lib.lib().enerf_train_step_mse = real
     print(f"Python around a stubbed enerf_train_step_mse: {1e3 * (t1 - t0) / 12:.3f} ms/step")
+    prs = cProfile.Profile()
+    prs.enable()
+    for i in range(116, 116 + 12):
+        step(i)
+    prs.disable()
+    torch.cuda.synchronize()
+    _lib.lib().enerf_train_step_mse = real
+    pstats.Stats(prs).sort_stats("tottime").print_stats(22)
 if _a.no_profile:
     sys.exit(0)
 pr = cProfile.Profile()
