@@ -85,6 +85,7 @@ SIGNATURES = {
     "enerf_occupied_box_update": [_vp, _u32, _u32, _f32, _vp],
     "enerf_debug_mlp32_fused_backward": [_int],
     "enerf_mlp32_precision": [_int],
+    "enerf_mlp32_recompute": [_int],
     "enerf_debug_grid_bwd_binned": [_u32, _u32],
     "enerf_density_grid_cells": [_vp, _u32, _u32, _f32, _u32, _c.c_uint64, _vp, _vp, _vp],
     "enerf_mark_untrained_grid": [_vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _f32, _vp, _vp],

@@ -830,10 +830,18 @@ static ReduceJob g_pending;
 bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
 int g_precision = 1;                // enerf_mlp32_precision: 0 = fp32 MFMA (bit-exact fmaf chains), 1 = split-bf16 (x3),
                                     // 2 = bf16 operands (the FFMLP nets' arithmetic: one product, 16-bit roundings)
+bool g_recompute = true;            // enerf_mlp32_recompute: the split backward recomputes the hidden activations
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
 uint32_t g_fwd_blocks = 0;          // 0: default cap of the forward grid
 uint32_t g_bwd_blocks = 0;          // 0: default cap of the fused backward grid
+
+// shapes the split / bf16 backward kernel serves: one or two hidden layers in either mode, three (the FFMLP colour net,
+// row-major input) with bf16 operands
+bool split_bwd_shape(uint32_t num_hidden, uint32_t out_dim, uint32_t x_layout) {
+    return g_fused_bwd && g_precision != 0 && out_dim <= 16 &&
+           (num_hidden <= 2 || (g_precision == 2 && num_hidden == 3 && x_layout == 0));
+}
 
 uint32_t pgrid(uint32_t B, uint32_t cap) {
     const uint32_t blocks = div_up(div_up(B, 32), 4);
@@ -859,6 +867,16 @@ int enerf_mlp32_valid_rows(const int32_t* device_count) {
 int enerf_mlp32_precision(int mode) {
     const int prev = g_precision;
     if (mode >= 0 && mode <= 2) g_precision = mode;
+    return prev;
+}
+
+// 1 (default): in the split / bf16 modes the backward kernel recomputes the hidden activations from X (bit-identical to
+// the forward's) and the training forward does not write them: `fb` is then neither written nor read (it may be NULL
+// in the backward; the forward still takes "fb != NULL" as "training").  0: the forward stores them, the backward loads
+// them.  Forward and backward of a batch must run under the same setting.  Returns the previous setting; on < 0 queries.
+int enerf_mlp32_recompute(int on) {
+    const int prev = g_recompute ? 1 : 0;
+    if (on >= 0) g_recompute = on != 0;
     return prev;
 }
 
@@ -953,7 +971,9 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     } while (0)
     const bool sigma_only = num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1;
     if (g_precision != 0) {
-        mlp32s_launch_fwd(g_precision == 1 ? 3 : 1, num_hidden, fb != nullptr, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
+        // (a training forward whose backward recomputes the activations is the inference kernel)
+        const bool store_fb = fb != nullptr && !(g_recompute && split_bwd_shape(num_hidden, out_dim, x_layout));
+        mlp32s_launch_fwd(g_precision == 1 ? 3 : 1, num_hidden, store_fb, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
                           output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop());
     } else if (sh_dirs) {
         const ShNorm4 nrm = make_sh_norm4();
@@ -1038,8 +1058,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     const size_t lds_w = sizeof(float) * (((NW + 3u) & ~3u) + (x_layout == 1 ? 4 * 16 * XT_LD : 0));
     // the split / bf16 kernels: one or two hidden layers in either mode, three (the FFMLP colour net, row-major input) with
     // bf16 operands
-    const bool split_bwd = g_fused_bwd && g_precision != 0 && out_dim <= 16 &&
-                           (num_hidden <= 2 || (g_precision == 2 && num_hidden == 3 && x_layout == 0));
+    const bool split_bwd = split_bwd_shape(num_hidden, out_dim, x_layout);
     // timing (enerf_prof_*): the split kernel by its own begin / end stamps, the weight-gradient reduce launch as a family
     // of its own (ENERF_K_MLP_REDUCE); the fp32 MFMA route between two event packets around all of its launches
     ProfScope prof(ENERF_K_FFMLP_BWD, s, split_bwd);
@@ -1097,7 +1116,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     if (split_bwd) {
         (void)bb;
         mlp32s_launch_bwd(g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation,
-                          wgrid, s, prof.start(), prof.stop());
+                          wgrid, s, prof.start(), prof.stop(), g_recompute);
     } else if (fused) {
         (void)bb;
         if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }

@@ -263,6 +263,7 @@ void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X, const WSrc& W,
                        const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim, uint32_t act,
-                       uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                       bool recompute = false);
 
 }  // namespace enerf_mlp32

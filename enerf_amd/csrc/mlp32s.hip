@@ -359,14 +359,22 @@ __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp
 // so they are kept in LDS in operand order (hi and lo: 64 lanes x 16 B each, one conflict-free ds_read_b128 per half) and
 // read where they are used; one hidden layer keeps them in registers.
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-template <int NH, int XL, int P = 3>
+//
+// RC (recompute): the hidden activations are not read back from the forward's buffer but computed again from X, by the
+// forward's own instruction sequence (bit-identical values, hence identical ReLU masks): 12 (+ 24 per further hidden
+// layer) MFMAs per tile on a pipe that is mostly idle here, against 256 B per sample and layer written by the forward
+// and read by the backward -- at the 133 k-sample training batch that buffer was two thirds of the MLP kernels' HBM
+// traffic.  X arrives once, in the forward's operand layout; its transpose for the first layer's weight gradient is a
+// flip by the matrix pipe like every other tile's.  The forward-order weight operands join the others in LDS.
+template <int NH, int XL, int P = 3, bool RC = false>
 __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* __restrict__ X, WSrc W,
                                                     const float* __restrict__ fb, float* __restrict__ dX,
                                                     float* __restrict__ partial, uint32_t B, uint32_t out_dim,
                                                     uint32_t act) {
     constexpr uint32_t NW_MAX = HID * IN + (NH - 1) * HID * HID + 16 * HID;
-    constexpr bool WL = NH > 1;                                        // weight operands from LDS
-    constexpr int NFRAG = 2 + 4 + 8 * (NH - 1);
+    constexpr bool WL = NH > 1 || RC;                                  // weight operands from LDS
+    constexpr int NFRAG_T = 2 + 4 + 8 * (NH - 1);                      // transposed operands (dgrad)
+    constexpr int NFRAG = NFRAG_T + (RC ? 4 + 8 * (NH - 1) : 0);       // + forward operands (recompute)
     constexpr int FRQ = P == 3 ? 2 : 1;                                // 64 x 16 B pieces per operand (hi, lo)
     // the final sums: four regions (one per wave) where they fit, two otherwise (three hidden layers: 4 x 44 KiB would
     // not), see the end of the kernel
@@ -432,7 +440,45 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
                     whT[l][ib][ob][t] = split8<P>(v);
                     if (WL) put(6 + ((l * 2 + ib) * 2 + ob) * 2 + t, whT[l][ib][ob][t]);
                 }
+    if constexpr (RC) {
+        // forward operands (k_mlp32s_fwd's w0 / wh), each built by the wave that stores it, straight from the weights in
+        // global memory: rows across lanes is a 32-way bank conflict in the staged (un-rotated) copy
+#pragma unroll
+        for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int f = NFRAG_T + 2 * ob + t;
+                if ((f & 3) == wid) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int c = w0_col((uint32_t)kmap<XL>(8 * t + e, h), W.nerf_perm);
+                        v[e] = c < 0 ? 0.0f : W.seg[0][(size_t)(32 * ob + j) * W.w0_cols + c];
+                    }
+                    put(f, split8<P>(v));
+                }
+            }
+#pragma unroll
+        for (int l = 0; l < NH - 1; l++)
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+                for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const int f = NFRAG_T + 4 + ((l * 2 + ob) * 2 + ib) * 2 + t;
+                        if ((f & 3) == wid) {
+                            const float* row = W.seg[1 + l] + (size_t)(32 * ob + j) * HID + 32 * ib;
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 8; e++) v[e] = row[nrow(8 * t + e, h)];
+                            put(f, split8<P>(v));
+                        }
+                    }
+    }
     if (WL) __syncthreads();
+    auto W0F = [&](int ob, int t) -> Frag { return get(NFRAG_T + 2 * ob + t); };
+    auto WHF = [&](int l, int ob, int ib, int t) -> Frag { return get(NFRAG_T + 4 + ((l * 2 + ob) * 2 + ib) * 2 + t); };
     auto WO = [&](int ib) -> Frag { return WL ? get(ib) : woT[ib]; };
     auto WI = [&](int ob, int t) -> Frag { return WL ? get(2 + 2 * ob + t) : wiT[ob][t]; };
     auto WH = [&](int l, int ib, int ob, int t) -> Frag {
@@ -473,15 +519,23 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             ds_raw = dys.dsigma[sc];
             h0_raw = dys.h0[sc * dys.h0_stride];
         }
+        if constexpr (!RC) {
 #pragma unroll
-        for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)(NH - 1) * Bp + sn) * HID, ib, h, fwl[NH - 1][ib]);
+            for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)(NH - 1) * Bp + sn) * HID, ib, h, fwl[NH - 1][ib]);
+        }
     };
     auto request_hidden = [&](uint32_t t, int l) {
+        if constexpr (RC) return;
         const size_t sn = (size_t)t * 32 + j;
 #pragma unroll
         for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + sn) * HID, ib, h, fwl[l][ib]);
     };
+    float xfw[16];                                     // RC: X in the forward's operand layout (load_x), a tile ahead
     auto request_x = [&](uint32_t t) {
+        if constexpr (RC) {
+            load_x<XL>(X, t, j, h, B, Bp, xfw);
+            return;
+        }
         const size_t t0 = (size_t)t * 32;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -525,6 +579,45 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
                 }
             }
             continue;
+        }
+        Frag xop[2];                                   // RC: X as the forward's first-layer operand
+        if constexpr (RC) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = xfw[8 * t + e];
+                xop[t] = split8<P>(v);
+            }
+            request_x(tnext);
+            // the forward, instruction for instruction (k_mlp32s_fwd): same operands, same order of the products
+            const int relu_lim = act == 0 ? 0 : (int)0x80000000;
+#pragma unroll
+            for (int ob = 0; ob < 2; ob++) {
+                f32x16 a = (f32x16)(0.0f);
+#pragma unroll
+                for (int t = 0; t < 2; t++) a = mmap(W0F(ob, t), xop[t], a);
+#pragma unroll
+                for (int q = 0; q < 16; q++) a[q] = __int_as_float(max(__float_as_int(a[q]), relu_lim));
+                fwl[0][ob] = a;
+            }
+#pragma unroll
+            for (int l = 1; l < NH; l++) {
+                Frag af[2][2];
+                split_tile<P>(fwl[l - 1][0], af[0]);
+                split_tile<P>(fwl[l - 1][1], af[1]);
+#pragma unroll
+                for (int ob = 0; ob < 2; ob++) {
+                    f32x16 n = (f32x16)(0.0f);
+#pragma unroll
+                    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                        for (int t = 0; t < 2; t++) n = mmap(WHF(l - 1, ob, ib, t), af[ib][t], n);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) n[q] = __int_as_float(max(__float_as_int(n[q]), relu_lim));
+                    fwl[l][ob] = n;
+                }
+            }
         }
         // ---- output layer
         Frag dyf;
@@ -608,17 +701,27 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
         // ---- input layer: dW0[o][i] += G_0[o][s] * X[s][i]
         {
             Frag xf[2];
+            if constexpr (RC) {
+                // X^T by the matrix pipe: K-step t of the operand holds input columns kmap(8t + e, h)
+                bf16x8 sx[2];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                float v[8];
+                for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int q = 8 * t + e;
-                    v[e] = (XL == 0 && s0 + nrow(q, h) >= B) ? 0.0f : xT[q];
+                    for (int e = 0; e < 8; e++) sx[t][e] = kmap<XL>(8 * t + e, h) == j ? (__bf16)1.0f : (__bf16)0.0f;
+                flip_tile<P>(xop, sx[0], sx[1], xf);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int q = 8 * t + e;
+                        v[e] = (XL == 0 && s0 + nrow(q, h) >= B) ? 0.0f : xT[q];
+                    }
+                    xf[t] = split8<P>(v);
                 }
-                xf[t] = split8<P>(v);
+                request_x(tnext);
             }
-            request_x(tnext);
 #pragma unroll
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
@@ -743,15 +846,21 @@ void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
 
 void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
                        const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
-                       uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
+                       bool recompute) {
     if (ev_start) hipExtLaunchKernelGGL(k_mlp32s_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);
-#define S_BWD(NHV, XLV, PV)                                                                                              \
-    hipExtLaunchKernelGGL((k_mlp32s_bwd<NHV, XLV, PV>), dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, dys, X, W, fb, dX, \
-                          partial, B, out_dim, act)
-#define S_BWD_P(NHV, XLV)                  \
-    do {                                   \
-        if (prec == 3) S_BWD(NHV, XLV, 3); \
-        else S_BWD(NHV, XLV, 1);           \
+#define S_BWD(NHV, XLV, PV, RCV)                                                                                         \
+    hipExtLaunchKernelGGL((k_mlp32s_bwd<NHV, XLV, PV, RCV>), dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, dys, X, W, fb, \
+                          dX, partial, B, out_dim, act)
+#define S_BWD_R(NHV, XLV, PV)                     \
+    do {                                          \
+        if (recompute) S_BWD(NHV, XLV, PV, true); \
+        else S_BWD(NHV, XLV, PV, false);          \
+    } while (0)
+#define S_BWD_P(NHV, XLV)                    \
+    do {                                     \
+        if (prec == 3) S_BWD_R(NHV, XLV, 3); \
+        else S_BWD_R(NHV, XLV, 1);           \
     } while (0)
     if (num_hidden == 1) {
         if (x_layout == 0) S_BWD_P(1, 0);
@@ -760,9 +869,10 @@ void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const D
         if (x_layout == 0) S_BWD_P(2, 0);
         else S_BWD_P(2, 1);
     } else {                                 // three hidden layers: the FFMLP colour net (row-major input), P == 1 only
-        S_BWD(3, 0, 1);
+        S_BWD_R(3, 0, 1);
     }
 #undef S_BWD_P
+#undef S_BWD_R
 #undef S_BWD
 }
 

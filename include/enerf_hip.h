@@ -443,6 +443,13 @@ int enerf_mlp32_valid_rows(const int32_t* device_count);
  *      fused training step of nerf/network_ff.py (sigma net: two hidden layers + SH epilogue, colour net: three).
  * Returns the previous mode (NOT a status); a negative `mode` only queries. */
 int enerf_mlp32_precision(int mode);
+/* 1 (default): in modes 1 / 2 the fused backward recomputes the hidden activations from X with the forward's own
+ * instruction sequence (bit-identical values and ReLU masks) and the training forward does not store them -- `fb` is
+ * then neither written nor read (two thirds of these kernels' HBM traffic at the training batch).  0: the forward
+ * stores them and the backward loads them (the reference's data flow, ffmlp.cu:711-895 / autograd's saved tensors).
+ * Forward and backward of a batch must run under the same setting.  Returns the previous setting (NOT a status);
+ * a negative `on` only queries. */
+int enerf_mlp32_recompute(int on);
 /* Testing aid: 1 (default) lets enerf_mlp32_backward use its fused dgrad + wgrad kernel (num_hidden <= 2; `bb` is then
  * not written), 0 forces the separate dgrad / wgrad kernels. */
 int enerf_debug_mlp32_fused_backward(int on);

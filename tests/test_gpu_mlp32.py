@@ -317,3 +317,54 @@ def test_pending_record_lists_refuse_foreign_calls_and_can_be_discarded():
     again = torch.zeros_like(ref)
     bwd(again)
     assert float((again - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("nh,out,xl,B", [(1, 16, 1, 4097), (1, 16, 0, 5000), (2, 3, 0, 5000), (2, 16, 1, 96),
+                                         (3, 16, 0, 4100), (2, 3, 0, 31)])
+def test_backward_recomputing_the_activations_is_bit_identical_to_loading_them(mode, nh, out, xl, B):
+    """enerf_mlp32_recompute(1) (default): the split / bf16 backward computes the hidden activations again from X and
+    the training forward does not store them.  Same instruction sequence as the forward -> same values, same ReLU
+    masks: dX and dW must be BIT-identical to the stored-activation route, for every shape the kernel serves; and the
+    forward buffer really is left alone."""
+    from enerf_amd import _lib as L
+    from enerf_amd.fused_mlp import pad32
+    if nh == 3 and mode != 2:
+        pytest.skip("three hidden layers: bf16 operands only")
+    lib, s = L.lib(), L.stream_handle()
+    prev_mode = lib.enerf_mlp32_precision(mode)
+    prev_rc = lib.enerf_mlp32_recompute(-1)
+    try:
+        torch.manual_seed(11)
+        Bp = pad32(B)
+        dims = [32] + [64] * nh + [out]
+        ws = [(torch.rand(dims[k + 1], dims[k], device=DEV) * 2 - 1) * (3.0 / dims[k]) ** 0.5 for k in range(len(dims) - 1)]
+        W = torch.cat([w.reshape(-1) for w in ws]).contiguous()
+        xr = torch.rand(B, 32, device=DEV) * 2 - 1
+        if xl:
+            X = torch.zeros(16, Bp, 2, device=DEV)
+            X[:, :B] = xr.view(B, 16, 2).permute(1, 0, 2)
+        else:
+            X = xr.contiguous()
+        dY = torch.randn(B, out, device=DEV)
+        res = {}
+        for rc in (0, 1):
+            lib.enerf_mlp32_recompute(rc)
+            fb = torch.full((nh * Bp * 64,), 7.0, device=DEV)
+            bb = torch.empty(nh, Bp, 64, device=DEV)
+            Y = torch.empty(B, out, device=DEV)
+            dX, dW = torch.zeros_like(X), torch.zeros_like(W)
+            L.check(lib.enerf_mlp32_forward(X.data_ptr(), W.data_ptr(), B, 32, out, nh, 0, 6, fb.data_ptr(), Y.data_ptr(),
+                                            xl, 0, None, s), "fwd")
+            L.check(lib.enerf_mlp32_backward(dY.data_ptr(), X.data_ptr(), W.data_ptr(), fb.data_ptr(), B, 32, out, nh, 0,
+                                             bb.data_ptr(), dX.data_ptr(), dW.data_ptr(), xl, 0, None, 0, None, None, 0, s),
+                    "bwd")
+            torch.cuda.synchronize()
+            res[rc] = (Y, dX, dW, fb)
+        assert bool((res[1][3] == 7.0).all()) and not bool((res[0][3][:B * 64] == 7.0).all())
+        for a, b, what in zip(res[0][:3], res[1][:3], ("Y", "dX", "dW")):
+            assert torch.equal(a, b), what
+        assert float(res[1][2].abs().max()) > 0 and float(res[1][1].abs().max()) > 0
+    finally:
+        lib.enerf_mlp32_recompute(prev_rc)
+        lib.enerf_mlp32_precision(prev_mode)

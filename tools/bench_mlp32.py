@@ -33,9 +33,11 @@ def main():
     ap.add_argument("--fwd-blocks", type=int, default=0)
     ap.add_argument("--bwd-blocks", type=int, default=0)
     ap.add_argument("--all-shapes", action="store_true")
+    ap.add_argument("--recompute", type=int, default=1, help="enerf_mlp32_recompute: 1 = the backward recomputes the activations")
     ap.add_argument("--precision", type=int, default=1, help="enerf_mlp32_precision: 0 = fp32 MFMA, 1 = split-bf16")
     a = ap.parse_args()
     L.lib().enerf_mlp32_precision(a.precision)
+    L.lib().enerf_mlp32_recompute(a.recompute)
     if a.unfused_backward:
         L.lib().enerf_debug_mlp32_fused_backward(0)
     L.lib().enerf_debug_mlp32_grid_caps(a.fwd_blocks, a.bwd_blocks)

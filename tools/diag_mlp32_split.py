@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--B", type=int, default=5000)
     a = ap.parse_args()
     lib, s, dev = L.lib(), L.stream_handle(), "cuda"
+    lib.enerf_mlp32_recompute(0)             # this tool reads the forward buffer (the default leaves it unwritten)
     torch.manual_seed(5)
     for name, nh, out, xl in (("sigma 32-64-16 xl=1", 1, 16, 1), ("colour 32-64-64-3 xl=0", 2, 3, 0),
                               ("32-64-16 xl=0", 1, 16, 0)):
@@ -91,6 +92,7 @@ def main():
                 print(f"      dW{k}: max err {float((got - gws[k]).abs().max()):.2e} / max {float(gws[k].abs().max()):.2e} "
                       f"= {float((got - gws[k]).abs().max() / gws[k].abs().max()):.2e}")
     lib.enerf_mlp32_precision(1)
+    lib.enerf_mlp32_recompute(1)
 
 
 if __name__ == "__main__":
