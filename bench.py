@@ -83,6 +83,9 @@ def parse():
                     help="tuning: no hipEvent timing inside the timed region (the line then carries no `roofline`)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="live hipEvent timing of the roofline kernel: one launch in N of the timed region (a timed launch "
+                         "costs ~10-15 us of queue time: completion signals + a marker launch; 1 = every launch)")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
     ap.add_argument("--other-legs", type=int, default=48,
                     help="steps of each extra leg (event step of configs[2], network_ff step, fp16=True step); 0 = skip")
@@ -372,6 +375,7 @@ def main():
     timed_families = None if args.prof_all else (("grid_fwd",) if probe_ok else ("grid_fwd", "grid_bwd"))
     if args.no_live_timing:
         timed_families = ()
+    _lib.prof.sample_every(max(1, args.time_every))
     _lib.prof.enable(True, only=timed_families)
     for i in range(args.warmup):
         one_step(i)
@@ -381,7 +385,12 @@ def main():
     gb.STATS.update(fwd_points=0, fwd_calls=0, bwd_points=0, bwd_calls=0)
     _lib.prof.reset()
     # live hipEvent timing of the roofline kernel (and its backward) over the timed region; the other kernel families
-    # are in profiles/ (rocprofv3) -- timing all of them costs ~25 event records per step, 5 % of a 1 ms step
+    # are in profiles/ (rocprofv3) -- timing all of them costs ~25 event records per step, 5 % of a 1 ms step.
+    # One launch in --time-every is timed (deterministically: launch k of the region when k % N == 0): a timed launch
+    # holds the queue for ~15 us (tools/step_timeline.py: marker kernel 4.4 + 6.8 us before it + 4.8 us after the kernel),
+    # 5 % of a 0.3 ms step when every launch carries it; the figures below are over the timed launches only
+    # (enerf_prof_read_units: their points).
+    _lib.prof.sample_every(max(1, args.time_every))
     _lib.prof.enable(True, only=timed_families)
     sync()
 
@@ -462,10 +471,17 @@ def main():
     for name in ("grid_fwd", "grid_bwd", "march_train", "composite_fwd", "composite_bwd", "sh_fwd"):
         ms, n = _lib.prof.read(name)
         if n:
-            kernels[name] = {"avg_ms": ms / n, "launches": int(n)}
+            units, seen = _lib.prof.read_units(name)
+            kernels[name] = {"avg_ms": ms / n, "launches": int(n), "launches_in_region": int(seen),
+                             "timed_one_in": max(1, args.time_every)}
+            if units:
+                kernels[name]["units_per_timed_launch"] = units / n
+    _lib.prof.sample_every(1)
     roofline = None
     if "grid_fwd" in kernels and gb.STATS["fwd_calls"]:
-        pts = gb.STATS["fwd_points"] / gb.STATS["fwd_calls"]
+        # points per launch of the launches that were TIMED (the region mixes 133 k-point training batches with
+        # 6.3 M-point density sweeps: time and points must come from the same launches)
+        pts = kernels["grid_fwd"].get("units_per_timed_launch", gb.STATS["fwd_points"] / gb.STATS["fwd_calls"])
         # (--fp16: the timed launches mix half-table training batches, 588 B/point, with fp32 density sweeps; the
         # fp32 figure is kept so that the fraction is a lower bound)
         achieved = pts * GRID_FWD_BYTES_PER_POINT / (kernels["grid_fwd"]["avg_ms"] * 1e-3) / 1e9
@@ -476,11 +492,14 @@ def main():
                     f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run), "
                     f"bytes per point x this run's points per launch",
                     "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"],
+                    "timed_launches": kernels["grid_fwd"]["launches"],
+                    "launches_in_region": kernels["grid_fwd"]["launches_in_region"],
+                    "points_per_launch_all_region": gb.STATS["fwd_points"] / gb.STATS["fwd_calls"],
                     # every grid_encode_forward launch of this process so far (what a whole-process profile averages over)
                     "lifetime": {"launches": gb.LIFETIME["fwd_calls"],
                                  "points_per_launch": gb.LIFETIME["fwd_points"] / max(gb.LIFETIME["fwd_calls"], 1)}}
         if "grid_bwd" in kernels and gb.STATS["bwd_calls"]:
-            ptsb = gb.STATS["bwd_points"] / gb.STATS["bwd_calls"]
+            ptsb = kernels["grid_bwd"].get("units_per_timed_launch", gb.STATS["bwd_points"] / gb.STATS["bwd_calls"])
             roofline["table_backward"] = table_backward_object(ptsb, kernels["grid_bwd"]["avg_ms"], None, n_table_params,
                                                                harness.fuse_table_adam and world == 1,
                                                                "the timed region")

@@ -100,6 +100,8 @@ SIGNATURES = {
     "enerf_prof_read": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],
     "enerf_adam_step_multi": [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _int, _vp],
     "enerf_prof_enable_mask": [_u32],
+    "enerf_prof_sample_every": [_u32],
+    "enerf_prof_read_units": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],
     "enerf_train_step_mse": [_vp],
     "enerf_debug_step_timing": [_int, _c.POINTER(_c.c_double)],
     "enerf_dp_unique_id": [_vp, _sz],
@@ -255,3 +257,16 @@ class prof:
         n = ctypes.c_uint64(0)
         check(lib().enerf_prof_read(prof.KERNELS[name], ctypes.byref(ms), ctypes.byref(n)), "prof_read")
         return ms.value, n.value
+
+    @staticmethod
+    def sample_every(n):
+        """Time one eligible call in n per family (a timed launch costs ~10 us of queue time)."""
+        lib().enerf_prof_sample_every(int(n))
+
+    @staticmethod
+    def read_units(name):
+        """(work units of the TIMED calls -- grid_encode: points, mlp32: samples --, eligible calls seen)."""
+        u = ctypes.c_double(0)
+        n = ctypes.c_uint64(0)
+        check(lib().enerf_prof_read_units(prof.KERNELS[name], ctypes.byref(u), ctypes.byref(n)), "prof_read_units")
+        return u.value, n.value

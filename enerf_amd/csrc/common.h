@@ -45,6 +45,7 @@ struct ProfScope {
     ~ProfScope();
     hipEvent_t start() const;      // nullptr when this launch is not being timed
     hipEvent_t stop() const;
+    void units(double n) const;    // work units of this call (points, samples): summed over the TIMED calls only
 };
 
 // ---- workspace owned by the library (grow-only, per process) --------------

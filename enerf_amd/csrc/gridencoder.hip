@@ -1199,6 +1199,7 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
     if (out_layout < 0 || out_layout > 2) ENERF_BADARG("GridEncoding: out_layout must be 0, 1 or 2, got %d", out_layout);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_FWD, s, true);   // timed with the kernel's own begin / end stamps
+    prof.units((double)B);
     int rc = 0;
     const bool calc = calc_grad_inputs != 0;
     if (dtype == ENERF_F32) {
@@ -1234,6 +1235,7 @@ int enerf_grid_encode_forward_sweep(const void* embeddings, const int32_t* offse
     const uint32_t B = n_cascades << (3 * gen.logH);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_FWD, s, true);
+    prof.units((double)B);
     const int rc = launch_fwd<float, 3>(nullptr, (const float*)embeddings, offsets, (float*)outputs, B, C, L, tab, false,
                                         (float*)nullptr, gridtype, out_layout, s, prof.start(), prof.stop(), gen);
     if (rc) return rc;
@@ -1254,6 +1256,7 @@ int enerf_grid_encode_backward_ex(const void* grad, const float* inputs, const v
     if (grad_layout < 0 || grad_layout > 2) ENERF_BADARG("GridEncoding: grad_layout must be 0, 1 or 2, got %d", grad_layout);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_BWD, s);
+    prof.units((double)B);
     int rc = 0;
     const bool calc = calc_grad_inputs != 0;
     if (dtype == ENERF_F32) {

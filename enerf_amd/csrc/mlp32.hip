@@ -20,6 +20,7 @@
 // out_layout 2 (gridencoder.hip), so the encoding never has to be transposed into rows: a wavefront reads / writes
 // 256 contiguous bytes per level.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 
 #include "common.h"
@@ -823,6 +824,7 @@ static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
 static bool g_signal_armed = false;      // enerf_mlp32_signal_next_reduce
 static bool g_signal_recorded = false;
 static hipEvent_t g_signal_event = nullptr;
+static int g_signal_flags = getenv("ENERF_SIGNAL_SYSTEM_SCOPE") ? 0 : 1;
 static bool g_defer_next = false;        // one-shot: set by enerf_mlp32_defer_reduce
 static bool g_have_pending = false;
 static ReduceJob g_pending;
@@ -948,6 +950,7 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     hipStream_t s = (hipStream_t)stream;
     // (the split kernels are timed by their own begin / end stamps; the fp32 MFMA kernels between two event packets)
     ProfScope prof(ENERF_K_FFMLP_FWD, s, g_precision != 0);
+    prof.units((double)B);
     // two workgroups per CU are resident (the weights sit in ~130-210 registers): one round of them, each wave
     // setting up once, beats four short-lived ones per CU (measured at the 138 k-sample training batch)
     // (split operands: the weights sit in LDS as operands -- 2 KiB per fragment, hi + lo -- over the staged fp32 copy,
@@ -1062,6 +1065,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     // timing (enerf_prof_*): the split kernel by its own begin / end stamps, the weight-gradient reduce launch as a family
     // of its own (ENERF_K_MLP_REDUCE); the fp32 MFMA route between two event packets around all of its launches
     ProfScope prof(ENERF_K_FFMLP_BWD, s, split_bwd);
+    prof.units((double)B);
     if (g_precision == 2 && !split_bwd)
         ENERF_BADARG("mlp32_backward: bf16 operands (precision 2) need out_dim <= 16 and at most three hidden layers");
     const bool fused = split_bwd || (g_fused_bwd && num_hidden <= 2);
@@ -1139,7 +1143,9 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         hipEvent_t sig = nullptr;
         if (g_signal_armed) {
             g_signal_armed = false;
-            if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming) != hipSuccess)
+            // (device-scope release: the waiter is another queue of this device, nothing has to reach the host)
+            if (!g_signal_event &&
+                hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming | (g_signal_flags ? hipEventReleaseToDevice : 0)) != hipSuccess)
                 g_signal_event = nullptr;
             sig = g_signal_event;
             g_signal_recorded = sig != nullptr;

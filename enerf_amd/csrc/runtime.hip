@@ -110,10 +110,14 @@ static uint32_t g_prof_mask = 0;     // bit k: time kernel family k
 static std::vector<EvPair> g_prof_ev[ENERF_K_COUNT];      // created once, reused after enerf_prof_reset
 static size_t g_prof_used[ENERF_K_COUNT] = {};
 static const size_t kMaxPairs = 1 << 16;
+static uint32_t g_prof_every = 1;                        // enerf_prof_sample_every: time one call in g_prof_every
+static uint64_t g_prof_calls[ENERF_K_COUNT] = {};        // eligible calls seen since the last reset
+static double g_prof_units[ENERF_K_COUNT] = {};          // work units (ProfScope::units) of the TIMED calls
 
 ProfScope::ProfScope(int kernel_id, hipStream_t stream, bool ext_) : id(kernel_id), s(stream), slot(nullptr), ext(ext_) {
     if (!((g_prof_mask >> id) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_calls[id]++ % g_prof_every != 0) return;
     if (g_prof_used[id] >= kMaxPairs) return;
     if (g_prof_used[id] == g_prof_ev[id].size()) {
         EvPair p;
@@ -138,6 +142,12 @@ hipEvent_t ProfScope::stop() const {
     if (!slot) return nullptr;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     return g_prof_ev[id][(size_t)(uintptr_t)slot - 1].b;
+}
+
+void ProfScope::units(double n) const {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_units[id] += n;
 }
 
 ProfScope::~ProfScope() {
@@ -174,7 +184,25 @@ int enerf_prof_enable_mask(uint32_t mask) {
 
 int enerf_prof_reset(void) {
     std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
-    for (int k = 0; k < ENERF_K_COUNT; k++) enerf::g_prof_used[k] = 0;     // the events themselves are kept for reuse
+    for (int k = 0; k < ENERF_K_COUNT; k++) {
+        enerf::g_prof_used[k] = 0;                      // the events themselves are kept for reuse
+        enerf::g_prof_calls[k] = 0;
+        enerf::g_prof_units[k] = 0.0;
+    }
+    return 0;
+}
+
+int enerf_prof_sample_every(uint32_t n) {
+    std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
+    enerf::g_prof_every = n ? n : 1u;
+    return 0;
+}
+
+int enerf_prof_read_units(int kernel_id, double* units, uint64_t* calls_seen) {
+    if (kernel_id < 0 || kernel_id >= ENERF_K_COUNT) ENERF_BADARG("prof_read_units: bad kernel id %d", kernel_id);
+    std::lock_guard<std::mutex> lk(enerf::g_prof_mu);
+    if (units) *units = enerf::g_prof_units[kernel_id];
+    if (calls_seen) *calls_seen = enerf::g_prof_calls[kernel_id];
     return 0;
 }
 

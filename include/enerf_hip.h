@@ -639,6 +639,13 @@ int enerf_prof_enable(int on);
 /* bit k of `mask` enables timing of kernel family k only (each timed call costs two event records on the stream) */
 int enerf_prof_enable_mask(uint32_t mask);
 int enerf_prof_reset(void);
+/* Time one eligible call in `n` per kernel family (default 1: every call).  A timed launch carries completion signals
+ * (and, for kernel-stamped families, a one-wavefront marker launch before it): ~10 us of queue time per timed call, so a
+ * benchmark that must not perturb what it measures samples.  enerf_prof_read_units: the work units (grid_encode: points;
+ * mlp32: samples) of the TIMED calls only -- the denominator that goes with enerf_prof_read's time -- and the number of
+ * eligible calls seen since the last reset. [host ptrs] */
+int enerf_prof_sample_every(uint32_t n);
+int enerf_prof_read_units(int kernel_id, double* units, uint64_t* calls_seen);
 /* Synchronises the recorded events; returns total milliseconds and launch count for `kernel_id`. [host ptrs] */
 int enerf_prof_read(int kernel_id, double* total_ms, uint64_t* launches);
 

@@ -17,13 +17,18 @@ def main():
         if fam not in d.get("kernels", {}):
             continue
         n = d["kernels"][fam]["launches"]
+        # bench.py times launch k of its timed region when k % every == 0: the same launches are picked here
+        region = d["kernels"][fam].get("launches_in_region", n)
+        every = d["kernels"][fam].get("timed_one_in", 1)
         rows = [r for r in csv.DictReader(open(trace))]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         if needle:
             durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if needle in r["Kernel_Name"]]
-            tail = durs[-n:]
-            res[fam] = {"launches": n, "hipEvent_avg_ms": d["kernels"][fam]["avg_ms"],
-                        "rocprofv3_avg_ms": sum(tail) / len(tail) / 1e6}
+            tail = durs[-region:][::every]
+            res[fam] = {"launches": n, "launches_in_region": region, "timed_one_in": every,
+                        "hipEvent_avg_ms": d["kernels"][fam]["avg_ms"],
+                        "rocprofv3_avg_ms_same_launches": sum(tail) / len(tail) / 1e6,
+                        "rocprofv3_avg_ms_all_region_launches": sum(durs[-region:]) / max(len(durs[-region:]), 1) / 1e6}
         else:
             # the backward is a family of kernels per call: atomic pass + bin + tile
             per = {}

@@ -1,52 +1,63 @@
-"""Host enqueue time vs drained time of the training step, with and without the early march (development aid)."""
-import os
+"""Timeline of the steady-state training step from a rocprofv3 kernel trace (development aid): for every kernel of a
+step, in start order, its duration and the idle time of ITS stream before it -- where the step's time goes between the
+kernels.  usage: python tools/step_timeline.py kernel_trace.csv [steps-from-the-end=40]"""
+import collections
+import csv
+import re
 import sys
-import time
 
-import torch
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from enerf_amd.network import NeRFNetwork  # noqa: E402
-from enerf_amd.trainer import TrainHarness  # noqa: E402
-
-os.sched_setaffinity(0, set(range(8)))
-dev = torch.device("cuda", 0)
-torch.manual_seed(0)
-model = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(dev)
-h = TrainHarness(model, occupancy="synthetic", world=1)
-batches = bench.build_batches(8, 4096, dev, 0, 3)
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+rows.sort(key=lambda r: r["s"])
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 
 
-def run(n, nxt):
-    for i in range(n):
-        b = batches[(i + 1) % 8]
-        h.step_rgb(*batches[i % 8], next_rays=(b[0], b[1]) if nxt else None)
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::|enerf_mlp32::|void ", "", n)
+    return re.sub(r"\(.*", "", n)[:44]
 
 
-for pf in (False, True, False, True):
-    run(48, pf)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(96, pf)
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print(f"prefetch={pf}: enqueue {1e3 * (t1 - t0) / 96:.3f} ms/step, drained {1e3 * (t2 - t0) / 96:.3f} ms/step")
-
-# cost of the density-grid update itself (runs every 16th step): full sweep (first 16 updates) and partial update
-for label, it in (("full", 0), ("partial", 100)):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    h.model.iter_density = it
-    h.model.update_extra_state()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    a.record()
-    for _ in range(8):
-        h.model.iter_density = it
-        h.model.update_extra_state()
-    b.record()
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    print(f"update_extra_state[{label}]: host {1e3 * (t1 - t0) / 8:.3f} ms, device {a.elapsed_time(b) / 8:.3f} ms")
+# a step starts at the training-size k_grid_fwd launch (the sweeps are 10x longer: drop steps that contain one)
+starts = [i for i, r in enumerate(rows) if "k_grid_fwd<" in r["Kernel_Name"]]
+steps = []
+for a, b in zip(starts[:-1], starts[1:]):
+    seg = rows[a:b]
+    if any("k_packbits" in r["Kernel_Name"] or "k_ema" in r["Kernel_Name"] for r in seg):
+        continue
+    if rows[a]["e"] - rows[a]["s"] > 200000:
+        continue
+    steps.append((a, b))
+steps = steps[-nsteps:]
+qkey = "Queue_Id" if "Queue_Id" in rows[0] else ("Stream_Id" if "Stream_Id" in rows[0] else None)
+acc = collections.OrderedDict()
+span = []
+for a, b in steps:
+    seg = rows[a:b]
+    last_end = {}
+    span.append(rows[b]["s"] - rows[a]["s"])
+    seen = collections.Counter()
+    for r in seg:
+        q = r.get(qkey, "0")
+        name = short(r["Kernel_Name"])
+        seen[name] += 1
+        key = (name, seen[name], q)
+        gap = r["s"] - last_end[q] if q in last_end else 0
+        last_end[q] = r["e"]
+        d = acc.setdefault(key, [0, 0, 0, 0])
+        d[0] += 1
+        d[1] += r["e"] - r["s"]
+        d[2] += gap
+        d[3] += r["s"] - rows[a]["s"]
+print(f"{len(steps)} steady steps, start-to-start {sum(span) / len(span) / 1e3:.1f} us")
+print(f"{'kernel':46s} {'queue':>6s} {'n':>4s} {'start':>8s} {'dur us':>8s} {'gap before':>10s}")
+tot_d = collections.Counter()
+tot_g = collections.Counter()
+for (name, k, q), (n, d, g, s0) in sorted(acc.items(), key=lambda kv: kv[1][3] / kv[1][0]):
+    if n < len(steps) // 2:
+        continue
+    print(f"{name:46s} {q:>6s} {n:4d} {s0 / n / 1e3:8.1f} {d / n / 1e3:8.1f} {g / n / 1e3:10.1f}")
+    tot_d[q] += d / len(steps) / 1e3
+    tot_g[q] += g / len(steps) / 1e3
+for q in tot_d:
+    print(f"queue {q}: kernels {tot_d[q]:.1f} us/step, gaps {tot_g[q]:.1f} us/step")
