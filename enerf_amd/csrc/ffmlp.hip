@@ -32,9 +32,24 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
     constexpr int IN = 16 * IN_KB;
     constexpr uint32_t NW = HID * (IN + HID * (NL - 1) + OUT);
     __shared__ __attribute__((aligned(16))) E wl[NW];
-    stage_weights(wl, W, NW);
-
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
+    // Two 32-sample tiles (64 consecutive samples) per iteration: two independent MFMA dependency chains per layer,
+    // and the next iteration's inputs are already in flight while this one computes (B % 128 == 0 => pairs are whole).
+    // The first pair's inputs are requested before the weights are staged: they travel during the set-up.
+    constexpr int T = 2;
+    const uint32_t npairs = B / (32 * T);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    x8 xn[T][IN_KB];
+    if (gw < npairs) {
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int kb = 0; kb < IN_KB; kb++)
+                xn[t][kb] = *reinterpret_cast<const x8*>(X + ((size_t)(gw * T + t) * 32 + j) * IN + 16 * kb + 8 * h);
+    }
+    stage_weights_n<NW>(wl, W);
+
     // weight fragments (A operands): lane = output neuron
     x8 w0[2][IN_KB], wh[NL - 1][2][4], wo[4];
 #pragma unroll
@@ -59,20 +74,6 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
         }
     }
 
-    // Two 32-sample tiles (64 consecutive samples) per iteration: two independent MFMA dependency chains per layer,
-    // and the next iteration's inputs are already in flight while this one computes (B % 128 == 0 => pairs are whole).
-    constexpr int T = 2;
-    const uint32_t npairs = B / (32 * T);
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    x8 xn[T][IN_KB];
-    if (gw < npairs) {
-#pragma unroll
-        for (int t = 0; t < T; t++)
-#pragma unroll
-            for (int kb = 0; kb < IN_KB; kb++)
-                xn[t][kb] = *reinterpret_cast<const x8*>(X + ((size_t)(gw * T + t) * 32 + j) * IN + 16 * kb + 8 * h);
-    }
     for (uint32_t pair = gw; pair < npairs; pair += nw) {
         x8 xb[T][IN_KB];
 #pragma unroll
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_bwd_act(const E* __restrict__ dY,
     constexpr int IN_MB = (IN + 31) / 32;
     constexpr uint32_t NW = HID * (IN + HID * (NL - 1) + OUT);
     __shared__ __attribute__((aligned(16))) E wl[NW];
-    stage_weights(wl, W, NW);
+    stage_weights_n<NW>(wl, W);
 
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     // transposed weight fragments: lane = INPUT neuron of the layer, K runs over its output neurons

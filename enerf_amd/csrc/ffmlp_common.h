@@ -232,6 +232,26 @@ __device__ __forceinline__ void stage_weights(E* wl, const E* __restrict__ w, ui
     for (uint32_t i = threadIdx.x; i < n / 8; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
+// The same with the element count known at compile time (256 threads): every load of the thread is issued before its
+// first LDS store, so the copy costs one memory latency instead of one per pass (9 passes for the largest net).
+template <uint32_t N, typename E>
+__device__ __forceinline__ void stage_weights_n(E* wl, const E* __restrict__ w) {
+    constexpr uint32_t V = N / 8, PASSES = (V + 255u) / 256u;
+    const uint4* src = reinterpret_cast<const uint4*>(w);
+    uint4* dst = reinterpret_cast<uint4*>(wl);
+    uint4 v[PASSES];
+#pragma unroll
+    for (uint32_t k = 0; k < PASSES; k++) {
+        const uint32_t i = threadIdx.x + k * 256u;
+        v[k] = src[i < V ? i : V - 1u];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PASSES; k++) {
+        const uint32_t i = threadIdx.x + k * 256u;
+        if (i < V) dst[i] = v[k];
+    }
+    __syncthreads();
+}
 
 #define FFMLP_DISPATCH_ACT(E, CALL)                                                 \
     switch (act_class(act)) {                                                       \

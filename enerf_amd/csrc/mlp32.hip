@@ -824,7 +824,6 @@ static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
 static bool g_signal_armed = false;      // enerf_mlp32_signal_next_reduce
 static bool g_signal_recorded = false;
 static hipEvent_t g_signal_event = nullptr;
-static int g_signal_flags = getenv("ENERF_SIGNAL_SYSTEM_SCOPE") ? 0 : 1;
 static bool g_defer_next = false;        // one-shot: set by enerf_mlp32_defer_reduce
 static bool g_have_pending = false;
 static ReduceJob g_pending;
@@ -1143,9 +1142,10 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         hipEvent_t sig = nullptr;
         if (g_signal_armed) {
             g_signal_armed = false;
-            // (device-scope release: the waiter is another queue of this device, nothing has to reach the host)
-            if (!g_signal_event &&
-                hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming | (g_signal_flags ? hipEventReleaseToDevice : 0)) != hipSuccess)
+            // (tried and dropped, tools/step_timeline.py: a device-scope release event -- same ~6 us before the next
+            // kernel of this stream; a generation number published by the reduce launch's last workgroup + a sleeping
+            // wait kernel on the other stream -- the gap goes, the reduce launch grows by 3 us, the step does not move)
+            if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming) != hipSuccess)
                 g_signal_event = nullptr;
             sig = g_signal_event;
             g_signal_recorded = sig != nullptr;
