@@ -103,6 +103,7 @@ SIGNATURES = {
     "enerf_prof_sample_every": [_u32],
     "enerf_prof_read_units": [_int, _c.POINTER(_c.c_double), _c.POINTER(_c.c_uint64)],
     "enerf_train_step_mse": [_vp],
+    "enerf_train_step_events": [_vp],
     "enerf_debug_step_timing": [_int, _c.POINTER(_c.c_double)],
     "enerf_dp_unique_id": [_vp, _sz],
     "enerf_dp_init": [_vp, _sz, _int, _int],

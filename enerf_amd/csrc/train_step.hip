@@ -121,6 +121,112 @@ done:
     return rc;
 }
 
+// The event-only step (two renders, one loss, one optimizer pass): events.train_step_events_manual +
+// FusedAdam.step_grid_table, call for call.
+extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
+    if (!a) ENERF_BADARG("train_step_events: null arguments");
+    if (a->struct_bytes != sizeof(enerf_event_step_args))
+        ENERF_BADARG("train_step_events: struct of %u bytes, this library expects %zu", a->struct_bytes,
+                     sizeof(enerf_event_step_args));
+    if (a->r[0].N == 0 || a->r[0].N != a->r[1].N || a->r[0].M == 0 || a->r[1].M == 0)
+        ENERF_BADARG("train_step_events: both renders take the same (non-zero) number of rays and a sample budget");
+    if (!a->bg_color || !a->pols) ENERF_BADARG("train_step_events: bg_color and pols are required");
+    enerf_stream_t s = a->stream;
+    const uint32_t N = a->r[0].N, total = a->r[0].M + a->r[1].M;
+    const float in_add = a->bound, in_mul = a->inv_two_bound;
+    int prev_prec = -1;
+    if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
+    int rc = 0;
+    bool rows_set = false, defer_set = false, signal_set = false;
+    const bool march_next = a->r[0].next_rays_o != nullptr || a->r[1].next_rays_o != nullptr;
+#define STEP(call)           \
+    do {                     \
+        rc = (call);         \
+        if (rc) goto done;   \
+    } while (0)
+    // ---- the two renders' forward
+    for (int k = 0; k < 2; k++) {
+        const enerf_step_render& r = a->r[k];
+        STEP(enerf_grid_encode_forward(r.xyzs, a->embeddings, a->offsets, r.feats, r.M, 3, 2, 16, a->level_scale_log2,
+                                       a->base_resolution, 0, r.feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
+        if (r.counter) {
+            enerf_mlp32_valid_rows(r.counter);
+            rows_set = true;
+        }
+        STEP(enerf_mlp32_forward_p(r.feats, a->wseg_s, 32, 0, r.M, 32, 16, a->nh_s, 0, 6, r.fb_s, r.h32, 1, 32, r.sigma,
+                                   r.dirs, s));
+        STEP(enerf_mlp32_forward_p(r.h32, a->wseg_c, a->w0_cols_c, 1, r.M, 32, a->out_c, a->nh_c, 0, 3, r.fb_c, r.rgb, 0, 0,
+                                   nullptr, nullptr, s));
+        if (rows_set) {
+            enerf_mlp32_valid_rows(nullptr);
+            rows_set = false;
+        }
+        STEP(enerf_composite_rays_train_forward_blend(r.sigma, r.rgb, r.deltas, r.rays, r.M, N, r.weights_sum, nullptr,
+                                                      r.image, a->bg_color, 0, 0.0f, r.out_image, s));
+    }
+    // ---- the loss and its gradient with respect to the two images
+    STEP(enerf_event_loss_fwd_bwd(a->r[0].out_image, a->r[1].out_image, a->pols, N, a->use_luma, a->linlog, a->C_thres,
+                                  a->log_thres, a->upstream, a->r[0].g_image, a->r[1].g_image, a->delta, a->loss, s));
+    // ---- the two renders' backward (the second adds its weight gradients to the first's)
+    for (int k = 0; k < 2; k++) {
+        const enerf_step_render& r = a->r[k];
+        STEP(enerf_composite_rays_train_backward_mse(r.g_image, nullptr, 1.0f, a->bg_color, 0, 0.0f, r.counter, r.sigma,
+                                                     r.rgb, r.deltas, r.rays, r.weights_sum, r.image, r.M, N, r.g_sigmas,
+                                                     r.g_rgbs, nullptr, s));
+        if (r.counter) {
+            enerf_mlp32_valid_rows(r.counter);
+            rows_set = true;
+        }
+        if (k == 1 && march_next) {
+            enerf_mlp32_signal_next_reduce(1);
+            signal_set = true;
+        }
+        enerf_mlp32_defer_reduce(1);
+        defer_set = true;
+        const uint32_t overwrite = k == 0 ? 1u : 0u;
+        STEP(enerf_mlp32_backward_p(r.g_rgbs, r.h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, overwrite, r.fb_c, r.M, 32,
+                                    a->out_c, a->nh_c, 0, nullptr, r.dx32, 0, 0, r.rgb, a->out_c, nullptr, nullptr, 0, s));
+        STEP(enerf_mlp32_backward_p(r.dx32, r.feats, a->wseg_s, a->dwseg_s, 32, 0, overwrite, r.fb_s, r.M, 32, 16, a->nh_s, 0,
+                                    nullptr, r.dfeat, 1, 32, nullptr, 0, r.g_sigmas, r.h32, 32, s));
+        enerf_mlp32_defer_reduce(0);
+        defer_set = false;
+        if (rows_set) {
+            enerf_mlp32_valid_rows(nullptr);
+            rows_set = false;
+        }
+        if (k == 1 && march_next) {
+            // the next step's two marches, on the side stream, behind this step's last MLP backward
+            enerf_mlp32_signal_next_reduce(0);
+            signal_set = false;
+            enerf_stream_t ss = a->side_stream;
+            STEP(enerf_stream_wait_mlp32_signal(ss));
+            for (int q = 0; q < 2; q++) {
+                const enerf_step_render& n = a->r[q];
+                if (!n.next_rays_o) continue;
+                STEP(enerf_near_far_from_aabb(n.next_rays_o, n.next_rays_d, a->aabb, n.next_N, a->min_near, n.next_nears,
+                                              n.next_fars, ss));
+                STEP(enerf_march_rays_train_ex(n.next_rays_o, n.next_rays_d, a->bitfield, a->bound, a->dt_gamma,
+                                               a->max_steps, n.next_N, a->cascade, a->grid_size, n.next_M, n.next_nears,
+                                               n.next_fars, n.next_xyzs, n.next_dirs, n.next_deltas, n.next_rays,
+                                               n.next_counter, a->perturb, a->march_flags, ss));
+            }
+        }
+        STEP(enerf_grid_encode_backward_ex(r.dfeat, r.xyzs, a->embeddings, a->offsets, a->table_grad, r.M, 3, 2, 16,
+                                           a->level_scale_log2, a->base_resolution, 0, r.dfeat, r.dfeat, a->gridtype,
+                                           ENERF_F32, 2, in_add, in_mul, 1, total, s));
+    }
+    STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr,
+                                         a->beta1, a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g,
+                                         a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step, s));
+done:
+#undef STEP
+    if (defer_set) enerf_mlp32_defer_reduce(0);
+    if (signal_set) enerf_mlp32_signal_next_reduce(0);
+    if (rows_set) enerf_mlp32_valid_rows(nullptr);
+    if (prev_prec >= 0) enerf_mlp32_precision(prev_prec);
+    return rc;
+}
+
 // development aid: on != 0 starts (and clears) the per-call host timers of enerf_train_step_mse; out (16 doubles, may
 // be NULL) receives the microseconds per call slot, in call order, averaged over the steps since the last start
 extern "C" int enerf_debug_step_timing(int on, double* out) {

@@ -664,3 +664,218 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                 if p.grad is not g:
                     p.grad = g
     return (ctx["out_image"], ctx["dw"]) if raw else ctx["out_image"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The event-only step (two renders, event loss, one optimizer pass) as ONE library call: csrc/train_step.hip
+# enerf_train_step_events -- events.train_step_events_manual + FusedAdam.step_grid_table, call for call.
+class _StepRender(_ct.Structure):         # enerf_step_render
+    _fields_ = ([("N", _u32), ("M", _u32)]
+                + [(n, _vp) for n in ("xyzs", "dirs", "deltas", "rays", "counter")]
+                + [(n, _vp) for n in ("feats", "h32", "fb_s", "fb_c", "sigma", "rgb", "weights_sum", "image", "out_image",
+                                      "g_image", "g_sigmas", "g_rgbs", "dx32", "dfeat")]
+                + [("next_rays_o", _vp), ("next_rays_d", _vp), ("next_N", _u32), ("next_M", _u32)]
+                + [(n, _vp) for n in ("next_nears", "next_fars", "next_xyzs", "next_dirs", "next_deltas", "next_rays",
+                                      "next_counter")])
+
+
+class _EventStepArgs(_ct.Structure):      # enerf_event_step_args
+    _fields_ = ([("struct_bytes", _u32), ("mlp_precision", _ct.c_int), ("stream", _vp), ("side_stream", _vp),
+                 ("r", _StepRender * 2), ("bg_color", _vp), ("pols", _vp), ("use_luma", _u32), ("linlog", _u32),
+                 ("C_thres", _f32c), ("log_thres", _f32c), ("upstream", _f32c), ("delta", _vp), ("loss", _vp),
+                 ("embeddings", _vp), ("offsets", _vp), ("level_scale_log2", _f32c), ("bound", _f32c),
+                 ("inv_two_bound", _f32c), ("base_resolution", _u32), ("gridtype", _u32)]
+                + [(n, _vp) for n in ("wseg_s", "wseg_c", "dwseg_s", "dwseg_c")]
+                + [(n, _u32) for n in ("nh_s", "nh_c", "w0_cols_c", "out_c")]
+                + [("aabb", _vp), ("bitfield", _vp), ("min_near", _f32c), ("dt_gamma", _f32c)]
+                + [(n, _u32) for n in ("cascade", "grid_size", "max_steps", "perturb", "march_flags", "reserved0")]
+                + [(n, _vp) for n in ("table", "table_grad", "table_m", "table_v")]
+                + [(n, _f32c) for n in ("lr", "beta1", "beta2", "eps")]
+                + [("table_step", _u32), ("n_small", _u32)]
+                + [(n, _vp) for n in ("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step")]
+                + [("flags", _u32), ("reserved", _u32)])
+
+
+def native_events_supported(model, data, loss_opt, opt):
+    """What enerf_train_step_events serves: the steady state (a sample budget exists) of the event-only step with the
+    fused loss kernel (C_thres != -1, fp32, one background colour: a batch of one image), unit density scale, the fused
+    optimizer, default march parameters."""
+    ro, rd = data["rays_evs_o1"], data["rays_evs_d1"]
+    return (NATIVE_STEP and _budget(model) > 0 and float(model.density_scale) == 1.0 and hasattr(opt, "grid_table_plan")
+            and loss_opt.event_only and loss_opt.C_thres != -1 and not loss_opt.render_kwargs
+            and int(getattr(loss_opt, "out_dim_color", 3)) == 3
+            and data["images"].shape[0] == 1 and data["pols"].dtype == torch.float32 and data["pols"].is_cuda
+            and data["rays_evs_o1"].shape == data["rays_evs_o2"].shape
+            and data["pols"].numel() * 3 == data["rays_evs_o1"].numel()
+            and supported(model, ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3), 1, 0)
+            and supported(model, data["rays_evs_o2"].contiguous().view(-1, 3),
+                          data["rays_evs_d2"].contiguous().view(-1, 3), 1, 0))
+
+
+def _native_events_ctx(model, N, Ms, Nn, Mn, luma, dev):
+    params = fnet.network_params(model)
+    emb, weights = params[0], params[1:]
+    kind = fnet.kind_of(model)
+    arch = fnet._ARCH[kind]
+    prec = model.__dict__.get("mlp_precision")
+    prec = arch["prec"] if prec is None else int(prec)
+    out_c = weights[-1].shape[0] if kind == "linear" else 3
+    key = (N, Ms, Nn, Mn, kind, prec, out_c, luma, emb.data_ptr(), tuple(w.data_ptr() for w in weights), dev)
+    ctx = model.__dict__.get("_native_events_ctx")
+    if ctx is not None and ctx["key"] == key:
+        return ctx
+    import numpy as _np
+    enc = model._modules["encoder"]
+    bufs = model._buffers
+    f32 = dict(dtype=torch.float32, device=dev)
+    seg_s, seg_c = fnet._weight_segments(kind, weights)
+    dw, (dseg_s, dseg_c) = fnet._grad_segments(kind, dev, out_c)
+    grads = fnet.unpack_weight_grads(dw, out_c, kind)
+    a = _EventStepArgs()
+    a.struct_bytes = _ct.sizeof(_EventStepArgs)
+    a.mlp_precision = -1 if prec is None else prec
+    ts, stages = [], []
+    for q, M in enumerate(Ms):
+        Mp = (M + 31) // 32 * 32
+        t = dict(feats=torch.empty(16, Mp, 2, **f32), h32=torch.empty(M, 32, **f32),
+                 fb_s=torch.empty(arch["nh_s"], Mp, 64, **f32), fb_c=torch.empty(arch["nh_c"], Mp, 64, **f32),
+                 sigma=torch.empty(M, **f32), rgb=torch.empty(M, out_c, **f32), weights_sum=torch.empty(N, **f32),
+                 image=torch.empty(N, 3, **f32), out_image=torch.empty(N, 3, **f32), g_image=torch.empty(N, 3, **f32),
+                 g_sigmas=torch.empty(M, **f32), g_rgbs=torch.empty(M, out_c, **f32), dx32=torch.empty(M, 32, **f32),
+                 dfeat=torch.empty(16, Mp, 2, **f32))
+        ts.append(t)
+        a.r[q].N, a.r[q].M = N, M
+        for name, buf in t.items():
+            setattr(a.r[q], name, buf.data_ptr())
+        sets = []
+        if Nn:
+            for _ in range(2):
+                sets.append(dict(nears=torch.empty(Nn, **f32), fars=torch.empty(Nn, **f32),
+                                 rays=torch.empty(Nn, 3, dtype=torch.int32, device=dev), xyzs=torch.empty(Mn, 3, **f32),
+                                 dirs=torch.empty(Mn, 3, **f32), deltas=torch.empty(Mn, 2, **f32), M=Mn))
+        stages.append(sets)
+    delta = torch.empty(1, N, 1 if luma else 3, **f32)
+    a.delta = delta.data_ptr()
+    a.embeddings, a.offsets = emb.data_ptr(), enc._buffers["offsets"].data_ptr()
+    a.level_scale_log2 = float(_np.log2(enc.per_level_scale))
+    a.bound, a.inv_two_bound = float(model.bound), float(_np.float32(1.0) / _np.float32(2 * model.bound))
+    a.base_resolution, a.gridtype = int(enc.base_resolution), int(enc.gridtype_id)
+    a.wseg_s, a.wseg_c = _ct.cast(seg_s, _vp), _ct.cast(seg_c, _vp)
+    a.dwseg_s, a.dwseg_c = _ct.cast(dseg_s, _vp), _ct.cast(dseg_c, _vp)
+    a.nh_s, a.nh_c, a.w0_cols_c, a.out_c = arch["nh_s"], arch["nh_c"], arch["w0c"], out_c
+    a.aabb, a.bitfield = bufs["aabb_train"].data_ptr(), bufs["density_bitfield"].data_ptr()
+    a.min_near = float(model.min_near)
+    a.cascade, a.grid_size = int(model.cascade), int(model.grid_size)
+    a.table = emb.data_ptr()
+    ctx = dict(key=key, t=ts, seg=(seg_s, seg_c), dseg=(dseg_s, dseg_c), dw=dw, grads=grads, stages=stages, flip=[0, 0],
+               a=a, emb=emb, weights=weights, delta=delta, kind=kind, out_c=out_c)
+    model.__dict__["_native_events_ctx"] = ctx
+    return ctx
+
+
+def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_stream=None, bg_color=None, perturb=True,
+                             dt_gamma=0, max_steps=1024):
+    """One event-only training step through enerf_train_step_events: both renders (marched ahead of time when the
+    previous step asked for it), the event loss, both backwards, the optimizer, and the two marches of `next_data` on
+    `side_stream`.  -> (loss, delta).  Gradients of the MLP weights are left in p.grad, the table's dense gradient buffer
+    comes back clean, the optimizer's step counts advance.  Values: those of events.train_step_events_manual +
+    FusedAdam.step_grid_table (the same library calls, in the same order)."""
+    pairs = ((data["rays_evs_o1"], data["rays_evs_d1"]), (data["rays_evs_o2"], data["rays_evs_d2"]))
+    dev = pairs[0][0].device
+    with torch.no_grad():
+        bg = torch.rand((1, 1, 3), device=dev) if bg_color is None else bg_color.detach().to(torch.float32).contiguous()
+        pres, slots = [], []
+        for ro, rd in pairs:
+            ro, rd = ro.contiguous().view(-1, 3), rd.contiguous().view(-1, 3)
+            pre = _take_premarched(model, ro, rd, perturb, dt_gamma, max_steps)
+            if pre is not None:
+                model.rendered_counter_slot = pre["slot"]
+            else:
+                counter = _next_counter(model)
+                model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
+                pre = march_stage(model, ro, rd, counter, _budget(model), bool(perturb), False, float(dt_gamma),
+                                  int(max_steps))
+            pres.append(pre)
+            slots.append(model.rendered_counter_slot)
+        N = pairs[0][0].numel() // 3
+        nxt_pairs = None
+        Nn = Mn = 0
+        stash = getattr(model, "_premarched", None)
+        if not isinstance(stash, dict):
+            stash = model._premarched = {}
+        if next_data is not None and side_stream is not None and not any("pending" in p for p in stash.values()):
+            nxt_pairs = [(next_data["rays_evs_o1"].contiguous().view(-1, 3), next_data["rays_evs_d1"].contiguous().view(-1, 3)),
+                         (next_data["rays_evs_o2"].contiguous().view(-1, 3), next_data["rays_evs_d2"].contiguous().view(-1, 3))]
+            Nn = nxt_pairs[0][0].shape[0]
+            mc = _budget(model)
+            Mn = mc + (128 - mc % 128)
+        ctx = _native_events_ctx(model, N, (pres[0]["M"], pres[1]["M"]), Nn, Mn, bool(loss_opt.use_luma), dev)
+        a, emb, weights, grads = ctx["a"], ctx["emb"], ctx["weights"], ctx["grads"]
+        if emb.grad is None:
+            emb.grad = torch.zeros_like(emb)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        a.stream = L.stream_handle()
+        a.bg_color = bg.data_ptr()
+        a.pols = data["pols"].contiguous().data_ptr()
+        a.use_luma, a.linlog = int(bool(loss_opt.use_luma)), int(bool(loss_opt.linlog))
+        a.C_thres, a.log_thres, a.upstream = float(loss_opt.C_thres), float(loss_opt.log_thres), 1.0
+        a.loss = loss.data_ptr()
+        for q, pre in enumerate(pres):
+            r = a.r[q]
+            r.xyzs, r.dirs, r.deltas = pre["xyzs"].data_ptr(), pre["dirs"].data_ptr(), pre["deltas"].data_ptr()
+            r.rays = pre["rays"].data_ptr()
+            r.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
+            r.next_rays_o = None
+        staged = []
+        if nxt_pairs is not None:
+            a.side_stream = side_stream.cuda_stream
+            a.dt_gamma, a.max_steps, a.perturb = float(dt_gamma), int(max_steps), 1 if perturb else 0
+            a.march_flags = occupied_box_flag(model) | 3 | 8
+            for q, (no, nd) in enumerate(nxt_pairs):
+                st_bufs = ctx["stages"][q][ctx["flip"][q]]
+                if any(pres[q][k] is st_bufs[k] for k in ("xyzs", "rays")):
+                    st_bufs = ctx["stages"][q][ctx["flip"][q] ^ 1]
+                else:
+                    ctx["flip"][q] ^= 1
+                nxt = _Stage(st_bufs)
+                nxt["counter"] = _next_counter(model)
+                nxt["slot"] = getattr(model, "last_counter_slot", None)
+                r = a.r[q]
+                r.next_rays_o, r.next_rays_d, r.next_N, r.next_M = no.data_ptr(), nd.data_ptr(), Nn, Mn
+                for name in ("nears", "fars", "xyzs", "dirs", "deltas", "rays", "counter"):
+                    setattr(r, "next_" + name, nxt[name].data_ptr())
+                staged.append(((no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps)), nxt))
+        a.table_grad = emb.grad.data_ptr()
+        plan = ctx.get("plan")
+        if plan is None or ctx.get("plan_opt") is not opt:
+            plan = ctx["plan"] = opt.grid_table_plan(emb, list(weights), list(grads))
+            ctx["plan_opt"] = opt
+            small, st = plan.arrays, plan.state
+            a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            a.n_small = small[0]
+            for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"), small[1:]):
+                setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
+        a.lr, a.beta1, a.beta2, a.eps, a.table_step = plan()
+        L.check(L.lib().enerf_train_step_events(_ct.byref(a)), "train_step_events")
+        from .backends import _gridencoder as _gbk
+        for pre in pres:
+            _gbk.STATS["fwd_points"] += pre["M"]
+            _gbk.STATS["fwd_calls"] += 1
+            _gbk.STATS["bwd_points"] += pre["M"]
+            _gbk.STATS["bwd_calls"] += 1
+            _gbk.LIFETIME["fwd_points"] += pre["M"]
+            _gbk.LIFETIME["fwd_calls"] += 1
+        if staged:
+            ready = torch.cuda.Event()
+            ready.record(side_stream)
+            for key, nxt in staged:
+                nxt["ready"] = ready
+                stash[key] = nxt
+        views = ctx.get("grad_views")
+        if views is None:
+            views = ctx["grad_views"] = [g.view_as(p) for p, g in zip(weights, grads)]
+        for p, g in zip(weights, views):
+            if p.grad is not g:
+                p.grad = g
+        model.rendered_counter_slot = slots[-1]
+    return loss, ctx["delta"]

@@ -840,6 +840,12 @@ class TrainHarness:
             return loss.detach()
         if self._events_manual_ok(data, opt):
             from .events import train_step_events_manual
+            if (self.native_step and self.fuse_table_adam and self.avg is None and not self.use_graphs
+                    and self.prefetch_at == "mlp_backward" and hasattr(self.opt, "grid_table_plan")
+                    and getattr(self.model, "graph_counter", None) is None):
+                from . import fused_render
+                if fused_render.native_events_supported(self.model, data, opt, self.opt):
+                    return self._step_events_native(data, opt, next_data)
             side = None
             if next_data is not None and not opt.render_kwargs:
                 side = self._side_prefetch((next_data["rays_evs_o1"], next_data["rays_evs_d1"]),
@@ -872,6 +878,31 @@ class TrainHarness:
             self.avg()
         self.opt.step()
         return loss.detach()
+
+    def _step_events_native(self, data, opt, next_data):
+        """The steady-state event-only step as one library call (fused_render.train_step_events_native ->
+        enerf_train_step_events): the launches of the manual route below, in its order, issued from C."""
+        from . import fused_render
+        m = self.model
+        emb = m._modules["encoder"]._parameters["embeddings"]
+        if not (self._cleared_grad is not None and emb.grad is self._cleared_grad):
+            emb.grad = None                     # only a buffer the last flush left clean may be added into
+        self._cleared_grad = None
+        nxt = None
+        if (next_data is not None and self.prefetch and self.global_step % self.update_interval != 0
+                and all(fused_render.supported(m, next_data[o].contiguous().view(-1, 3),
+                                               next_data[d].contiguous().view(-1, 3), 1, 0)
+                        for o, d in (("rays_evs_o1", "rays_evs_d1"), ("rays_evs_o2", "rays_evs_d2")))):
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            nxt = next_data
+        try:
+            loss, _ = fused_render.train_step_events_native(m, data, opt, self.opt, next_data=nxt, side_stream=self._side)
+        except BaseException:
+            self._discard_pending_records()
+            raise
+        self._cleared_grad = emb.grad
+        return loss
 
     def _events_manual_ok(self, data, opt):
         from . import fused_render

@@ -582,6 +582,65 @@ int enerf_train_step_mse(const enerf_train_step_args* args);
  * over the steps since timing was switched on); on >= 0 switches the timers (and clears them), on < 0 only reads. */
 int enerf_debug_step_timing(int on, double* out16);
 
+/* The event-only step (Trainer.train_step_events, nerf/utils.py:482-546, event_only = 1, C_thres != -1) the same way: TWO
+ * renders -- the event pairs' rays at the two poses -- blended with one background colour, the event loss on the two
+ * images and its gradient (enerf_event_loss_fwd_bwd), both renders' backward, ONE optimizer pass; optionally the two
+ * marches of the next step on `side_stream` behind the second render's MLP backward.  Calls, in order (what
+ * enerf_amd/events.train_step_events_manual + FusedAdam.step_grid_table issue): per render grid_encode_forward,
+ * mlp32_forward_p x 2, composite_rays_train_forward_blend; event_loss_fwd_bwd; per render
+ * composite_rays_train_backward_mse(target = NULL), mlp32_backward_p x 2 (the second render's weight gradients are
+ * added to the first's), grid_encode_backward_ex(defer, reserve = M1 + M2); grid_adam_from_records_ex. */
+typedef struct enerf_step_render {
+    uint32_t N, M;                      /* rays, sample rows budgeted (counter[0] real) */
+    const float *xyzs, *dirs, *deltas;
+    const int32_t *rays, *counter;
+    /* scratch, fp32 (shapes as in enerf_train_step_args; g_image [N,3] receives d loss / d out_image) */
+    float *feats, *h32, *fb_s, *fb_c, *sigma, *rgb, *weights_sum, *image, *out_image, *g_image, *g_sigmas, *g_rgbs, *dx32,
+        *dfeat;
+    /* the next step's march of this render's rays (next_rays_o == NULL: none) */
+    const float *next_rays_o, *next_rays_d;
+    uint32_t next_N, next_M;
+    float *next_nears, *next_fars, *next_xyzs, *next_dirs, *next_deltas;
+    int32_t *next_rays, *next_counter;
+} enerf_step_render;
+typedef struct enerf_event_step_args {
+    uint32_t struct_bytes;              /* sizeof(enerf_event_step_args): checked */
+    int mlp_precision;
+    enerf_stream_t stream, side_stream;
+    enerf_step_render r[2];
+    const float* bg_color;              /* [3] device floats: one colour for both renders (nerf/utils.py:497) */
+    const float* pols;                  /* [N] */
+    uint32_t use_luma, linlog;
+    float C_thres, log_thres, upstream;
+    float *delta, *loss;                /* [N,1] (use_luma) or [N,3]; device scalar (written, may be NULL) */
+    /* networks, march parameters, optimizer: as in enerf_train_step_args */
+    const float* embeddings;
+    const int32_t* offsets;
+    float level_scale_log2, bound, inv_two_bound;
+    uint32_t base_resolution, gridtype;
+    const float* const* wseg_s;
+    const float* const* wseg_c;
+    float* const* dwseg_s;
+    float* const* dwseg_c;
+    uint32_t nh_s, nh_c, w0_cols_c, out_c;
+    const float* aabb;
+    const uint8_t* bitfield;
+    float min_near, dt_gamma;
+    uint32_t cascade, grid_size, max_steps, perturb, march_flags, reserved0;
+    float *table, *table_grad, *table_m, *table_v;
+    float lr, beta1, beta2, eps;
+    uint32_t table_step, n_small;
+    float* const* small_p;
+    const float* const* small_g;
+    float* const* small_m;
+    float* const* small_v;
+    const uint32_t* small_n;
+    const float* small_lr;
+    const uint32_t* small_step;
+    uint32_t flags, reserved;           /* flags: 0 */
+} enerf_event_step_args;
+int enerf_train_step_events(const enerf_event_step_args* args);
+
 /* ------------------------------------------------------------------ data-parallel tail (not in the reference,
  * whose Trainer wraps the model in DistributedDataParallel: nerf/utils.py:353-355)
  * One process per GPU; rays shard over the ranks, and the step's only exchange is the average of the hash-table gradient

@@ -428,6 +428,11 @@ def test_event_step_with_closed_render_backward_matches_autograd_step(monkeypatc
     calls = []
     orig = events.train_step_events_manual
     monkeypatch.setattr(events, "train_step_events_manual", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    # (steady-state steps of the closed-form route go through the one-call step, enerf_train_step_events)
+    from enerf_amd import fused_render
+    orig_native = fused_render.train_step_events_native
+    monkeypatch.setattr(fused_render, "train_step_events_native",
+                        lambda *a, **k: (calls.append(1), orig_native(*a, **k))[1])
     runs = []
     for manual in (False, True):
         torch.manual_seed(0)
@@ -703,3 +708,49 @@ def test_native_step_call_equals_the_python_driven_step(net):
     for n, a in pa.items():
         assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
     assert set(ga) == set(gb)
+
+
+def test_native_event_step_call_equals_the_python_driven_event_step():
+    """enerf_train_step_events (csrc/train_step.hip: the steady-state event-only step -- two renders, the event loss, both
+    backwards, one optimizer pass, the next step's two marches -- as ONE library call) issues the same entry points in the
+    same order as events.train_step_events_manual + FusedAdam.step_grid_table: same sample counters, same losses, same
+    weights (to the float atomics of the table's smallest levels)."""
+    from enerf_amd import fused_render
+    from enerf_amd.events import EventOptions
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 4096, 2)
+    opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
+
+    def batch(i):
+        ro, rd, tg = data[i % len(data)]
+        ro2, rd2, _ = data[(i + 1) % len(data)]
+        return {"images": tg.view(1, -1, 3), "rays_evs_o1": ro.view(1, -1, 3), "rays_evs_d1": rd.view(1, -1, 3),
+                "rays_evs_o2": ro2.view(1, -1, 3), "rays_evs_d2": rd2.view(1, -1, 3),
+                "pols": torch.sign(tg[..., 0] - 0.5).view(1, -1)}
+    runs = {}
+    for native in (True, False):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.native_step = native
+        calls = []
+        orig = fused_render.train_step_events_native
+        fused_render.train_step_events_native = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            torch.manual_seed(3)                               # the step draws a random background colour
+            losses = [h.step_events(batch(i), opt, next_data=batch(i + 1)).clone() for i in range(40)]
+        finally:
+            fused_render.train_step_events_native = orig
+        torch.cuda.synchronize()
+        runs[native] = (torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
+                        {n: p.detach().clone() for n, p in model.named_parameters()}, len(calls),
+                        {n for n, p in model.named_parameters() if p.grad is not None})
+    (la, ca, pa, na, ga), (lb, cb, pb, nb, gb) = runs[True], runs[False]
+    # (8 steps without a sample budget -- two renders per step fill the 16-slot ring -- then every step is steady)
+    assert na >= 24 and nb == 0
+    assert torch.equal(ca, cb)
+    assert float(((la - lb).abs() / lb.abs().clamp(min=1e-9)).max()) <= 1e-5
+    for n, a in pa.items():
+        assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
+    assert ga == gb
