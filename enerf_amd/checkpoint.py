@@ -92,7 +92,8 @@ def load_checkpoint(harness, checkpoint, model_only=False, map_location=None):
             m.mean_density = checkpoint["mean_density"]
         # what was marched ahead, and the library's box of occupied cells, belong to the old bitfield
         m._premarched = None
-        m.__dict__.pop("_native_ctx", None)       # (cached pointers of the one-call step: parameters / moments may move)
+        m.__dict__.pop("_native_ctx", None)       # (cached pointers of the one-call steps: parameters / moments may move)
+        m.__dict__.pop("_native_events_ctx", None)
         from . import raymarching
         epoch = getattr(raymarching, "BITFIELD_EPOCH", None)
         if epoch is not None:
@@ -108,6 +109,7 @@ def load_checkpoint(harness, checkpoint, model_only=False, map_location=None):
     if getattr(harness, "opt", None) is not None and "optimizer" in checkpoint:
         _load_optimizer_state(harness.opt, checkpoint["optimizer"])
         m.__dict__.pop("_native_ctx", None)
+        m.__dict__.pop("_native_events_ctx", None)
         if hasattr(harness, "_cleared_grad"):
             harness._cleared_grad = None
     sched = getattr(harness, "lr_scheduler", None)
