@@ -1126,6 +1126,7 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
         region = g_pending.region;                    // later calls of the session append to the same lists
     }
     if (binned) {
+        if (int eg = single_device_guard("grid_encode_backward")) return eg;
         if (int ew = workspace_family_enter(1, s)) return ew;
         recs = (uint32_t*)workspace(WS_GRIDBWD, sizeof(uint32_t) * (size_t)L * region * (1 + C));
         cursors = bin_cursors();
@@ -1317,6 +1318,7 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
     if (g_pending.region != 0 && (g_pending.L != L || g_pending.C != C))
         ENERF_BADARG("grid_adam_from_records: the pending records belong to a table with L=%u C=%u", g_pending.L, g_pending.C);
     hipStream_t s = (hipStream_t)stream;
+    if (int eg = single_device_guard("grid_adam_from_records")) return eg;
     // torch.optim.Adam's scalars, as enerf_adam_step_multi computes them
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     AdamScalars ad = {beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2))};

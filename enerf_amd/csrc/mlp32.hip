@@ -946,6 +946,7 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
         ENERF_BADARG("mlp32: output activation must be relu (0), sigmoid (3) or none (6)");
     if (y_stride == 0) y_stride = out_dim;
     if (y_stride < out_dim) ENERF_BADARG("mlp32: y_stride %u < out_dim %u", y_stride, out_dim);
+    if (int eg = single_device_guard("mlp32_forward")) return eg;
     hipStream_t s = (hipStream_t)stream;
     // (the split kernels are timed by their own begin / end stamps; the fp32 MFMA kernels between two event packets)
     ProfScope prof(ENERF_K_FFMLP_FWD, s, g_precision != 0);
@@ -1046,6 +1047,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     if (num_hidden < 1 || num_hidden > 3) ENERF_BADARG("mlp32: num_hidden must be 1..3, got %u", num_hidden);
     if (x_layout > 1) ENERF_BADARG("mlp32: x_layout must be 0 (row-major) or 1 (level-major), got %u", x_layout);
     if ((dsigma == nullptr) != (h0 == nullptr)) ENERF_BADARG("mlp32: dsigma and h0 go together");
+    if (int eg = single_device_guard("mlp32_backward")) return eg;
     DySource dys;
     dys.dY = dY;
     dys.stride = dy_stride ? dy_stride : out_dim;

@@ -1826,6 +1826,7 @@ static uint32_t g_march_wave_min_steps = 16u;
 int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float bound, enerf_stream_t stream) {
     if (!grid || C == 0 || H < 2 || (H * H * H) % 8 != 0) ENERF_BADARG("occupied_box_update: bad C=%u H=%u", C, H);
     hipStream_t s = (hipStream_t)stream;
+    if (int eg = single_device_guard("occupied_box_update")) return eg;
     if (int e = workspace_family_enter(0, s)) return e;
     int* keys = (int*)workspace(WS_AABB, 6 * sizeof(int));
     if (!keys) return ENERF_E_NOMEM;

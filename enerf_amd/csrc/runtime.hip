@@ -71,9 +71,13 @@ int workspace_family_enter(int family, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &capturing);
+    // (a capture stream is no "previous user": its work runs when the graph is replayed, not now -- recording an event on
+    // it after the capture has ended would fail.  Graph replays are ordered against side-stream users by the harness:
+    // TrainHarness never runs the side-stream march in graph mode.)
+    if (capturing != hipStreamCaptureStatusNone) return 0;
     // (a stream under graph capture cannot wait for an event of a stream outside the capture; captures start from a
     // drained device -- torch.cuda.graph synchronises first -- so there is nothing in flight to wait for)
-    if (used[dev][family] && last[dev][family] != s && capturing == hipStreamCaptureStatusNone) {
+    if (used[dev][family] && last[dev][family] != s) {
         if (!ev[dev][family] && hipEventCreateWithFlags(&ev[dev][family], hipEventDisableTiming) != hipSuccess) {
             ev[dev][family] = nullptr;
             set_error("workspace_family_enter: hipEventCreate failed");
@@ -87,6 +91,22 @@ int workspace_family_enter(int family, hipStream_t s) {
     }
     used[dev][family] = true;
     last[dev][family] = s;
+    return 0;
+}
+
+// The library's session state -- the table backward's pending record lists and overflow counters, the MLP kernels'
+// valid-row pointer / reduce signal / deferred sums, the marcher's occupied box -- is per PROCESS: one process drives one
+// GPU.  The first device that uses it owns it; a call from another device is refused instead of
+// interleaving two models' sessions.
+int single_device_guard(const char* what) {
+    static int owner = -1;
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (owner < 0) owner = dev;
+    if (owner != dev) {
+        set_error("%s: this process drives device %d (one process per GPU); called with device %d current", what, owner, dev);
+        return ENERF_E_UNSUPPORTED;
+    }
     return 0;
 }
 
