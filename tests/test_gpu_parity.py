@@ -903,3 +903,31 @@ def test_marcher_workspaces_are_ordered_between_streams():
         assert torch.equal(pre["counter"], want_counter)
         for k in want:
             assert torch.equal(pre[k], want[k]), k
+
+
+def test_prof_hooks_time_one_launch_in_n_and_count_their_points():
+    """enerf_prof_sample_every(n): launch k of a family is timed when k % n == 0 (counted from the last reset);
+    enerf_prof_read_units returns the points of the TIMED launches only -- the pair bench.py's roofline is made of."""
+    from enerf_amd import _lib
+    from enerf_amd.backends import _gridencoder as gb
+    from enerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=15,
+                      desired_resolution=512).to(DEV)
+    sizes = [1000, 2000, 3000, 4000, 5000, 6000, 7000]
+    try:
+        _lib.prof.reset()
+        _lib.prof.sample_every(3)
+        _lib.prof.enable(True, only=("grid_fwd",))
+        for n in sizes:
+            with torch.no_grad():
+                enc(torch.rand(n, 3, device=DEV) * 2 - 1, bound=1)
+        torch.cuda.synchronize()
+        ms, timed = _lib.prof.read("grid_fwd")
+        units, seen = _lib.prof.read_units("grid_fwd")
+    finally:
+        _lib.prof.enable(False)
+        _lib.prof.sample_every(1)
+        _lib.prof.reset()
+    assert seen == len(sizes) and timed == 3                       # launches 0, 3, 6
+    assert units == sizes[0] + sizes[3] + sizes[6]
+    assert 0.0 < ms < 50.0
