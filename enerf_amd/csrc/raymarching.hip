@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
         RayCtx c;
         ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
         float t0 = nears[n];
-        if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+        if (perturb) t0 = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t0);   // contracted by the reference's compiler (:351)
         float far = fars[n];
         uint32_t cnt = 0;
         if (occ_keys && !clip_to_occupied(c, occ_keys, far)) {
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(256) k_march_write_w(const float* __restrict__
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
     float t0 = nears[n];
-    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    if (perturb) t0 = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t0);   // contracted by the reference's compiler (:351)
     const uint32_t entries = __builtin_amdgcn_readfirstlane(nlog[n]);
     if (entries != kLogOverflow)
         lattice_replay(c, t0, log + (size_t)n * kLogCap, entries, xyzs + (size_t)point_index * 3,
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ ra
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
     float t0 = nears[n];
-    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    if (perturb) t0 = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t0);   // contracted by the reference's compiler (:351)
     rays[(size_t)n * 3 + 2] = (int32_t)march_one_ray<false>(c, t0, fars[n], max_steps, nullptr, nullptr, nullptr);
 }
 
@@ -898,7 +898,7 @@ __global__ void __launch_bounds__(64) k_march_write(const float* __restrict__ ra
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, dt_gamma, max_steps, C, H);
     float t0 = nears[n];
-    if (perturb) t0 += c.dt_min * pcg_first_float((uint64_t)n, 1u);
+    if (perturb) t0 = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t0);   // contracted by the reference's compiler (:351)
     (void)march_one_ray<true>(c, t0, fars[n], num_steps, xyzs + (size_t)point_index * 3,
                               dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
 }
@@ -1275,7 +1275,7 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     float t = rays_t[n];
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, dt_gamma, max_steps, C, H);
-    if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
+    if (perturb) t = fmaf(c.dt_min, pcg_first_float((uint64_t)n, (uint64_t)perturb), t);   // :744, contracted
     const size_t base = (size_t)n * n_step;
     uint32_t got;
     if (fast) {
@@ -1314,7 +1314,7 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
     float t = rays_t[n];
     RayCtx c;
     ray_ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, grid, bound, 0.0f, max_steps, C, H);
-    if (perturb) t += c.dt_min * pcg_first_float((uint64_t)n, (uint64_t)perturb);
+    if (perturb) t = fmaf(c.dt_min, pcg_first_float((uint64_t)n, (uint64_t)perturb), t);   // :744, contracted
     const size_t base = (size_t)n * n_step;
     uint32_t got;
     if (fast)

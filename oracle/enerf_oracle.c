@@ -6,16 +6,21 @@
  * leg use it, and only as the checker.
  *
  * PARITY STATUS: the reference (knelk/enerf) ships no tests, golden vectors or
- * known-answer fixtures for any of these functions, and its
- * native code is CUDA (needs cuda_fp16.h / mma.h / an un-vendored CUTLASS), so
- * it cannot be compiled in this image (oracle/_ref: unbuildable).  This oracle
- * is therefore pinned by (a) the canonical PCG32 demo stream, (b) golden
- * fixtures minted by importing the reference's *Python* (NeRFRenderer.run
- * compositing, gridencoder/grid.py + shencoder + ffmlp wrappers driven through
- * this oracle, nerf/network.py, train_step_events) -- see oracle/make_golden.py
- * -- and (c) independent second statements (numpy.packbits, sympy real SH,
- * torch autograd).  For march_rays_train / march_rays no second statement
- * exists anywhere: parity for those is "unpinned" beyond this transliteration.
+ * known-answer fixtures for any of these functions.  Pins:
+ * (a) the canonical PCG32 demo stream; (b) golden fixtures minted by importing
+ * the reference's *Python* (NeRFRenderer.run compositing, gridencoder/grid.py +
+ * shencoder + ffmlp wrappers driven through this oracle, nerf/network.py,
+ * train_step_events) -- oracle/make_golden.py; (c) independent second statements
+ * (numpy.packbits, scipy real SH, torch autograd, oracle/march_second.py);
+ * (d) since round 3, the reference's OWN raymarching.cu and shencoder.cu built
+ * for gfx950 (oracle/build_ref.py -> oracle/_ref) and run on an MI355X: every
+ * raymarching entry point and sh_encode fwd/bwd of this file equals the
+ * reference kernel -- bit for bit for the marchers -- on the GPU box
+ * (tests/test_gpu_ref_kernels.py) and against arrays those kernels wrote
+ * (tests/golden/ref_kernels_gfx950.npz, tests/test_oracle_vs_ref_kernels_golden.py).
+ * STILL UNPINNED against the reference's native code: grid_encode_* and ffmlp_*
+ * (gridencoder.cu / ffmlp.cu cannot be built in this image, see build_ref.py);
+ * they rest on (b) and (c).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference).  Floating-point convention: nvcc contracts a*b+c into FMA by
@@ -281,7 +286,8 @@ void orc_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
         if (perturb) {
             orc_pcg32 rng;
             orc_pcg32_seed(&rng, (uint64_t)n, 1u);
-            t0 += c.dt_min * orc_pcg32_next_float(&rng);
+            t0 = fmaf(c.dt_min, orc_pcg32_next_float(&rng), t0);   /* :351 `t0 += dt_min * rng.next_float()`: contracted by the
+                                                                       reference's compiler (seen on oracle/_ref: 1 ulp on ~0.2 % of rays otherwise) */
         }
         /* first pass: count */
         float t = t0, x, y, z, dt, ts = 0;
@@ -413,7 +419,7 @@ void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, co
         if (perturb) {
             orc_pcg32 rng;
             orc_pcg32_seed(&rng, (uint64_t)n, (uint64_t)perturb);   /* :743: seed = slot n, stream = perturb */
-            t += c.dt_min * orc_pcg32_next_float(&rng);
+            t = fmaf(c.dt_min, orc_pcg32_next_float(&rng), t);      /* :744, contracted like :351 */
         }
         float last_t = t, x, y, z, dt, ts = 0;
         uint32_t step = 0;

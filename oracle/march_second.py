@@ -68,7 +68,7 @@ def march_one(o, d, grid_bits, bound, dt_gamma, max_steps, C, H, near, far, pert
     dt_max = F(F(2) * SQRT3 * F(1 << (C - 1)) / F(H))
     t = F(near)
     if perturb:
-        t = F(t + F(dt_min * pcg32_first_float(n, seq)))
+        t = fma(dt_min, pcg32_first_float(n, seq), t)
     steps = 0
     hm1 = F(H - 1)
     while t < F(far) and steps < limit:
@@ -142,7 +142,7 @@ def march_rays_train(rays_o, rays_d, grid_bits, bound, dt_gamma, max_steps, C, H
         dt_min = F(F(2) * SQRT3 / F(max_steps))
         t0 = F(nears[n])
         if perturb:
-            t0 = F(t0 + F(dt_min * pcg32_first_float(n, 1)))
+            t0 = fma(dt_min, pcg32_first_float(n, 1), t0)
         state["t0"] = t0
         march_one(*args, num, emit)                                                # pass 2: write
     return xyzs, dirs, deltas, rays, counter
@@ -161,7 +161,7 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, grid_bits, b
         idx = int(rays_alive[n])
         t0 = F(rays_t[n])
         if perturb:
-            t0 = F(t0 + F(dt_min * pcg32_first_float(n, perturb)))
+            t0 = fma(dt_min, pcg32_first_float(n, perturb), t0)
         row = [n * n_step]
         last = [t0]
 
