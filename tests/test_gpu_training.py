@@ -123,7 +123,11 @@ def test_manual_mse_step_matches_autograd_step(monkeypatch):
     # compare the weights in the mean, the trajectory through the losses
     for n in p0:
         assert float((p0[n] - p1[n]).abs().mean()) <= 1e-3 * float(p0[n].abs().mean()), n
-    assert float(((l0 - l1).abs() / l0.abs().clamp(min=1e-9)).max()) < 1e-4
+    rel = ((l0 - l1).abs() / l0.abs().clamp(min=1e-9))
+    # the first steps agree to rounding; after that the two runs drift apart at the rate the atomics' summation order
+    # allows (the same route run twice does too: 0.6e-4 ... 1.04e-4 at step 40 from run to run)
+    assert float(rel[:10].max()) < 5e-6, rel.tolist()
+    assert float(rel.max()) < 3e-4, rel.tolist()
 
 
 def test_graph_replay_matches_eager_steps():
