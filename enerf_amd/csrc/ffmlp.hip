@@ -143,14 +143,22 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
 #pragma unroll
         for (int t = 0; t < T; t++) {
             apply_act(ao[t], out_act);
-            // rows 0..15 of the tile: registers 0..7 (g = 0, 1): outputs 8*g + 4*h + r
+            // rows 0..15 of the tile: registers 0..7 (g = 0, 1): outputs 8*g + 4*h + r.  The two lanes of a sample trade
+            // pieces (v_permlane32_swap) so that the lower lane holds outputs 0..7 and the upper lane 8..15: one 16-byte
+            // store per lane, every 32-byte row written whole by one instruction (was: two 8-byte stores per lane, each
+            // instruction covering half of every row).
+            x4 q0, q1;
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
-                x4 q;
+            for (int r = 0; r < 4; r++) { q0[r] = (E)ao[t][r]; q1[r] = (E)ao[t][4 + r]; }
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            u32x2_t lo = __builtin_bit_cast(u32x2_t, q0), hi = __builtin_bit_cast(u32x2_t, q1);
 #pragma unroll
-                for (int r = 0; r < 4; r++) q[r] = (E)ao[t][4 * g + r];
-                *reinterpret_cast<x4*>(Y + s[t] * OUT + 8 * g + 4 * h) = q;
+            for (int d = 0; d < 2; d++) {
+                const auto r = __builtin_amdgcn_permlane32_swap(lo[d], hi[d], false, false);
+                lo[d] = r[0];
+                hi[d] = r[1];
             }
+            *reinterpret_cast<u32x4_t*>(Y + s[t] * OUT + 8 * h) = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
         }
     }
 }

@@ -13,6 +13,7 @@ Here both are tensor programs that run where the tensors live (HIP device in pro
 Given the same random draws the results are those of the reference's loops (oracle/event_collate.py restates them;
 tests/test_event_sampler.py).  The draws themselves come from a torch generator instead of numpy's global state.
 """
+import numpy as np
 import torch
 
 from .events import get_event_rays
@@ -149,3 +150,84 @@ def event_pair_rays(tables, track, intrinsics, batch_size, acc_max_num_evs=0, ge
         L.stream_handle()), "event_pair_rays")
     return {"rays_evs_o1": o1[None], "rays_evs_d1": d1[None], "rays_evs_o2": o2[None], "rays_evs_d2": d2[None],
             "pols": pols[None], "start": s_out, "end": e_out, "outside_track": outside}
+
+
+# ------------------------------------------------------------------------------------------------ negative events
+def build_no_event_tables(events, H, W, start_time_us, end_time_us, chunk_len_ms=20.0, rectify_map=None, generator=None,
+                          keep=None):
+    """Where NOTHING happened (`--negative_event_sampling`, nerf/provider.py:1283-1345): the event batch's time span
+    [start_time_us, end_time_us) is cut into N = int(duration_ms / chunk_len_ms) + 1 equal chunks; for every chunk the
+    pixels without an event in it are listed and a random 1/N of them is kept (the reference's memory cap).
+
+    events [n, >=3] rows (x, y, t_ns, ...) on any device (the lists are built where the events live: one scatter into an
+    H*W mask and one nonzero per chunk instead of the host's linspace / fancy-index / np.random.choice);
+    rectify_map [H, W, 2] (x, y) or None for the identity map (esim).  `keep(j, candidates)` overrides the random choice
+    (tests: the reference's own draw).
+    -> {"coords": [N] list of [n_j, 2] float32 (x, y), "start_time_us" / "end_time_us": [N] lists, "N_ev_chunks": N,
+        "dt_us": chunk length}."""
+    ev = events if isinstance(events, torch.Tensor) else torch.as_tensor(np.asarray(events))
+    dev = ev.device
+    dur_ms = end_time_us / 1e3 - start_time_us / 1e3
+    if not end_time_us > start_time_us:
+        raise ValueError("no-event tables: the batch must span a positive time")
+    n_chunks = int(dur_ms / chunk_len_ms) + 1
+    dt_us = 1e3 * dur_ms / n_chunks
+    xs = ev[:, 0].to(torch.int64)
+    ys = ev[:, 1].to(torch.int64)
+    t_us = ev[:, 2].to(torch.float64) * 1e-3
+    out = {"coords": [], "start_time_us": [], "end_time_us": [], "N_ev_chunks": n_chunks, "dt_us": dt_us}
+    ts = float(start_time_us)
+    for j in range(n_chunks):
+        m = (t_us >= ts) & (t_us < ts + dt_us)
+        hit = torch.zeros(H * W, dtype=torch.bool, device=dev)
+        hit[(ys[m] * W + xs[m])] = True
+        cand = torch.nonzero(~hit).squeeze(1)                        # linear pixel index, ascending (the reference's order)
+        n_keep = int(cand.numel() / n_chunks)
+        if keep is not None:
+            sel = torch.as_tensor(keep(j, cand), device=dev, dtype=torch.int64)
+        else:
+            sel = cand[torch.randperm(cand.numel(), device=dev, generator=generator)[:n_keep]]
+        py, px = sel // W, sel % W
+        if rectify_map is not None:
+            rm = rectify_map if isinstance(rectify_map, torch.Tensor) else torch.as_tensor(np.asarray(rectify_map))
+            xy = rm.to(dev)[py, px].to(torch.float32)
+        else:
+            xy = torch.stack([px, py], dim=1).to(torch.float32)
+        if xy.shape[0] == 0:
+            xy = torch.zeros(1, 2, dtype=torch.float32, device=dev)       # the reference's one dummy pixel (:1342-1343)
+        out["coords"].append(xy)
+        out["start_time_us"].append(ts)
+        out["end_time_us"].append(ts + dt_us)
+        ts += dt_us
+    return out
+
+
+def no_event_rays(no_evs, track, intrinsics, batch_size_evs, generator=None, draws=None):
+    """One step's `rays_no_evs_*` entries of collate (nerf/provider.py:1443-1476): N = batch_size_evs / 2 pixels of one
+    random chunk (with replacement), two uniform times inside the chunk in ascending order, the camera at both times
+    (PoseTrack = the reference's Slerp + cubic interp1d, on the device), rays through both poses.
+    `draws` = {"chunk", "idx" [N], "u" [N, 2]} replaces the random draws (tests).
+    -> {"rays_no_evs_o1", "rays_no_evs_d1", "rays_no_evs_o2", "rays_no_evs_d2"} [1, N, 3] (+ "chunk", "tss_us")."""
+    draws = draws or {}
+    n = int(batch_size_evs * 0.5)
+    n_chunks = int(no_evs["N_ev_chunks"])
+    dev = no_evs["coords"][0].device
+    if "chunk" in draws:
+        j = int(draws["chunk"])
+    else:
+        j = int(torch.randint(0, n_chunks, (1,), generator=generator, device=dev if generator is not None else "cpu"))
+    coords = no_evs["coords"][j]
+    if coords.shape[0] == 0:
+        raise ValueError(f"no-event chunk {j} is empty")
+    idx = draws["idx"].to(dev) if "idx" in draws else torch.randint(0, coords.shape[0], (n,), device=dev, generator=generator)
+    u = draws["u"].to(dev, torch.float64) if "u" in draws else torch.rand(n, 2, device=dev, generator=generator,
+                                                                           dtype=torch.float64)
+    t0, t1 = no_evs["start_time_us"][j], no_evs["end_time_us"][j]
+    tss = torch.sort(t0 + (t1 - t0) * u, dim=1).values                # [n, 2] microseconds, ascending per pixel
+    xs = coords[idx, 0].unsqueeze(0)
+    ys = coords[idx, 1].unsqueeze(0)
+    p1 = track.poses_at(tss[:, 0] * 1000).to(dev)                     # the track is in nanoseconds
+    p2 = track.poses_at(tss[:, 1] * 1000).to(dev)
+    r = get_event_rays(xs, ys, p1.unsqueeze(0), p2.unsqueeze(0), intrinsics)
+    return {"rays_no_evs_o1": r["rays_evs_o1"], "rays_no_evs_d1": r["rays_evs_d1"],
+            "rays_no_evs_o2": r["rays_evs_o2"], "rays_no_evs_d2": r["rays_evs_d2"], "chunk": j, "tss_us": tss}

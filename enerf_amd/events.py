@@ -92,6 +92,11 @@ class EventOptions:
         self.event_only = True
         self.weight_loss_rgb = 1.0
         self.render_kwargs = {}
+        # --negative_event_sampling (main_nerf.py; nerf/utils.py:340-345,548): off in every shipped config
+        self.negative_event_sampling = False
+        self.w_no_ev = 1.0
+        self.epoch = 1
+        self.epoch_start_noEvLoss = 0
         self.__dict__.update(kw)
 
 
@@ -126,6 +131,24 @@ def event_loss(image1, image2, pols, opt):
     return loss, delta
 
 
+def no_event_loss(image1, image2, opt):
+    """The no-event term (nerf/utils.py:548-565): where no event fired between two times the (lin-)log intensity may not
+    have changed by more than the contrast threshold: w_no_ev * mean(relu(|L2 - L1| - C)), C = C_thres if > 0 else 0.25.
+    The reference uses lin_log here whatever `linlog` says."""
+    if opt.use_luma:
+        p1 = lin_log(rgb_to_luma(image1, esim=True) * 255, linlog_thres=20)
+        p2 = lin_log(rgb_to_luma(image2, esim=True) * 255, linlog_thres=20)
+    else:
+        p1 = lin_log(image1 * 255, linlog_thres=20)
+        p2 = lin_log(image2 * 255, linlog_thres=20)
+    cno = opt.C_thres if opt.C_thres > 0 else 0.25
+    return opt.w_no_ev * torch.mean(torch.relu(torch.abs(p2 - p1) - cno))
+
+
+def wants_no_event_term(opt):
+    return bool(getattr(opt, "negative_event_sampling", False)) and opt.epoch > opt.epoch_start_noEvLoss
+
+
 def event_loss_with_grads(image1, image2, pols, opt):
     """-> (loss, delta, d loss / d image1, d loss / d image2).  On the device, fp32, C_thres != -1: one launch
     (enerf_event_loss_fwd_bwd, csrc/event_pairs.hip) in place of the ~50 elementwise / reduction launches of
@@ -154,9 +177,10 @@ def event_loss_with_grads(image1, image2, pols, opt):
     return loss.detach(), delta.detach(), g1, g2
 
 
-def train_step_events(model, data, opt, criterion=None, bg_color=None):
-    """One event training step's forward: two renders (+ optional frame render) -> loss.  nerf/utils.py:482-546.
-    `bg_color` [B,1,C] replaces the step's random background draw (tests)."""
+def train_step_events(model, data, opt, criterion=None, bg_color=None, bg_color_no_evs=None):
+    """One event training step's forward: two renders (+ optional frame render, + optional no-event pair of renders)
+    -> loss.  nerf/utils.py:482-573.  `bg_color` / `bg_color_no_evs` [B,1,C] replace the step's random background draws
+    (tests)."""
     images = data["images"]
     B = images.shape[0]
     dev = data["rays_evs_o1"].device
@@ -179,11 +203,17 @@ def train_step_events(model, data, opt, criterion=None, bg_color=None):
         out = model.render(data["rays_o"], data["rays_d"], staged=False, bg_color=bg_color, perturb=True, **kw)
         crit = criterion if criterion is not None else torch.nn.MSELoss(reduction="none")
         loss = loss + opt.weight_loss_rgb * crit(out["image"], gt).mean()
+    if wants_no_event_term(opt):
+        # two more renders at pixels / times without events, a fresh background draw (nerf/utils.py:548-565)
+        bg_no = torch.rand((B, 1, opt.out_dim_color), device=dev) if bg_color_no_evs is None else bg_color_no_evs
+        n1 = model.render(data["rays_no_evs_o1"], data["rays_no_evs_d1"], staged=False, bg_color=bg_no, perturb=True, **kw)
+        n2 = model.render(data["rays_no_evs_o2"], data["rays_no_evs_d2"], staged=False, bg_color=bg_no, perturb=True, **kw)
+        loss = loss + no_event_loss(n1["image"], n2["image"], opt)
     return loss, delta
 
 
 def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None, defer_table=False,
-                             after_mlp_backward=None):
+                             after_mlp_backward=None, bg_color_no_evs=None):
     """The event-only step with the two renders driven without autograd (fused_render.render_train_raw /
     backward_raw): only the loss itself -- a few elementwise ops on two [N,3] images -- goes through autograd, and its
     gradient is handed to the renders' closed backward.  Same values as train_step_events + loss.backward()
@@ -198,9 +228,27 @@ def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None
     shape = data["rays_evs_o1"].shape[:-1]
     img1, ctx1 = fr.render_train_raw(model, data["rays_evs_o1"], data["rays_evs_d1"], bg, True, **kw)
     img2, ctx2 = fr.render_train_raw(model, data["rays_evs_o2"], data["rays_evs_d2"], bg, True, **kw)
+    ctxs = [ctx1, ctx2]
+    no_ev = wants_no_event_term(opt)
+    if no_ev:
+        # the no-event pair of renders (nerf/utils.py:548-551): same closed-form route, its own background draw
+        bg_no = torch.rand((B, 1, opt.out_dim_color), device=dev) if bg_color_no_evs is None else bg_color_no_evs
+        nshape = data["rays_no_evs_o1"].shape[:-1]
+        img3, ctx3 = fr.render_train_raw(model, data["rays_no_evs_o1"], data["rays_no_evs_d1"], bg_no, True, **kw)
+        img4, ctx4 = fr.render_train_raw(model, data["rays_no_evs_o2"], data["rays_no_evs_d2"], bg_no, True, **kw)
+        ctxs += [ctx3, ctx4]
     if after_forward is not None:
         after_forward()                                 # e.g. the next step's two marches on a side stream
     loss, delta, g1, g2 = event_loss_with_grads(img1.view(*shape, 3), img2.view(*shape, 3), data["pols"], opt)
+    grads = [g1, g2]
+    if no_ev:
+        a = img3.view(*nshape, 3).detach().requires_grad_(True)
+        b = img4.view(*nshape, 3).detach().requires_grad_(True)
+        with torch.enable_grad():
+            loss_no = no_event_loss(a, b, opt)
+            g3, g4 = torch.autograd.grad(loss_no, [a, b])
+        loss = loss + loss_no.detach()
+        grads += [g3, g4]
     params = fnet.network_params(model)
     emb = params[0]
     keep = emb.grad if defer_table else None            # (deferred flush: the dense buffer is kept, and kept clean)
@@ -208,16 +256,20 @@ def train_step_events_manual(model, data, opt, after_forward=None, bg_color=None
         p.grad = None
     if defer_table:
         emb.grad = keep if keep is not None else torch.zeros_like(emb)
-    # defer_table: both renders' table gradients stay record lists for FusedAdam.step_grid_table (one flush)
-    total = (ctx1["M"] + ctx2["M"]) if defer_table else 0
-    g_emb, dw1 = fr.backward_raw(ctx1, g_image=g1, raw=True, defer_table=total)
-    if g_emb is not None:
-        emb.grad = g_emb                                # the second backward adds straight into it ...
-    g_emb2, dw2 = fr.backward_raw(ctx2, g_image=g2, raw=True, defer_table=total, after_mlp=after_mlp_backward)
-    if g_emb2 is not None:                              # ... unless it could not (then it returns its own buffer)
-        emb.grad.add_(g_emb2)
-    dw1 += dw2
+    # defer_table: every render's table gradients stay record lists for FusedAdam.step_grid_table (one flush)
+    total = sum(c["M"] for c in ctxs) if defer_table else 0
+    dw = None
+    for i, (c, g) in enumerate(zip(ctxs, grads)):
+        last = i == len(ctxs) - 1
+        g_emb, dwi = fr.backward_raw(c, g_image=g, raw=True, defer_table=total,
+                                     after_mlp=after_mlp_backward if last else None)
+        if g_emb is not None:                           # the first backward's buffer; later ones add straight into it
+            if emb.grad is None:                        # ... unless they could not (then they return their own)
+                emb.grad = g_emb
+            else:
+                emb.grad.add_(g_emb)
+        dw = dwi if dw is None else dw.add_(dwi)
     kind = ctx1["sv"]["kind"]
-    for p, g in zip(params[1:], fnet.unpack_weight_grads(dw1, ctx1["sv"]["out_c"], kind)):
+    for p, g in zip(params[1:], fnet.unpack_weight_grads(dw, ctx1["sv"]["out_c"], kind)):
         p.grad = g.view_as(p)
     return loss.detach(), delta

@@ -818,7 +818,9 @@ class TrainHarness:
             self.model.train()
         self.maybe_update_extra_state()
         self.global_step += 1
-        if opt.event_only and self._graphable(data["rays_evs_o1"], data["rays_evs_d1"]):
+        from .events import wants_no_event_term
+        no_ev = wants_no_event_term(opt)                 # two more renders per step: neither graphs nor the one-call step
+        if opt.event_only and not no_ev and self._graphable(data["rays_evs_o1"], data["rays_evs_d1"]):
             names = ("images", "rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols")
             key = self._graph_key("events", data["rays_evs_o1"])
             inputs = tuple(data[n] for n in names)
@@ -840,7 +842,7 @@ class TrainHarness:
             return loss.detach()
         if self._events_manual_ok(data, opt):
             from .events import train_step_events_manual
-            if (self.native_step and self.fuse_table_adam and self.avg is None and not self.use_graphs
+            if (self.native_step and self.fuse_table_adam and self.avg is None and not self.use_graphs and not no_ev
                     and self.prefetch_at == "mlp_backward" and hasattr(self.opt, "grid_table_plan")
                     and getattr(self.model, "graph_counter", None) is None):
                 from . import fused_render

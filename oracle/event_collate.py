@@ -6,6 +6,12 @@
                                                   polarity sum) -- with the uniform draws passed in instead of taken
                                                   from numpy's global generator
 
+  no_event_tables    nerf/provider.py:1283-1351   --negative_event_sampling: per 20 ms chunk of an event batch, the pixels
+                                                  without an event, subsampled to 1 / N_chunks of them
+  no_event_rays      nerf/provider.py:1443-1476   the per-step no-event entries of collate: pixels of one chunk, two
+                                                  sorted uniform times, scipy Slerp / cubic interp1d poses, get_event_rays
+                                                  (draws passed in)
+
 Parity status: "unpinned" against a run of the reference itself -- EventNeRFDataset needs its dataset files on disk to
 be constructed; these functions are a line-by-line transcription, checked against an independent brute-force
 definition in tests/test_event_sampler.py.
@@ -112,3 +118,63 @@ def slicer_window(t_us, ms_to_idx, t_start_us, t_end_us, t_offset=0):
         else:
             break
     return a + i0, a + i1
+
+
+def no_event_tables(evs_batch_ns, coords, H_ev, W_ev, start_time_us, end_time_us, rectify_map, choice, chunk_len_ms=20):
+    """provider.py:1283-1351 for ONE event batch.  evs_batch_ns [n, >=3] (x, y, t_ns, ...), coords [n, 2] the pixel
+    coordinates used for the lookup (:1305-1306), rectify_map [H, W, 2].  `choice(j, idxs, size)` stands for
+    np.random.choice(idxs, size=size, replace=False) (:1327)."""
+    out = {"coords": [], "tss_bds": {"N_ev_chunks": [], "start_time_us": [], "end_time_us": [], "dt_us": []}}
+    assert end_time_us > start_time_us
+    dur_ms = end_time_us / 1e3 - start_time_us / 1e3                                # :1299
+    N_ev_chunks = int(dur_ms / chunk_len_ms) + 1                                    # :1302
+    dt_us = 1e3 * dur_ms / N_ev_chunks
+    xsall = coords[:, 0].astype(np.uint32)
+    ysall = coords[:, 1].astype(np.uint32)
+    ts_iter = start_time_us
+    for j in range(N_ev_chunks):
+        ts_mask = (evs_batch_ns[:, 2] * 1e-3 >= ts_iter) & (evs_batch_ns[:, 2] * 1e-3 < (ts_iter + dt_us))   # :1309
+        xstmp, ystmp = xsall[ts_mask], ysall[ts_mask]
+        idxs_no_evs = np.linspace(1, H_ev * W_ev, H_ev * W_ev).astype(np.uint32)    # :1316
+        idxs_evs = ystmp * W_ev + xstmp
+        idxs_no_evs[idxs_evs] = 0
+        N_noevs = (idxs_no_evs > 0).sum()
+        idxs_no_evs = idxs_no_evs[idxs_no_evs > 0]
+        idxs_no_evs = choice(j, idxs_no_evs, int(N_noevs / N_ev_chunks))            # :1327
+        N_noevs = (idxs_no_evs > 0).sum()
+        ys, xs = (idxs_no_evs - 1) // W_ev, (idxs_no_evs - 1) % W_ev                # :1331
+        rect = rectify_map[ys, xs]
+        no_evs_batch = np.zeros((N_noevs, 2))
+        no_evs_batch[:, 0] = rect[:, 0]
+        no_evs_batch[:, 1] = rect[:, 1]
+        if len(no_evs_batch) == 0:
+            no_evs_batch = np.zeros((1, 2))                                          # :1342
+        out["coords"].append(no_evs_batch.astype(np.float32))                        # (float32 cast: :1231-1232)
+        out["tss_bds"]["start_time_us"].append(ts_iter)
+        out["tss_bds"]["end_time_us"].append(ts_iter + dt_us)
+        ts_iter += dt_us
+    out["tss_bds"]["N_ev_chunks"].append(N_ev_chunks)
+    out["tss_bds"]["dt_us"].append(dt_us)
+    return out
+
+
+def no_event_rays(no_evs, rot_interpolator, trans_interpolator, get_event_rays, intrinsics, batch_size_evs, chunk_j, neidx,
+                  u01):
+    """provider.py:1443-1476 with the three random draws (chunk, pixel indices, the [N, 2] uniforms) passed in.
+    rot_interpolator / trans_interpolator: scipy Slerp / interp1d(kind="cubic") over the pose track in nanoseconds."""
+    import torch
+    N_noevs = int(batch_size_evs * 0.5)
+    assert len(neidx) == N_noevs and u01.shape == (N_noevs, 2)
+    c = torch.from_numpy(np.asarray(no_evs["coords"][chunk_j], dtype=np.float32))
+    xsno = c[neidx, 0].unsqueeze(0)
+    ysno = c[neidx, 1].unsqueeze(0)
+    t0, t1 = no_evs["tss_bds"]["start_time_us"][chunk_j], no_evs["tss_bds"]["end_time_us"][chunk_j]
+    tss = np.sort(t0 + (t1 - t0) * u01, axis=1)                                      # :1457-1458
+    poses = []
+    for col in (0, 1):
+        ts_ns = tss[:, col] * 1000                                                   # :1461 / :1467
+        rots = rot_interpolator(ts_ns).as_matrix()
+        trans = trans_interpolator(ts_ns)
+        hom = np.concatenate([rots, trans[:, :, None]], axis=2)                      # get_hom_trafos(...)[:, :3, :]
+        poses.append(torch.from_numpy(hom.astype(np.float32)))
+    return get_event_rays(xsno, ysno, poses[0].unsqueeze(0), poses[1].unsqueeze(0), intrinsics), tss

@@ -278,6 +278,68 @@ def gold_events():
          rays_d=full["rays_d"], xs=xs, ys=ys, c2w_b=c2w_b, c2w_a=c2w_a, **{k: v for k, v in ev.items()})
 
 
+def gold_no_events():
+    """`--negative_event_sampling` (nerf/utils.py:548-565): Trainer.train_step_events with the no-event pair of renders on,
+    event-only and with the frame render, C_thres > 0 and = -1 (Cno falls back to 0.25), luma and RGB; and with the term
+    gated off by epoch_start_noEvLoss.  The fake model hands out img1, img2, img3, img1, ... per render call."""
+    import argparse as ap
+    from nerf.utils import Trainer
+
+    g = torch.Generator().manual_seed(171)
+    B, N, Nn = 1, 48, 24
+    img1 = torch.rand(B, N, 3, generator=g)
+    img2 = (img1 + 0.3 * (torch.rand(B, N, 3, generator=g) - 0.5)).clamp(0, 1)
+    img3 = torch.rand(B, N, 3, generator=g) * 0.1
+    pols = torch.sign(torch.rand(B, N, generator=g) - 0.5)
+    frames = torch.rand(B, N, 3, generator=g)
+    imgs = [img1, img2, img3]
+
+    class FakeModel:
+        def __init__(self):
+            self.calls, self.last = 0, []
+
+        def render(self, o, d, **kw):
+            im = imgs[self.calls % 3][:, : o.shape[1]].clone().requires_grad_(True)
+            self.calls += 1
+            self.last.append(im)
+            return {"image": im, "depth": im[..., 0]}
+
+    results = {}
+    cfgs = {
+        "neg_luma": dict(use_luma=1, C_thres=0.2, event_only=1, w_no_ev=0.7, epoch=2, start=0),
+        "neg_rgb": dict(use_luma=0, C_thres=0.2, event_only=1, w_no_ev=1.0, epoch=2, start=0),
+        "neg_normed": dict(use_luma=1, C_thres=-1, event_only=1, w_no_ev=2.0, epoch=2, start=0),
+        "neg_both": dict(use_luma=1, C_thres=0.2, event_only=0, w_no_ev=0.7, epoch=2, start=0),
+        "neg_gated": dict(use_luma=1, C_thres=0.2, event_only=1, w_no_ev=0.7, epoch=1, start=1),
+    }
+    for name, c in cfgs.items():
+        t = Trainer.__new__(Trainer)
+        t.device = torch.device("cpu")
+        t.out_dim_color = 3
+        t.use_luma, t.linlog, t.C_thres, t.event_only = c["use_luma"], 1, c["C_thres"], c["event_only"]
+        t.log_implicit_C_thres = False
+        t.negative_event_sampling = True
+        t.w_no_ev = c["w_no_ev"]
+        t.weight_loss_rgb = 1.0
+        t.epoch, t.epoch_start_noEvLoss = c["epoch"], c["start"]
+        t.criterion = torch.nn.MSELoss(reduction="none")
+        t.opt = ap.Namespace()
+        t.model = FakeModel()
+        z, zn = torch.zeros(B, N, 3), torch.zeros(B, Nn, 3)
+        data = {"images": frames, "rays_evs_o1": z, "rays_evs_d1": z, "rays_evs_o2": z, "rays_evs_d2": z, "pols": pols,
+                "rays_o": z, "rays_d": z, "rays_no_evs_o1": zn, "rays_no_evs_d1": zn, "rays_no_evs_o2": zn,
+                "rays_no_evs_d2": zn}
+        delta, gt_pol, loss, _, losses = t.train_step_events(data)
+        loss.backward()
+        results[f"{name}_loss"] = loss
+        results[f"{name}_delta"] = delta
+        results[f"{name}_loss_no_evs"] = torch.as_tensor(float(losses["loss_no_evs"]))
+        results[f"{name}_calls"] = np.int64(t.model.calls)
+        for i, im in enumerate(t.model.last):
+            results[f"{name}_g{i}"] = im.grad if im.grad is not None else torch.zeros_like(im)
+    save("ref_no_event_loss", img1=img1, img2=img2, img3=img3, pols=pols, frames=frames, Nn=np.int64(Nn), **results)
+
+
 def gold_misc():
     from activation import trunc_exp
     from encoding import FreqEncoder
@@ -479,7 +541,7 @@ def main():
     ref_import.install()
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
-            gold_composite_vs_run, gold_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
+            gold_composite_vs_run, gold_events, gold_no_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
             gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint]
     for j in jobs:
         if a.only and a.only not in j.__name__:

@@ -251,3 +251,102 @@ def test_esim_loader_batches_and_polarities(tmp_path):
     signed[0, 3] = -1
     np.save(tmp_path / "0000.npy", signed)
     assert np.array_equal(load_esim_event_batches(str(tmp_path), [0], hwf=(48, 64, 1.0))[0][:, 3], signed[:, 3])
+
+
+# ------------------------------------------------------------------------------------------------ negative events
+def _no_event_case(seed, W=40, H=30, n=6000, dur_ms=57.0):
+    rng = np.random.default_rng(seed)
+    t0_us = 1.0e6
+    ts_ns = np.sort(rng.uniform(t0_us * 1e3, (t0_us + dur_ms * 1e3) * 1e3, n))
+    ev = np.stack([rng.integers(0, W, n), rng.integers(0, H, n), ts_ns, rng.choice([-1.0, 1.0], n)], 1)
+    rect = np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=2).astype(np.float64) + 0.25      # a "rectified" map
+    return ev, rect, W, H, t0_us, t0_us + dur_ms * 1e3
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_no_event_tables_match_the_reference_loop(device):
+    """build_no_event_tables (one scatter + one nonzero per chunk, where the events live) against the restated loop of
+    nerf/provider.py:1283-1351 with the same subsampling draw; float64 event times (ns) as the loader holds them."""
+    from enerf_amd.event_sampler import build_no_event_tables
+    ev, rect, W, H, t0, t1 = _no_event_case(3)
+    picks = {}
+
+    def choice(j, idxs, size):
+        picks[j] = np.random.default_rng(100 + j).choice(idxs, size=size, replace=False)
+        return picks[j]
+
+    ref = EC.no_event_tables(ev, ev[:, :2], H, W, t0, t1, rect, choice)
+    assert ref["tss_bds"]["N_ev_chunks"][0] == 3                       # 57 ms -> three 19 ms chunks
+    got = build_no_event_tables(torch.from_numpy(ev).to(device), H, W, t0, t1, rectify_map=rect,
+                                keep=lambda j, cand: torch.from_numpy(picks[j].astype(np.int64) - 1))
+    assert got["N_ev_chunks"] == 3 and abs(got["dt_us"] - ref["tss_bds"]["dt_us"][0]) < 1e-9
+    for j in range(3):
+        assert np.array_equal(got["coords"][j].cpu().numpy(), ref["coords"][j])
+        assert got["start_time_us"][j] == ref["tss_bds"]["start_time_us"][j]
+        assert got["end_time_us"][j] == ref["tss_bds"]["end_time_us"][j]
+    # the candidates themselves (before subsampling) are exactly the pixels without an event in the chunk, ascending
+    seen = []
+    build_no_event_tables(torch.from_numpy(ev).to(device), H, W, t0, t1,
+                          keep=lambda j, cand: (seen.append(cand.cpu().numpy()), cand[:5])[1])
+    for j in range(3):
+        lo, hi = ref["tss_bds"]["start_time_us"][j], ref["tss_bds"]["end_time_us"][j]
+        m = (ev[:, 2] * 1e-3 >= lo) & (ev[:, 2] * 1e-3 < hi)
+        hit = np.zeros(H * W, bool); hit[(ev[m, 1] * W + ev[m, 0]).astype(np.int64)] = True
+        assert np.array_equal(seen[j], np.nonzero(~hit)[0])
+    # its own random choice: the right number, no duplicates, all event-free
+    own = build_no_event_tables(torch.from_numpy(ev).to(device), H, W, t0, t1)
+    for j in range(3):
+        c = own["coords"][j].cpu().numpy().astype(np.int64)
+        lin = c[:, 1] * W + c[:, 0]
+        assert len(lin) == int(len(seen[j]) / 3) and len(np.unique(lin)) == len(lin) and np.isin(lin, seen[j]).all()
+
+
+def test_no_event_tables_degenerate_chunk_keeps_the_dummy_pixel():
+    from enerf_amd.event_sampler import build_no_event_tables
+    W, H = 4, 3
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    ev = np.stack([xs.ravel(), ys.ravel(), np.linspace(1e9, 1.004e9, W * H), np.ones(W * H)], 1)   # every pixel fires
+    got = build_no_event_tables(torch.from_numpy(ev), H, W, 1e6, 1.005e6)
+    assert got["N_ev_chunks"] == 1 and got["coords"][0].shape == (1, 2) and float(got["coords"][0].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_no_event_rays_match_the_reference_collate_with_scipy_poses(device):
+    """no_event_rays against provider.py:1443-1476 restated with the reference's own scipy interpolators and the
+    reference-pinned get_event_rays, same draws."""
+    from scipy.interpolate import interp1d
+    from scipy.spatial.transform import Slerp
+    from enerf_amd.event_sampler import build_no_event_tables, no_event_rays
+    from enerf_amd.events import get_event_rays
+    from enerf_amd.pose_interp import PoseTrack
+    ev, rect, W, H, t0, t1 = _no_event_case(5)
+    t, R, p = _track(50, t0 * 1e3 - 5e6, t1 * 1e3 + 5e6, 8)            # nanoseconds, covering the batch
+    picks = {}
+
+    def choice(j, idxs, size):
+        picks[j] = np.random.default_rng(7 + j).choice(idxs, size=size, replace=False)
+        return picks[j]
+
+    ref_tab = EC.no_event_tables(ev, ev[:, :2], H, W, t0, t1, rect, choice)
+    tab = build_no_event_tables(torch.from_numpy(ev).to(device), H, W, t0, t1, rectify_map=rect,
+                                keep=lambda j, cand: torch.from_numpy(picks[j].astype(np.int64) - 1))
+    rng = np.random.default_rng(11)
+    B = 512
+    intr = (35.0, 34.0, 19.5, 14.5)
+    track = PoseTrack(t, R.as_matrix(), p, device=device)
+    for chunk in (0, 2):
+        neidx = rng.integers(0, len(ref_tab["coords"][chunk]), B // 2)
+        u = rng.random((B // 2, 2))
+        ref, tss = EC.no_event_rays(ref_tab, Slerp(t, R), interp1d(x=t, y=p, axis=0, kind="cubic", bounds_error=True),
+                                    get_event_rays, intr, B, chunk, neidx, u)
+        got = no_event_rays(tab, track, intr, B, draws={"chunk": chunk, "idx": torch.from_numpy(neidx),
+                                                       "u": torch.from_numpy(u)})
+        assert np.allclose(got["tss_us"].cpu().numpy(), tss, rtol=0, atol=1e-6)
+        for a, b in (("rays_no_evs_o1", "rays_evs_o1"), ("rays_no_evs_d1", "rays_evs_d1"),
+                     ("rays_no_evs_o2", "rays_evs_o2"), ("rays_no_evs_d2", "rays_evs_d2")):
+            assert got[a].shape == (1, B // 2, 3)
+            np.testing.assert_allclose(got[a].cpu().numpy(), ref[b].numpy(), rtol=2e-6, atol=2e-6)
+    own = no_event_rays(tab, track, intr, B)                           # its own draws: shapes, chunk range, ordered times
+    assert 0 <= own["chunk"] < 3 and bool((own["tss_us"][:, 0] <= own["tss_us"][:, 1]).all())
+    lo, hi = tab["start_time_us"][own["chunk"]], tab["end_time_us"][own["chunk"]]
+    assert float(own["tss_us"].min()) >= lo and float(own["tss_us"].max()) <= hi

@@ -466,6 +466,56 @@ def test_event_step_with_closed_render_backward_matches_autograd_step(monkeypatc
         assert float((p0[n] - p1[n]).abs().mean()) <= 2e-3 * float(p0[n].abs().mean()), n
 
 
+def test_event_step_with_negative_event_sampling_closed_form_matches_autograd(monkeypatch):
+    """--negative_event_sampling: the step makes FOUR training renders (event pair + no-event pair, nerf/utils.py:482-565).
+    The closed-form route (all four without autograd, record lists of all four flushed once into the tile Adam) against
+    the autograd route: same counters, first losses to rounding, trajectory and weights as the two-render test; and the
+    no-event term is really in the loss (a run with the term gated off differs)."""
+    from enerf_amd import events
+    from enerf_amd.events import EventOptions
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 2048, 2)
+    calls = []
+    orig = events.train_step_events_manual
+    monkeypatch.setattr(events, "train_step_events_manual", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+
+    def batch(i):
+        ro, rd, tg = data[i % len(data)]
+        ro2, rd2, _ = data[(i + 1) % len(data)]
+        ro3, rd3, _ = data[(i + 2) % len(data)]
+        ro4, rd4, _ = data[(i + 3) % len(data)]
+        v = lambda x, n: x.view(1, -1, 3)[:, :n].contiguous()
+        return {"images": tg.view(1, -1, 3), "rays_evs_o1": v(ro, 2048), "rays_evs_d1": v(rd, 2048),
+                "rays_evs_o2": v(ro2, 2048), "rays_evs_d2": v(rd2, 2048), "pols": torch.sign(tg[..., 0] - 0.5).view(1, -1),
+                "rays_no_evs_o1": v(ro3, 1024), "rays_no_evs_d1": v(rd3, 1024), "rays_no_evs_o2": v(ro4, 1024),
+                "rays_no_evs_d2": v(rd4, 1024)}
+
+    def run(manual, opt, steps=24):
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        h.manual_mse = manual
+        torch.manual_seed(3)
+        losses = [h.step_events(batch(i), opt).clone() for i in range(steps)]
+        return (torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
+                {n: p.detach().clone() for n, p in model.named_parameters()})
+
+    on = dict(C_thres=0.05, use_luma=True, linlog=True, event_only=True, negative_event_sampling=True, w_no_ev=5.0,
+              epoch=2, epoch_start_noEvLoss=0)
+    l0, c0, p0 = run(False, EventOptions(**on))
+    assert not calls
+    l1, c1, p1 = run(True, EventOptions(**on))
+    assert len(calls) == 24
+    assert torch.equal(c0, c1)                                   # four renders per step on both routes, same samples
+    rel = (l0 - l1).abs() / l0.abs().clamp(min=1e-9)
+    assert float(rel[:4].max()) < 1e-5 and float(rel.max()) < 3e-4, rel.tolist()
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().mean()) <= 2e-3 * float(p0[n].abs().mean()), n
+    l2, c2, _ = run(True, EventOptions(**dict(on, epoch=0)))     # gated off: two renders per step, a different loss
+    assert float((l2[0] - l1[0]).abs()) > 1e-4 * float(l1[0].abs())
+
+
 def test_long_run_with_learned_occupancy_converges():
     """600 steps with the occupancy grid maintained by update_extra_state itself (not the analytic one): through the 16
     full sweeps and into the partial-update regime, with the closed-form step, the side-stream march and the device-side

@@ -242,3 +242,48 @@ def test_state_dict_layout_matches_reference(which, bound):
     assert not missing and not unexpected
     for k, v in model.state_dict().items():
         assert torch.equal(v, ckpt[k]), k
+
+
+NEG_CFG = {
+    "neg_luma": dict(use_luma=1, C_thres=0.2, event_only=1, w_no_ev=0.7, epoch=2, epoch_start_noEvLoss=0),
+    "neg_rgb": dict(use_luma=0, C_thres=0.2, event_only=1, w_no_ev=1.0, epoch=2, epoch_start_noEvLoss=0),
+    "neg_normed": dict(use_luma=1, C_thres=-1, event_only=1, w_no_ev=2.0, epoch=2, epoch_start_noEvLoss=0),
+    "neg_both": dict(use_luma=1, C_thres=0.2, event_only=0, w_no_ev=0.7, epoch=2, epoch_start_noEvLoss=0),
+    "neg_gated": dict(use_luma=1, C_thres=0.2, event_only=1, w_no_ev=0.7, epoch=1, epoch_start_noEvLoss=1),
+}
+
+
+@pytest.mark.parametrize("name", list(NEG_CFG))
+def test_event_step_with_negative_event_sampling(name):
+    """--negative_event_sampling (nerf/utils.py:548-565): the no-event pair of renders and its hinge on the (lin-)log
+    intensity change, against the reference's own Trainer.train_step_events (loss, delta, the gradient reaching every
+    render's image, how many renders were made)."""
+    from enerf_amd.events import EventOptions, train_step_events
+    g = golden("ref_no_event_loss")
+    imgs = [t(g["img1"]), t(g["img2"]), t(g["img3"])]
+
+    class FakeModel:
+        def __init__(self):
+            self.calls, self.last = 0, []
+
+        def render(self, o, d, **kw):
+            im = imgs[self.calls % 3][:, : o.shape[1]].clone().requires_grad_(True)
+            self.calls += 1
+            self.last.append(im)
+            return {"image": im, "depth": im[..., 0]}
+
+    opt = EventOptions(negative_event_sampling=True, linlog=True, **NEG_CFG[name])
+    m = FakeModel()
+    B, N = g["pols"].shape
+    z, zn = torch.zeros(B, N, 3), torch.zeros(B, int(g["Nn"]), 3)
+    data = {"images": t(g["frames"]), "rays_evs_o1": z, "rays_evs_d1": z, "rays_evs_o2": z, "rays_evs_d2": z,
+            "pols": t(g["pols"]), "rays_o": z, "rays_d": z, "rays_no_evs_o1": zn, "rays_no_evs_d1": zn,
+            "rays_no_evs_o2": zn, "rays_no_evs_d2": zn}
+    loss, delta = train_step_events(m, data, opt)
+    loss.backward()
+    assert m.calls == int(g[f"{name}_calls"])
+    assert_close(loss, g[f"{name}_loss"], rtol=1e-6, atol=1e-7)
+    assert_close(delta, g[f"{name}_delta"], rtol=1e-6, atol=1e-7)
+    for i, im in enumerate(m.last):
+        gi = im.grad if im.grad is not None else torch.zeros_like(im)
+        assert_close(gi, g[f"{name}_g{i}"], rtol=1e-5, atol=1e-8)
