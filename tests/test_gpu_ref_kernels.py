@@ -263,6 +263,58 @@ def test_reference_inference_loop_equals_oracle(ref, scenes):
     assert_close(g_dp, dp, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("bound,N,perturb", [(3, 65536, 1), (2, 307200, 0)])
+def test_reference_march_at_full_sizes_equals_product(ref, prod, scenes, bound, N, perturb):
+    """BASELINE's largest shapes -- configs[3]'s 65 536 rays (bound 3) and configs[4]'s 640 x 480 = 307 200 rays (bound 2,
+    23 M samples) -- marched by the reference's kernel and by the product's: every ray's sample count and every sample
+    bit for bit (no oracle in between: it would take minutes at this size; the oracle is held to the same kernel at 4096
+    rays above), then composited by both (1e-5)."""
+    rm, pm = ref["rm"], prod["_raymarching"]
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(N, 900 + bound, bound)
+    co, cd, cb = cu(o), cu(d), cu(bits)
+    nears, fars = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    rm.near_far_from_aabb(co, cd, cu(aabb), N, 0.2, nears, fars)
+    M = N * 128
+    outs = []
+    for mod in (rm, pm):
+        xyzs, deltas = torch.zeros(M, 3, device=DEV), torch.zeros(M, 2, device=DEV)
+        dirs = torch.zeros(M, 3, device=DEV)
+        rays = torch.full((N, 3), -1, dtype=torch.int32, device=DEV)
+        counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        mod.march_rays_train(co, cd, cb, float(bound), 0.0, 1024, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                             perturb)
+        outs.append((xyzs, deltas, rays, counter))
+        del dirs
+    (x_r, l_r, rays_r, c_r), (x_p, l_p, rays_p, c_p) = outs
+    assert torch.equal(c_r, c_p) and int(c_r[0]) + 128 < M and int(c_r[0]) > 30 * N
+    # canonical order on the device: sort the reference's table by ray, gather each ray's rows
+    order = torch.argsort(rays_r[:, 0].long(), stable=True)
+    tr = rays_r[order].long()
+    tp = rays_p.long()
+    assert torch.equal(tr[:, 0], torch.arange(N, device=DEV)) and torch.equal(tp[:, 0], tr[:, 0])
+    assert torch.equal(tr[:, 2], tp[:, 2])                                          # per-ray sample counts
+    tot = int(c_r[0])
+    ray_of_row = torch.repeat_interleave(torch.arange(N, device=DEV), tp[:, 2])      # product rows are in ray order
+    within = torch.arange(tot, device=DEV) - tp[ray_of_row, 1]
+    rows_r = tr[ray_of_row, 1] + within
+    assert torch.equal(x_r[rows_r], x_p[:tot]) and torch.equal(l_r[rows_r], l_p[:tot])
+    # compositing of the same samples by both (each on its own table / row order)
+    m = tot + 128 - tot % 128
+    g = torch.Generator(device=DEV).manual_seed(5)
+    sig_p = torch.rand(m, device=DEV, generator=g) * 25
+    rgb_p = torch.rand(m, 3, device=DEV, generator=g)
+    sig_r, rgb_r = torch.zeros(M, device=DEV), torch.zeros(M, 3, device=DEV)
+    sig_r[rows_r] = sig_p[:tot]; rgb_r[rows_r] = rgb_p[:tot]
+    res = []
+    for mod, sig, rgb, dl, rays, mm in ((rm, sig_r, rgb_r, l_r, rays_r, M), (pm, sig_p, rgb_p, l_p[:m].contiguous(), rays_p, m)):
+        ws, dp, im = torch.empty(N, device=DEV), torch.empty(N, device=DEV), torch.empty(N, 3, device=DEV)
+        mod.composite_rays_train_forward(sig, rgb, dl, rays, mm, N, ws, dp, im)
+        res.append((ws, dp, im))
+    for a, b in zip(res[0], res[1]):
+        assert_close(b, a.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_reference_sh_encode_equals_oracle_and_product(ref, prod, degree):
     sh, ps = ref["sh"], prod["_shencoder"]
