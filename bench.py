@@ -81,6 +81,9 @@ def parse():
                     help="tuning: where the next batch's march is released on the side stream (default: the harness's)")
     ap.add_argument("--no-live-timing", action="store_true",
                     help="tuning: no hipEvent timing inside the timed region (the line then carries no `roofline`)")
+    ap.add_argument("--no-early-budget", action="store_true",
+                    help="A/B switch: update_extra_state waits for its own read-back before the step is queued (the route "
+                         "before TrainHarness.early_budget)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not march the next batch early (side stream under the backward / gradient all-reduce)")
     ap.add_argument("--time-every", type=int, default=4,
@@ -287,6 +290,7 @@ def main():
         args.probe_steps = 0
         args.graph_leg_steps = 0
     harness.prefetch = not args.no_prefetch
+    harness.early_budget = not args.no_early_budget
     if args.prefetch_at:
         harness.prefetch_at = args.prefetch_at
     if args.comm_bf16:

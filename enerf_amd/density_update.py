@@ -35,6 +35,7 @@ def _sigmas(model, xyzs):
 @torch.no_grad()
 def update(model, decay=0.95, split=False):
     """One update_extra_state: density grid EMA, bitfield, mean_density, mean_count, counters reset."""
+    resolve_pending(model)                       # (an earlier update's mean_density, long since on the host)
     lib = L.lib()
     stream = L.stream_handle()
     dev = model.density_grid.device
@@ -90,11 +91,35 @@ def update_begin(model, decay=0.95):
     return update(model, decay, split=True)
 
 
-def update_end(model, handle):
-    """Wait for the update's 16 bytes and set mean_density / mean_count."""
+def update_end(model, handle, early=None):
+    """Wait for the update's 16 bytes and set mean_density / mean_count.  `early` = (mean_count or None, total_step) from
+    fused_render.early_mean_count, taken before the update was queued: the budget is set from it and NOTHING is waited
+    for -- mean_density (read on the host by checkpoints only) is filled in when the copy has landed (resolve_pending)."""
     done, host, _stats, total_step = handle
+    if early is not None and early[1] == total_step:
+        if early[0] is not None:
+            model.mean_count = early[0]
+        model._pending_density_stats = (done, host, _stats, total_step, early[0])
+        return
     done.synchronize()
     _finish(model, host.tolist(), total_step)
+
+
+def resolve_pending(model, wait=True):
+    """mean_density of the last update whose read-back was left in flight (update_end(early=...))."""
+    pend = getattr(model, "_pending_density_stats", None)
+    if pend is None:
+        return
+    done, host, _stats, total_step, early_count = pend
+    if not wait and not done.query():
+        return
+    done.synchronize()
+    mean, counted = host.tolist()
+    model.mean_density = mean
+    if total_step > 0 and early_count is not None:
+        # the update kernel's own sum of the ring: must be what was read early
+        assert int(counted / total_step) == early_count, (counted, total_step, early_count)
+    model._pending_density_stats = None
 
 
 @torch.no_grad()

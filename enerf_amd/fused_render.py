@@ -155,6 +155,7 @@ def march_stage(model, rays_o, rays_d, counter, mean_count, perturb, force_all_r
         if launch_stream is not None:
             pre["ready"] = torch.cuda.Event()
             pre["ready"].record(launch_stream)
+            model._last_march_event = (pre["ready"], launch_stream)
     if not budgeted and not defer:
         finish_march(model, pre)
     return pre
@@ -247,12 +248,44 @@ def _next_counter(model):
     marcher to start from (0, 0) (flag bit 3) -- a fill launch per step in the middle of the training stream, ~14 us of
     it with the idle queue around it, for eight bytes."""
     # graph replay needs the counter at a fixed address; the harness copies it into the step_counter ring afterwards
+    model._last_march_event = None              # (set again by whoever marches on a side stream: see early_mean_count)
     counter = getattr(model, "graph_counter", None)
     if counter is None:
         model.last_counter_slot = model.local_step % 16
         counter = model._buffers["step_counter"][model.last_counter_slot]
         model.local_step += 1
     return counter
+
+
+def early_mean_count(model):
+    """The sample budget update_extra_state is about to compute (mean of the window's step counters,
+    nerf/renderer.py:550-552), read BEFORE the update is queued: -> (mean_count or None, total_step), or None when it
+    cannot be had without waiting for the training stream.
+
+    update_extra_state's read-back sits behind ~2 ms of sweep kernels, and the host -- which needs the budget to size and
+    queue the step that follows -- used to wait for it with an empty queue behind (0.15-0.3 ms of idle device per
+    update).  The window's counters are final much earlier: every march of the window has been issued, and when the last
+    one ran on the side stream (the normal case: each step marches its successor's rays there) a copy queued behind it
+    on that stream completes while the training stream is still a step away from the update.  The copy waits for that
+    march only; the value is the same sum of the same ring slots the update kernel forms."""
+    total_step = min(16, int(model.local_step))
+    if total_step == 0:
+        return (None, 0)                           # nothing to average: mean_count keeps its value
+    last = getattr(model, "_last_march_event", None)
+    stash = getattr(model, "_premarched", None)
+    if last is None or stash:                      # the last march ran on the training stream / an unconsumed stage
+        return None
+    _ready, stream = last
+    host = getattr(model, "_ring_host", None)
+    if host is None:
+        host = model._ring_host = torch.empty(16, 2, dtype=torch.int32, pin_memory=True)
+    with torch.cuda.stream(stream):
+        host.copy_(model._buffers["step_counter"], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(stream)
+    done.synchronize()
+    counted = int(host[:total_step, 0].to(torch.int64).sum())
+    return (int(counted / total_step), total_step)
 
 
 def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None, background=True,
@@ -656,6 +689,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             nxt["ready"] = torch.cuda.Event()
             nxt["ready"].record(side_stream)
             stash[key] = nxt
+            model._last_march_event = (nxt["ready"], side_stream)
         if not raw:
             views = ctx.get("grad_views")
             if views is None:
@@ -871,6 +905,7 @@ def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_st
             for key, nxt in staged:
                 nxt["ready"] = ready
                 stash[key] = nxt
+            model._last_march_event = (ready, side_stream)
         views = ctx.get("grad_views")
         if views is None:
             views = ctx["grad_views"] = [g.view_as(p) for p, g in zip(weights, grads)]

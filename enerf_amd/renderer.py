@@ -130,6 +130,19 @@ class NeRFRenderer(nn.Module):
         else:
             density_update.mark_untrained_torch(self, poses, intrinsic, cam_chunk=S)
 
+    @property
+    def mean_density(self):
+        """Mean of the density grid after the last update_extra_state (nerf/renderer.py:547).  The device-side update leaves
+        its read-back in flight when the harness already has the sample budget (density_update.update_end(early=...)):
+        whoever reads the value -- checkpoints -- gets it resolved here."""
+        if getattr(self, "_pending_density_stats", None) is not None:
+            density_update.resolve_pending(self)
+        return self._mean_density
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self._mean_density = value
+
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
         """Every 16 training steps: refresh density_grid (EMA-max), density_bitfield, mean_density and the sample budget
@@ -150,6 +163,6 @@ class NeRFRenderer(nn.Module):
         self.update_extra_state(decay)
         return None
 
-    def update_extra_state_end(self, handle):
+    def update_extra_state_end(self, handle, early=None):
         if handle is not None:
-            density_update.update_end(self, handle)
+            density_update.update_end(self, handle, early)

@@ -34,6 +34,7 @@ class TrainHarness:
         self._syn = None
         if model.cuda_ray and occupancy == "synthetic":
             self._syn = scene.install_occupancy(model)
+        self.early_budget = True      # update_extra_state: the sample budget is read before the update is queued (no stall)
         self.prefetch = True          # data parallel: march the next batch underneath the gradient all-reduce
         self.perturb = True           # training renders jitter their rays (nerf/utils.py:605 `perturb=True`); tests of
         #                               shard-vs-whole-batch equality switch it off: the jitter is seeded by the ray's
@@ -127,10 +128,16 @@ class TrainHarness:
         m = self.model
         if m.cuda_ray and self.global_step % self.update_interval == 0:
             begin = getattr(m, "update_extra_state_begin", None)
+            early = None
             if begin is None or coming_render is None or not self.overlap_update or self.use_graphs:
                 m.update_extra_state()
                 handle = None
             else:
+                if self.early_budget:
+                    # the window's step counters, read behind the last march on the side stream: the budget is known
+                    # before the update is even queued, and the host never waits behind the sweep
+                    from . import fused_render as _fr
+                    early = _fr.early_mean_count(m)
                 handle = begin()
             if self._syn is not None:
                 m.density_grid.copy_(self._syn[0])
@@ -139,7 +146,10 @@ class TrainHarness:
                 from . import fused_render
                 m._premarched = None                    # (anything marched against the old bitfield is void)
                 fused_render.premarch_count(m, *coming_render, perturb=self.perturb)
-                m.update_extra_state_end(handle)
+                if early is not None:
+                    m.update_extra_state_end(handle, early)
+                else:
+                    m.update_extra_state_end(handle)
             self._agree_on_budget()
 
     def _agree_on_budget(self):

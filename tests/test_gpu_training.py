@@ -516,6 +516,59 @@ def test_event_step_with_negative_event_sampling_closed_form_matches_autograd(mo
     assert float((l2[0] - l1[0]).abs()) > 1e-4 * float(l1[0].abs())
 
 
+def test_early_sample_budget_equals_the_update_kernels_own(monkeypatch):
+    """TrainHarness.early_budget: update_extra_state's sample budget is read behind the window's last march (side stream)
+    before the update is queued, and the update's own read-back is never waited for.  The value must be the one the
+    update kernel forms from the same ring (checked here against the read-back, update by update), the route must really
+    be taken in the steady state, and mean_density resolves to the grid's mean when somebody asks."""
+    from enerf_amd import density_update, fused_render
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 2048, 2)
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    h = TrainHarness(model, lr=1e-2, occupancy="learned")
+    assert h.early_budget
+    seen = []
+    orig_end, orig_early = density_update.update_end, fused_render.early_mean_count
+
+    def end(model_, handle, early=None):
+        orig_end(model_, handle, early)
+        done, host, _stats, total_step = handle[:4]
+        done.synchronize()
+        mean, counted = host.tolist()
+        seen.append((early, total_step, int(counted / total_step) if total_step else None, int(model_.mean_count), mean))
+
+    monkeypatch.setattr(density_update, "update_end", end)
+    for i in range(70):
+        ro, rd, tg = data[i % len(data)]
+        nxt = data[(i + 1) % len(data)]
+        h.step_rgb(ro, rd, tg, next_rays=(nxt[0], nxt[1]))
+    torch.cuda.synchronize()
+    assert len(seen) == 5                                        # updates at steps 0, 16, 32, 48, 64
+    assert seen[0][0] == (None, 0)                               # nothing marched yet: no wait, no budget
+    early_used = 0
+    for early, total_step, device_count, host_count, mean in seen[1:]:
+        assert total_step == 16 and host_count == device_count  # whichever route: the budget is the update kernel's
+        if early is not None:
+            assert early == (device_count, 16)
+            early_used += 1
+    assert early_used >= 3                                       # every update whose last march ran on the side stream
+    want = float(torch.mean(model.density_grid.clamp(min=0)))
+    assert abs(model.mean_density - want) <= 1e-6 * max(1.0, abs(want)) and model._pending_density_stats is None
+    # switched off: the old route, same budgets
+    torch.manual_seed(0)
+    model2 = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    h2 = TrainHarness(model2, lr=1e-2, occupancy="learned")
+    h2.early_budget = False
+    seen2, seen[:] = seen[:], []
+    for i in range(20):
+        ro, rd, tg = data[i % len(data)]
+        nxt = data[(i + 1) % len(data)]
+        h2.step_rgb(ro, rd, tg, next_rays=(nxt[0], nxt[1]))
+    assert [s[0] for s in seen] == [None, None] and seen[1][3] == seen2[1][3]   # step 16: the cold window's counts agree
+
+
 def test_long_run_with_learned_occupancy_converges():
     """600 steps with the occupancy grid maintained by update_extra_state itself (not the analytic one): through the 16
     full sweeps and into the partial-update regime, with the closed-form step, the side-stream march and the device-side
