@@ -353,6 +353,7 @@ def _finish_counted(model, pre):
     if mean_count <= 0:                         # no budget after all (first window): the reference's crop of N * max_steps
         m = int(pre["counter"][0].item())
         M = min(m + (128 - m % 128), N * max_steps)
+        model._cold_rows = M
     else:
         M = mean_count + (128 - mean_count % 128)
     xyzs = torch.empty(M, 3, dtype=torch.float32, device=dev)
@@ -381,7 +382,34 @@ def render_train(model, rays_o, rays_d, bg_color, perturb, force_all_rays, dt_ga
                                    bool(force_all_rays), float(dt_gamma), int(max_steps), pre, *params)
 
 
-def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
+def _check_cold_stage(model, pre, rays_o, rays_d, perturb, dt_gamma, max_steps):
+    """A stage marched by the one-call step of the cold window into `cap` reserved rows, budgeted-style, is valid iff
+    nothing was dropped, i.e. iff the count that came back (behind the march, on its stream) fits.  Waits for that count
+    (the only host wait of such a step), records the rows for later reservations, repairs the stage when it does not fit:
+    count, scan and ray table do not depend on the rows (same counter slot, nothing marched since), so the write pass
+    alone is repeated into buffers of the exact size -- what finish_march does for a speculative write pass that did not
+    fit.  -> the stage to use."""
+    done, host, cap = pre.pop("cold_check")
+    done.synchronize()
+    m = int(host[0])
+    N = rays_o.shape[0]
+    rows = min(m + (128 - m % 128), N * int(max_steps))
+    model._cold_rows = rows
+    if rows <= cap:
+        return pre
+    dev = rays_o.device
+    xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+    deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    _rb.march_rays_train_write(rays_o, rays_d, model._buffers["density_bitfield"], model.bound, float(dt_gamma),
+                               int(max_steps), N, model.cascade, model.grid_size, rows, pre["nears"], pre["fars"], xyzs,
+                               dirs, deltas, pre["rays"], pre["counter"], bool(perturb), 1)
+    out = dict(pre)
+    out.update(xyzs=xyzs, dirs=dirs, deltas=deltas, M=rows)
+    return out
+
+
+def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps, defer_cold_check=False):
     stash = getattr(model, "_premarched", None)
     if not stash:
         return None
@@ -390,6 +418,13 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps):
     if pre is None:
         stash.clear()                                # marched for rays that are not coming: drop, march afresh
         return None
+    if "cold_check" in pre:
+        ready = pre.pop("ready", None)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
+        if defer_cold_check:
+            return pre                               # the one-call step checks right before its call (host work first)
+        return _check_cold_stage(model, pre, rays_o, rays_d, perturb, dt_gamma, max_steps)
     if "counted" in pre:
         return _finish_counted(model, pre)
     ready = pre.pop("ready", None)
@@ -525,10 +560,26 @@ class _StepArgs(_ct.Structure):          # enerf_train_step_args (include/enerf_
                 + [("flags", _u32), ("reserved", _u32)])
 
 
-def native_step_supported(model, rays_o, rays_d, opt):
-    """The one-call step serves the steady state of the closed-form RGB step: a sample budget exists (the cold window
-    sizes its buffers from a read-back), unit density scale, the fused optimizer."""
-    return (NATIVE_STEP and _budget(model) > 0 and float(model.density_scale) == 1.0
+COLD_NATIVE = True            # the one-call step also serves the window before the first sample budget (see cold_capacity)
+
+
+def cold_capacity(rows, N, max_steps, floor=0):
+    """Rows reserved for a march of the cold window (no sample budget yet: nothing may be dropped), from an earlier
+    render's row count: + 1/20, rounded up to 4 Ki rows, and never below what an earlier step of the window reserved
+    (`floor`) -- the persistent buffers of the one-call step are keyed by these sizes, so the reservation has to settle
+    after a step or two.  A march that turns out to need more gets its write pass repeated at the exact size
+    (_repair_cold_stage), which costs one small launch."""
+    c = rows + rows // 20
+    c = (c + 4095) // 4096 * 4096
+    return min(max(c, floor), N * max_steps)
+
+
+def native_step_supported(model, rays_o, rays_d, opt, data_parallel=False):
+    """The one-call step serves the closed-form RGB step with unit density scale and the fused optimizer: in the steady
+    state (a sample budget exists) and -- one GPU -- in the cold window from its second step on, where the rows of an
+    earlier render size the buffers (cold_capacity) and the count that comes back is checked before the stage is used."""
+    ready = _budget(model) > 0 or (COLD_NATIVE and not data_parallel and int(getattr(model, "_cold_rows", 0)) > 0)
+    return (NATIVE_STEP and ready and float(model.density_scale) == 1.0
             and hasattr(opt, "grid_table_args") and supported(model, rays_o, rays_d, 1, 0))
 
 
@@ -605,7 +656,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
     rays_d = rays_d.contiguous().view(-1, 3)
     N, dev = rays_o.shape[0], rays_o.device
     with torch.no_grad():
-        pre = _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps)
+        pre = _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps, defer_cold_check=True)
         if pre is not None:
             model.rendered_counter_slot = pre["slot"]
         else:
@@ -613,9 +664,9 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             model.rendered_counter_slot = getattr(model, "last_counter_slot", None)
             pre = march_stage(model, rays_o, rays_d, counter, _budget(model), bool(perturb), False, float(dt_gamma),
                               int(max_steps))
-        M = pre["M"]
-        nxt_ok = False
+        nxt_ok = cold_next = False
         Nn = Mn = 0
+        no = nd = None
         if next_rays is not None and side_stream is not None:
             no, nd = next_rays[0].contiguous().view(-1, 3), next_rays[1].contiguous().view(-1, 3)
             stash = getattr(model, "_premarched", None)
@@ -625,57 +676,86 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                 nxt_ok = True
                 Nn = no.shape[0]
                 mc = _budget(model)
-                Mn = mc + (128 - mc % 128)
-        ctx = _native_ctx(model, N, M, Nn, Mn, dev)
-        a, emb, weights, grads = ctx["a"], ctx["emb"], ctx["weights"], ctx["grads"]
-        if emb.grad is None:                    # the dense part of the table's gradient (levels too small to bin)
-            emb.grad = torch.zeros_like(emb)
-        a.stream = L.stream_handle()
-        a.xyzs, a.dirs, a.deltas = pre["xyzs"].data_ptr(), pre["dirs"].data_ptr(), pre["deltas"].data_ptr()
-        a.rays = pre["rays"].data_ptr()
-        a.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
-        a.target = target.contiguous().view(-1, 3).data_ptr()
-        a.loss = None if loss_out is None else loss_out.data_ptr()
-        a.flags = 1 if raw else 0
-        # the next batch's march: kernels on the side stream, into the buffer set the current batch is NOT using
-        nxt = None
-        a.next_rays_o = None
+                cold_next = mc <= 0
+                if cold_next:                    # cold window: rows reserved from the last render whose count is known
+                    Mn = model._cold_cap = cold_capacity(int(model._cold_rows), Nn, int(max_steps),
+                                                         int(getattr(model, "_cold_cap", 0)))
+                else:
+                    Mn = mc + (128 - mc % 128)
+        nxt_counter = nxt_slot = None
         if nxt_ok:
-            st_bufs = ctx["stages"][ctx["flip"]]
-            if any(pre[k] is st_bufs[k] for k in ("xyzs", "rays")):
-                st_bufs = ctx["stages"][ctx["flip"] ^ 1]
+            nxt_counter = _next_counter(model)
+            nxt_slot = getattr(model, "last_counter_slot", None)
+
+        def prepare(pre):
+            M = pre["M"]
+            ctx = _native_ctx(model, N, M, Nn, Mn, dev)
+            a, emb, weights, grads = ctx["a"], ctx["emb"], ctx["weights"], ctx["grads"]
+            if emb.grad is None:                    # the dense part of the table's gradient (levels too small to bin)
+                emb.grad = torch.zeros_like(emb)
+            a.stream = L.stream_handle()
+            a.xyzs, a.dirs, a.deltas = pre["xyzs"].data_ptr(), pre["dirs"].data_ptr(), pre["deltas"].data_ptr()
+            a.rays = pre["rays"].data_ptr()
+            a.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
+            a.target = target.contiguous().view(-1, 3).data_ptr()
+            a.loss = None if loss_out is None else loss_out.data_ptr()
+            a.flags = 1 if raw else 0
+            # the next batch's march: kernels on the side stream, into the buffer set the current batch is NOT using
+            nxt = key = None
+            a.next_rays_o = None
+            if nxt_ok:
+                st_bufs = ctx["stages"][ctx["flip"]]
+                if any(pre[k] is st_bufs[k] for k in ("xyzs", "rays")):
+                    st_bufs = ctx["stages"][ctx["flip"] ^ 1]
+                    which = ctx["flip"] ^ 1
+                else:
+                    which = ctx["flip"]
+                nxt = _Stage(st_bufs)
+                nxt["counter"] = nxt_counter
+                nxt["slot"] = nxt_slot
+                nxt["_which"] = which
+                a.side_stream = side_stream.cuda_stream
+                a.next_rays_o, a.next_rays_d = no.data_ptr(), nd.data_ptr()
+                a.dt_gamma = float(dt_gamma)
+                a.next_N, a.next_M, a.max_steps = Nn, Mn, int(max_steps)
+                a.perturb = 1 if perturb else 0
+                a.march_flags = occupied_box_flag(model) | 3 | 8
+                for name in ("nears", "fars", "xyzs", "dirs", "deltas", "rays", "counter"):
+                    setattr(a, "next_" + name, nxt[name].data_ptr())
+                key = (no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps))
+            a.table_grad = emb.grad.data_ptr()
+            if raw:
+                a.n_small = 0
+                ctx["plan"] = None                  # (a later optimizer-carrying step rebuilds its arrays)
             else:
-                ctx["flip"] ^= 1
-            nxt = _Stage(st_bufs)
-            nxt["counter"] = _next_counter(model)
-            nxt["slot"] = getattr(model, "last_counter_slot", None)
-            a.side_stream = side_stream.cuda_stream
-            a.next_rays_o, a.next_rays_d = no.data_ptr(), nd.data_ptr()
-            a.dt_gamma = float(dt_gamma)
-            a.next_N, a.next_M, a.max_steps = Nn, Mn, int(max_steps)
-            a.perturb = 1 if perturb else 0
-            a.march_flags = occupied_box_flag(model) | 3 | 8
-            for name in ("nears", "fars", "xyzs", "dirs", "deltas", "rays", "counter"):
-                setattr(a, "next_" + name, nxt[name].data_ptr())
-            key = (no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps))
-        a.table_grad = emb.grad.data_ptr()
-        if raw:
-            a.n_small = 0
-            ctx["plan"] = None                  # (a later optimizer-carrying step rebuilds its arrays)
-        else:
-            plan = ctx.get("plan")
-            if plan is None or ctx.get("plan_opt") is not opt:
-                # the optimizer's host arrays (pointers, sizes, learning rates, step counts of the MLP weights): built once
-                plan = ctx["plan"] = opt.grid_table_plan(emb, list(weights), list(grads))
-                ctx["plan_opt"] = opt
-                small = plan.arrays
-                st = plan.state
-                a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                a.n_small = small[0]
-                for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"),
-                                     small[1:]):
-                    setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
-            a.lr, a.beta1, a.beta2, a.eps, a.table_step = plan()
+                plan = ctx.get("plan")
+                if plan is None or ctx.get("plan_opt") is not opt:
+                    # the optimizer's host arrays (pointers, sizes, learning rates, step counts of the MLP weights): built once
+                    plan = ctx["plan"] = opt.grid_table_plan(emb, list(weights), list(grads))
+                    ctx["plan_opt"] = opt
+                    small = plan.arrays
+                    st = plan.state
+                    a.table_m, a.table_v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    a.n_small = small[0]
+                    for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"),
+                                         small[1:]):
+                        setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
+            return ctx, a, nxt, key, M
+
+        ctx, a, nxt, key, M = prepare(pre)
+        if "cold_check" in pre:
+            # everything above was host work that did not need the count; only now is it waited for
+            fixed = _check_cold_stage(model, pre, rays_o, rays_d, perturb, dt_gamma, max_steps)
+            if fixed is not pre:
+                pre = fixed
+                ctx, a, nxt, key, M = prepare(pre)
+        emb, weights, grads = ctx["emb"], ctx["weights"], ctx["grads"]
+        which = 0
+        if nxt is not None:
+            which = nxt.pop("_which")
+            ctx["flip"] = which ^ 1              # (the set the next call looks at first is the one this stage does not use)
+        if not raw:
+            a.lr, a.beta1, a.beta2, a.eps, a.table_step = ctx["plan"]()
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
         from .backends import _gridencoder as _gbk
@@ -686,8 +766,21 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
         _gbk.LIFETIME["fwd_points"] += M
         _gbk.LIFETIME["fwd_calls"] += 1
         if nxt is not None:
-            nxt["ready"] = torch.cuda.Event()
-            nxt["ready"].record(side_stream)
+            if cold_next:
+                # the count of the march just queued travels to pinned memory behind it (one slot per stage set)
+                hosts = ctx.get("cold_hosts")
+                if hosts is None:
+                    hosts = ctx["cold_hosts"] = [torch.empty(2, dtype=torch.int32, pin_memory=True) for _ in range(2)]
+                host = hosts[which]
+                with torch.cuda.stream(side_stream):
+                    host.copy_(nxt["counter"], non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(side_stream)
+                nxt["cold_check"] = (done, host, Mn)
+                nxt["ready"] = done
+            else:
+                nxt["ready"] = torch.cuda.Event()
+                nxt["ready"].record(side_stream)
             stash[key] = nxt
             model._last_march_event = (nxt["ready"], side_stream)
         if not raw:

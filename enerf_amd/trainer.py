@@ -722,7 +722,7 @@ class TrainHarness:
                 and ((self.avg is None and self.fuse_table_adam) or chunked)):
             from . import fused_render
             if fused_render.native_step_supported(self.model, rays_o.contiguous().view(-1, 3),
-                                                  rays_d.contiguous().view(-1, 3), self.opt):
+                                                  rays_d.contiguous().view(-1, 3), self.opt, data_parallel=chunked):
                 return self._step_rgb_native(rays_o, rays_d, target, next_rays, data_parallel=chunked)
         side = self._side_prefetch(next_rays) if not render_kw else None
         late = chunked and side is not None and self.prefetch_at == "collectives"
@@ -799,7 +799,7 @@ class TrainHarness:
         # everything the route decision below reads, as one tuple: a step whose tuple equals that of the last step that
         # went the one-call route skips the checks (five `supported` walks, ~60 us of a 0.3 ms host budget)
         sig = None
-        if self.native_step and not render_kw and self.model.mean_count > 0:
+        if self.native_step and not render_kw and (self.model.mean_count > 0 or getattr(self.model, "_cold_rows", 0) > 0):
             sig = self._route_signature(rays_o, rays_d, target, next_rays)
             if sig == self._native_route_sig:
                 return self._step_rgb_native(rays_o, rays_d, target, next_rays, data_parallel=self._native_route_dp,

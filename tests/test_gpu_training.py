@@ -569,6 +569,52 @@ def test_early_sample_budget_equals_the_update_kernels_own(monkeypatch):
     assert [s[0] for s in seen] == [None, None] and seen[1][3] == seen2[1][3]   # step 16: the cold window's counts agree
 
 
+def test_cold_window_one_call_step_equals_the_python_driven_cold_step(monkeypatch):
+    """Before the first sample budget (the reference's first 16 steps: nothing may be dropped) the one-call step reserves
+    rows from an earlier render's count (fused_render.cold_capacity) and checks the count that comes back.  Against the
+    Python-driven cold step: the same samples per step (counters bit-exact), the same losses to rounding; and with the
+    reservation forced too small every stage is repaired (write pass repeated at the exact size) to the same result."""
+    from enerf_amd import fused_render
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    data = _batches(4, 2048, 2)
+    native_calls = []
+    orig = fused_render.train_step_native
+    monkeypatch.setattr(fused_render, "train_step_native", lambda *a, **k: (native_calls.append(1), orig(*a, **k))[1])
+
+    def run(cold_native, capacity=None, steps=15):
+        monkeypatch.setattr(fused_render, "COLD_NATIVE", cold_native)
+        if capacity is not None:
+            monkeypatch.setattr(fused_render, "cold_capacity", capacity)
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        del native_calls[:]
+        losses = []
+        for i in range(steps):
+            ro, rd, tg = data[i % len(data)]
+            nxt = data[(i + 1) % len(data)]
+            losses.append(h.step_rgb(ro, rd, tg, next_rays=(nxt[0], nxt[1])).clone())
+        assert model.mean_count == 0                                   # still the cold window
+        return (torch.stack(losses).cpu(), model.step_counter.clone().cpu(), len(native_calls),
+                {n: p.detach().clone() for n, p in model.named_parameters()})
+
+    l0, c0, n0, p0 = run(False)
+    assert n0 == 0
+    l1, c1, n1, p1 = run(True)
+    assert n1 == 14                                                    # every step but the first
+    assert torch.equal(c0, c1)                                         # same samples, same ring slots
+    rel = (l0 - l1).abs() / l0.abs().clamp(min=1e-9)
+    assert float(rel[:3].max()) < 5e-6 and float(rel.max()) < 3e-4, rel.tolist()
+    for n in p0:
+        assert float((p0[n] - p1[n]).abs().mean()) <= 2e-3 * float(p0[n].abs().mean()), n
+    # reservation always too small: every stage overflows and is repaired
+    l2, c2, n2, p2 = run(True, capacity=lambda rows, N, max_steps, floor=0: max(128, (rows // 2) // 128 * 128))
+    assert n2 == 14 and torch.equal(c0, c2)
+    rel = (l0 - l2).abs() / l0.abs().clamp(min=1e-9)
+    assert float(rel[:3].max()) < 5e-6 and float(rel.max()) < 3e-4, rel.tolist()
+
+
 def test_long_run_with_learned_occupancy_converges():
     """600 steps with the occupancy grid maintained by update_extra_state itself (not the analytic one): through the 16
     full sweeps and into the partial-update regime, with the closed-form step, the side-stream march and the device-side
@@ -807,9 +853,9 @@ def test_native_step_call_equals_the_python_driven_step(net):
         runs[native] = (losses, torch.stack(counters), {n: p.detach().clone() for n, p in model.named_parameters()},
                         len(calls), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
     (la, ca, pa, na, ga), (lb, cb, pb, nb, gb) = runs[True], runs[False]
-    # steps 0..15 have no sample budget (cold window), steps 16 and 32 start with update_extra_state: all of them steady
-    # from the render on, i.e. native from step 16
-    assert na == 24 and nb == 0
+    # every step but the first: the cold window (steps 0..15, no sample budget: rows reserved from an earlier render's
+    # count) and the steady state; steps 16 and 32 start with update_extra_state and are native from the render on
+    assert na == 39 and nb == 0
     assert torch.equal(ca, cb)
     assert np.abs(np.array(la) - np.array(lb)).max() <= 1e-5 * np.abs(lb).max()
     for n, a in pa.items():
