@@ -121,6 +121,119 @@ done:
     return rc;
 }
 
+// valid rows of the merged 2 M-row batch: the first render's M rows (its padding included: zero gradients) + the second's
+__global__ void k_event_merged_rows(const int32_t* __restrict__ counter1, uint32_t M, int32_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int32_t c = counter1[0];
+        out[0] = (int32_t)(M + (c <= 0 ? 0u : ((uint32_t)c < M ? (uint32_t)c : M)));
+    }
+}
+
+// The event-only step with both renders' samples as ONE batch of 2 M rows (enerf_event_step_args.flags bit 1)
+static int train_step_events_merged(const enerf_event_step_args* a) {
+    enerf_stream_t s = a->stream;
+    const enerf_step_render &r0 = a->r[0], &r1 = a->r[1];
+    const uint32_t N = r0.N, M = r0.M, M2 = 2 * M;
+    const float in_add = a->bound, in_mul = a->inv_two_bound;
+    if (r1.M != M || r1.xyzs != r0.xyzs + (size_t)3 * M || r1.dirs != r0.dirs + (size_t)3 * M ||
+        r1.deltas != r0.deltas + (size_t)2 * M)
+        ENERF_BADARG("train_step_events(merged): the second render's samples must follow the first's M rows");
+    if (!a->m_feats || !a->m_h32 || !a->m_sigma || !a->m_rgb || !a->m_g_sigmas || !a->m_g_rgbs || !a->m_dx32 || !a->m_dfeat ||
+        !a->m_rows)
+        ENERF_BADARG("train_step_events(merged): the m_* scratch buffers are required");
+    int prev_prec = -1;
+    if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
+    int rc = 0;
+    bool rows_set = false, defer_set = false, signal_set = false;
+    const bool march_next = r0.next_rays_o != nullptr || r1.next_rays_o != nullptr;
+    const bool skip = r0.counter != nullptr && r1.counter != nullptr;
+#define STEP(call)           \
+    do {                     \
+        rc = (call);         \
+        if (rc) goto done;   \
+    } while (0)
+    STEP(enerf_grid_encode_forward(r0.xyzs, a->embeddings, a->offsets, a->m_feats, M2, 3, 2, 16, a->level_scale_log2,
+                                   a->base_resolution, 0, a->m_feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
+    if (skip) {
+        k_event_merged_rows<<<1, 64, 0, (hipStream_t)s>>>(r1.counter, M, a->m_rows);
+        enerf_mlp32_valid_rows(a->m_rows);
+        rows_set = true;
+    }
+    STEP(enerf_mlp32_forward_p(a->m_feats, a->wseg_s, 32, 0, M2, 32, 16, a->nh_s, 0, 6, a->m_fb_s, a->m_h32, 1, 32,
+                               a->m_sigma, r0.dirs, s));
+    STEP(enerf_mlp32_forward_p(a->m_h32, a->wseg_c, a->w0_cols_c, 1, M2, 32, a->out_c, a->nh_c, 0, 3, a->m_fb_c, a->m_rgb, 0,
+                               0, nullptr, nullptr, s));
+    if (rows_set) {
+        enerf_mlp32_valid_rows(nullptr);
+        rows_set = false;
+    }
+    for (int k = 0; k < 2; k++) {
+        const enerf_step_render& r = a->r[k];
+        STEP(enerf_composite_rays_train_forward_blend(a->m_sigma + (size_t)k * M, a->m_rgb + (size_t)k * M * a->out_c, r.deltas,
+                                                      r.rays, M, N, r.weights_sum, nullptr, r.image, a->bg_color, 0, 0.0f,
+                                                      r.out_image, s));
+    }
+    STEP(enerf_event_loss_fwd_bwd(r0.out_image, r1.out_image, a->pols, N, a->use_luma, a->linlog, a->C_thres, a->log_thres,
+                                  a->upstream, r0.g_image, r1.g_image, a->delta, a->loss, s));
+    for (int k = 0; k < 2; k++) {
+        const enerf_step_render& r = a->r[k];
+        // (its tail blocks zero the gradients of rows [counter, M): the padding between the two renders' samples)
+        STEP(enerf_composite_rays_train_backward_mse(r.g_image, nullptr, 1.0f, a->bg_color, 0, 0.0f, r.counter,
+                                                     a->m_sigma + (size_t)k * M, a->m_rgb + (size_t)k * M * a->out_c, r.deltas,
+                                                     r.rays, r.weights_sum, r.image, M, N, a->m_g_sigmas + (size_t)k * M,
+                                                     a->m_g_rgbs + (size_t)k * M * a->out_c, nullptr, s));
+    }
+    if (skip) {
+        enerf_mlp32_valid_rows(a->m_rows);
+        rows_set = true;
+    }
+    if (march_next) {
+        enerf_mlp32_signal_next_reduce(1);
+        signal_set = true;
+    }
+    enerf_mlp32_defer_reduce(1);
+    defer_set = true;
+    STEP(enerf_mlp32_backward_p(a->m_g_rgbs, a->m_h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, 1u, a->m_fb_c, M2, 32, a->out_c,
+                                a->nh_c, 0, nullptr, a->m_dx32, 0, 0, a->m_rgb, a->out_c, nullptr, nullptr, 0, s));
+    STEP(enerf_mlp32_backward_p(a->m_dx32, a->m_feats, a->wseg_s, a->dwseg_s, 32, 0, 1u, a->m_fb_s, M2, 32, 16, a->nh_s, 0,
+                                nullptr, a->m_dfeat, 1, 32, nullptr, 0, a->m_g_sigmas, a->m_h32, 32, s));
+    enerf_mlp32_defer_reduce(0);
+    defer_set = false;
+    if (rows_set) {
+        enerf_mlp32_valid_rows(nullptr);
+        rows_set = false;
+    }
+    if (march_next) {
+        enerf_mlp32_signal_next_reduce(0);
+        signal_set = false;
+        enerf_stream_t ss = a->side_stream;
+        STEP(enerf_stream_wait_mlp32_signal(ss));
+        for (int q = 0; q < 2; q++) {
+            const enerf_step_render& n = a->r[q];
+            if (!n.next_rays_o) continue;
+            STEP(enerf_near_far_from_aabb(n.next_rays_o, n.next_rays_d, a->aabb, n.next_N, a->min_near, n.next_nears,
+                                          n.next_fars, ss));
+            STEP(enerf_march_rays_train_ex(n.next_rays_o, n.next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
+                                           n.next_N, a->cascade, a->grid_size, n.next_M, n.next_nears, n.next_fars,
+                                           n.next_xyzs, n.next_dirs, n.next_deltas, n.next_rays, n.next_counter, a->perturb,
+                                           a->march_flags, ss));
+        }
+    }
+    STEP(enerf_grid_encode_backward_ex(a->m_dfeat, r0.xyzs, a->embeddings, a->offsets, a->table_grad, M2, 3, 2, 16,
+                                       a->level_scale_log2, a->base_resolution, 0, a->m_dfeat, a->m_dfeat, a->gridtype,
+                                       ENERF_F32, 2, in_add, in_mul, 1, M2, s));
+    STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr, a->beta1,
+                                         a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g, a->small_m,
+                                         a->small_v, a->small_n, a->small_lr, a->small_step, s));
+done:
+#undef STEP
+    if (defer_set) enerf_mlp32_defer_reduce(0);
+    if (signal_set) enerf_mlp32_signal_next_reduce(0);
+    if (rows_set) enerf_mlp32_valid_rows(nullptr);
+    if (prev_prec >= 0) enerf_mlp32_precision(prev_prec);
+    return rc;
+}
+
 // The event-only step (two renders, one loss, one optimizer pass): events.train_step_events_manual +
 // FusedAdam.step_grid_table, call for call.
 extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
@@ -131,6 +244,7 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
     if (a->r[0].N == 0 || a->r[0].N != a->r[1].N || a->r[0].M == 0 || a->r[1].M == 0)
         ENERF_BADARG("train_step_events: both renders take the same (non-zero) number of rays and a sample budget");
     if (!a->bg_color || !a->pols) ENERF_BADARG("train_step_events: bg_color and pols are required");
+    if (a->flags & 2u) return train_step_events_merged(a);
     enerf_stream_t s = a->stream;
     const uint32_t N = a->r[0].N, total = a->r[0].M + a->r[1].M;
     const float in_add = a->bound, in_mul = a->inv_two_bound;

@@ -820,7 +820,12 @@ class _EventStepArgs(_ct.Structure):      # enerf_event_step_args
                 + [(n, _f32c) for n in ("lr", "beta1", "beta2", "eps")]
                 + [("table_step", _u32), ("n_small", _u32)]
                 + [(n, _vp) for n in ("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step")]
-                + [("flags", _u32), ("reserved", _u32)])
+                + [("flags", _u32), ("reserved", _u32)]
+                + [(n, _vp) for n in ("m_feats", "m_h32", "m_fb_s", "m_fb_c", "m_sigma", "m_rgb", "m_g_sigmas", "m_g_rgbs",
+                                      "m_dx32", "m_dfeat", "m_rows")])
+
+
+MERGE_EVENT_RENDERS = True    # the one-call event step runs both renders' samples as one batch of 2 M rows (flags bit 1)
 
 
 def native_events_supported(model, data, loss_opt, opt):
@@ -861,25 +866,53 @@ def _native_events_ctx(model, N, Ms, Nn, Mn, luma, dev):
     a = _EventStepArgs()
     a.struct_bytes = _ct.sizeof(_EventStepArgs)
     a.mlp_precision = -1 if prec is None else prec
-    ts, stages = [], []
+    ts, stages, pair_bufs = [], [], []
+    tm = None
+    if MERGE_EVENT_RENDERS and Ms[0] == Ms[1]:
+        M2 = 2 * Ms[0]                                  # (2 M is a multiple of 256: no extra padding of the level-major rows)
+        tm = dict(m_feats=torch.empty(16, M2, 2, **f32), m_h32=torch.empty(M2, 32, **f32),
+                  m_fb_s=torch.empty(arch["nh_s"], M2, 64, **f32), m_fb_c=torch.empty(arch["nh_c"], M2, 64, **f32),
+                  m_sigma=torch.empty(M2, **f32), m_rgb=torch.empty(M2, out_c, **f32), m_g_sigmas=torch.empty(M2, **f32),
+                  m_g_rgbs=torch.empty(M2, out_c, **f32), m_dx32=torch.empty(M2, 32, **f32),
+                  m_dfeat=torch.empty(16, M2, 2, **f32), m_rows=torch.zeros(1, dtype=torch.int32, device=dev))
+        for name, buf in tm.items():
+            setattr(a, name, buf.data_ptr())
     for q, M in enumerate(Ms):
         Mp = (M + 31) // 32 * 32
-        t = dict(feats=torch.empty(16, Mp, 2, **f32), h32=torch.empty(M, 32, **f32),
-                 fb_s=torch.empty(arch["nh_s"], Mp, 64, **f32), fb_c=torch.empty(arch["nh_c"], Mp, 64, **f32),
-                 sigma=torch.empty(M, **f32), rgb=torch.empty(M, out_c, **f32), weights_sum=torch.empty(N, **f32),
-                 image=torch.empty(N, 3, **f32), out_image=torch.empty(N, 3, **f32), g_image=torch.empty(N, 3, **f32),
-                 g_sigmas=torch.empty(M, **f32), g_rgbs=torch.empty(M, out_c, **f32), dx32=torch.empty(M, 32, **f32),
-                 dfeat=torch.empty(16, Mp, 2, **f32))
+        if tm is not None:
+            # the per-render scratch (steps whose two stages were not marched together: right after an update) is the two
+            # halves of the merged allocations, each half in the per-render shape: no second set of buffers
+            def half(name, *shape):
+                flat = tm["m_" + name].view(-1)
+                n = flat.numel() // 2
+                return flat[q * n:(q + 1) * n].view(*shape)
+            t = dict(feats=half("feats", 16, Mp, 2), h32=half("h32", M, 32), fb_s=half("fb_s", arch["nh_s"], Mp, 64),
+                     fb_c=half("fb_c", arch["nh_c"], Mp, 64), sigma=half("sigma", M), rgb=half("rgb", M, out_c),
+                     g_sigmas=half("g_sigmas", M), g_rgbs=half("g_rgbs", M, out_c), dx32=half("dx32", M, 32),
+                     dfeat=half("dfeat", 16, Mp, 2))
+        else:
+            t = dict(feats=torch.empty(16, Mp, 2, **f32), h32=torch.empty(M, 32, **f32),
+                     fb_s=torch.empty(arch["nh_s"], Mp, 64, **f32), fb_c=torch.empty(arch["nh_c"], Mp, 64, **f32),
+                     sigma=torch.empty(M, **f32), rgb=torch.empty(M, out_c, **f32), g_sigmas=torch.empty(M, **f32),
+                     g_rgbs=torch.empty(M, out_c, **f32), dx32=torch.empty(M, 32, **f32), dfeat=torch.empty(16, Mp, 2, **f32))
+        t.update(weights_sum=torch.empty(N, **f32), image=torch.empty(N, 3, **f32), out_image=torch.empty(N, 3, **f32),
+                 g_image=torch.empty(N, 3, **f32))
         ts.append(t)
         a.r[q].N, a.r[q].M = N, M
         for name, buf in t.items():
             setattr(a.r[q], name, buf.data_ptr())
         sets = []
         if Nn:
-            for _ in range(2):
+            for f in range(2):
+                # the two renders' sample buffers of one stage generation are the halves of ONE allocation: a step that
+                # consumes both finds the second render's rows right behind the first's M (merged layout, see below)
+                if q == 0:
+                    pair_bufs.append(dict(xyzs=torch.empty(2 * Mn, 3, **f32), dirs=torch.empty(2 * Mn, 3, **f32),
+                                          deltas=torch.empty(2 * Mn, 2, **f32)))
+                pb = pair_bufs[f]
                 sets.append(dict(nears=torch.empty(Nn, **f32), fars=torch.empty(Nn, **f32),
-                                 rays=torch.empty(Nn, 3, dtype=torch.int32, device=dev), xyzs=torch.empty(Mn, 3, **f32),
-                                 dirs=torch.empty(Mn, 3, **f32), deltas=torch.empty(Mn, 2, **f32), M=Mn))
+                                 rays=torch.empty(Nn, 3, dtype=torch.int32, device=dev), xyzs=pb["xyzs"][q * Mn:(q + 1) * Mn],
+                                 dirs=pb["dirs"][q * Mn:(q + 1) * Mn], deltas=pb["deltas"][q * Mn:(q + 1) * Mn], M=Mn))
         stages.append(sets)
     delta = torch.empty(1, N, 1 if luma else 3, **f32)
     a.delta = delta.data_ptr()
@@ -894,8 +927,8 @@ def _native_events_ctx(model, N, Ms, Nn, Mn, luma, dev):
     a.min_near = float(model.min_near)
     a.cascade, a.grid_size = int(model.cascade), int(model.grid_size)
     a.table = emb.data_ptr()
-    ctx = dict(key=key, t=ts, seg=(seg_s, seg_c), dseg=(dseg_s, dseg_c), dw=dw, grads=grads, stages=stages, flip=[0, 0],
-               a=a, emb=emb, weights=weights, delta=delta, kind=kind, out_c=out_c)
+    ctx = dict(key=key, t=ts, tm=tm, seg=(seg_s, seg_c), dseg=(dseg_s, dseg_c), dw=dw, grads=grads, stages=stages,
+               flip=[0, 0], a=a, emb=emb, weights=weights, delta=delta, kind=kind, out_c=out_c)
     model.__dict__["_native_events_ctx"] = ctx
     return ctx
 
@@ -953,6 +986,13 @@ def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_st
             r.rays = pre["rays"].data_ptr()
             r.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
             r.next_rays_o = None
+        # merged layout: the second render's samples lie right behind the first's M rows (stages of one generation do)
+        M0 = pres[0]["M"]
+        merged = (ctx["tm"] is not None and pres[1]["M"] == M0
+                  and pres[1]["xyzs"].data_ptr() == pres[0]["xyzs"].data_ptr() + 12 * M0
+                  and pres[1]["dirs"].data_ptr() == pres[0]["dirs"].data_ptr() + 12 * M0
+                  and pres[1]["deltas"].data_ptr() == pres[0]["deltas"].data_ptr() + 8 * M0)
+        a.flags = 2 if merged else 0
         staged = []
         if nxt_pairs is not None:
             a.side_stream = side_stream.cuda_stream

@@ -637,7 +637,16 @@ typedef struct enerf_event_step_args {
     const uint32_t* small_n;
     const float* small_lr;
     const uint32_t* small_step;
-    uint32_t flags, reserved;           /* flags: 0 */
+    /* flags bit 1: MERGED layout.  Both renders have the same M, r[1].xyzs / dirs / deltas are the M rows that follow
+     * r[0]'s in one buffer, and the m_* pointers hold scratch for 2 M rows (shapes of the per-render scratch with 2 M
+     * for M).  Then grid_encode_forward, the four mlp32 launches, grid_encode_backward run ONCE over the 2 M rows (rows
+     * [counter0, M) are padding whose gradients the first render's composite backward zero-fills; m_rows, one device
+     * int32 the call writes, = M + min(counter1, M) is what the MLP kernels take as their valid-row count); compositing
+     * and its backward stay per render, on the halves.  Same per-sample values; the weight gradients are summed over both
+     * renders in one pass instead of two passes added. */
+    uint32_t flags, reserved;
+    float *m_feats, *m_h32, *m_fb_s, *m_fb_c, *m_sigma, *m_rgb, *m_g_sigmas, *m_g_rgbs, *m_dx32, *m_dfeat;
+    int32_t* m_rows;
 } enerf_event_step_args;
 int enerf_train_step_events(const enerf_event_step_args* args);
 

@@ -889,16 +889,37 @@ def test_native_event_step_call_equals_the_python_driven_event_step():
         h.native_step = native
         calls = []
         orig = fused_render.train_step_events_native
-        fused_render.train_step_events_native = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+
+        def counted(m_, *a, **k):
+            out = orig(m_, *a, **k)
+            calls.append(int(m_._native_events_ctx["a"].flags))
+            return out
+        fused_render.train_step_events_native = counted
         try:
             torch.manual_seed(3)                               # the step draws a random background colour
             losses = [h.step_events(batch(i), opt, next_data=batch(i + 1)).clone() for i in range(40)]
         finally:
             fused_render.train_step_events_native = orig
+        if native:
+            # both renders' samples as ONE batch of 2 M rows (flags bit 1) whenever the two stages were marched together by
+            # the previous call: every steady step except the ones right after an update_extra_state
+            assert sum(1 for f in calls if f & 2) >= len(calls) - 4 and len(calls) >= 24
         torch.cuda.synchronize()
         runs[native] = (torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
                         {n: p.detach().clone() for n, p in model.named_parameters()}, len(calls),
                         {n for n, p in model.named_parameters() if p.grad is not None})
+    # the one-call step with the renders kept apart (the layout before the merge) still agrees with both
+    fused_render.MERGE_EVENT_RENDERS = False
+    try:
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+        torch.manual_seed(3)
+        lc = torch.stack([h.step_events(batch(i), opt, next_data=batch(i + 1)).clone() for i in range(40)]).cpu()
+        assert int(model._native_events_ctx["a"].flags) == 0
+    finally:
+        fused_render.MERGE_EVENT_RENDERS = True
+    assert float(((lc - runs[False][0]).abs() / runs[False][0].abs().clamp(min=1e-9)).max()) <= 1e-5
     (la, ca, pa, na, ga), (lb, cb, pb, nb, gb) = runs[True], runs[False]
     # (8 steps without a sample budget -- two renders per step fill the 16-slot ring -- then every step is steady)
     assert na >= 24 and nb == 0
