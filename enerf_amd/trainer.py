@@ -826,7 +826,13 @@ class TrainHarness:
         from .events import train_step_events
         if not self.model.training:
             self.model.train()
-        self.maybe_update_extra_state()
+        coming = None
+        if (self.global_step % self.update_interval == 0 and self.overlap_update and not self.fp16 and opt.event_only
+                and not opt.render_kwargs and self._events_manual_ok(data, opt)):
+            # (the first render's count pass only: the marcher's chunk log holds ONE outstanding count pass, the second
+            # render is marched whole once the first's write pass has run)
+            coming = (data["rays_evs_o1"], data["rays_evs_d1"])
+        self.maybe_update_extra_state(coming)
         self.global_step += 1
         from .events import wants_no_event_term
         no_ev = wants_no_event_term(opt)                 # two more renders per step: neither graphs nor the one-call step
