@@ -116,10 +116,12 @@ def resolve_pending(model, wait=True):
     done.synchronize()
     mean, counted = host.tolist()
     model.mean_density = mean
-    if total_step > 0 and early_count is not None:
-        # the update kernel's own sum of the ring: must be what was read early
-        assert int(counted / total_step) == early_count, (counted, total_step, early_count)
     model._pending_density_stats = None
+    if total_step > 0 and early_count is not None and int(counted / total_step) != early_count:
+        # the update kernel's own sum of the ring is the reference value: it must be what was read early (nothing may
+        # march between the early read and the update -- fused_render.early_mean_count's conditions)
+        raise RuntimeError(f"update_extra_state: the early sample budget {early_count} is not the update's own "
+                           f"{int(counted / total_step)} (counted {counted} over {total_step} renders)")
 
 
 @torch.no_grad()
