@@ -1025,12 +1025,13 @@ def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_st
         a.lr, a.beta1, a.beta2, a.eps, a.table_step = plan()
         L.check(L.lib().enerf_train_step_events(_ct.byref(a)), "train_step_events")
         from .backends import _gridencoder as _gbk
-        for pre in pres:
-            _gbk.STATS["fwd_points"] += pre["M"]
+        # (the launch counters bench.py reads: merged, the library issued ONE grid_encode_forward / backward over 2 M points)
+        for points in ([pres[0]["M"] + pres[1]["M"]] if merged else [pre["M"] for pre in pres]):
+            _gbk.STATS["fwd_points"] += points
             _gbk.STATS["fwd_calls"] += 1
-            _gbk.STATS["bwd_points"] += pre["M"]
+            _gbk.STATS["bwd_points"] += points
             _gbk.STATS["bwd_calls"] += 1
-            _gbk.LIFETIME["fwd_points"] += pre["M"]
+            _gbk.LIFETIME["fwd_points"] += points
             _gbk.LIFETIME["fwd_calls"] += 1
         if staged:
             ready = torch.cuda.Event()

@@ -8,7 +8,12 @@ B = the reference's structure over the same HIP entry points: run_cuda op by op 
 
 Same model seed, same batches, the occupancy grid learned by update_extra_state itself.  Reports held-out PSNR
 (16 K pixels never trained on) for several seeds of each; writes a JSON summary.
-python tools/psnr_ab.py [steps] [seeds] [out.json] [first_seed]"""
+python tools/psnr_ab.py [steps] [seeds] [out.json] [first_seed] [refkernels]
+
+`refkernels` (needs oracle/_ref, see oracle/build_ref.py): route B's ray marching, compositing (forward and backward) and SH
+encoding run on the REFERENCE's own kernels -- its raymarching.cu / shencoder.cu built for gfx950 -- bound to the wrappers
+exactly as the reference's raymarching.py / sphere_harmonics.py bind them; only the hash grid and the MLPs of route B stay
+on this library (gridencoder.cu / ffmlp cannot be built here)."""
 import json
 import math
 import os
@@ -29,6 +34,14 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 out_path = sys.argv[3] if len(sys.argv) > 3 else None
 first_seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+ref_kernels = len(sys.argv) > 5 and sys.argv[5] == "refkernels"
+_own = None
+if ref_kernels:
+    from oracle import build_ref
+    import enerf_amd.raymarching as _rmod
+    import enerf_amd.shencoder as _smod
+    _ref = (build_ref.load("raymarching"), build_ref.load("shencoder"))
+    _own = (_rmod._backend, _smod._backend)
 data = _batches(32, 4096, 2, seed=5)
 held = _batches(1, 16384, 2, seed=77)[0]
 
@@ -36,6 +49,8 @@ held = _batches(1, 16384, 2, seed=77)[0]
 def run(route, seed):
     fused = route == "A"
     fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = fused
+    if _own is not None:
+        _rmod._backend, _smod._backend = _own if fused else _ref
     torch.manual_seed(seed)
     model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).cuda()
     h = TrainHarness(model, lr=1e-2, occupancy="learned")
@@ -71,13 +86,15 @@ for seed in range(first_seed, first_seed + seeds):
         rows.append(r)
         print(route, seed, round(r["psnr_db"], 3), flush=True)
 fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = True
+if _own is not None:
+    _rmod._backend, _smod._backend = _own
 mean = {k: sum(r["psnr_db"] for r in rows if r["route"] == k) / seeds for k in ("A", "B")}
 spread = {k: max(r["psnr_db"] for r in rows if r["route"] == k) - min(r["psnr_db"] for r in rows if r["route"] == k)
           for k in ("A", "B")}
 diffs = [a["psnr_db"] - b["psnr_db"] for a, b in zip(rows[0::2], rows[1::2])]           # paired by seed
 dmean = sum(diffs) / len(diffs)
 dstd = (sum((d - dmean) ** 2 for d in diffs) / max(len(diffs) - 1, 1)) ** 0.5
-summary = {"steps": steps, "seeds": seeds, "mean_psnr_db": mean, "seed_spread_db": spread,
+summary = {"steps": steps, "seeds": seeds, "route_B_kernels": "reference raymarching.cu + shencoder.cu (oracle/_ref)" if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
            "A_minus_B_db": dmean, "paired_std_db": dstd, "standard_error_db": dstd / len(diffs) ** 0.5,
            "runs": rows}
 print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
