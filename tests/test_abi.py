@@ -94,3 +94,12 @@ def test_extension_modules_import_as_top_level_and_match_the_reference_prototype
             sys.path.remove(d)
         for n in sigs:
             sys.modules.pop(n, None)
+
+
+def test_reference_kernel_build_recipe_is_declared():
+    """oracle/build_ref.py: which reference modules are built for gfx950 as the GPU tests' cross-check, which are not and
+    why (no compute here: the recipe needs /root/reference to build and a GPU to run)."""
+    from oracle import build_ref as br
+    assert set(br.MODULES) == {"raymarching", "shencoder"} and set(br.UNBUILDABLE) == {"gridencoder", "ffmlp"}
+    assert all(name.startswith("_ref_") for _, name in br.MODULES.values())
+    assert isinstance(br.built(), list)
