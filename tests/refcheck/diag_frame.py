@@ -2,7 +2,7 @@
 import math, sys, os, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from enerf_amd import frame, scene
 from enerf_amd.backends import _raymarching as rb

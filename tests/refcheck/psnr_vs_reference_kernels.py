@@ -1,0 +1,13 @@
+"""tools/psnr_ab.py with route B on the reference's OWN ray-marching / compositing / SH kernels (oracle/_ref, built by
+oracle/build_ref.py).  TEST INFRASTRUCTURE: it lives under tests/ because it runs the checker's kernels.
+    python -B tests/refcheck/psnr_vs_reference_kernels.py [steps] [seeds] [out.json] [first_seed]"""
+import os
+import runpy
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import build_ref  # noqa: E402
+
+backends = (build_ref.load("raymarching"), build_ref.load("shencoder"))
+runpy.run_path(os.path.join(ROOT, "tools", "psnr_ab.py"), init_globals={"ROUTE_B_BACKENDS": backends}, run_name="__main__")

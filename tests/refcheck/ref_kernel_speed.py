@@ -1,9 +1,9 @@
 """The reference's own kernels (oracle/_ref: raymarching.cu / shencoder.cu built for gfx950 with default flags) timed beside
-this library's kernels on the same MI355X, same inputs, BASELINE shapes.  Test / measurement infrastructure: the product
-never loads oracle/_ref.  Both sides are called through their pybind modules (same signatures), hipEvents around 20
+this library's kernels on the same MI355X, same inputs, BASELINE shapes.  TEST INFRASTRUCTURE (it lives under tests/ because it
+runs the checker's kernels): the product never loads oracle/_ref.  Both sides are called through their pybind modules (same signatures), hipEvents around 20
 back-to-back launches after 3 warm-ups; outputs are the ones tests/test_gpu_ref_kernels.py proves equal.
 
-    gpurun -- 'python tools/ref_kernel_speed.py > gpurun_out/ref_kernel_speed.txt'
+    gpurun -- 'python tests/refcheck/ref_kernel_speed.py > gpurun_out/ref_kernel_speed.txt'
 """
 import importlib
 import math
@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as O, build_ref as br   # noqa: E402
 from util import synthetic_density_grid, camera_rays   # noqa: E402

@@ -2,7 +2,7 @@
 samples / by how many ulps.  GPU box only."""
 import math, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as O, build_ref as br
 from util import synthetic_density_grid, camera_rays

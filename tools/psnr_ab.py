@@ -8,12 +8,12 @@ B = the reference's structure over the same HIP entry points: run_cuda op by op 
 
 Same model seed, same batches, the occupancy grid learned by update_extra_state itself.  Reports held-out PSNR
 (16 K pixels never trained on) for several seeds of each; writes a JSON summary.
-python tools/psnr_ab.py [steps] [seeds] [out.json] [first_seed] [refkernels]
+python tools/psnr_ab.py [steps] [seeds] [out.json] [first_seed]
 
-`refkernels` (needs oracle/_ref, see oracle/build_ref.py): route B's ray marching, compositing (forward and backward) and SH
-encoding run on the REFERENCE's own kernels -- its raymarching.cu / shencoder.cu built for gfx950 -- bound to the wrappers
-exactly as the reference's raymarching.py / sphere_harmonics.py bind them; only the hash grid and the MLPs of route B stay
-on this library (gridencoder.cu / ffmlp cannot be built here)."""
+tests/refcheck/psnr_vs_reference_kernels.py runs the same experiment with route B's ray marching, compositing (forward and
+backward) and SH encoding on the REFERENCE's own kernels (its raymarching.cu / shencoder.cu built for gfx950, oracle/_ref),
+bound to the wrappers exactly as the reference's raymarching.py / sphere_harmonics.py bind them; only the hash grid and the
+MLPs of route B stay on this library (gridencoder.cu / ffmlp cannot be built here)."""
 import json
 import math
 import os
@@ -34,16 +34,15 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 out_path = sys.argv[3] if len(sys.argv) > 3 else None
 first_seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-ref_kernels = len(sys.argv) > 5 and sys.argv[5] == "refkernels"
+# ROUTE_B_BACKENDS = (raymarching module, shencoder module): set by tests/refcheck/psnr_vs_reference_kernels.py, which runs this
+# file with the reference's own kernels bound to route B's wrappers (this tool itself never touches oracle/)
+_ref = globals().get("ROUTE_B_BACKENDS")
+ref_kernels = _ref is not None
 _own = None
 if ref_kernels:
-    from oracle import build_ref
     import enerf_amd.raymarching as _rmod
     import enerf_amd.shencoder as _smod
-    _ref = (build_ref.load("raymarching"), build_ref.load("shencoder"))
     _own = (_rmod._backend, _smod._backend)
-data = _batches(32, 4096, 2, seed=5)
-held = _batches(1, 16384, 2, seed=77)[0]
 
 
 def run(route, seed):
