@@ -43,6 +43,8 @@ if ref_kernels:
     import enerf_amd.raymarching as _rmod
     import enerf_amd.shencoder as _smod
     _own = (_rmod._backend, _smod._backend)
+data = _batches(32, 4096, 2, seed=5)
+held = _batches(1, 16384, 2, seed=77)[0]
 
 
 def run(route, seed):
