@@ -342,3 +342,84 @@ def test_reference_sh_encode_equals_oracle_and_product(ref, prod, degree):
     gs = max(1.0, float(np.abs(gi_o).max()))
     assert_close(gi_r, gi_o, rtol=1e-4, atol=1e-5 * gs)
     assert_close(gi_p, gi_r.cpu().numpy(), rtol=1e-4, atol=1e-5 * gs)
+
+
+def test_config4_frame_on_the_reference_inference_kernels_equals_the_whole_frame_pass(ref, monkeypatch):
+    """BASELINE configs[4] end to end: the 640 x 480 frame rendered by the product's whole-frame pass (one march, one
+    compositing pass) against the reference's round schedule (nerf/renderer.py:330-380) running on the REFERENCE's
+    near_far_from_aabb / march_rays / composite_rays / compact_rays kernels, same FFMLP networks evaluated in between.
+    Equal up to the round schedule's own hand-over of t (see tests/test_gpu_baseline_configs.py: a pixel in 10^3, by a bf16
+    activation flip at most)."""
+    import enerf_amd.raymarching as rmod
+    from enerf_amd import frame, scene
+    from enerf_amd.network_ff import NeRFNetwork
+    bound = 2
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True).to(DEV).eval()
+    model.encoder.embeddings.data.uniform_(-1, 1)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    model.sigma_net.weights.data.copy_((torch.rand(model.sigma_net.weights.shape, generator=g, device=DEV) - 0.5) * 0.9)
+    model.color_net.weights.data.copy_((torch.rand(model.color_net.weights.shape, generator=g, device=DEV) - 0.5) * 0.6)
+    bits = O.packbits(synthetic_density_grid(bound, H).reshape(-1), 0.01)
+    model.density_bitfield.copy_(torch.from_numpy(bits))
+    model.density_scale = 40.0
+    inds = torch.arange(scene.H * scene.W)
+    o, d = scene.pixel_rays(scene.pose(3), inds, "cpu")
+    ro, rd = o[0].contiguous().to(DEV), d[0].contiguous().to(DEV)
+    assert ro.shape[0] == 307200
+    with torch.no_grad():
+        depth, image = frame.render_frame(model, ro, rd, 1)
+        with monkeypatch.context() as mp:
+            mp.setattr(rmod, "_backend", ref["rm"])              # the wrappers bind the reference's module, as its own do
+            d_ref, im_ref = frame.render_rounds(model, ro, rd, 1)
+        torch.cuda.synchronize()
+    diff = (image - im_ref).abs()
+    assert float(diff.max()) < 2e-3 and float((diff > 1e-4).float().mean()) < 2e-3, (float(diff.max()),
+                                                                                    float((diff > 1e-4).float().mean()))
+    dd = (depth - d_ref).abs()
+    dd = dd[torch.isfinite(dd)]
+    assert float(dd.max()) < 2e-4 and float((dd > 1e-5).float().mean()) < 2e-3
+    assert float(image.std()) > 0.01 and float((image - 1).abs().max()) > 0.1       # a real picture, not the background
+
+
+def test_training_render_on_the_reference_kernels_equals_the_fused_product_render(ref, monkeypatch):
+    """BASELINE configs[1] end to end (4096 rays, bound 3, jitter on): a training render + backward with the reference-shaped
+    wrappers bound to the REFERENCE's raymarching and SH modules (op by op, autograd; the hash grid and the nn.Linear nets on
+    this library -- gridencoder.cu cannot be built here) against the product's fused route (one render node, closed
+    backward, split-bf16 MLP kernels): sample counters bit-exact, image 1e-4, every parameter's gradient to the bars of the
+    product's own route-equivalence tests."""
+    import enerf_amd.raymarching as rmod, enerf_amd.shencoder as smod
+    from enerf_amd import fused_network, fused_render, density_update
+    from enerf_amd.network import NeRFNetwork
+    bound = 3
+    bits = O.packbits(synthetic_density_grid(bound, H).reshape(-1), 0.01)
+    o, d = camera_rays(4096, 56, bound)
+
+    def run(on_reference):
+        with monkeypatch.context() as mp:
+            if on_reference:
+                mp.setattr(rmod, "_backend", ref["rm"]); mp.setattr(smod, "_backend", ref["sh"])
+                mp.setattr(fused_render, "ENABLED", False); mp.setattr(fused_network, "ENABLED", False)
+                mp.setattr(density_update, "ENABLED", False)
+            torch.manual_seed(0)
+            model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3)
+            gg = torch.Generator().manual_seed(5)
+            model.encoder.embeddings.data.copy_(torch.rand(model.encoder.embeddings.shape, generator=gg) * 2 - 1)
+            model.density_bitfield.copy_(torch.from_numpy(bits))
+            model.to(DEV).train()
+            ro, rd = torch.from_numpy(o)[None].to(DEV), torch.from_numpy(d)[None].to(DEV)
+            out = model.render(ro, rd, staged=False, bg_color=torch.full((3,), 0.3, device=DEV), perturb=True,
+                               force_all_rays=True)
+            (out["image"] ** 2).sum().backward()
+            torch.cuda.synchronize()
+            return (out["image"].detach().cpu(), model.step_counter[0].cpu().clone(),
+                    {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+
+    im_r, c_r, g_r = run(True)
+    im_p, c_p, g_p = run(False)
+    assert torch.equal(c_r, c_p) and int(c_r[0]) > 100_000          # the same ~300 k samples, 4096 rays
+    assert_close(im_p, im_r, rtol=1e-4, atol=2e-5)
+    for n in g_r:
+        scale = float(g_r[n].abs().max())
+        assert scale > 0
+        assert float((g_p[n] - g_r[n]).abs().max()) < 2e-3 * scale, (n, float((g_p[n] - g_r[n]).abs().max()) / scale)
