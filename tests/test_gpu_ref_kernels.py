@@ -209,7 +209,8 @@ def test_reference_composite_train_equals_oracle_and_product(ref, prod, scenes):
         assert_close(b, a.cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def test_reference_inference_loop_equals_oracle(ref, scenes):
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 256])
+def test_reference_inference_loop_equals_oracle(ref, scenes, dt_gamma):
     """march_rays / composite_rays / compact_rays for the whole loop of `run_cuda`'s inference branch: every round's samples
     bit-exact against the oracle, same rays terminate, same survivors (the reference compacts through an atomic counter:
     its survivors come in any order, so both sides continue from the oracle's order)."""
@@ -243,9 +244,9 @@ def test_reference_inference_loop_equals_oracle(ref, scenes):
         n_step = max(min(N // n_alive, 8), 1)
         Mi = n_alive * n_step; Mi += 128 - Mi % 128
         perturb = 0 if it % 2 == 0 else 1
-        x, dd, dl = O.march_rays(n_alive, n_step, alive, rt, o, d, bound, 0.0, 1024, C, H, bits, nears, fars, Mi, perturb)
+        x, dd, dl = O.march_rays(n_alive, n_step, alive, rt, o, d, bound, dt_gamma, 1024, C, H, bits, nears, fars, Mi, perturb)
         gx = torch.zeros(Mi, 3, device=DEV); gd = torch.zeros(Mi, 3, device=DEV); gl = torch.zeros(Mi, 2, device=DEV)
-        rm.march_rays(n_alive, n_step, g_alive, g_rt, co, cd, float(bound), 0.0, 1024, C, H, cb, cn, cf, gx, gd, gl, perturb)
+        rm.march_rays(n_alive, n_step, g_alive, g_rt, co, cd, float(bound), dt_gamma, 1024, C, H, cb, cn, cf, gx, gd, gl, perturb)
         assert np.array_equal(gx.cpu().numpy(), x) and np.array_equal(gl.cpu().numpy(), dl)
         assert np.array_equal(gd.cpu().numpy(), dd)
         sig = (rng.random(Mi) * 30).astype(np.float32); rgb = rng.random((Mi, 3)).astype(np.float32)
