@@ -54,6 +54,7 @@ SIGNATURES = {
     "enerf_stream_wait_mlp32_signal": [_vp],
     "enerf_debug_workspace_ordering": [_int],
     "enerf_mlp32_valid_rows": [_vp],
+    "enerf_mlp32_valid_rows_ex": [_vp, _u32, _u32],
     "enerf_grid_adam_from_records_ex": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _vp, _vp,
                                         _vp, _vp, _vp, _vp, _vp, _vp],
     "enerf_grid_adam_from_records": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _f32, _f32, _f32, _u32, _vp],

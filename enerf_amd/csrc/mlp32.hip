@@ -821,6 +821,7 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob
 }
 
 static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
+static uint32_t g_valid_base = 0, g_valid_cap = 0;  // enerf_mlp32_valid_rows_ex
 static bool g_signal_armed = false;      // enerf_mlp32_signal_next_reduce
 static bool g_signal_recorded = false;
 static hipEvent_t g_signal_event = nullptr;
@@ -856,6 +857,14 @@ extern "C" {
 // Applies to the mlp32 forward / backward calls that follow, until set again (NULL: every row is real).
 int enerf_mlp32_valid_rows(const int32_t* device_count) {
     g_valid_rows = device_count;
+    g_valid_base = g_valid_cap = 0;
+    return 0;
+}
+// real rows = base + min(*device_count, cap)  (cap == 0: as enerf_mlp32_valid_rows)
+int enerf_mlp32_valid_rows_ex(const int32_t* device_count, uint32_t base, uint32_t cap) {
+    g_valid_rows = device_count;
+    g_valid_base = device_count ? base : 0;
+    g_valid_cap = device_count ? cap : 0;
     return 0;
 }
 
@@ -914,6 +923,8 @@ static WSrc blob_src(const float* W, uint32_t num_hidden) {
     w.w0_cols = IN;
     w.nerf_perm = 0;
     w.valid_rows = g_valid_rows;
+    w.valid_base = g_valid_base;
+    w.valid_cap = g_valid_cap;
     return w;
 }
 static int segs_ok(const void* const* seg, uint32_t num_hidden, uint32_t w0_cols, uint32_t nerf_perm, const char* what) {
@@ -1030,6 +1041,8 @@ int enerf_mlp32_forward_p(const float* X, const float* const* wseg, uint32_t w0_
     w.w0_cols = w0_cols;
     w.nerf_perm = nerf_perm;
     w.valid_rows = g_valid_rows;
+    w.valid_base = g_valid_base;
+    w.valid_cap = g_valid_cap;
     return mlp32_forward_impl(X, w, B, in_dim, out_dim, num_hidden, activation, output_activation, fb, Y, x_layout,
                               y_stride, y0_exp, sh_dirs, stream);
 }
@@ -1220,6 +1233,8 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
     w.w0_cols = d.w0_cols = w0_cols;
     w.nerf_perm = d.nerf_perm = nerf_perm;
     w.valid_rows = g_valid_rows;
+    w.valid_base = g_valid_base;
+    w.valid_cap = g_valid_cap;
     d.overwrite = overwrite;
     return mlp32_backward_impl(dY, X, w, fb, B, in_dim, out_dim, num_hidden, activation, bb, dX, d, x_layout, dy_stride,
                                y_sigmoid, y_sigmoid_stride, dsigma, h0, h0_stride, stream);

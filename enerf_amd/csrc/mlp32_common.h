@@ -70,10 +70,14 @@ struct WSrc {
     // is skipped is its LAST round: at 4163 tiles over 2048 (1024) resident waves, a batch of <= 4096 real tiles takes
     // two (four) rounds instead of three (five).
     const int32_t* valid_rows;
+    // enerf_mlp32_valid_rows_ex: the real rows are valid_base + min(*valid_rows, valid_cap) (two renders' samples in one
+    // batch: the first render's M rows -- its padding included -- then the second's counter, capped at its own M)
+    uint32_t valid_base, valid_cap;
 };
 __device__ __forceinline__ uint32_t valid_tiles(const WSrc& W, uint32_t B, uint32_t ntiles) {
     if (!W.valid_rows) return ntiles;
-    const int32_t v = W.valid_rows[0];
+    int32_t v = W.valid_rows[0];
+    if (W.valid_cap) v = (int32_t)W.valid_base + (v <= 0 ? 0 : (v < (int32_t)W.valid_cap ? v : (int32_t)W.valid_cap));
     const uint32_t rows = v <= 0 ? 0u : ((uint32_t)v < B ? (uint32_t)v : B);
     const uint32_t t = (rows + 31u) / 32u;
     return t < ntiles ? t : ntiles;

@@ -121,14 +121,6 @@ done:
     return rc;
 }
 
-// valid rows of the merged 2 M-row batch: the first render's M rows (its padding included: zero gradients) + the second's
-__global__ void k_event_merged_rows(const int32_t* __restrict__ counter1, uint32_t M, int32_t* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int32_t c = counter1[0];
-        out[0] = (int32_t)(M + (c <= 0 ? 0u : ((uint32_t)c < M ? (uint32_t)c : M)));
-    }
-}
-
 // The event-only step with both renders' samples as ONE batch of 2 M rows (enerf_event_step_args.flags bit 1)
 static int train_step_events_merged(const enerf_event_step_args* a) {
     enerf_stream_t s = a->stream;
@@ -138,8 +130,7 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     if (r1.M != M || r1.xyzs != r0.xyzs + (size_t)3 * M || r1.dirs != r0.dirs + (size_t)3 * M ||
         r1.deltas != r0.deltas + (size_t)2 * M)
         ENERF_BADARG("train_step_events(merged): the second render's samples must follow the first's M rows");
-    if (!a->m_feats || !a->m_h32 || !a->m_sigma || !a->m_rgb || !a->m_g_sigmas || !a->m_g_rgbs || !a->m_dx32 || !a->m_dfeat ||
-        !a->m_rows)
+    if (!a->m_feats || !a->m_h32 || !a->m_sigma || !a->m_rgb || !a->m_g_sigmas || !a->m_g_rgbs || !a->m_dx32 || !a->m_dfeat)
         ENERF_BADARG("train_step_events(merged): the m_* scratch buffers are required");
     int prev_prec = -1;
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
@@ -155,8 +146,7 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     STEP(enerf_grid_encode_forward(r0.xyzs, a->embeddings, a->offsets, a->m_feats, M2, 3, 2, 16, a->level_scale_log2,
                                    a->base_resolution, 0, a->m_feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
     if (skip) {
-        k_event_merged_rows<<<1, 64, 0, (hipStream_t)s>>>(r1.counter, M, a->m_rows);
-        enerf_mlp32_valid_rows(a->m_rows);
+        enerf_mlp32_valid_rows_ex(r1.counter, M, M);         // real rows: the first render's M + min(counter_2, M)
         rows_set = true;
     }
     STEP(enerf_mlp32_forward_p(a->m_feats, a->wseg_s, 32, 0, M2, 32, 16, a->nh_s, 0, 6, a->m_fb_s, a->m_h32, 1, 32,
@@ -184,7 +174,7 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
                                                      a->m_g_rgbs + (size_t)k * M * a->out_c, nullptr, s));
     }
     if (skip) {
-        enerf_mlp32_valid_rows(a->m_rows);
+        enerf_mlp32_valid_rows_ex(r1.counter, M, M);
         rows_set = true;
     }
     if (march_next) {

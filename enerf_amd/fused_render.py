@@ -822,7 +822,7 @@ class _EventStepArgs(_ct.Structure):      # enerf_event_step_args
                 + [(n, _vp) for n in ("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step")]
                 + [("flags", _u32), ("reserved", _u32)]
                 + [(n, _vp) for n in ("m_feats", "m_h32", "m_fb_s", "m_fb_c", "m_sigma", "m_rgb", "m_g_sigmas", "m_g_rgbs",
-                                      "m_dx32", "m_dfeat", "m_rows")])
+                                      "m_dx32", "m_dfeat")])
 
 
 MERGE_EVENT_RENDERS = True    # the one-call event step runs both renders' samples as one batch of 2 M rows (flags bit 1)
@@ -874,7 +874,7 @@ def _native_events_ctx(model, N, Ms, Nn, Mn, luma, dev):
                   m_fb_s=torch.empty(arch["nh_s"], M2, 64, **f32), m_fb_c=torch.empty(arch["nh_c"], M2, 64, **f32),
                   m_sigma=torch.empty(M2, **f32), m_rgb=torch.empty(M2, out_c, **f32), m_g_sigmas=torch.empty(M2, **f32),
                   m_g_rgbs=torch.empty(M2, out_c, **f32), m_dx32=torch.empty(M2, 32, **f32),
-                  m_dfeat=torch.empty(16, M2, 2, **f32), m_rows=torch.zeros(1, dtype=torch.int32, device=dev))
+                  m_dfeat=torch.empty(16, M2, 2, **f32))
         for name, buf in tm.items():
             setattr(a, name, buf.data_ptr())
     for q, M in enumerate(Ms):

@@ -431,6 +431,9 @@ int enerf_mlp32_backward(const float* dY, const float* X, const float* W, const 
  * ray covers (forward: left unwritten; fused backward: zero input gradients) -- until it is set again; NULL: every row
  * is real. */
 int enerf_mlp32_valid_rows(const int32_t* device_count);
+/* The same with real rows = base + min(*device_count, cap): two renders' samples as one batch (the first render's M rows,
+ * its padding included, then the second's counter capped at its own M).  cap == 0: as enerf_mlp32_valid_rows. */
+int enerf_mlp32_valid_rows_ex(const int32_t* device_count, uint32_t base, uint32_t cap);
 /* Arithmetic of the enerf_mlp32_* kernels (the nn.Linear nets of nerf/network.py:40-77 are fp32):
  *   0  v_mfma_f32_32x32x2_f32: every dot product an fp32 fmaf chain, bit-comparable with an fp32 GEMM;
  *   1  (default) split-bf16: every fp32 operand as bf16 hi + lo, three bf16 MFMA products per fp32 product (hi*hi +
@@ -640,13 +643,12 @@ typedef struct enerf_event_step_args {
     /* flags bit 1: MERGED layout.  Both renders have the same M, r[1].xyzs / dirs / deltas are the M rows that follow
      * r[0]'s in one buffer, and the m_* pointers hold scratch for 2 M rows (shapes of the per-render scratch with 2 M
      * for M).  Then grid_encode_forward, the four mlp32 launches, grid_encode_backward run ONCE over the 2 M rows (rows
-     * [counter0, M) are padding whose gradients the first render's composite backward zero-fills; m_rows, one device
-     * int32 the call writes, = M + min(counter1, M) is what the MLP kernels take as their valid-row count); compositing
-     * and its backward stay per render, on the halves.  Same per-sample values; the weight gradients are summed over both
-     * renders in one pass instead of two passes added. */
+     * [counter0, M) are padding whose gradients the first render's composite backward zero-fills; the MLP kernels take
+     * M + min(counter1, M) as their valid-row count: enerf_mlp32_valid_rows_ex); compositing and its backward stay per
+     * render, on the halves.  Same per-sample values; the weight gradients are summed over both renders in one pass
+     * instead of two passes added. */
     uint32_t flags, reserved;
     float *m_feats, *m_h32, *m_fb_s, *m_fb_c, *m_sigma, *m_rgb, *m_g_sigmas, *m_g_rgbs, *m_dx32, *m_dfeat;
-    int32_t* m_rows;
 } enerf_event_step_args;
 int enerf_train_step_events(const enerf_event_step_args* args);
 
