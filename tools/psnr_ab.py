@@ -43,6 +43,7 @@ if ref_kernels:
     import enerf_amd.raymarching as _rmod
     import enerf_amd.shencoder as _smod
     _own = (_rmod._backend, _smod._backend)
+SHUFFLE = os.environ.get("ENERF_PSNR_SHUFFLE", "0") == "1"
 data = _batches(32, 4096, 2, seed=5)
 held = _batches(1, 16384, 2, seed=77)[0]
 
@@ -63,9 +64,27 @@ def run(route, seed):
     torch.cuda.synchronize()
     t0 = time.time()
     psnrs = []
+    gperm = torch.Generator(device="cuda").manual_seed(10_000 + seed)
+
+    def batch(i):
+        """ENERF_PSNR_SHUFFLE=1: the rays of a batch in a fresh order every time it is used (the same order for both
+        routes).  With a sample budget the marcher drops the rays that do not fit: the reference in the order its atomics
+        land, this library the LAST rays of the batch -- with 32 fixed batches cycled in a fixed order those are always
+        the same pixels, which a data loader that draws fresh rays every step never produces."""
+        ro, rd, tg = data[i % len(data)]
+        if not SHUFFLE:
+            return ro, rd, tg
+        if i not in cache:
+            for k in [k for k in cache if k < i - 1]:
+                del cache[k]
+            p = torch.randperm(ro.shape[-2], device=ro.device, generator=gperm)
+            cache[i] = (ro[..., p, :].contiguous(), rd[..., p, :].contiguous(), tg[..., p, :].contiguous())
+        return cache[i]
+    cache = {}
     for i in range(steps):
-        nxt = data[(i + 1) % len(data)]
-        loss = h.step_rgb(*data[i % len(data)], next_rays=(nxt[0], nxt[1]) if fused else None)
+        cur = batch(i)
+        nxt = batch(i + 1)
+        loss = h.step_rgb(*cur, next_rays=(nxt[0], nxt[1]) if fused else None)
         if i + 1 > steps - steps // 5 and (steps - 1 - i) % (steps // 25) == 0:      # 5 evaluations over the last fifth
             model.eval()
             with torch.no_grad():
@@ -95,7 +114,7 @@ spread = {k: max(r["psnr_db"] for r in rows if r["route"] == k) - min(r["psnr_db
 diffs = [a["psnr_db"] - b["psnr_db"] for a, b in zip(rows[0::2], rows[1::2])]           # paired by seed
 dmean = sum(diffs) / len(diffs)
 dstd = (sum((d - dmean) ** 2 for d in diffs) / max(len(diffs) - 1, 1)) ** 0.5
-summary = {"steps": steps, "seeds": seeds, "route_B_kernels": "reference raymarching.cu + shencoder.cu (oracle/_ref)" if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
+summary = {"steps": steps, "seeds": seeds, "rays_reshuffled_per_use": SHUFFLE, "route_B_kernels": "reference raymarching.cu + shencoder.cu (oracle/_ref)" if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
            "A_minus_B_db": dmean, "paired_std_db": dstd, "standard_error_db": dstd / len(diffs) ** 0.5,
            "runs": rows}
 print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
