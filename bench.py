@@ -61,12 +61,12 @@ def parse():
                     help="render leg: the reference's round schedule (8x wider rounds) instead of the whole-frame pass")
     ap.add_argument("--net", choices=["linear", "ff"], default="linear",
                     help="linear = nerf/network.py (BASELINE configs[1-3]); ff = nerf/network_ff.py FFMLP bf16 (configs[4])")
-    ap.add_argument("--fp16", action="store_true",
-                    help="the shipped configs' fp16 = True regime on its MI355X route: the closed-form step with the "
+    ap.add_argument("--amp-bf16", dest="fp16", action="store_true",
+                    help="TrainHarness(amp='bf16') -- not the reference's fp16 regime: the closed-form step with the "
                          "networks on bf16 operands (fp32 accumulation, fp32 table, no loss scaling); dtype bf16-amp")
-    ap.add_argument("--fp16-autocast", action="store_true",
-                    help="fp16 = True taken literally: autocast(float16) + GradScaler, half hash table (588 B/point), "
-                         "op-by-op autograd route (dtype f16-autocast)")
+    ap.add_argument("--fp16", "--fp16-autocast", dest="fp16_autocast", action="store_true",
+                    help="the shipped configs' fp16 = True as the reference runs it: autocast(float16) + GradScaler, half "
+                         "hash table (588 B/point) (dtype f16-autocast)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
                          "timing behind `roofline` only sees the launches that stay eager)")
@@ -107,6 +107,13 @@ def parse():
                     help="tuning: do not test rays against the occupied cells' bounding box before marching")
     ap.add_argument("--no-comm-tune", action="store_true", help="N > 1: keep comm_chunks = 4 instead of timing 1/2/4/8")
     ap.add_argument("--backend", default=None, help="torch.distributed backend override (default: nccl = RCCL)")
+    ap.add_argument("--strong-rays", type=int, default=65536,
+                    help="second object `strong` on the line: BASELINE configs[3], this many rays per step over ALL ranks "
+                         "(65536 / N per rank), timed after the main region on a model of its own; 0 = skip")
+    ap.add_argument("--strong-steps", type=int, default=32, help="timed steps of the `strong` leg (after 20 warm-up steps)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only the launch plumbing: rendezvous, barrier, MAX all-reduce, rank 0 prints one JSON line; no "
+                         "compute, no GPU needed (tests/test_bench_launch.py drives `--gpus 2 --backend gloo` through it)")
     ap.add_argument("--force-device", type=int, default=None, help="put every rank on this device index")
     return ap.parse_args()
 
@@ -236,11 +243,58 @@ def cpu_baseline(args):
         torch.set_num_threads(prev_threads)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, one process per
+    GPU, through the same module the driver uses (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same flags>`), on a free port.  The ranks inherit stdout, so rank
+    0's ONE JSON line is this process's output; the exit code is the launcher's.  The reference's own hook for this is
+    `torch.distributed.get_rank/world_size` read by its Trainer (nerf/utils.py:299-300,351-354): launch is left to the
+    user there as well."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver stack
+    env.setdefault("OMP_NUM_THREADS", "8")                   # (torchrun would set 1 and say so on stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args):
+    """The launch contract without the hot path (it has no CPU form): what a rank does around the timed region --
+    rendezvous from the launcher's environment, barrier, MAX over ranks of a local time, rank 0 prints the line."""
+    from enerf_amd import parallel
+    import torch.distributed as dist
+    rank, world, local_rank = parallel.init_from_env(backend=args.backend)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "max_over_ranks": float(t.item()),
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "global_rays": args.global_rays or world * args.rays,
+                          "strong_rays_per_rank": args.strong_rays // world if args.strong_rays else 0}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.launch_check:
+        return launch_check(args)
     from enerf_amd import parallel, _lib
     from enerf_amd.backends import _gridencoder as gb, _raymarching as rb
     import torch.distributed as dist
@@ -250,8 +304,6 @@ def main():
         local_rank = args.force_device
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     if args.global_rays:
         if args.global_rays % world:
@@ -285,7 +337,7 @@ def main():
         frame.FRAME_ENABLED = False
         model.infer_batch_mult = 8
     harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs,
-                           fp16="autocast" if args.fp16_autocast else args.fp16)
+                           fp16=args.fp16_autocast, amp="bf16" if args.fp16 and not args.fp16_autocast else None)
     if args.fp16 or args.fp16_autocast:
         args.probe_steps = 0
         args.graph_leg_steps = 0
@@ -608,6 +660,7 @@ def main():
         # training run of thousands of steps spends its time in; the headline's K steps all fall in the full-sweep phase
         for tag, net_kind, mode, bound, fp16, iter_density in (("events_configs2", "linear", "events", 2, False, 0),
                                                                ("network_ff_rgb", "ff", "rgb", args.bound, False, 0),
+                                                               ("amp_bf16_rgb", "linear", "rgb", args.bound, "bf16", 0),
                                                                ("fp16_true_rgb", "linear", "rgb", args.bound, True, 0),
                                                                ("after_step_256_rgb", "linear", "rgb", args.bound, False, 16)):
             try:
@@ -617,7 +670,8 @@ def main():
                     from enerf_amd.network import NeRFNetwork as LegNet
                 torch.manual_seed(0)
                 m2 = LegNet(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3).to(device)
-                h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16)
+                h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16 is True,
+                                  amp="bf16" if fp16 == "bf16" else None)
                 m2.iter_density = iter_density
                 b2 = batches if bound == args.bound else build_batches(8, args.rays, device, rank, bound)
 
@@ -643,6 +697,62 @@ def main():
                 del m2, h2
             except Exception as e:          # a leg that breaks must not take the headline down with it
                 other_steps[tag] = {"error": repr(e)[:300]}
+
+    # ---- `strong`: BASELINE configs[3] -- 65 536 rays per step over ALL ranks (8192 per rank at N = 8), the same step on a
+    # model of its own with the main region's communication settings, timed like the main region (barrier + synchronise
+    # on both sides, MAX over ranks).  One launch of this file at N = 1, 2, 4, 8 therefore yields the weak curve (`value`)
+    # AND the strong curve of configs[3] (`strong.value`).
+    strong = None
+    if args.strong_rays > 0 and not args.global_rays and args.mode == "rgb" and args.net == "linear" and not args.fp16 \
+            and not args.fp16_autocast and not args.graphs and args.strong_rays % world == 0:
+        try:
+            rays_s = args.strong_rays // world
+            torch.manual_seed(0)
+            m3 = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
+            h3 = TrainHarness(m3, occupancy="synthetic", world=world)
+            for k in ("prefetch", "early_budget", "prefetch_at", "comm_dtype", "comm_chunks", "comm_mode", "native_tail"):
+                setattr(h3, k, getattr(harness, k))
+            parallel.broadcast_state(m3)
+            b3 = build_batches(4, rays_s, device, rank, args.bound)
+
+            def strong_step(i):
+                nxt = b3[(i + 1) % len(b3)]
+                return h3.step_rgb(*b3[i % len(b3)], next_rays=(nxt[0], nxt[1]))
+            for i in range(20):
+                strong_step(i)
+            sync()
+            before = marched_total(reset=False) - sum(
+                int(m3.step_counter[p_["slot"], 0]) for p_ in (getattr(m3, "_premarched", None) or {}).values()
+                if p_.get("slot") is not None)
+            sync()
+            ts0 = time.perf_counter()
+            for i in range(20, 20 + args.strong_steps):
+                strong_step(i)
+            ts_enq = time.perf_counter()
+            sync()
+            ts = time.perf_counter() - ts0
+            after = marched_total(reset=False) - sum(
+                int(m3.step_counter[p_["slot"], 0]) for p_ in (getattr(m3, "_premarched", None) or {}).values()
+                if p_.get("slot") is not None)
+            st = torch.tensor([ts, float(after - before)], dtype=torch.float64, device=device)
+            if world > 1:
+                t_max = st[:1].clone()
+                dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+                dist.all_reduce(st[1:], op=dist.ReduceOp.SUM)
+                st[0] = t_max[0]
+            ts, smp = float(st[0]), float(st[1])
+            strong = {"workload": f"BASELINE configs[3]: {args.strong_rays} rays/step ray-sharded over {world} rank(s) = "
+                                  f"{rays_s} rays/GPU, bound={args.bound}, nn.Linear nets, RCCL gradient exchange",
+                      "scaling": "strong", "global_rays": args.strong_rays, "rays_per_gpu": rays_s, "n_gpus": world,
+                      "value": args.strong_rays * args.strong_steps / ts, "unit": "rays/s",
+                      "ms_per_step": ts / args.strong_steps * 1e3, "steps": args.strong_steps, "warmup": 20,
+                      "train_ray_samples_per_sec": smp / ts,
+                      "host_enqueue_ms_per_step": (ts_enq - ts0) / args.strong_steps * 1e3,
+                      "includes_update_extra_state_steps": sum(1 for i in range(20, 20 + args.strong_steps) if i % 16 == 0),
+                      "tail": (h3.comm_mode + (" native" if h3.native_tail else " torch.distributed")) if world > 1 else None}
+            del m3, h3, b3
+        except Exception as e:                  # the headline must survive a leg that breaks
+            strong = {"error": repr(e)[:300]}
 
     # ---- render leg (not part of `value`): full 640x480 frame, pixels sharded over the ranks + all_gather of the tiles
     # (SURVEY.md 8e).  msamples_per_sec is the whole job's: samples marched on all ranks / slowest rank's time.
@@ -769,6 +879,7 @@ def main():
             "render": render,
             "step_split": split,
             "other_steps": other_steps,
+            "strong": strong,
             # every grid_encode_forward launch of this process (all legs): the population a whole-process counter profile
             # averages over (tools/profile_round.sh divides its per-dispatch FETCH / WRITE averages by this)
             "grid_fwd_lifetime": {"launches": gb.LIFETIME["fwd_calls"],

@@ -72,20 +72,33 @@ def save_checkpoint(harness, path, full=False):
     return path
 
 
-def load_checkpoint(harness, checkpoint, model_only=False, map_location=None):
+def _warn(what, err):
+    import warnings
+    warnings.warn(f"[checkpoint] failed to load {what}: {err!r} (continuing without it, as the reference's "
+                  f"Trainer.load_checkpoint does, nerf/utils.py:1396-1415)")
+
+
+def load_checkpoint(harness, checkpoint, model_only=False, map_location=None, trusted=False):
     """`checkpoint`: a path / file object, or an already loaded dict.  Mirrors Trainer.load_checkpoint: a bare
     state_dict is accepted; the model loads non-strictly and the (missing, unexpected) key lists are returned; the
     sample budget and mean density follow when the model marches on the occupancy grid; optimizer / scheduler / scaler
-    are restored when present and wanted."""
+    are restored when present and wanted, and -- as in the reference (nerf/utils.py:1396-1415) -- one of those failing
+    to load is a warning, not an error.
+    Files are read with `weights_only=True` (the reference-format dict is tensors, numbers, strings, lists and dicts: it
+    loads that way, whoever wrote it); `trusted=True` allows the full unpickler for a file that holds more."""
     m = harness.model
     if not isinstance(checkpoint, dict):
         dev = map_location or next(m.parameters()).device
-        checkpoint = torch.load(checkpoint, map_location=dev, weights_only=False)
+        checkpoint = torch.load(checkpoint, map_location=dev, weights_only=not trusted)
     if "model" not in checkpoint:
         m.load_state_dict(checkpoint)
         return [], []
     missing, unexpected = m.load_state_dict(checkpoint["model"], strict=False)
     if m.cuda_ray:
+        # an update whose read-back is still in flight belongs to the run before the load: drop it, or the next read
+        # of mean_density would resolve it over the loaded value (or raise from inside the property)
+        if getattr(m, "_pending_density_stats", None) is not None:
+            m._pending_density_stats = None
         if "mean_count" in checkpoint:
             m.mean_count = checkpoint["mean_count"]
         if "mean_density" in checkpoint:
@@ -107,15 +120,24 @@ def load_checkpoint(harness, checkpoint, model_only=False, map_location=None):
     if "global_step" in checkpoint:
         harness.global_step = checkpoint["global_step"]
     if getattr(harness, "opt", None) is not None and "optimizer" in checkpoint:
-        _load_optimizer_state(harness.opt, checkpoint["optimizer"])
+        try:
+            _load_optimizer_state(harness.opt, checkpoint["optimizer"])
+        except Exception as e:                  # noqa: BLE001
+            _warn("optimizer", e)
         m.__dict__.pop("_native_ctx", None)
         m.__dict__.pop("_native_events_ctx", None)
         if hasattr(harness, "_cleared_grad"):
             harness._cleared_grad = None
     sched = getattr(harness, "lr_scheduler", None)
     if sched is not None and "lr_scheduler" in checkpoint:
-        sched.load_state_dict(checkpoint["lr_scheduler"])
+        try:
+            sched.load_state_dict(checkpoint["lr_scheduler"])
+        except Exception as e:                  # noqa: BLE001
+            _warn("scheduler", e)
     scaler = getattr(harness, "scaler", None)
     if scaler is not None and checkpoint.get("scaler"):
-        scaler.load_state_dict(checkpoint["scaler"])
+        try:
+            scaler.load_state_dict(checkpoint["scaler"])
+        except Exception as e:                  # noqa: BLE001
+            _warn("scaler", e)
     return list(missing), list(unexpected)

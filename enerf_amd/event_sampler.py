@@ -215,13 +215,17 @@ def no_event_rays(no_evs, track, intrinsics, batch_size_evs, generator=None, dra
     if "chunk" in draws:
         j = int(draws["chunk"])
     else:
-        j = int(torch.randint(0, n_chunks, (1,), generator=generator, device=dev if generator is not None else "cpu"))
+        # (the draws happen where the generator lives: a CPU generator with the tables on the GPU is the usual case)
+        j = int(torch.randint(0, n_chunks, (1,), generator=generator,
+                              device=generator.device if generator is not None else "cpu"))
     coords = no_evs["coords"][j]
     if coords.shape[0] == 0:
         raise ValueError(f"no-event chunk {j} is empty")
-    idx = draws["idx"].to(dev) if "idx" in draws else torch.randint(0, coords.shape[0], (n,), device=dev, generator=generator)
-    u = draws["u"].to(dev, torch.float64) if "u" in draws else torch.rand(n, 2, device=dev, generator=generator,
-                                                                           dtype=torch.float64)
+    gdev = generator.device if generator is not None else dev
+    idx = draws["idx"].to(dev) if "idx" in draws else torch.randint(0, coords.shape[0], (n,), device=gdev,
+                                                                     generator=generator).to(dev)
+    u = draws["u"].to(dev, torch.float64) if "u" in draws else torch.rand(n, 2, device=gdev, generator=generator,
+                                                                           dtype=torch.float64).to(dev)
     t0, t1 = no_evs["start_time_us"][j], no_evs["end_time_us"][j]
     tss = torch.sort(t0 + (t1 - t0) * u, dim=1).values                # [n, 2] microseconds, ascending per pixel
     xs = coords[idx, 0].unsqueeze(0)

@@ -21,9 +21,12 @@ from .optim import FusedAdam
 from .parallel import GradAverager
 
 
+_UNSET = object()
+
+
 class TrainHarness:
     def __init__(self, model, lr=1e-2, occupancy="synthetic", world=1, update_interval=16, use_graphs=False,
-                 optimizer=None, fp16=False):
+                 optimizer=None, fp16=False, amp=None, prime_pool=None):
         self.model = model
         adam = optimizer or (FusedAdam if next(model.parameters()).is_cuda else torch.optim.Adam)
         self.opt = adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
@@ -53,9 +56,10 @@ class TrainHarness:
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
         self.comm_mode = "allreduce"  # or "sharded": reduce-scatter -> Adam on this rank's slice -> all-gather
         self.comm_dtype = None        # torch.bfloat16: halve the table gradient's bytes on the wire (changes rounding)
-        # the tail through the library's own RCCL communicator (csrc/dp_tail.hip: two C calls per step); None = use it
-        # when parallel.native_tail_init() succeeds (RCCL backend, every rank), False = the torch.distributed tail
-        self.native_tail = None
+        # the tail through the library's own RCCL communicator (csrc/dp_tail.hip: two C calls per step).  Opt-in: False =
+        # the torch.distributed tail (the default: it is the one the world-size-2 tests cover), None = use the native one
+        # when parallel.native_tail_init() succeeds (RCCL backend, every rank), True = likewise, decided already
+        self.native_tail = False
         # where the next batch's march is released on the side stream: once the "forward" is queued (runs beside the
         # MLP backward), once the MLP backward is ("mlp_backward": runs beside the hash table's backward and the
         # optimizer -- the MFMA kernels, one register-filling wavefront per SIMD, then have the CUs to themselves:
@@ -64,32 +68,31 @@ class TrainHarness:
         self._raw_grads = None
         self._cleared_grad = None     # the embeddings' gradient buffer as the last Adam pass left it (all zeros)
         dev0 = next(model.parameters()).device
-        if dev0.type == "cuda" and not getattr(TrainHarness, "_pool_primed", False):
-            # once per process: leave one large free block in torch's caching pool.  The first 16 steps size their sample
-            # buffers from each render's own count (a different size every step), and every size the pool cannot serve is
-            # a hipMalloc in the middle of a step -- milliseconds on a fresh process, in a loop whose step is 0.4 ms.
-            torch.empty(2 << 30, dtype=torch.uint8, device=dev0)
-            TrainHarness._pool_primed = True
+        self._prime_pool(dev0, prime_pool)
         self._loss_ring = torch.zeros(64, device=dev0)
         self._loss_cursor = 0
-        # fp16 = the shipped configs' `fp16 = True` (nerf/utils.py:350,964-975: mixed-precision training).  Two routes:
-        #   True / "bf16": the MI355X form of it -- the closed-form step with the networks on bf16 operands (fp32
-        #     accumulation, every layer's activations and activation gradients rounded to 16 bits: mlp32 precision 2),
-        #     fp32 hash table, fp32 marching / compositing, fp32 master weights.  bf16 has fp32's exponent range, so
-        #     there is no loss scaling to do: the GradScaler is kept disabled (its state_dict() is what a checkpoint
-        #     stores for a run without overflow handling).
-        #   "autocast": the literal statement -- torch.autocast(float16) + GradScaler around the op-by-op route: half hash
-        #     table + half table gradient (gridencoder/grid.py:38-39,72), half SH, half nn.Linear GEMMs.  Also what runs
-        #     when the model is not one the fused path serves.
-        self.fp16 = fp16 == "autocast"
+        # Mixed precision, two separate switches:
+        #   fp16=True (or "autocast"): the shipped configs' `fp16 = True` as the reference runs it (nerf/utils.py:350,
+        #     964-975) -- torch.autocast(float16) + GradScaler around the op-by-op route: half hash table + half table
+        #     gradient (gridencoder/grid.py:38-39,72), half SH, half nn.Linear GEMMs; the scaler's state lands in full
+        #     checkpoints and is restored from a reference checkpoint.
+        #   amp="bf16": NOT the reference's regime, named apart for that reason -- the closed-form step with the networks
+        #     on bf16 operands (fp32 accumulation, every layer's activations and activation gradients rounded to 16 bits:
+        #     mlp32 precision 2), fp32 hash table, fp32 marching / compositing, fp32 master weights.  bf16 has fp32's
+        #     exponent range, so there is no loss scaling: the GradScaler is kept disabled.  The model's own
+        #     `mlp_precision` is only overridden for the duration of this harness's steps.
+        if fp16 == "bf16":                      # (the spelling of earlier rounds)
+            fp16, amp = False, "bf16"
+        if amp not in (None, "bf16"):
+            raise ValueError(f"amp={amp!r}: None or 'bf16'")
+        self.fp16 = bool(fp16)                  # True / "autocast": the reference's regime, as the shipped configs ask
         self.amp_bf16 = False
-        if fp16 is True or fp16 == "bf16":
+        if amp == "bf16" and not self.fp16:
             from . import fused_network
             if next(model.parameters()).is_cuda and fused_network.kind_of(model) is not None:
-                model.mlp_precision = 2
-                self.amp_bf16 = True
+                self.amp_bf16 = True            # (scoped to this harness's own steps: _amp_scope)
             else:
-                self.fp16 = True
+                raise ValueError("amp='bf16' needs a CUDA model the fused path serves (network.py / network_ff.py nets)")
         self.scaler = (torch.amp.GradScaler("cuda", enabled=self.fp16) if (self.fp16 or self.amp_bf16) else None)
         # what Trainer keeps beside the model and lands in its checkpoints (nerf/utils.py:381-389,1300-1304)
         self.epoch = 1
@@ -100,6 +103,43 @@ class TrainHarness:
         self._graph_generation = 0
         if self.use_graphs:
             model.sample_budget_quantum = 8192
+
+    @staticmethod
+    def _prime_pool(dev, want):
+        """Once per process: leave one large free block in torch's caching pool.  The first 16 steps size their sample
+        buffers from each render's own count (a different size every step), and every size the pool cannot serve is a
+        hipMalloc in the middle of a step -- milliseconds on a fresh process, in a loop whose step is 0.4 ms.
+        `want`: None = on unless ENERF_PRIME_POOL=0, False = off, True = on, an int = that many bytes.  Sized from what
+        is actually free (at most a quarter of it, 2 GiB at most, nothing under 1 GiB free): several ranks on one device
+        or a nearly full GPU must not lose a harness to it, and a failed priming is a no-op."""
+        import os
+        if dev.type != "cuda" or getattr(TrainHarness, "_pool_primed", False) or want is False:
+            return
+        if want is None and os.environ.get("ENERF_PRIME_POOL", "1") == "0":
+            return
+        try:
+            free, _total = torch.cuda.mem_get_info(dev)
+            size = int(want) if (want is not True and want is not None) else min(2 << 30, free // 4)
+            if free < (1 << 30) or size <= 0 or size > free // 2:
+                return
+            torch.empty(size, dtype=torch.uint8, device=dev)
+            TrainHarness._pool_primed = True
+        except Exception:                       # noqa: BLE001 -- out of memory or no device API: train without it
+            pass
+
+    def _amp_scope(self):
+        """amp='bf16': the fused kernels read `model.mlp_precision` at launch -- set for this harness's step, restored
+        after it (the model keeps its own arithmetic for inference and for other harnesses)."""
+        m = self.model
+        prev = m.__dict__.get("mlp_precision", _UNSET)
+        m.mlp_precision = 2
+        return prev
+
+    def _amp_restore(self, prev):
+        if prev is _UNSET:
+            self.model.__dict__.pop("mlp_precision", None)
+        else:
+            self.model.mlp_precision = prev
 
     def set_lr_scheduler(self, factory):
         """`factory(optimizer) -> scheduler`, as the reference's Trainer takes it (main_nerf.py:212: LambdaLR with
@@ -760,7 +800,14 @@ class TrainHarness:
 
     def step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
-        loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
+        if self.amp_bf16:
+            prev = self._amp_scope()
+            try:
+                loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
+            finally:
+                self._amp_restore(prev)
+        else:
+            loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         return loss
@@ -817,7 +864,14 @@ class TrainHarness:
 
     def step_events(self, data, opt, next_data=None):
         """One event training step: two renders sharing one backward (nerf/utils.py:482-573)."""
-        loss = self._step_events(data, opt, next_data)
+        if self.amp_bf16:
+            prev = self._amp_scope()
+            try:
+                loss = self._step_events(data, opt, next_data)
+            finally:
+                self._amp_restore(prev)
+        else:
+            loss = self._step_events(data, opt, next_data)
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         return loss

@@ -677,12 +677,13 @@ def test_fused_table_adam_step_matches_dense_gradient_step():
 
 @pytest.mark.parametrize("route", ["bf16", "autocast"])
 def test_fp16_training_variant(route):
-    """The shipped configs' `fp16 = True` (nerf/utils.py:964-975), both routes of TrainHarness(fp16=...):
-    "autocast" -- the literal one (autocast(float16) + GradScaler): half hash table and half table gradient through the
-    grid kernels (gridencoder/grid.py:38-39,72: the 588 B/point case), half SH, fp32 marching / compositing; the scaler
-    must not see overflows after its first steps;
-    "bf16" (what fp16=True selects) -- the closed-form step with the networks on bf16 operands (mlp32 precision 2), fp32
-    table, no loss scaling.
+    """Mixed precision, the harness's two switches:
+    "autocast" = TrainHarness(fp16=True), the shipped configs' `fp16 = True` as the reference runs it
+    (nerf/utils.py:964-975: autocast(float16) + GradScaler): half hash table and half table gradient through the grid
+    kernels (gridencoder/grid.py:38-39,72: the 588 B/point case), half SH, fp32 marching / compositing; the scaler must
+    not see overflows after its first steps;
+    "bf16" = TrainHarness(amp="bf16"), this library's own regime -- the closed-form step with the networks on bf16
+    operands (mlp32 precision 2), fp32 table, no loss scaling; the model's arithmetic is restored after each step.
     Either way the loss must fall, the sample counters must be those of the fp32 run (marching does not depend on the
     networks), and the first step's loss must agree with the fp32 step's to 16-bit precision."""
     import functools
@@ -692,10 +693,10 @@ def test_fp16_training_variant(route):
     from enerf_amd.trainer import TrainHarness
     data = _batches(4, 4096, 2)
     runs = []
-    for fp16 in (False, True if route == "bf16" else "autocast"):
+    for fp16 in (False, "bf16" if route == "bf16" else True):
         torch.manual_seed(0)
         model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
-        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16 is True, amp="bf16" if fp16 == "bf16" else None)
         seen, closed = [], []
         orig, orig_step = ge.grid_encode_forward, fused_render.train_step_mse
         # (functools.wraps: gridencoder._supports_layout reads the backend function's signature)
@@ -715,7 +716,8 @@ def test_fp16_training_variant(route):
         assert torch.float16 in d16 and n16 == 0                     # training renders used the half table (the density
         assert float(h16.scaler.get_scale()) >= 1024.0               # sweep of update_extra_state stays fp32); no run of
     else:                                                            # overflow-halvings
-        assert d16 == {torch.float32} and n16 == 48 and h16.model.mlp_precision == 2
+        assert d16 == {torch.float32} and n16 == 48 and h16.amp_bf16
+        assert "mlp_precision" not in h16.model.__dict__             # (scoped to the harness's steps, not left on the model)
         assert not h16.scaler.is_enabled() and h16.scaler.state_dict() == {}
     assert torch.equal(c32, c16)
     assert np.isfinite(l16).all() and abs(l16[0] - l32[0]) <= 0.02 * abs(l32[0])

@@ -158,3 +158,39 @@ def test_lr_schedule_reaches_every_optimizer_route():
         outs.append((w.detach().clone(), lrs))
     assert outs[0][1] == outs[1][1] and outs[0][1][-1] == pytest.approx(1e-3)
     assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7)
+
+
+def test_reference_checkpoint_file_loads_without_the_unpickler_and_a_bad_optimizer_only_warns(cpu_oracle_backend, tmp_path):
+    """load_checkpoint(path) reads with weights_only=True: the file the reference's Trainer wrote holds nothing but
+    tensors, numbers, strings, lists and dicts.  An optimizer state that does not fit warns and leaves the rest loaded
+    (nerf/utils.py:1396-1401), and an update_extra_state read-back left in flight by the run before the load must not
+    overwrite the loaded mean_density."""
+    path = str(tmp_path / "ref.pth")
+    with gzip.open(os.path.join(GOLDEN, "ref_checkpoint_freq.pth.gz")) as f, open(path, "wb") as out:
+        out.write(f.read())
+    model, h = _freq_harness()
+    model._pending_density_stats = ("stale",)            # (whatever it holds: the load drops it)
+    missing, unexpected = h.load_checkpoint(path)
+    assert not missing and not unexpected and model._pending_density_stats is None
+    assert model.mean_count == 1200 and model.mean_density == 0.37 and h.global_step == 3
+    ref = _reference_checkpoint()
+    ref["optimizer"]["param_groups"] = ref["optimizer"]["param_groups"][:1]       # a group short: load_state_dict raises
+    model2, h2 = _freq_harness()
+    with pytest.warns(UserWarning, match="optimizer"):
+        h2.load_checkpoint(ref)
+    assert h2.global_step == 3 and h2.lr_scheduler.last_epoch == 3 and not h2.opt.state
+
+
+def test_harness_precision_switches_are_named_apart(cpu_oracle_backend):
+    """fp16=True is the reference's regime (autocast + GradScaler); the bf16 regime has its own name and is refused
+    where the fused path cannot serve it -- no silent remap of one onto the other."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    model = NeRFNetwork(encoding="frequency", encoding_dir="frequency", bound=1, cuda_ray=True, out_dim_color=3)
+    h = TrainHarness(model, occupancy="learned", fp16=True)
+    assert h.fp16 and not h.amp_bf16 and h.scaler is not None and "mlp_precision" not in model.__dict__
+    with pytest.raises(ValueError):
+        TrainHarness(model, occupancy="learned", amp="bf16")
+    with pytest.raises(ValueError):
+        TrainHarness(model, occupancy="learned", amp="fp8")
+    assert TrainHarness(model, occupancy="learned").native_tail is False          # the library's own RCCL tail is opt-in
