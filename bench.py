@@ -16,7 +16,11 @@ Extra objects on that line:
                 fwd + bwd + Adam) re-stated in enerf_amd and run on the host cores with the C oracle as the native
                 backend, on a bounded sample (256 rays/step); rank 0, N=1 only.
   render        full 640x480 frame through the inference loop (fp32 nets, and the FFMLP bf16 nets: BASELINE configs[4])
-  graph_replay  the same steps with render + loss + backward replayed as a HIP graph (N = 1)
+  other_steps   one GPU: the event step of configs[2], the network_ff step, amp='bf16', the literal fp16 = True regime,
+                the step after the 16 full density sweeps, the exact-fp32 MFMA arithmetic (enerf_mlp32_precision(0)) and
+                `dropin_route_rgb`: the reference-shaped run_cuda op by op through the four pybind modules with autograd
+                and torch.optim.Adam -- what an unmodified nerf/renderer.py:281-342 gets from this library
+  strong        BASELINE configs[3]: 65 536 rays per step over all ranks, timed like the main region
   comm_tuning   N > 1: measured ms/step per cut of the table-gradient all-reduce and per placement of the next batch's
                 march (TrainHarness.tune_comm, untimed, before the warm-up) with the choices made, and the step time the
                 opt-in bf16 wire format would give (reported only)
@@ -73,8 +77,8 @@ def parse():
     ap.add_argument("--no-pin", action="store_true",
                     help="do not pin this rank to a block of 8 host cores (unpinned, the launch thread migrates over the "
                          "box's 256 cores and the host-bound step time jitters by 10-15 %)")
-    ap.add_argument("--graph-leg-steps", type=int, default=48,
-                    help="extra steps timed with HIP-graph replay after the main (eager) timed region; 0 = skip")
+    ap.add_argument("--graph-leg-steps", type=int, default=0, help="(retired: graph replay lost to the one-call eager "
+                    "step, 0.50 vs 0.41 ms; --graphs still runs the main region that way)")
     ap.add_argument("--comm-bf16", action="store_true",
                     help="N > 1: all-reduce the hash-table gradient in bf16 (opt-in; fp32 is the default and the headline)")
     ap.add_argument("--prefetch-at", choices=("forward", "mlp_backward"), default=None,
@@ -602,21 +606,25 @@ def main():
                 flop_step = MLP_LINEAR_FLOP_STEP if args.net == "linear" else 3 * FFMLP_FLOP_FWD
                 tf = probe_samples * flop_step / (per_step_ms * 1e-3) / 1e12
                 issued = 3.0 if mode == 1 else 1.0          # MFMA products issued per algorithmic fp32 product
+                # headline = the pipe the kernels actually run on: split-bf16 issues three bf16 MFMA products per fp32
+                # product (flips of the weight-gradient tiles not counted), priced against the dense bf16 peak; the
+                # algorithmic fp32 FLOP against the fp32 MFMA peak (the reference's arithmetic type) is the secondary view
+                on_bf16 = mode in (1, 2)
+                peak = MFMA_BF16_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF
                 roofline_mfma = {"bound": "mfma", "kernel": "mlp32 sigma + colour nets, forward + fused dgrad/wgrad ("
                                  + ("v_mfma_f32_32x32x2_f32: fp32 fmaf chains" if mode == 0 else
                                     "v_mfma_f32_32x32x16_bf16 on split operands: hi*hi + hi*lo + lo*hi per fp32 product, "
                                     "fp32 accumulation" if mode == 1 else "v_mfma_f32_32x32x16_bf16, bf16 operands") + ")",
-                                 "achieved": tf, "peak": MFMA_BF16_PEAK_TF if mode == 2 else MFMA_F32_PEAK_TF,
-                                 "unit": "TFLOP/s",
-                                 "frac": tf / (MFMA_BF16_PEAK_TF if mode == 2 else MFMA_F32_PEAK_TF),
-                                 "peak_note": ("bf16 nets: FLOP of the nets against the dense bf16 MFMA peak" if mode == 2 else
-                                               "algorithmic fp32 FLOP of the nn.Linear nets against the dense fp32 MFMA peak "
-                                               "(the speed of light of the reference's arithmetic type)"),
-                                 # the same kernels priced against the pipe they actually run on: flops issued (the
-                                 # flips of the weight-gradient tiles not counted) / dense bf16 peak
-                                 "issued": None if mode != 1 else {
-                                     "products_per_fp32_product": issued, "achieved": tf * issued,
-                                     "peak": MFMA_BF16_PEAK_TF, "frac": tf * issued / MFMA_BF16_PEAK_TF},
+                                 "achieved": tf * issued, "peak": peak, "unit": "TFLOP/s", "frac": tf * issued / peak,
+                                 "peak_note": ("flops ISSUED on the bf16 matrix pipe (3 products per algorithmic fp32 product) "
+                                               "against the dense bf16 MFMA peak" if mode == 1 else
+                                               "bf16 nets: FLOP of the nets against the dense bf16 MFMA peak" if mode == 2 else
+                                               "fp32 FLOP of the nn.Linear nets against the dense fp32 MFMA peak"),
+                                 "products_per_fp32_product": issued,
+                                 "algorithmic_fp32": None if mode != 1 else {
+                                     "achieved": tf, "peak": MFMA_F32_PEAK_TF, "frac": tf / MFMA_F32_PEAK_TF,
+                                     "note": "algorithmic fp32 FLOP of the nn.Linear nets against the dense fp32 MFMA peak "
+                                             "(what the reference's arithmetic type could reach at best)"},
                                  "mlp32_precision": mode, "flop_per_sample": flop_step,
                                  "samples_per_step": probe_samples, "kernel_ms_per_step": per_step_ms,
                                  "forward_ms_per_step": fwd_ms / args.probe_steps,
@@ -626,26 +634,6 @@ def main():
                                            "weight-gradient reduce launch between two event packets"}
         finally:
             harness.update_interval = keep_interval
-
-    # ---- graph-replay leg (not part of `value`; single GPU, fp32 fused path): the same steps with render + loss +
-    # backward replayed as a HIP graph.  Reported beside the eager number because the per-kernel hipEvent timing that
-    # `roofline` needs cannot see launches inside a replayed graph.
-    graph_replay = None
-    if world == 1 and not args.graphs and args.net == "linear" and args.graph_leg_steps > 0:
-        harness.use_graphs = True
-        model.sample_budget_quantum = 8192
-        for i in range(args.warmup + args.steps, args.warmup + args.steps + 24):
-            one_step(i)
-        sync()
-        tg0 = time.perf_counter()
-        for i in range(args.graph_leg_steps):
-            one_step(i)
-        sync()
-        tg = (time.perf_counter() - tg0) / args.graph_leg_steps
-        harness.use_graphs = False
-        graph_replay = {"ms_per_step": tg * 1e3,
-                        "rays_per_sec": args.rays * (2 if args.mode == "events" else 1) / tg,
-                        "steps": args.graph_leg_steps, "graphs_captured": len(harness._graphs)}
 
     # ---- other steps (not part of `value`; one GPU): the event step of BASELINE configs[2] (two renders per step, rays
     # drawn from the event stream) and the training step of nerf/network_ff.py (FFMLP nets), each on a model of its own,
@@ -662,16 +650,42 @@ def main():
                                                                ("network_ff_rgb", "ff", "rgb", args.bound, False, 0),
                                                                ("amp_bf16_rgb", "linear", "rgb", args.bound, "bf16", 0),
                                                                ("fp16_true_rgb", "linear", "rgb", args.bound, True, 0),
-                                                               ("after_step_256_rgb", "linear", "rgb", args.bound, False, 16)):
+                                                               ("after_step_256_rgb", "linear", "rgb", args.bound, False, 16),
+                                                               ("mlp32_fp32_exact_rgb", "linear", "rgb", args.bound, False, 0),
+                                                               ("dropin_route_rgb", "linear", "rgb", args.bound, False, 0)):
+            restore = []
             try:
+                if tag == "mlp32_fp32_exact_rgb":
+                    # the headline's step with the nn.Linear nets on v_mfma_f32_32x32x2_f32 (bit-comparable fmaf chains)
+                    # instead of the default split-bf16 products
+                    prev_prec = _lib.lib().enerf_mlp32_precision(0)
+                    restore.append(lambda p_=prev_prec: _lib.lib().enerf_mlp32_precision(p_))
+                if tag == "dropin_route_rgb":
+                    # the boundary as the reference uses it: `_backend` of the reference-shaped wrappers = the pybind11
+                    # modules _raymarching / _gridencoder / _shencoder (enerf_amd/ext), every fused route off, autograd,
+                    # torch.optim.Adam -- what tests/test_gpu_ext.py checks against the oracle, timed
+                    import importlib
+                    import enerf_amd.raymarching as rmod, enerf_amd.gridencoder as gmod, enerf_amd.shencoder as smod
+                    from enerf_amd import ext as ext_pkg, fused_network as fn_, fused_render as fr_, density_update as du_
+                    ext_pkg.activate()
+                    mods = [importlib.import_module(n) for n in ("_raymarching", "_gridencoder", "_shencoder")]
+                    for obj, name, val in ((rmod, "_backend", mods[0]), (gmod, "_backend", mods[1]),
+                                           (smod, "_backend", mods[2]), (fr_, "ENABLED", False), (fn_, "ENABLED", False),
+                                           (du_, "ENABLED", False), (gmod, "_layout_support", {})):
+                        restore.append(lambda o_=obj, n_=name, v_=getattr(obj, name): setattr(o_, n_, v_))
+                        setattr(obj, name, val)
                 if net_kind == "ff":
                     from enerf_amd.network_ff import NeRFNetwork as LegNet
                 else:
                     from enerf_amd.network import NeRFNetwork as LegNet
                 torch.manual_seed(0)
                 m2 = LegNet(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3).to(device)
-                h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16 is True,
-                                  amp="bf16" if fp16 == "bf16" else None)
+                if tag == "dropin_route_rgb":
+                    h2 = TrainHarness(m2, occupancy="synthetic", world=1, optimizer=torch.optim.Adam)
+                    h2.native_step = h2.manual_mse = h2.fuse_table_adam = h2.prefetch = False
+                else:
+                    h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16 is True,
+                                      amp="bf16" if fp16 == "bf16" else None)
                 m2.iter_density = iter_density
                 b2 = batches if bound == args.bound else build_batches(8, args.rays, device, rank, bound)
 
@@ -697,6 +711,9 @@ def main():
                 del m2, h2
             except Exception as e:          # a leg that breaks must not take the headline down with it
                 other_steps[tag] = {"error": repr(e)[:300]}
+            finally:
+                for undo in reversed(restore):
+                    undo()
 
     # ---- `strong`: BASELINE configs[3] -- 65 536 rays per step over ALL ranks (8192 per rank at N = 8), the same step on a
     # model of its own with the main region's communication settings, timed like the main region (barrier + synchronise
@@ -867,6 +884,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f16-autocast" if args.fp16_autocast else ("bf16-amp" if args.fp16 else ("bf16" if args.net == "ff" else "f32")),
             "data": "synthetic",
+            "arithmetic": None if (args.net != "linear" or args.fp16 or args.fp16_autocast) else (
+                "fp32 storage and accumulation; products of the nn.Linear nets as three bf16 MFMA terms per fp32 product "
+                "(split-bf16: ~5e-6 relative forward error, profiles/r03_mlp32_accuracy.txt); the same step on the exact "
+                "fp32 MFMA is other_steps.mlp32_fp32_exact_rgb" if _lib.lib().enerf_mlp32_precision(-1) == 1 else
+                "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
             "config": {"workload": (f"BASELINE configs[3]: {args.global_rays} rays/step ray-sharded over {world} rank(s), "
                                     if args.global_rays else "BASELINE configs[1]: ") +
                                    f"shakeCarpet1-shaped train step, bound={args.bound}, hashgrid "
@@ -887,7 +909,6 @@ def main():
             "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
             "roofline_mfma": roofline_mfma,
             "roofline_mfma_ffmlp": ffmlp_kernel,
-            "graph_replay": graph_replay,
             "comm_tuning": comm_tuning,
             "kernels": kernels,
             "roofline": roofline,

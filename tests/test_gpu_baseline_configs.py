@@ -82,6 +82,14 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch, mlp32_mode):
                     x = inp[0].detach()
                     outp.register_hook(lambda g, key=key, x=x: terms.setdefault(key, []).append((x, g.detach())))
                 hooks.append(layer.register_forward_hook(fwd_hook))
+        # every encoder call's (normalised) query points and the gradient of its output: the table gradient of a row is
+        # the sum of corner weight x dL/dfeature over the samples of both renders whose cells touch it
+        enc_terms = []
+
+        def enc_hook(mod, inp, outp):
+            xq = inp[0].detach()
+            outp.register_hook(lambda g, xq=xq: enc_terms.append((xq, g.detach())))
+        hooks.append(ref.encoder.register_forward_hook(enc_hook))
         loss_ref, _ = events.train_step_events(ref, data, opt, bg_color=bg)
         loss_ref.backward()
         for h_ in hooks:
@@ -148,10 +156,34 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch, mlp32_mode):
         else:
             # the table: per row a sum over the few hundred (coarse levels) to a handful (fine levels) of samples in its
             # cells, accumulated by fp32 atomics in an arbitrary order on the oracle side, in fp64 per tile here
-            tol = (4e-3 if mlp32_mode == "split-bf16" else 1.5e-3) * float(r.abs().max())
-            err = float((got_g - r).abs().max())
-            worst[n] = err / float(r.abs().max())
-            assert err < tol, (n, err, float(r.abs().max()))
+            # Bounded per entry like the MLP gradients, from the oracle side's own terms: A = sum over the samples of
+            # corner weight x (largest |dL/dfeature| of that sample) -- the scale any evaluation of the sample's
+            # feature gradient is accurate against (its 32 entries are sums with cancellation of the same chain).  Every
+            # entry must hold north_star's 1e-4 against |reference| + A, except the rows of the few samples whose ReLU
+            # pre-activation lies within round-off of zero (a knife-edge sample changes its whole feature gradient, i.e.
+            # 8 rows x 16 levels per render); those are counted, and held to A itself.
+            assert len(enc_terms) == 2, len(enc_terms)
+            enc = ref.encoder
+            emb_np = enc.embeddings.detach().numpy()
+            offs = enc.offsets.numpy()
+            S_ = float(np.log2(enc.per_level_scale))
+            A = np.zeros_like(emb_np)
+            for xq, gq in enc_terms:
+                xn = ((xq.reshape(-1, 3) + bound) / (2 * bound)).numpy().astype(np.float32)
+                gmax = gq.reshape(-1, 32).abs().amax(dim=1, keepdim=True).expand(-1, 32)
+                g_lbc = gmax.reshape(-1, 16, 2).permute(1, 0, 2).contiguous().numpy()
+                A += O.grid_encode_backward(g_lbc, xn, emb_np, offs, S_, enc.base_resolution)[0]
+            A = torch.from_numpy(A)
+            err = (got_g - r).abs()
+            tight = 1e-4 * (r.abs() + A) + 1e-12
+            over = err > tight
+            n_over_rows = int(over.any(dim=1).sum())
+            knife_samples = 16 if mlp32_mode == "split-bf16" else 4
+            worst[n] = {"rows_over_1e-4": n_over_rows, "allowed": knife_samples * 128 * 2,
+                        "max err/(|r|+A)": float((err / (r.abs() + A + 1e-30)).max()),
+                        "max err/max|r|": float(err.max() / r.abs().max())}
+            assert n_over_rows <= knife_samples * 128 * 2, (n, worst[n])
+            assert bool((err <= 1e-4 * r.abs() + A + 1e-12).all()), (n, worst[n])
     print("configs[2] gradient bars (MLP: per-entry error / bar, and both relative to the largest entry; table: / max):", worst)
     assert float(grads_ref["encoder.embeddings"].abs().max()) > 0
 

@@ -47,8 +47,14 @@ def test_fused_mlp_forward_backward(dims, B, precision):
     (y * g).sum().backward()
     xb = x.clone().requires_grad_(True)
     wb = [w.clone().requires_grad_(True) for w in ws]
-    # fp64 reference of the same stack
-    yr = _ref(xb.double(), [w.double() for w in wb])
+    # fp64 reference of the same stack, keeping every layer's input and output gradient (the terms of dW = dY^T X)
+    acts, pres = [xb.double()], []
+    for li, w in enumerate(wb):
+        pre = acts[-1] @ w.double().t()
+        pre.retain_grad()
+        pres.append(pre)
+        acts.append(torch.relu(pre) if li != len(wb) - 1 else pre)
+    yr = acts[-1]
     (yr * g.double()).sum().backward()
     sc = float(yr.detach().abs().max())
     assert float((y.double() - yr).abs().max()) < k * 2e-6 * max(sc, 1.0)
@@ -64,8 +70,25 @@ def test_fused_mlp_forward_backward(dims, B, precision):
     assert n_kink <= k * (2 + B // 500)
     ok = ~kink
     assert float((xa.grad.double() - xb.grad)[ok].abs().max()) < k * 1e-5 * float(xb.grad.abs().max())
-    for a, b in zip(wa, wb):
-        assert float((a.grad.double() - b.grad).abs().max()) < (k * 2e-5 + 2e-3 * n_kink) * float(b.grad.abs().max())
+    # Weight gradients, bounded per entry from the reference's own terms: dW[o][i] = sum_s dY[s][o] X[s][i].  A = the sum
+    # of the terms' magnitudes, T = the largest single term.  The bar is north_star's 1e-4 of the entry + the arithmetic's
+    # worst case per product against A (2^-16 for the split-bf16 products, 16 eps32 for the fp32 chains) + one whole term
+    # per knife-edge sample (whose ReLU may legitimately sit on the other side).
+    u = 2.0 ** -16 if k > 1 else 16 * 2.0 ** -23
+    worst = 0.0
+    for li, (a, b) in enumerate(zip(wa, wb)):
+        X, dY = acts[li].detach(), pres[li].grad
+        G = dY.t() @ X
+        assert float((G - b.grad.double()).abs().max()) <= 1e-9 * max(float(G.abs().max()), 1.0)
+        A = dY.abs().t() @ X.abs()
+        T = torch.zeros_like(G)
+        for c0 in range(0, B, 2048):
+            T = torch.maximum(T, (dY[c0:c0 + 2048, :, None].abs() * X[c0:c0 + 2048, None, :].abs()).amax(0))
+        err = (a.grad.double() - G).abs()
+        bar = 1e-4 * G.abs() + u * A + n_kink * T + 1e-12
+        worst = max(worst, float((err / bar).max()))
+        assert bool((err <= bar).all()), (li, float((err / bar).max()), float(err.max() / G.abs().max()))
+    print(f"dW per-entry error / bar (dims {dims}, B {B}, {'split-bf16' if k > 1 else 'fp32'}): worst {worst:.3f}, kinks {n_kink}")
     # inference path (no grad) gives the same values
     with torch.no_grad():
         y2 = fused_mlp(x, ws)
