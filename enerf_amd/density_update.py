@@ -51,8 +51,8 @@ def update(model, decay=0.95, split=False):
         indices = None
         sigmas = fused_network.density_sigma_sweep(model, C, H, seed)
     else:
-        indices = torch.empty(P, dtype=torch.int32, device=dev)
-        xyzs = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        indices = fused_network._density_scratch(model, "indices", (P,), torch.int32, dev)
+        xyzs = fused_network._density_scratch(model, "xyzs", (P, 3), torch.float32, dev)
         L.check(lib.enerf_density_grid_cells(None if full else model.density_grid.data_ptr(), C, H, float(model.bound), N,
                                              ctypes.c_uint64(seed), indices.data_ptr(), xyzs.data_ptr(), stream),
                 "density_grid_cells")
