@@ -1255,6 +1255,150 @@ __device__ __forceinline__ uint32_t march_one_ray_fast(const RayCtx& c, const Ra
     return step;
 }
 
+// ------------------------------------------------------------------ march_rays_train, one thread per ray (many rays)
+// The wave-per-ray lattice marcher evaluates every lattice point of a ray, 64 at a time; the reference's loop only
+// VISITS one point per empty voxel crossed (a jump of 4 - 9 lattice points at the usual cell sizes), so the lattice does
+// ~6 evaluations per visited point.  That buys latency when rays are few (4096 rays = 4096 wavefronts of parallel work
+// instead of 64), and costs throughput when they are many: at 65 536+ rays every SIMD has several wavefronts of
+// one-thread-per-ray work to hide its loads behind, and the sequential walk (fast cell evaluator, closed-form skip of an
+// empty stretch) issues a sixth of the instructions.  So large batches -- a whole 640 x 480 frame, a 65 536-ray training
+// step -- count with one thread per ray, logging the RUNS of consecutive samples it emits (first lattice point, length);
+// the write pass stays one wavefront per ray and replays the runs with coalesced stores (the points of a run are
+// t_first + k * delta exactly inside a binade, as in the lattice marcher).  Same samples, offsets and counters, bit for
+// bit: the thread walks the reference's own loop.
+struct RunEntry {
+    float t_first;
+    uint32_t len;
+};
+constexpr uint32_t kRunCap = 64;                 // runs per ray; a ray with more is re-marched by the write pass
+
+__global__ void __launch_bounds__(256) k_march_count_t(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
+                                                       uint32_t N, uint32_t C, uint32_t H,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars,
+                                                       int32_t* rays, uint32_t perturb, RunEntry* __restrict__ log,
+                                                       uint32_t* __restrict__ nlog, const int* __restrict__ occ_keys) {
+    __shared__ float s_face[kTabH + 1];
+    __shared__ uint32_t s_expand[kTabH];
+    build_march_tabs(s_face, s_expand, H);
+    const MarchTabs tabs = {s_face, s_expand};
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
+    float t = nears[n];
+    if (perturb) t = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t);     // contracted by the reference's compiler (:351)
+    float far = fars[n];
+    uint32_t cnt = 0, nruns = 0;
+    if (!occ_keys || clip_to_occupied(c, occ_keys, far)) {
+        RayFixed rf;
+        ray_fixed_init(rf, c);
+        RunEntry* lg = log + (size_t)n * kRunCap;
+        const float dt = c.dt_min;
+        float run_first = 0.0f;
+        uint32_t run_len = 0;
+        while (t < far && cnt < max_steps) {
+            float x, y, z, tt;
+            if (eval_cell_fixed(c, rf, tabs, t, x, y, z, tt)) {
+                if (run_len == 0) run_first = t;
+                run_len++;
+                cnt++;
+                t += dt;
+            } else {
+                if (run_len) {
+                    if (nruns < kRunCap) lg[nruns] = RunEntry{run_first, run_len};
+                    nruns++;
+                    run_len = 0;
+                }
+                t = skip_empty(t, tt, dt);
+            }
+        }
+        if (run_len) {
+            if (nruns < kRunCap) lg[nruns] = RunEntry{run_first, run_len};
+            nruns++;
+        }
+    }
+    nlog[n] = nruns <= kRunCap ? nruns : kLogOverflow;
+    rays[(size_t)n * 3 + 2] = (int32_t)cnt;
+}
+
+// replay of a ray's runs by one wavefront: 64 consecutive lattice points per round while the progression holds
+__device__ __forceinline__ void run_replay(const RayCtx& c, float t0, const RunEntry* __restrict__ log, uint32_t nruns,
+                                           float* xyzs, float* dirs, float* deltas) {
+    const int lane = lane_id();
+    const float dt = c.dt_min;
+    float last_t = t0;
+    uint32_t count = 0;
+    for (uint32_t e = 0; e < nruns; e++) {
+        float base = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(log[e].t_first)));
+        uint32_t rem = __builtin_amdgcn_readfirstlane(log[e].len);
+        while (rem) {
+            const float delta = (base + dt) - base;
+            const float delta2 = ((base + delta) + dt) - (base + delta);
+            int ex;
+            (void)frexpf(base, &ex);
+            const float bin_top = ldexpf(1.0f, ex);
+            const bool progression = base >= 2.0f * dt && delta2 == delta;
+            const float ti = progression ? fmaf((float)lane, delta, base) : base;
+            const bool ok = lane == 0 || (progression && ti < bin_top);
+            const unsigned long long okm = __ballot(ok);
+            const uint32_t nvalid = okm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okm);
+            const uint32_t take = nvalid < rem ? nvalid : rem;
+            const float t_next = ti + dt;
+            const float prev_next = __shfl(t_next, lane ? lane - 1 : 0, 64);
+            if ((uint32_t)lane < take) {
+                const size_t k = (size_t)count + (uint32_t)lane;
+                xyzs[k * 3] = clampf_(fmaf(ti, c.dx, c.ox), -c.bound, c.bound);
+                xyzs[k * 3 + 1] = clampf_(fmaf(ti, c.dy, c.oy), -c.bound, c.bound);
+                xyzs[k * 3 + 2] = clampf_(fmaf(ti, c.dz, c.oz), -c.bound, c.bound);
+                dirs[k * 3] = c.dx; dirs[k * 3 + 1] = c.dy; dirs[k * 3 + 2] = c.dz;
+                deltas[k * 2] = dt;
+                deltas[k * 2 + 1] = t_next - (lane ? prev_next : last_t);
+            }
+            last_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_next), (int)take - 1));
+            base = last_t;                               // the true next lattice value after the last point taken
+            count += take;
+            rem -= take;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_march_write_r(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
+                                                       uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars,
+                                                       float* xyzs, float* dirs, float* deltas,
+                                                       const int32_t* __restrict__ rays, uint32_t perturb,
+                                                       const RunEntry* __restrict__ log, const uint32_t* __restrict__ nlog,
+                                                       const int32_t* __restrict__ counter, uint32_t ray_blocks) {
+    if (blockIdx.x >= ray_blocks) {
+        const uint32_t used = min((uint32_t)counter[0], M);
+        zero_rows(xyzs, dirs, deltas, used, M, (blockIdx.x - ray_blocks) * blockDim.x + threadIdx.x,
+                  (gridDim.x - ray_blocks) * blockDim.x);
+        return;
+    }
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (n >= N) return;
+    const uint32_t point_index = (uint32_t)rays[(size_t)n * 3 + 1];
+    const uint32_t num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (num_steps == 0) return;
+    if (point_index + num_steps >= M) {
+        if (counter && point_index < M) zero_rows(xyzs, dirs, deltas, point_index, M, lane_id(), 64);
+        return;
+    }
+    RayCtx c;
+    ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
+    float t0 = nears[n];
+    if (perturb) t0 = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t0);   // contracted by the reference's compiler (:351)
+    const uint32_t entries = __builtin_amdgcn_readfirstlane(nlog[n]);
+    if (entries != kLogOverflow)
+        run_replay(c, t0, log + (size_t)n * kRunCap, entries, xyzs + (size_t)point_index * 3,
+                   dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
+    else
+        (void)lattice_march<true>(c, t0, fars[n], num_steps, xyzs + (size_t)point_index * 3,
+                                  dirs + (size_t)point_index * 3, deltas + (size_t)point_index * 2);
+}
+
 __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n_step,
                                                     const int32_t* __restrict__ rays_alive,
                                                     const float* __restrict__ rays_t,
@@ -1578,6 +1722,16 @@ int enerf_march_rays_train(const float* rays_o, const float* rays_d, const uint8
 static inline bool march_uses_lattice(float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
     return dt_gamma == 0.0f && (uint64_t)max_steps * (1ull << (C - 1)) >= (uint64_t)H;
 }
+// ... and of the fixed-step marchers, the one-thread-per-ray walk with its run log (k_march_count_t / k_march_write_r)
+// takes over from the wave-per-ray lattice once there are enough rays to keep every SIMD busy that way
+// (enerf_debug_march_thread_min_rays; count and write pass of a batch see the same N, hence the same choice)
+static uint32_t g_march_thread_min_rays = 32768u;
+static inline bool march_uses_threads(uint32_t N, uint32_t H) {
+    return N >= g_march_thread_min_rays && H <= kTabH && (H & (H - 1u)) == 0u;
+}
+static inline size_t march_log_bytes(uint32_t N, uint32_t H) {
+    return march_uses_threads(N, H) ? (size_t)N * kRunCap * sizeof(RunEntry) : (size_t)N * kLogCap * sizeof(ChunkEntry);
+}
 
 // count pass (+ scan): rays[n] = (n, offset, count), counter += (sum, N); the fixed-step marcher also fills the chunk log
 static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -1588,7 +1742,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
-        const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
+        const size_t log_bytes = march_log_bytes(N, H);
         char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
         if (!ws) return ENERF_E_NOMEM;
         ChunkEntry* log = (ChunkEntry*)ws;
@@ -1604,8 +1758,12 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         const int* occ_keys = nullptr;
         if (use_box && g_march_clip && g_box_grid == grid && g_box_C == C && g_box_H == H && g_box_bound == bound)
             occ_keys = (const int*)workspace(WS_AABB, 6 * sizeof(int));
-        k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
-            rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys);
+        if (march_uses_threads(N, H))
+            k_march_count_t<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars,
+                                                           rays, perturb, (RunEntry*)ws, nlog, occ_keys);
+        else
+            k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
+                rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys);
     } else {
         k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
                                                    fars, rays, perturb);
@@ -1630,15 +1788,20 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
                              const int32_t* counter, uint32_t perturb, uint32_t zero_unwritten, hipStream_t s) {
     if (int e = workspace_family_enter(0, s)) return e;
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
-        const size_t log_bytes = (size_t)N * kLogCap * sizeof(ChunkEntry);
+        const size_t log_bytes = march_log_bytes(N, H);
         char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
         if (!ws) return ENERF_E_NOMEM;
         const ChunkEntry* log = (const ChunkEntry*)ws;
         const uint32_t* nlog = (const uint32_t*)(ws + log_bytes);
         const uint32_t ray_blocks = div_up(N, 4);
-        k_march_write_w<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
-            rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, perturb, log, nlog,
-            zero_unwritten ? counter : nullptr, ray_blocks);
+        if (march_uses_threads(N, H))
+            k_march_write_r<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
+                rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, perturb,
+                (const RunEntry*)ws, nlog, zero_unwritten ? counter : nullptr, ray_blocks);
+        else
+            k_march_write_w<<<ray_blocks + (zero_unwritten ? 128u : 0u), 256, 0, s>>>(
+                rays_o, rays_d, grid, bound, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, perturb, log,
+                nlog, zero_unwritten ? counter : nullptr, ray_blocks);
     } else {
         if (zero_unwritten) {
             (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, s);
@@ -1835,6 +1998,12 @@ int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float
     g_box_grid = grid; g_box_C = C; g_box_H = H; g_box_bound = bound;
     ENERF_LAUNCH_CHECK("occupied_box_update");
     return 0;
+}
+
+int enerf_debug_march_thread_min_rays(uint32_t n) {
+    const uint32_t prev = g_march_thread_min_rays;
+    if (n) g_march_thread_min_rays = n;
+    return (int)prev;
 }
 
 int enerf_debug_march_clip(int on) {

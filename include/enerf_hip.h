@@ -474,6 +474,10 @@ int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
 int enerf_debug_march_wave_max_rays(uint32_t n);
 /* test / measurement aid: 0 switches off the occupied-box test (below) globally */
 int enerf_debug_march_clip(int on);
+/* tuning / test aid: smallest ray count for which the fixed-step enerf_march_rays_train* counts with one thread per ray
+ * and a run log (instead of one wavefront per ray and a chunk log); 0 only reads.  Returns the previous value.  The
+ * count and the write pass of a batch must see the same setting. */
+int enerf_debug_march_thread_min_rays(uint32_t n);
 /* Testing aid: 0 switches off the cross-stream ordering of the library's shared workspaces (a stream that is about to
  * use a kernel family's scratch waits for the family's previous user when that was another stream); 1 = default. */
 int enerf_debug_workspace_ordering(int on);

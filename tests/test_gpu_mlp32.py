@@ -79,7 +79,8 @@ def test_fused_mlp_forward_backward(dims, B, precision):
     for li, (a, b) in enumerate(zip(wa, wb)):
         X, dY = acts[li].detach(), pres[li].grad
         G = dY.t() @ X
-        assert float((G - b.grad.double()).abs().max()) <= 1e-9 * max(float(G.abs().max()), 1.0)
+        # (the hooks saw the real terms: autograd's own gradient, rounded to the fp32 leaf, is this sum)
+        assert float((G - b.grad.double()).abs().max()) <= 4 * 2.0 ** -23 * max(float(G.abs().max()), 1.0)
         A = dY.abs().t() @ X.abs()
         T = torch.zeros_like(G)
         for c0 in range(0, B, 2048):

@@ -97,6 +97,17 @@ def test_polar_from_ray(rm):
 
 
 # ------------------------------------------------------------------ march_rays_train: rays/counter/samples bit-exact
+@pytest.fixture(params=["wave-per-ray", "thread-per-ray"])
+def march_route(request):
+    """Both fixed-step training marchers on every march_rays_train test: the wave-per-ray lattice marcher with its chunk
+    log (what small batches take) and the one-thread-per-ray walk with its run log (what batches of 32 768+ rays take),
+    forced through enerf_debug_march_thread_min_rays whatever the test's ray count."""
+    from enerf_amd import _lib
+    prev = _lib.lib().enerf_debug_march_thread_min_rays(1 if request.param == "thread-per-ray" else 0x7fffffff)
+    yield request.param
+    _lib.lib().enerf_debug_march_thread_min_rays(prev)
+
+
 def _gpu_march_train(rm, o, d, bits, bound, dt_gamma, C, M, nears, fars, perturb, max_steps=1024):
     N = len(o)
     xyzs = torch.zeros(M, 3, device=DEV); dirs = torch.zeros(M, 3, device=DEV); deltas = torch.zeros(M, 2, device=DEV)
@@ -110,7 +121,7 @@ def _gpu_march_train(rm, o, d, bits, bound, dt_gamma, C, M, nears, fars, perturb
 
 @pytest.mark.parametrize("bound,perturb,dt_gamma,N", [(1, 0, 0.0, 300), (2, 1, 0.0, 1000), (3, 1, 0.0, 4096),
                                                       (3, 0, 1.0 / 128, 500), (2, 1, 1.0 / 256, 257)])
-def test_march_rays_train_bit_exact(rm, scenes, bound, perturb, dt_gamma, N):
+def test_march_rays_train_bit_exact(rm, scenes, bound, perturb, dt_gamma, N, march_route):
     grid, bits, C = scenes[bound]
     o, d, aabb = _rays(N, 10 + bound, bound)
     nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
@@ -126,7 +137,7 @@ def test_march_rays_train_bit_exact(rm, scenes, bound, perturb, dt_gamma, N):
         assert not a[tot:].any()
 
 
-def test_march_rays_train_overflow_drop_rule(rm, scenes):
+def test_march_rays_train_overflow_drop_rule(rm, scenes, march_route):
     bound = 2
     grid, bits, C = scenes[bound]
     o, d, aabb = _rays(512, 21, bound)
@@ -143,7 +154,7 @@ def test_march_rays_train_overflow_drop_rule(rm, scenes):
 
 @pytest.mark.parametrize("overflow", [False, True])
 @pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
-def test_march_rays_train_ex_zero_fills_unwritten_rows(rm, scenes, overflow, dt_gamma):
+def test_march_rays_train_ex_zero_fills_unwritten_rows(rm, scenes, overflow, dt_gamma, march_route):
     """march_rays_train_ex(zero_unwritten=1) on NaN-filled buffers == march_rays_train on zero-filled ones, bit for bit:
     the budget tail and a dropped ray's clipped reservation are the rows no ray writes."""
     bound = 2
@@ -168,7 +179,7 @@ def test_march_rays_train_ex_zero_fills_unwritten_rows(rm, scenes, overflow, dt_
 
 
 @pytest.mark.parametrize("overflow", [False, True])
-def test_march_rays_train_background_mode_is_bit_identical(rm, scenes, overflow):
+def test_march_rays_train_background_mode_is_bit_identical(rm, scenes, overflow, march_route):
     """Flag bit 1 of march_rays_train_ex (batch prepared ahead on a side stream: one marching wavefront per SIMD,
     rays in turn) == the oracle, bit for bit, with more rays than the launch has wavefronts."""
     bound = 2
@@ -193,7 +204,7 @@ def test_march_rays_train_background_mode_is_bit_identical(rm, scenes, overflow)
 
 
 @pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
-def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm, scenes, dt_gamma):
+def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm, scenes, dt_gamma, march_route):
     """While no sample budget exists the reference allocates N * max_steps zero rows, marches, reads the count back and
     crops to the count rounded up past the next multiple of 128 (raymarching.py:195-228).  march_rays_train_count +
     march_rays_train_write into NaN-filled buffers of exactly that cropped size: same rows, rays and counter as the
@@ -229,7 +240,7 @@ def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm,
             assert tot == worst and m == worst and not ref[0][(N - 1) * 8:].any()      # the last ray was dropped
 
 
-def test_march_count_occupied_box_test_changes_nothing(rm, scenes):
+def test_march_count_occupied_box_test_changes_nothing(rm, scenes, march_route):
     """The count pass first tests each ray against the bounding box of the occupied cells and marches only to the box's
     far side (raymarching.hip: clip_to_occupied).  Same rays / counter / samples with the test switched off, and both
     equal the oracle, on a grid whose occupied region is a small off-centre block (most rays miss it, some graze it,
@@ -276,7 +287,7 @@ def test_march_count_occupied_box_test_changes_nothing(rm, scenes):
             assert 0.02 < hit < 0.6 and ref[3][5, 2] > 0 and ref[3][6, 2] == 0
 
 
-def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm):
+def test_march_rays_train_saturated_grid_and_chunk_log_overflow(rm, march_route):
     """Every cell occupied: rays emit a sample at every lattice point until max_steps (1024) -- the maximum the path
     can produce per ray, and more emitting 64-point chunks than the count pass's per-ray log holds for the longest
     rays (the write pass then re-marches those rays).  Bit-exact against the oracle, perturbed and not."""
