@@ -618,6 +618,10 @@ __device__ __forceinline__ int aabb_key(float v) {
 }
 __device__ __forceinline__ float aabb_unkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
+__global__ void k_aabb_init(int* __restrict__ keys) {
+    if (threadIdx.x < 6) keys[threadIdx.x] = 0x7f7f7f7f;
+}
+
 __global__ void __launch_bounds__(256) k_occupied_aabb(const uint8_t* __restrict__ grid, uint32_t C, uint32_t H,
                                                        float bound, int* __restrict__ keys) {
     // one byte = 8 consecutive morton indices = one 2x2x2 block of cells of one level
@@ -1725,7 +1729,7 @@ static inline bool march_uses_lattice(float dt_gamma, uint32_t max_steps, uint32
 // ... and of the fixed-step marchers, the one-thread-per-ray walk with its run log (k_march_count_t / k_march_write_r)
 // takes over from the wave-per-ray lattice once there are enough rays to keep every SIMD busy that way
 // (enerf_debug_march_thread_min_rays; count and write pass of a batch see the same N, hence the same choice)
-static uint32_t g_march_thread_min_rays = 32768u;
+static uint32_t g_march_thread_min_rays = 65536u;
 static inline bool march_uses_threads(uint32_t N, uint32_t H) {
     return N >= g_march_thread_min_rays && H <= kTabH && (H & (H - 1u)) == 0u;
 }
@@ -1743,7 +1747,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
         const size_t log_bytes = march_log_bytes(N, H);
-        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 512);
         if (!ws) return ENERF_E_NOMEM;
         ChunkEntry* log = (ChunkEntry*)ws;
         uint32_t* nlog = (uint32_t*)(ws + log_bytes);
@@ -1754,10 +1758,21 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         // rays the turn-taking only just fits the window -- 1.46 to 1.62 from run to run against a steady 1.52 -- and
         // at 65536 it does not: 5.50 against 4.94; larger batches keep the full launch)
         const uint32_t count_blocks = g_march_bg_blocks ? g_march_bg_blocks : (N <= 8192u ? num_cus() : div_up(N, 4));
-        // the occupied cells' box, if the caller says the one it had computed for this bitfield is current
+        // the occupied cells' box: the cached one if the caller says the one it had computed for this bitfield is current
+        // (the training loop: enerf_occupied_box_update once per bitfield), otherwise -- a plain march_rays_train call, whose
+        // bitfield may have changed behind the same pointer -- computed here for this call (two small launches, ~8 us,
+        // against a third to a half of the count pass: worth it from a few hundred rays up)
         const int* occ_keys = nullptr;
-        if (use_box && g_march_clip && g_box_grid == grid && g_box_C == C && g_box_H == H && g_box_bound == bound)
-            occ_keys = (const int*)workspace(WS_AABB, 6 * sizeof(int));
+        if (g_march_clip && (H * H * H) % 8 == 0) {
+            if (use_box && g_box_grid == grid && g_box_C == C && g_box_H == H && g_box_bound == bound) {
+                occ_keys = (const int*)workspace(WS_AABB, 6 * sizeof(int));
+            } else if (N >= 512u) {
+                int* keys = (int*)(ws + log_bytes + (((size_t)N * sizeof(uint32_t) + 255) & ~(size_t)255));
+                k_aabb_init<<<1, 64, 0, s>>>(keys);
+                k_occupied_aabb<<<min(div_up(C * H * H * H / 8, 256), 2u * num_cus()), 256, 0, s>>>(grid, C, H, bound, keys);
+                occ_keys = keys;
+            }
+        }
         if (march_uses_threads(N, H))
             k_march_count_t<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars,
                                                            rays, perturb, (RunEntry*)ws, nlog, occ_keys);
@@ -1789,7 +1804,7 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
     if (int e = workspace_family_enter(0, s)) return e;
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         const size_t log_bytes = march_log_bytes(N, H);
-        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t));
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 512);
         if (!ws) return ENERF_E_NOMEM;
         const ChunkEntry* log = (const ChunkEntry*)ws;
         const uint32_t* nlog = (const uint32_t*)(ws + log_bytes);

@@ -100,7 +100,7 @@ def test_polar_from_ray(rm):
 @pytest.fixture(params=["wave-per-ray", "thread-per-ray"])
 def march_route(request):
     """Both fixed-step training marchers on every march_rays_train test: the wave-per-ray lattice marcher with its chunk
-    log (what small batches take) and the one-thread-per-ray walk with its run log (what batches of 32 768+ rays take),
+    log (what small batches take) and the one-thread-per-ray walk with its run log (what batches of 65 536+ rays take),
     forced through enerf_debug_march_thread_min_rays whatever the test's ray count."""
     from enerf_amd import _lib
     prev = _lib.lib().enerf_debug_march_thread_min_rays(1 if request.param == "thread-per-ray" else 0x7fffffff)

@@ -78,7 +78,7 @@ def main():
             assert v[3] == ref[3] and torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]) and torch.equal(v[2], ref[2]), k
         print(line + f"   ({ref[3]} samples, routes bit-identical)")
         del m
-    lib.enerf_debug_march_thread_min_rays(32768)
+    lib.enerf_debug_march_thread_min_rays(65536)
 
 
 if __name__ == "__main__":
