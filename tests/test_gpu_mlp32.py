@@ -76,6 +76,13 @@ def test_fused_mlp_forward_backward(dims, B, precision):
     # carry the forward's / the later layers' errors of the same size; 64 eps32 A for the fp32 chains) + one whole term per
     # knife-edge sample (whose ReLU may legitimately sit on the other side).
     u = 2.0 ** -14 if k > 1 else 64 * 2.0 ** -23
+    # (knife-edge samples for this bar: pre-activations within 4x the forward error bound of zero -- at exactly the bound
+    # a unit may flip on the device without being counted above)
+    with torch.no_grad():
+        near = torch.zeros(B, dtype=torch.bool, device=DEV)
+        for pre in pres[:-1]:
+            near |= ((pre.abs() < 4 * k * 2e-6 * max(float(pre.abs().max()), 1.0)) & (pre != 0)).any(dim=1)
+    n_near = int(near.sum())
     worst = 0.0
     for li, (a, b) in enumerate(zip(wa, wb)):
         X, dY = acts[li].detach(), pres[li].grad
@@ -87,10 +94,10 @@ def test_fused_mlp_forward_backward(dims, B, precision):
         for c0 in range(0, B, 2048):
             T = torch.maximum(T, (dY[c0:c0 + 2048, :, None].abs() * X[c0:c0 + 2048, None, :].abs()).amax(0))
         err = (a.grad.double() - G).abs()
-        bar = 1e-4 * G.abs() + u * A + n_kink * T + 1e-12
+        bar = 1e-4 * G.abs() + u * A + n_near * T + 1e-12
         worst = max(worst, float((err / bar).max()))
         assert bool((err <= bar).all()), (li, float((err / bar).max()), float(err.max() / G.abs().max()))
-    print(f"dW per-entry error / bar (dims {dims}, B {B}, {'split-bf16' if k > 1 else 'fp32'}): worst {worst:.3f}, kinks {n_kink}")
+    print(f"dW per-entry error / bar (dims {dims}, B {B}, {'split-bf16' if k > 1 else 'fp32'}): worst {worst:.3f}, kinks {n_kink} (near: {n_near})")
     # inference path (no grad) gives the same values
     with torch.no_grad():
         y2 = fused_mlp(x, ws)
