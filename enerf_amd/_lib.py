@@ -80,6 +80,9 @@ SIGNATURES = {
     "enerf_debug_march_wave_max_rays": [_u32],
     "enerf_debug_march_bg_blocks": [_u32],
     "enerf_debug_march_clip": [_int],
+    "enerf_amp_begin": [_vp, _vp, _vp, _vp],
+    "enerf_amp_end": [_f32, _f32, _int, _vp],
+    "enerf_amp_cancel": [],
     "enerf_debug_march_thread_min_rays": [_u32],
     "enerf_event_loss_fwd_bwd": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "enerf_event_pair_rays": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _f32, _f32, _f32,

@@ -17,13 +17,15 @@ _TORCH_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False,
                                   differentiable=False, fused=None, decoupled_weight_decay=False)
 
 
-def _optimizer_state_for_file(opt):
+def _optimizer_state_for_file(opt, skipped=0):
+    """`skipped`: optimizer steps the fp16 closed form's loss scaling did not apply (TrainHarness.amp_skipped_steps): the
+    fused optimizer's host-side `step` counts them, torch's -- which the file holds -- does not."""
     sd = opt.state_dict()
     state = {}
     for k, st in sd["state"].items():
         st = dict(st)
         if "step" in st and not torch.is_tensor(st["step"]):
-            st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+            st["step"] = torch.tensor(float(max(int(st["step"]) - int(skipped), 0)), dtype=torch.float32)
         state[k] = st
     groups = []
     for g in sd["param_groups"]:
@@ -57,7 +59,8 @@ def checkpoint_dict(harness, full=False):
         gather = getattr(harness, "gather_sharded_optimizer_state", None)
         if gather is not None and getattr(harness, "comm_mode", None) == "sharded":
             gather()                      # the sharded data-parallel tail keeps 1/N of the table's moments per rank
-        state["optimizer"] = _optimizer_state_for_file(harness.opt)
+        skipped = getattr(harness, "amp_skipped_steps", lambda: 0)()
+        state["optimizer"] = _optimizer_state_for_file(harness.opt, skipped)
         sched = getattr(harness, "lr_scheduler", None)
         if sched is not None:
             state["lr_scheduler"] = sched.state_dict()
@@ -128,6 +131,8 @@ def load_checkpoint(harness, checkpoint, model_only=False, map_location=None, tr
         m.__dict__.pop("_native_events_ctx", None)
         if hasattr(harness, "_cleared_grad"):
             harness._cleared_grad = None
+        if getattr(harness, "_amp_words", None) is not None:
+            harness._amp_words.zero_()            # (the loaded step counts are net of skipped steps)
     sched = getattr(harness, "lr_scheduler", None)
     if sched is not None and "lr_scheduler" in checkpoint:
         try:

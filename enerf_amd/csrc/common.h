@@ -48,6 +48,17 @@ struct ProfScope {
     void units(double n) const;    // work units of this call (points, samples): summed over the TIMED calls only
 };
 
+// ---- loss scaling of the fp16 regime (include/enerf_hip.h: enerf_amp_begin / enerf_amp_end, csrc/optim.hip) ----------
+// Between the two calls: the closed-form loss gradient is multiplied by *scale (compositing / event-loss kernels), the MLP
+// weight-gradient reduce launch raises *found_inf when a sum is not finite, and the table / MLP Adam launch divides the
+// gradients by *scale, counts its step as (host step - *skipped) and leaves p / m / v alone when *found_inf is set.
+struct AmpState {
+    const float* scale;        // nullptr: loss scaling is off
+    uint32_t* found_inf;
+    const uint32_t* skipped;
+};
+AmpState amp_state();
+
 // ---- workspace owned by the library (grow-only, per process) --------------
 // Returns a device buffer of at least `bytes`; nullptr on failure.  Slots are independent.
 void* workspace(int slot, size_t bytes);

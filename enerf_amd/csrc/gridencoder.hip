@@ -857,7 +857,26 @@ __device__ __forceinline__ void tile_adam1(float& p, float g, float& m, float& v
     p = p - a.step_size * (m / denom);
 }
 
-template <int C>
+// AMP (enerf_amp_begin, the fp16 regime's loss scaling): the gradients arrive multiplied by *scale and are divided by it
+// here (GradScaler.unscale_: grad * (1 / scale)); a step whose weight gradients were not finite (*found_inf, raised by the
+// MLP reduce launch earlier in the stream) leaves p / m / v as they are -- lists and dense gradient are still consumed and
+// cleared -- and does not count: the bias corrections use (host step - *skipped), evaluated here.
+struct AmpAdam {
+    const float* scale;
+    const uint32_t* found_inf;
+    const uint32_t* skipped;
+    float lr;
+    uint32_t step;
+    float small_lr[kMaxSmallAdam];
+    uint32_t small_step[kMaxSmallAdam];
+};
+__device__ __forceinline__ void amp_scalars(AdamScalars& a, float lr, uint32_t step, uint32_t skipped) {
+    const double t = (double)(step > skipped ? step - skipped : 1u);
+    a.step_size = (float)((double)lr / (1.0 - pow((double)a.b1, t)));
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, t)));
+}
+
+template <int C, bool AMP = false>
 __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* __restrict__ offsets, float* __restrict__ P,
                                                                  float* __restrict__ G, float* __restrict__ M,
                                                                  float* __restrict__ V, uint32_t L, uint32_t min_tiles,
@@ -865,11 +884,20 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                                                                  uint32_t* __restrict__ cursors, uint32_t region,
                                                                  uint32_t* __restrict__ overflow,
                                                                  uint32_t* __restrict__ other_overflow, AdamScalars ad,
-                                                                 SmallAdam small) {
+                                                                 SmallAdam small, AmpAdam amp = AmpAdam{}) {
     __shared__ __attribute__((aligned(16))) double acc[kTileElems];
     __shared__ uint32_t s_n[64];
     constexpr uint32_t R = kTileElems / C;
     constexpr int U = 4;
+    float inv_scale = 1.0f;
+    bool skip = false;
+    uint32_t skipped = 0;
+    if (AMP) {
+        inv_scale = (float)(1.0 / (double)amp.scale[0]);
+        skip = amp.found_inf[0] != 0u;
+        skipped = amp.skipped[0];
+        amp_scalars(ad, amp.lr, amp.step, skipped);
+    }
     const bool have_records = region != 0;
     const bool spilled = have_records && overflow[0] != 0;
     if (other_overflow && blockIdx.x == 0 && threadIdx.x == 0) other_overflow[0] = 0;     // the next session's counter
@@ -974,27 +1002,31 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                     // (fp64 sum rounded once, then the dense part: what pass B + the dense buffer would have held)
                     g4.x += (float)a0.x; g4.y += (float)a0.y; g4.z += (float)a1.x; g4.w += (float)a1.y;
                 }
-                tile_adam1(p4[f].x, g4.x, m4[f].x, v4[f].x, ad);
-                tile_adam1(p4[f].y, g4.y, m4[f].y, v4[f].y, ad);
-                tile_adam1(p4[f].z, g4.z, m4[f].z, v4[f].z, ad);
-                tile_adam1(p4[f].w, g4.w, m4[f].w, v4[f].w, ad);
-                *reinterpret_cast<float4*>(P + base + i) = p4[f];
-                *reinterpret_cast<float4*>(M + base + i) = m4[f];
-                *reinterpret_cast<float4*>(V + base + i) = v4[f];
+                if (AMP) { g4.x *= inv_scale; g4.y *= inv_scale; g4.z *= inv_scale; g4.w *= inv_scale; }
+                if (!AMP || !skip) {
+                    tile_adam1(p4[f].x, g4.x, m4[f].x, v4[f].x, ad);
+                    tile_adam1(p4[f].y, g4.y, m4[f].y, v4[f].y, ad);
+                    tile_adam1(p4[f].z, g4.z, m4[f].z, v4[f].z, ad);
+                    tile_adam1(p4[f].w, g4.w, m4[f].w, v4[f].w, ad);
+                    *reinterpret_cast<float4*>(P + base + i) = p4[f];
+                    *reinterpret_cast<float4*>(M + base + i) = m4[f];
+                    *reinterpret_cast<float4*>(V + base + i) = v4[f];
+                }
                 if (dense) *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
     }
     // small parameters (MLP weights): workgroup k < small.count updates tensor k (dense gradient, not cleared)
-    if (blockIdx.x < small.count) {
+    if (blockIdx.x < small.count && (!AMP || !skip)) {
         const uint32_t k = blockIdx.x;
         AdamScalars a2 = ad;
         a2.step_size = small.step_size[k];
         a2.inv_bc2_sqrt = small.inv_bc2_sqrt[k];
+        if (AMP) amp_scalars(a2, amp.small_lr[k], amp.small_step[k], skipped);
         for (uint32_t i = threadIdx.x; i < small.n[k]; i += kTileThreads) {
             float pv = small.p[k][i], mv = small.m[k][i], vv = small.v[k][i];
-            tile_adam1(pv, small.g[k][i], mv, vv, a2);
+            tile_adam1(pv, AMP ? small.g[k][i] * inv_scale : small.g[k][i], mv, vv, a2);
             small.p[k][i] = pv; small.m[k][i] = mv; small.v[k][i] = vv;
         }
     }
@@ -1332,6 +1364,22 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
                                   : nullptr;
     const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;
     ProfScope prof(ENERF_K_TABLE_ADAM, s);
+    const AmpState as = amp_state();
+    if (as.scale) {
+        // loss scaling armed (enerf_amp_begin): unscale, skip on a non-finite step, bias corrections from the device
+        AmpAdam amp;
+        amp.scale = as.scale; amp.found_inf = as.found_inf; amp.skipped = as.skipped;
+        amp.lr = lr; amp.step = step;
+        for (uint32_t k = 0; k < n_small; k++) { amp.small_lr[k] = slr[k]; amp.small_step[k] = sstep[k]; }
+        if (C != 2) ENERF_BADARG("grid_adam_from_records: loss scaling serves C = 2 tables");
+        k_grid_tile_adam<2, true><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs,
+                                                                                    cursors, region, overflow, other, ad,
+                                                                                    small, amp);
+        if (g_pending.region != 0) g_session++;
+        g_pending = PendingRecords();
+        ENERF_LAUNCH_CHECK("grid_adam_from_records(amp)");
+        return 0;
+    }
     switch (C) {
         case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;

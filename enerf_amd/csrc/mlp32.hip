@@ -780,7 +780,7 @@ struct ReduceJob {
 };
 
 __device__ __forceinline__ void reduce_w_body(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                              const WDst& gw, uint32_t blk) {
+                                              const WDst& gw, uint32_t blk, uint32_t* found_inf) {
     // 64 weights per workgroup; each of the 16 waves sums every 16th partial block with four independent chains
     // (fixed order), then the waves' sums are combined in a fixed order: deterministic.
     __shared__ float acc[16][64];
@@ -805,19 +805,21 @@ __device__ __forceinline__ void reduce_w_body(const float* __restrict__ partial,
         for (int w = 0; w < 16; w++) t += acc[w][threadIdx.x];
         float* dst = wdst_at(gw, i);
         if (dst) *dst = gw.overwrite ? t : *dst + t;
+        // loss scaling (enerf_amp_begin): an activation gradient that left fp16's range shows up here as inf / NaN
+        if (found_inf && !(fabsf(t) <= 3.402823466e38f)) atomicOr(found_inf, 1u);
     }
 }
 
 __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                                         WDst gw) {
-    reduce_w_body(partial, nblocks, NW, gw, blockIdx.x);
+                                                         WDst gw, uint32_t* found_inf) {
+    reduce_w_body(partial, nblocks, NW, gw, blockIdx.x, found_inf);
 }
 
 // two networks' weight gradients in one launch (the first job was left pending by enerf_mlp32_defer_reduce)
-__global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob b) {
+__global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob b, uint32_t* found_inf) {
     const uint32_t na = (a.NW + 63u) / 64u;
-    if (blockIdx.x < na) reduce_w_body(a.partial, a.nblocks, a.NW, a.dst, blockIdx.x);
-    else reduce_w_body(b.partial, b.nblocks, b.NW, b.dst, blockIdx.x - na);
+    if (blockIdx.x < na) reduce_w_body(a.partial, a.nblocks, a.NW, a.dst, blockIdx.x, found_inf);
+    else reduce_w_body(b.partial, b.nblocks, b.NW, b.dst, blockIdx.x - na, found_inf);
 }
 
 static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
@@ -831,7 +833,9 @@ static ReduceJob g_pending;
 
 bool g_fused_bwd = true;            // dgrad + wgrad in one kernel (num_hidden <= 2)
 int g_precision = 1;                // enerf_mlp32_precision: 0 = fp32 MFMA (bit-exact fmaf chains), 1 = split-bf16 (x3),
-                                    // 2 = bf16 operands (the FFMLP nets' arithmetic: one product, 16-bit roundings)
+                                    // 2 = bf16 operands (the FFMLP nets' arithmetic: one product, 16-bit roundings),
+                                    // 3 = fp16 operands (the same kernels on IEEE half: the reference's fp16 regime)
+inline bool ops16() { return g_precision == 2 || g_precision == 3; }
 bool g_recompute = true;            // enerf_mlp32_recompute: the split backward recomputes the hidden activations
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
@@ -842,7 +846,7 @@ uint32_t g_bwd_blocks = 0;          // 0: default cap of the fused backward grid
 // row-major input) with bf16 operands
 bool split_bwd_shape(uint32_t num_hidden, uint32_t out_dim, uint32_t x_layout) {
     return g_fused_bwd && g_precision != 0 && out_dim <= 16 &&
-           (num_hidden <= 2 || (g_precision == 2 && num_hidden == 3 && x_layout == 0));
+           (num_hidden <= 2 || (ops16() && num_hidden == 3 && x_layout == 0));
 }
 
 uint32_t pgrid(uint32_t B, uint32_t cap) {
@@ -876,7 +880,7 @@ int enerf_mlp32_valid_rows_ex(const int32_t* device_count, uint32_t base, uint32
 // Returns the previous mode; mode < 0 only queries.
 int enerf_mlp32_precision(int mode) {
     const int prev = g_precision;
-    if (mode >= 0 && mode <= 2) g_precision = mode;
+    if (mode >= 0 && mode <= 3) g_precision = mode;
     return prev;
 }
 
@@ -987,8 +991,9 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     if (g_precision != 0) {
         // (a training forward whose backward recomputes the activations is the inference kernel)
         const bool store_fb = fb != nullptr && !(g_recompute && split_bwd_shape(num_hidden, out_dim, x_layout));
-        mlp32s_launch_fwd(g_precision == 1 ? 3 : 1, num_hidden, store_fb, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
-                          output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop());
+        (g_precision == 3 ? mlp32s_f16_launch_fwd : mlp32s_launch_fwd)(
+            g_precision == 1 ? 3 : 1, num_hidden, store_fb, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
+            output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop());
     } else if (sh_dirs) {
         const ShNorm4 nrm = make_sh_norm4();
         if (fb)
@@ -1080,8 +1085,8 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     // of its own (ENERF_K_MLP_REDUCE); the fp32 MFMA route between two event packets around all of its launches
     ProfScope prof(ENERF_K_FFMLP_BWD, s, split_bwd);
     prof.units((double)B);
-    if (g_precision == 2 && !split_bwd)
-        ENERF_BADARG("mlp32_backward: bf16 operands (precision 2) need out_dim <= 16 and at most three hidden layers");
+    if (ops16() && !split_bwd)
+        ENERF_BADARG("mlp32_backward: 16-bit operands (precision 2 / 3) need out_dim <= 16 and at most three hidden layers");
     const bool fused = split_bwd || (g_fused_bwd && num_hidden <= 2);
     if (!fused && W.valid_rows)
         ENERF_BADARG("mlp32_backward: enerf_mlp32_valid_rows needs the fused backward (num_hidden <= 2)");
@@ -1133,8 +1138,9 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
     } while (0)
     if (split_bwd) {
         (void)bb;
-        mlp32s_launch_bwd(g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation,
-                          wgrid, s, prof.start(), prof.stop(), g_recompute);
+        (g_precision == 3 ? mlp32s_f16_launch_bwd : mlp32s_launch_bwd)(
+            g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation, wgrid, s,
+            prof.start(), prof.stop(), g_recompute);
     } else if (fused) {
         (void)bb;
         if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }
@@ -1169,10 +1175,10 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         if (g_have_pending) {
             g_have_pending = false;
             hipExtLaunchKernelGGL(k_mlp32_reduce_w2, dim3(div_up(g_pending.NW, 64) + div_up(NW, 64)), dim3(1024), 0, s,
-                                  nullptr, sig, 0, g_pending, ReduceJob{partial, wgrid, NW, dW});
+                                  nullptr, sig, 0, g_pending, ReduceJob{partial, wgrid, NW, dW}, amp_state().found_inf);
         } else {
             hipExtLaunchKernelGGL(k_mlp32_reduce_w, dim3(div_up(NW, 64)), dim3(1024), 0, s, nullptr, sig, 0, partial,
-                                  wgrid, NW, dW);
+                                  wgrid, NW, dW, amp_state().found_inf);
         }
     }
     ENERF_LAUNCH_CHECK("mlp32_backward");

@@ -270,4 +270,14 @@ void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const D
                        uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                        bool recompute = false);
 
+// the same kernels with IEEE half operands (mlp32s_f16.hip; prec is 1 there: one product per operand pair)
+void mlp32s_f16_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
+                           const WSrc& W, float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
+                           uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void mlp32s_f16_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
+                           const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
+                           uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr, bool recompute = false);
+
 }  // namespace enerf_mlp32

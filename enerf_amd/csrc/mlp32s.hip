@@ -29,8 +29,26 @@ namespace enerf_mlp32 {
 // (order nrow(q, h), the same for both operands of the weight-gradient product, which is all that matters) -- exact,
 // since the operands are bf16 values times 1.0, and four MFMAs per 32 x 32 tile (hi and lo).  The backward therefore
 // uses LDS only for the staged weights and its final per-workgroup sums, and no wavefront-level fences at all.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// The 16-bit operand type is a property of the translation unit: bf16 here (the split operands of the fp32 nets, and the
+// FFMLP's bf16 nets); mlp32s_f16.hip compiles this file once more with ENERF_MLP32S_F16 for IEEE half operands (one
+// product, fp32 accumulation: the arithmetic of the reference's `fp16 = True` regime, nerf/utils.py:964-975 -- only the
+// P == 1 kernels are launched from there).  The names below keep their bf16 spelling.
+#ifdef ENERF_MLP32S_F16
+typedef _Float16 elem16;
+#define MLP32S_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define MLP32S_LAUNCH_FWD mlp32s_f16_launch_fwd
+#define MLP32S_LAUNCH_BWD mlp32s_f16_launch_bwd
+// (sigma = trunc_exp(h) is evaluated in fp32 under the reference's autocast: activation.py's cast_inputs=torch.float)
+constexpr bool kRoundExp = false;
+#else
+typedef __bf16 elem16;
+#define MLP32S_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define MLP32S_LAUNCH_FWD mlp32s_launch_fwd
+#define MLP32S_LAUNCH_BWD mlp32s_launch_bwd
+constexpr bool kRoundExp = true;
+#endif
+typedef elem16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef elem16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -46,7 +64,7 @@ struct FragT<1> {
 };
 
 __device__ __forceinline__ f32x16 mmab(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    return MLP32S_MFMA(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x16 mmap(const FragT<3>& a, const FragT<3>& b, f32x16 c) {
     c = mmab(a.lo, b.hi, c);
@@ -55,7 +73,7 @@ __device__ __forceinline__ f32x16 mmap(const FragT<3>& a, const FragT<3>& b, f32
 }
 __device__ __forceinline__ f32x16 mmap(const FragT<1>& a, const FragT<1>& b, f32x16 c) { return mmab(a.hi, b.hi, c); }
 
-__device__ __forceinline__ float bf16r(float x) { return (float)(__bf16)x; }      // round to nearest bf16, back to fp32
+__device__ __forceinline__ float bf16r(float x) { return (float)(elem16)x; }      // round to nearest 16-bit operand value, back to fp32
 
 template <int P>
 __device__ __forceinline__ FragT<P> split8(const float (&v)[8]) {
@@ -105,7 +123,7 @@ __device__ __forceinline__ bf16x8 selector(int c, int h, int kind) {
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int k = kind == 0 ? 8 * h + e : nrow(e, h) + (kind == 2 ? 16 : 0);
-        f[e] = k == c ? (__bf16)1.0f : (__bf16)0.0f;
+        f[e] = k == c ? (elem16)1.0f : (elem16)0.0f;
     }
     return f;
 }
@@ -145,6 +163,11 @@ __device__ __forceinline__ void flip_natural(const FragT<P>& f, bf16x8 selN, Fra
 constexpr bool fwd_weights_in_lds(bool SIG, int P) { return P == 3 && !SIG; }
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 
+#ifdef ENERF_MLP32S_F16
+#define k_mlp32s_fwd k_mlp32h_fwd
+#define k_mlp32s_bwd k_mlp32h_bwd
+#define k_mlp32s_mark k_mlp32h_mark
+#endif
 template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false, int P = 3>
 __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp32s_fwd(const float* __restrict__ X, WSrc W,
                                                     float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
@@ -336,7 +359,7 @@ __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp
                     const float yv = out_act_fwd(ov, out_act);
                     Y[s * y_stride + r] = (P == 1 && out_act != 6) ? bf16r(yv) : yv;
                 }
-                if (r == 0 && y0_exp) y0_exp[s] = P == 1 ? bf16r(expf(ov)) : expf(ov);
+                if (r == 0 && y0_exp) y0_exp[s] = (P == 1 && kRoundExp) ? bf16r(expf(ov)) : expf(ov);
             }
             if (SH) {
                 float sh[16];
@@ -707,7 +730,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
 #pragma unroll
                 for (int t = 0; t < 2; t++)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) sx[t][e] = kmap<XL>(8 * t + e, h) == j ? (__bf16)1.0f : (__bf16)0.0f;
+                    for (int e = 0; e < 8; e++) sx[t][e] = kmap<XL>(8 * t + e, h) == j ? (elem16)1.0f : (elem16)0.0f;
                 flip_tile<P>(xop, sx[0], sx[1], xf);
             } else {
 #pragma unroll
@@ -795,7 +818,7 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
 
 __global__ void k_mlp32s_mark() {}
 
-void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
+void MLP32S_LAUNCH_FWD(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
                        const WSrc& W, float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
                        uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s,
                        hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -805,11 +828,15 @@ void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
 #define S_FWD(NHV, TR, XLV, SIGV, SHV, PV)                                                                                  \
     hipExtLaunchKernelGGL((k_mlp32s_fwd<NHV, TR, XLV, SIGV, SHV, PV>), dim3(grid), dim3(256), lds, s, nullptr, ev_stop, 0, X, W, \
                           fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, sh_dirs, nrm)
+#ifdef ENERF_MLP32S_F16
+#define S_FWD_P(NHV, TR, XLV, SIGV, SHV) S_FWD(NHV, TR, XLV, SIGV, SHV, 1)
+#else
 #define S_FWD_P(NHV, TR, XLV, SIGV, SHV)                 \
     do {                                                 \
         if (prec == 3) S_FWD(NHV, TR, XLV, SIGV, SHV, 3); \
         else S_FWD(NHV, TR, XLV, SIGV, SHV, 1);          \
     } while (0)
+#endif
 #define S_FWD_XL(NHV, TR)                                   \
     do {                                                    \
         if (x_layout == 0) S_FWD_P(NHV, TR, 0, false, false); \
@@ -844,7 +871,7 @@ void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
 #undef S_FWD
 }
 
-void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
+void MLP32S_LAUNCH_BWD(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
                        const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
                        uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
                        bool recompute) {
@@ -857,11 +884,15 @@ void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const D
         if (recompute) S_BWD(NHV, XLV, PV, true); \
         else S_BWD(NHV, XLV, PV, false);          \
     } while (0)
+#ifdef ENERF_MLP32S_F16
+#define S_BWD_P(NHV, XLV) S_BWD_R(NHV, XLV, 1)
+#else
 #define S_BWD_P(NHV, XLV)                    \
     do {                                     \
         if (prec == 3) S_BWD_R(NHV, XLV, 3); \
         else S_BWD_R(NHV, XLV, 1);           \
     } while (0)
+#endif
     if (num_hidden == 1) {
         if (x_layout == 0) S_BWD_P(1, 0);
         else S_BWD_P(1, 1);

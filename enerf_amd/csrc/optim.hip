@@ -97,9 +97,68 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamTable tab, float b1, flo
     }
 }
 
+// torch.amp.GradScaler.update() (torch._amp_update_scale_) + the bookkeeping of a skipped step, one thread
+__global__ void k_amp_update(float* scale, int32_t* growth_tracker, uint32_t* found_inf, uint32_t* skipped,
+                             float growth_factor, float backoff_factor, int32_t growth_interval) {
+    if (found_inf[0]) {
+        scale[0] = scale[0] * backoff_factor;
+        growth_tracker[0] = 0;
+        skipped[0] += 1u;
+        found_inf[0] = 0u;
+    } else {
+        const int32_t ok = growth_tracker[0] + 1;
+        if (ok == growth_interval) {
+            const float grown = scale[0] * growth_factor;
+            if (fabsf(grown) <= 3.402823466e38f) scale[0] = grown;
+            growth_tracker[0] = 0;
+        } else {
+            growth_tracker[0] = ok;
+        }
+    }
+}
+
+AmpState g_amp = {nullptr, nullptr, nullptr};
+float* g_amp_scale = nullptr;
+int32_t* g_amp_tracker = nullptr;
+uint32_t* g_amp_skipped = nullptr;
+
 }  // namespace
 
+namespace enerf {
+AmpState amp_state() { return g_amp; }
+}  // namespace enerf
+
 extern "C" {
+
+// Loss scaling of the fp16 regime, the device side of torch.amp.GradScaler around a closed-form step (nerf/utils.py:964-975:
+// scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()).  `scale` (fp32) and `growth_tracker` (int32)
+// are the GradScaler's own device tensors, `found_inf` / `skipped` two uint32 words of the caller's (zero at first).
+// enerf_amp_begin arms the kernels named at AmpState (common.h) for the calls that follow; enerf_amp_end queues the
+// scale update on `stream` (backoff on a step with a non-finite weight gradient, which the optimizer launch has left
+// unapplied; growth after `growth_interval` clean steps in a row) and disarms them.  No host synchronisation anywhere.
+int enerf_amp_begin(float* scale, int32_t* growth_tracker, uint32_t* found_inf, uint32_t* skipped) {
+    if (!scale || !growth_tracker || !found_inf || !skipped) ENERF_BADARG("amp_begin: four device pointers are required");
+    g_amp = AmpState{scale, found_inf, skipped};
+    g_amp_scale = scale;
+    g_amp_tracker = growth_tracker;
+    g_amp_skipped = skipped;
+    return 0;
+}
+
+int enerf_amp_end(float growth_factor, float backoff_factor, int32_t growth_interval, enerf_stream_t stream) {
+    if (!g_amp.scale) return 0;
+    k_amp_update<<<1, 1, 0, (hipStream_t)stream>>>(g_amp_scale, g_amp_tracker, g_amp.found_inf, g_amp_skipped, growth_factor,
+                                                   backoff_factor, growth_interval);
+    g_amp = AmpState{nullptr, nullptr, nullptr};
+    ENERF_LAUNCH_CHECK("amp_end");
+    return 0;
+}
+
+// (an aborted step: disarm without an update)
+int enerf_amp_cancel(void) {
+    g_amp = AmpState{nullptr, nullptr, nullptr};
+    return 0;
+}
 
 // The same update for up to 16 parameters in one launch (per-tensor lr and step count; shared betas / eps).
 int enerf_adam_step_multi(uint32_t count, float* const* p, float* const* g, float* const* m, float* const* v,

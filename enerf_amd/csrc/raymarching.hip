@@ -1009,6 +1009,7 @@ struct MseTail {
     const int32_t* counter;
     float* loss;            // optional: += loss_scale * sum((out_image - target)^2) over the rays (one atomic per workgroup)
     float loss_scale;
+    const float* scale_mul; // optional (enerf_amp_begin): the gradient -- not the reported loss -- is multiplied by *scale_mul
 };
 
 template <bool MSE>
@@ -1069,7 +1070,8 @@ __global__ void __launch_bounds__(MSE ? 1024 : 256) k_composite_train_bwd(
             gi1 -= mse.target[(size_t)index * 3 + 1];
             gi2 -= mse.target[(size_t)index * 3 + 2];
         }
-        gi0 *= mse.scale; gi1 *= mse.scale; gi2 *= mse.scale;
+        const float gsc = mse.scale_mul ? mse.scale * mse.scale_mul[0] : mse.scale;
+        gi0 *= gsc; gi1 *= gsc; gi2 *= gsc;
         gws = -(gi0 * mse.bg.at(index, 0) + gi1 * mse.bg.at(index, 1) + gi2 * mse.bg.at(index, 2));
     } else {
         gws = grad_weights_sum[index];
@@ -1185,7 +1187,8 @@ __global__ void __launch_bounds__(1024) k_composite_train_fwd_bwd_mse(
     }
     float gi0 = o0 - mse.target[(size_t)index * 3], gi1 = o1 - mse.target[(size_t)index * 3 + 1],
           gi2 = o2 - mse.target[(size_t)index * 3 + 2];
-    gi0 *= mse.scale; gi1 *= mse.scale; gi2 *= mse.scale;
+    const float gsc = mse.scale_mul ? mse.scale * mse.scale_mul[0] : mse.scale;
+    gi0 *= gsc; gi1 *= gsc; gi2 *= gsc;
     const float gws = -(gi0 * mse.bg.at(index, 0) + gi1 * mse.bg.at(index, 1) + gi2 * mse.bg.at(index, 2));
     const float r_final = k.r, g_final = k.g, b_final = k.b, ws_final = k.ws;
     CompCarry kb = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1958,7 +1961,7 @@ int enerf_composite_rays_train_backward_mse(const float* out_image, const float*
     k_composite_train_bwd<true><<<ray_blocks + 16, 1024, 0, s>>>(
         nullptr, nullptr, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, grad_sigmas, grad_rgbs,
         MseTail{out_image, target, grad_scale, Background{bg_color, bg_stride, bg_scalar}, counter, loss,
-                1.0f / (3.0f * (float)N)},
+                1.0f / (3.0f * (float)N), amp_state().scale},
         ray_blocks);
     ENERF_LAUNCH_CHECK("composite_rays_train_backward_mse");
     return 0;
@@ -1986,7 +1989,7 @@ int enerf_composite_rays_train_fwd_bwd_mse(const float* sigmas, const float* rgb
     k_composite_train_fwd_bwd_mse<<<ray_blocks + 16, 1024, 0, s>>>(
         sigmas, rgbs, deltas, rays, M, N, weights_sum, image, out_image, grad_sigmas, grad_rgbs,
         MseTail{nullptr, target, grad_scale, Background{bg_color, bg_stride, bg_scalar}, counter, loss,
-                1.0f / (3.0f * (float)N)},
+                1.0f / (3.0f * (float)N), amp_state().scale},
         ray_blocks);
     ENERF_LAUNCH_CHECK("composite_rays_train_fwd_bwd_mse");
     return 0;

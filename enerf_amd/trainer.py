@@ -72,28 +72,47 @@ class TrainHarness:
         self._loss_ring = torch.zeros(64, device=dev0)
         self._loss_cursor = 0
         # Mixed precision, two separate switches:
-        #   fp16=True (or "autocast"): the shipped configs' `fp16 = True` as the reference runs it (nerf/utils.py:350,
-        #     964-975) -- torch.autocast(float16) + GradScaler around the op-by-op route: half hash table + half table
-        #     gradient (gridencoder/grid.py:38-39,72), half SH, half nn.Linear GEMMs; the scaler's state lands in full
-        #     checkpoints and is restored from a reference checkpoint.
+        #   fp16=True: the shipped configs' `fp16 = True` (nerf/utils.py:350,964-975: autocast(float16) + GradScaler).  Two
+        #     routes to the same regime, chosen here:
+        #       * the closed-form step on fp16 operands (`amp_f16`; one GPU, a model the fused path serves, FusedAdam): the
+        #         nn.Linear nets on v_mfma_f32_32x32x16_f16 with every layer's activations and activation gradients rounded
+        #         to fp16 (enerf_mlp32_precision(3)), fp32 accumulation, fp32 marching / compositing / trunc_exp as under
+        #         the reference's autocast, and the GradScaler's protocol on the device (csrc/optim.hip enerf_amp_*: the
+        #         loss gradient is multiplied by the scale, a step whose weight gradients are not finite is not applied
+        #         and halves the scale, 2000 clean steps double it) on the scaler's own tensors -- so its state_dict() is
+        #         what a checkpoint stores and restores.  What is NOT reproduced: the half copy of the hash table
+        #         (gridencoder/grid.py:38-39: the gather reads the fp32 table, features are fp32 until the first layer
+        #         rounds them).
+        #       * fp16="autocast" (and whatever the closed-form step does not serve): torch.autocast + GradScaler around
+        #         the op-by-op route, half hash table + half table gradient (gridencoder/grid.py:38-39,72), half SH.
         #   amp="bf16": NOT the reference's regime, named apart for that reason -- the closed-form step with the networks
-        #     on bf16 operands (fp32 accumulation, every layer's activations and activation gradients rounded to 16 bits:
-        #     mlp32 precision 2), fp32 hash table, fp32 marching / compositing, fp32 master weights.  bf16 has fp32's
-        #     exponent range, so there is no loss scaling: the GradScaler is kept disabled.  The model's own
-        #     `mlp_precision` is only overridden for the duration of this harness's steps.
+        #     on bf16 operands (mlp32 precision 2), fp32 hash table, fp32 master weights.  bf16 has fp32's exponent range,
+        #     so there is no loss scaling: the GradScaler is kept disabled.  The model's own `mlp_precision` is only
+        #     overridden for the duration of this harness's steps.
         if fp16 == "bf16":                      # (the spelling of earlier rounds)
             fp16, amp = False, "bf16"
         if amp not in (None, "bf16"):
             raise ValueError(f"amp={amp!r}: None or 'bf16'")
-        self.fp16 = bool(fp16)                  # True / "autocast": the reference's regime, as the shipped configs ask
-        self.amp_bf16 = False
-        if amp == "bf16" and not self.fp16:
+        self.fp16 = bool(fp16)                  # the autocast route (all of it, or the steps the closed form cannot take)
+        self.amp_bf16 = self.amp_f16 = False
+        cuda_fused = False
+        if (fp16 or amp) and next(model.parameters()).is_cuda:
             from . import fused_network
-            if next(model.parameters()).is_cuda and fused_network.kind_of(model) is not None:
+            cuda_fused = fused_network.kind_of(model) is not None
+        if fp16 is True and cuda_fused and world == 1 and hasattr(self.opt, "step_grid_table") \
+                and getattr(model, "cuda_ray", False):
+            self.fp16, self.amp_f16 = False, True
+        if amp == "bf16" and not fp16:
+            if cuda_fused:
                 self.amp_bf16 = True            # (scoped to this harness's own steps: _amp_scope)
             else:
                 raise ValueError("amp='bf16' needs a CUDA model the fused path serves (network.py / network_ff.py nets)")
-        self.scaler = (torch.amp.GradScaler("cuda", enabled=self.fp16) if (self.fp16 or self.amp_bf16) else None)
+        self.scaler = (torch.amp.GradScaler("cuda", enabled=self.fp16 or self.amp_f16)
+                       if (self.fp16 or self.amp_bf16 or self.amp_f16) else None)
+        self._amp_words = None
+        if self.amp_f16:
+            self.scaler._lazy_init_scale_growth_tracker(dev0)
+            self._amp_words = torch.zeros(2, dtype=torch.int32, device=dev0)       # [found_inf, skipped steps]
         # what Trainer keeps beside the model and lands in its checkpoints (nerf/utils.py:381-389,1300-1304)
         self.epoch = 1
         self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
@@ -128,12 +147,36 @@ class TrainHarness:
             pass
 
     def _amp_scope(self):
-        """amp='bf16': the fused kernels read `model.mlp_precision` at launch -- set for this harness's step, restored
-        after it (the model keeps its own arithmetic for inference and for other harnesses)."""
+        """amp='bf16' / the fp16 closed form: the fused kernels read `model.mlp_precision` at launch -- set for this
+        harness's step, restored after it (the model keeps its own arithmetic for inference and for other harnesses)."""
         m = self.model
         prev = m.__dict__.get("mlp_precision", _UNSET)
-        m.mlp_precision = 2
+        m.mlp_precision = 3 if self.amp_f16 else 2
         return prev
+
+    def amp_skipped_steps(self):
+        """fp16 closed form: optimizer steps the loss scaling has skipped so far (their gradients were not finite) -- the
+        optimizer's own `step` counts them, its bias corrections do not.  One 4-byte read-back."""
+        return int(self._amp_words[1]) if self._amp_words is not None else 0
+
+    def _amp_step(self, fn, *args, **kw):
+        """One step under the device-side GradScaler protocol (include/enerf_hip.h: enerf_amp_begin / enerf_amp_end)."""
+        from . import _lib as L
+        lib = L.lib()
+        sc = self.scaler
+        if self.use_graphs or self.avg is not None or not self.fuse_table_adam:
+            raise RuntimeError("the fp16 closed-form step needs one GPU, the fused table optimizer and no graph replay "
+                               "(use fp16='autocast')")
+        L.check(lib.enerf_amp_begin(sc._scale.data_ptr(), sc._growth_tracker.data_ptr(), self._amp_words.data_ptr(),
+                                    self._amp_words.data_ptr() + 4), "amp_begin")
+        try:
+            out = fn(*args, **kw)
+        except BaseException:
+            lib.enerf_amp_cancel()
+            raise
+        L.check(lib.enerf_amp_end(float(sc.get_growth_factor()), float(sc.get_backoff_factor()),
+                                  int(sc.get_growth_interval()), L.stream_handle()), "amp_end")
+        return out
 
     def _amp_restore(self, prev):
         if prev is _UNSET:
@@ -800,10 +843,19 @@ class TrainHarness:
 
     def step_rgb(self, rays_o, rays_d, target, next_rays=None, **render_kw):
         """One RGB training step (nerf/utils.py:575-640 train_step + the optimizer part of train_one_epoch)."""
-        if self.amp_bf16:
+        if self.amp_bf16 or self.amp_f16:
             prev = self._amp_scope()
             try:
-                loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
+                if self.amp_f16 and self._manual_ok(rays_o, rays_d, target, render_kw):
+                    loss = self._amp_step(self._step_rgb, rays_o, rays_d, target, next_rays, **render_kw)
+                elif self.amp_f16:              # a step the closed form does not serve: the autocast route, same scaler
+                    self.fp16 = True
+                    try:
+                        loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
+                    finally:
+                        self.fp16 = False
+                else:
+                    loss = self._step_rgb(rays_o, rays_d, target, next_rays, **render_kw)
             finally:
                 self._amp_restore(prev)
         else:
@@ -864,10 +916,19 @@ class TrainHarness:
 
     def step_events(self, data, opt, next_data=None):
         """One event training step: two renders sharing one backward (nerf/utils.py:482-573)."""
-        if self.amp_bf16:
+        if self.amp_bf16 or self.amp_f16:
             prev = self._amp_scope()
             try:
-                loss = self._step_events(data, opt, next_data)
+                if self.amp_f16 and opt.event_only and self._events_manual_ok(data, opt):
+                    loss = self._amp_step(self._step_events, data, opt, next_data)
+                elif self.amp_f16:
+                    self.fp16 = True
+                    try:
+                        loss = self._step_events(data, opt, next_data)
+                    finally:
+                        self.fp16 = False
+                else:
+                    loss = self._step_events(data, opt, next_data)
             finally:
                 self._amp_restore(prev)
         else:

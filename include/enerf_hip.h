@@ -444,6 +444,10 @@ int enerf_mlp32_valid_rows_ex(const int32_t* device_count, uint32_t base, uint32
  *      product, fp32 accumulation, outputs (and exp / sigmoid of them) rounded to bf16 -- the arithmetic of the FFMLP
  *      nets (enerf_ffmlp_*, ffmlp/src/ffmlp.cu:410-895) over this family's fp32 buffers and fused epilogues; serves the
  *      fused training step of nerf/network_ff.py (sigma net: two hidden layers + SH epilogue, colour net: three).
+ *   3  fp16 operands: mode 2's kernels and rounding points on IEEE half (v_mfma_f32_32x32x16_f16; trunc_exp of the density
+ *      head stays in fp32, activation.py:5-17 `cast_inputs=torch.float`) -- the arithmetic autocast(float16) gives the
+ *      nn.Linear nets in the reference's `fp16 = True` regime (nerf/utils.py:964-975).  fp16's range is why that regime
+ *      scales its loss: use with enerf_amp_begin / enerf_amp_end.
  * Returns the previous mode (NOT a status); a negative `mode` only queries. */
 int enerf_mlp32_precision(int mode);
 /* 1 (default): in modes 1 / 2 the fused backward recomputes the hidden activations from X with the forward's own
@@ -467,6 +471,18 @@ int enerf_mlp32_defer_reduce(int on);
  * launch has carried the signal since it was armed. */
 int enerf_mlp32_signal_next_reduce(int on);
 int enerf_stream_wait_mlp32_signal(enerf_stream_t stream);
+/* Loss scaling of the reference's fp16 regime (nerf/utils.py:964-975: scaler.scale(loss).backward(); scaler.step(optimizer);
+ * scaler.update()) around a closed-form step, on the device.  `scale` (fp32) and `growth_tracker` (int32) are the
+ * torch.amp.GradScaler's own device tensors, `found_inf` and `skipped` two zero-initialised uint32 words kept by the caller.
+ * Between enerf_amp_begin and enerf_amp_end: the compositing backward multiplies the loss gradient by *scale; the MLP
+ * weight-gradient reduce launch raises *found_inf when a sum is not finite; enerf_grid_adam_from_records(_ex) divides the
+ * gradients by *scale, counts its step as (step - *skipped) and leaves the parameters alone when *found_inf is set.
+ * enerf_amp_end queues GradScaler.update() (backoff after a non-finite step, growth after growth_interval clean ones),
+ * counts a skipped step in *skipped, clears *found_inf and disarms; enerf_amp_cancel only disarms.  No host
+ * synchronisation.  Use with enerf_mlp32_precision(3) (fp16 operands). */
+int enerf_amp_begin(float* scale, int32_t* growth_tracker, uint32_t* found_inf, uint32_t* skipped);
+int enerf_amp_end(float growth_factor, float backoff_factor, int32_t growth_interval, enerf_stream_t stream);
+int enerf_amp_cancel(void);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);

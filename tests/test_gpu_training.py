@@ -675,7 +675,7 @@ def test_fused_table_adam_step_matches_dense_gradient_step():
     assert float(l1[-4:].mean()) < 0.7 * float(l1[:4].mean())
 
 
-@pytest.mark.parametrize("route", ["bf16", "autocast"])
+@pytest.mark.parametrize("route", ["bf16", "autocast", "f16"])
 def test_fp16_training_variant(route):
     """Mixed precision, the harness's two switches:
     "autocast" = TrainHarness(fp16=True), the shipped configs' `fp16 = True` as the reference runs it
@@ -683,7 +683,9 @@ def test_fp16_training_variant(route):
     kernels (gridencoder/grid.py:38-39,72: the 588 B/point case), half SH, fp32 marching / compositing; the scaler must
     not see overflows after its first steps;
     "bf16" = TrainHarness(amp="bf16"), this library's own regime -- the closed-form step with the networks on bf16
-    operands (mlp32 precision 2), fp32 table, no loss scaling; the model's arithmetic is restored after each step.
+    operands (mlp32 precision 2), fp32 table, no loss scaling; the model's arithmetic is restored after each step;
+    "f16" = TrainHarness(fp16=True) on a model the fused path serves: the SAME regime as "autocast" on the closed-form
+    step -- fp16 operands (mlp32 precision 3), the GradScaler's protocol on the device, on the scaler's own tensors.
     Either way the loss must fall, the sample counters must be those of the fp32 run (marching does not depend on the
     networks), and the first step's loss must agree with the fp32 step's to 16-bit precision."""
     import functools
@@ -693,10 +695,11 @@ def test_fp16_training_variant(route):
     from enerf_amd.trainer import TrainHarness
     data = _batches(4, 4096, 2)
     runs = []
-    for fp16 in (False, "bf16" if route == "bf16" else True):
+    for fp16 in (False, {"bf16": "bf16", "autocast": "autocast", "f16": True}[route]):
         torch.manual_seed(0)
         model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
-        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16 is True, amp="bf16" if fp16 == "bf16" else None)
+        h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16 if fp16 in (True, "autocast") else False,
+                         amp="bf16" if fp16 == "bf16" else None)
         seen, closed = [], []
         orig, orig_step = ge.grid_encode_forward, fused_render.train_step_mse
         # (functools.wraps: gridencoder._supports_layout reads the backend function's signature)
@@ -715,13 +718,66 @@ def test_fp16_training_variant(route):
     if route == "autocast":
         assert torch.float16 in d16 and n16 == 0                     # training renders used the half table (the density
         assert float(h16.scaler.get_scale()) >= 1024.0               # sweep of update_extra_state stays fp32); no run of
-    else:                                                            # overflow-halvings
+    elif route == "f16":                                             # overflow-halvings
+        assert h16.amp_f16 and not h16.fp16 and d16 == {torch.float32} and n16 == 48        # every step closed-form
+        assert h16.scaler.is_enabled() and float(h16.scaler.get_scale()) >= 1024.0
+        assert h16.scaler.state_dict()["scale"] == float(h16.scaler.get_scale())
+        assert h16.amp_skipped_steps() <= 6 and "mlp_precision" not in h16.model.__dict__
+    else:
         assert d16 == {torch.float32} and n16 == 48 and h16.amp_bf16
         assert "mlp_precision" not in h16.model.__dict__             # (scoped to the harness's steps, not left on the model)
         assert not h16.scaler.is_enabled() and h16.scaler.state_dict() == {}
     assert torch.equal(c32, c16)
     assert np.isfinite(l16).all() and abs(l16[0] - l32[0]) <= 0.02 * abs(l32[0])
     assert np.mean(l16[-8:]) < 0.6 * np.mean(l16[:8])
+
+
+def test_fp16_closed_form_skips_non_finite_steps_and_backs_the_scale_off():
+    """The GradScaler protocol on the device (enerf_amp_begin / enerf_amp_end): with a loss scale far too large the
+    activation gradients leave fp16's range, the weight-gradient reduce launch flags it, the optimizer launch leaves every
+    parameter and moment as it was, the scale is halved and the step is counted as skipped -- step after step until the
+    scale fits, from where on the run trains; the optimizer state written to a checkpoint counts applied steps only."""
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    from enerf_amd.checkpoint import checkpoint_dict
+    data = _batches(4, 4096, 2)
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=True)
+    assert h.amp_f16
+    h.scaler._scale.fill_(2.0 ** 40)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    loss0 = float(h.step_rgb(*data[0]))
+    torch.cuda.synchronize()
+    assert np.isfinite(loss0)                                        # (the reported loss is not scaled)
+    assert h.amp_skipped_steps() == 1 and float(h.scaler.get_scale()) == 2.0 ** 39
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n                  # nothing moved
+    st = h.opt.state[model.encoder.embeddings]
+    assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
+    losses = [float(h.step_rgb(*data[i % 4])) for i in range(1, 80)]
+    skipped = h.amp_skipped_steps()
+    assert 10 <= skipped <= 40 and float(h.scaler.get_scale()) == 2.0 ** (40 - skipped)
+    assert any(not torch.equal(p.detach(), before[n]) for n, p in model.named_parameters())
+    assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.7 * np.mean(losses[:8])
+    ck = checkpoint_dict(h, full=True)
+    steps = {int(v["step"]) for v in ck["optimizer"]["state"].values()}
+    assert steps == {80 - skipped} and ck["scaler"]["scale"] == 2.0 ** (40 - skipped)
+
+
+def test_fp16_closed_form_event_step_runs_under_the_scaler():
+    from enerf_amd.events import EventOptions
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    from test_gpu_baseline_configs import _event_batch
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+    h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=True)
+    opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
+    data = _event_batch(4096, DEV)
+    losses = [float(h.step_events(data, opt)) for _ in range(40)]
+    assert h.amp_f16 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert float(h.scaler.get_scale()) >= 256.0 and h.amp_skipped_steps() <= 8
 
 
 def test_padding_rows_of_the_sample_budget_are_skipped_without_changing_anything(monkeypatch):
