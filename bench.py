@@ -68,9 +68,12 @@ def parse():
     ap.add_argument("--amp-bf16", dest="fp16", action="store_true",
                     help="TrainHarness(amp='bf16') -- not the reference's fp16 regime: the closed-form step with the "
                          "networks on bf16 operands (fp32 accumulation, fp32 table, no loss scaling); dtype bf16-amp")
-    ap.add_argument("--fp16", "--fp16-autocast", dest="fp16_autocast", action="store_true",
-                    help="the shipped configs' fp16 = True as the reference runs it: autocast(float16) + GradScaler, half "
-                         "hash table (588 B/point) (dtype f16-autocast)")
+    ap.add_argument("--fp16", dest="fp16_true", action="store_true",
+                    help="TrainHarness(fp16=True): the shipped configs' fp16 = True regime on the closed-form step -- fp16 "
+                         "operands (v_mfma_f32_32x32x16_f16), the GradScaler protocol on the device (dtype f16-amp)")
+    ap.add_argument("--fp16-autocast", dest="fp16_autocast", action="store_true",
+                    help="TrainHarness(fp16='autocast'): the same regime op by op: autocast(float16) + GradScaler, half hash "
+                         "table (588 B/point) (dtype f16-autocast)")
     ap.add_argument("--graphs", action="store_true",
                     help="replay render+loss+backward of the rgb step as a HIP graph (opt-in: the per-kernel hipEvent "
                          "timing behind `roofline` only sees the launches that stay eager)")
@@ -341,8 +344,9 @@ def main():
         frame.FRAME_ENABLED = False
         model.infer_batch_mult = 8
     harness = TrainHarness(model, occupancy="synthetic", world=world, use_graphs=args.graphs,
-                           fp16=args.fp16_autocast, amp="bf16" if args.fp16 and not args.fp16_autocast else None)
-    if args.fp16 or args.fp16_autocast:
+                           fp16="autocast" if args.fp16_autocast else args.fp16_true,
+                           amp="bf16" if args.fp16 and not (args.fp16_autocast or args.fp16_true) else None)
+    if args.fp16 or args.fp16_autocast or args.fp16_true:
         args.probe_steps = 0
         args.graph_leg_steps = 0
     harness.prefetch = not args.no_prefetch
@@ -587,7 +591,7 @@ def main():
             fwd_ms, nf = _lib.prof.read("ffmlp_fwd")
             bwd_ms, nb = _lib.prof.read("ffmlp_bwd")
             red_ms, _ = _lib.prof.read("mlp_reduce")
-            mode = 2 if (args.net == "ff" or args.fp16) else _lib.lib().enerf_mlp32_precision(-1)
+            mode = 2 if (args.net == "ff" or args.fp16 or args.fp16_true) else _lib.lib().enerf_mlp32_precision(-1)
             if mode != 0:                                 # (split kernels: timed by their own stamps, the reduce launch apart;
                 bwd_ms += red_ms                          # the fp32 MFMA route's interval already spans its reduce)
             gb_ms, gb_n = _lib.prof.read("grid_bwd")
@@ -641,7 +645,7 @@ def main():
     # whoever runs this file and not only quoted in DESIGN.md
     other_steps = None
     if world == 1 and args.other_legs > 0 and args.mode == "rgb" and args.net == "linear" and not args.fp16 \
-            and not args.fp16_autocast and not args.graphs:
+            and not args.fp16_autocast and not args.fp16_true and not args.graphs:
         other_steps = {}
         # "after_step_256_rgb": the headline's step once the density grid has had its 16 full sweeps (renderer.py:484:
         # update_extra_state then samples 128^3 / 4 points per cascade instead of sweeping all of them) -- the regime a
@@ -650,6 +654,7 @@ def main():
                                                                ("network_ff_rgb", "ff", "rgb", args.bound, False, 0),
                                                                ("amp_bf16_rgb", "linear", "rgb", args.bound, "bf16", 0),
                                                                ("fp16_true_rgb", "linear", "rgb", args.bound, True, 0),
+                                                               ("fp16_autocast_rgb", "linear", "rgb", args.bound, "autocast", 0),
                                                                ("after_step_256_rgb", "linear", "rgb", args.bound, False, 16),
                                                                ("mlp32_fp32_exact_rgb", "linear", "rgb", args.bound, False, 0),
                                                                ("dropin_route_rgb", "linear", "rgb", args.bound, False, 0)):
@@ -684,7 +689,7 @@ def main():
                     h2 = TrainHarness(m2, occupancy="synthetic", world=1, optimizer=torch.optim.Adam)
                     h2.native_step = h2.manual_mse = h2.fuse_table_adam = h2.prefetch = False
                 else:
-                    h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16 is True,
+                    h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16 if fp16 in (True, "autocast") else False,
                                       amp="bf16" if fp16 == "bf16" else None)
                 m2.iter_density = iter_density
                 b2 = batches if bound == args.bound else build_batches(8, args.rays, device, rank, bound)
@@ -721,7 +726,7 @@ def main():
     # AND the strong curve of configs[3] (`strong.value`).
     strong = None
     if args.strong_rays > 0 and not args.global_rays and args.mode == "rgb" and args.net == "linear" and not args.fp16 \
-            and not args.fp16_autocast and not args.graphs and args.strong_rays % world == 0:
+            and not args.fp16_autocast and not args.fp16_true and not args.graphs and args.strong_rays % world == 0:
         try:
             rays_s = args.strong_rays // world
             torch.manual_seed(0)
@@ -882,9 +887,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.global_rays else "weak",
             "vs_baseline": None,
-            "dtype": "f16-autocast" if args.fp16_autocast else ("bf16-amp" if args.fp16 else ("bf16" if args.net == "ff" else "f32")),
+            "dtype": "f16-autocast" if args.fp16_autocast else ("f16-amp" if args.fp16_true else (
+                "bf16-amp" if args.fp16 else ("bf16" if args.net == "ff" else "f32"))),
             "data": "synthetic",
-            "arithmetic": None if (args.net != "linear" or args.fp16 or args.fp16_autocast) else (
+            "arithmetic": None if (args.net != "linear" or args.fp16 or args.fp16_autocast or args.fp16_true) else (
                 "fp32 storage and accumulation; products of the nn.Linear nets as three bf16 MFMA terms per fp32 product "
                 "(split-bf16: ~5e-6 relative forward error, profiles/r03_mlp32_accuracy.txt); the same step on the exact "
                 "fp32 MFMA is other_steps.mlp32_fp32_exact_rgb" if _lib.lib().enerf_mlp32_precision(-1) == 1 else

@@ -9,7 +9,7 @@ cd $R
 timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $OUT/${TAG}_bench_steps20_warmup5.json
 timeout 600 python bench.py 2>&1 | tail -1 > $OUT/${TAG}_bench_default.json
 for spec in "1024rays:--rays 1024" "16384rays:--rays 16384" "65536rays:--rays 65536" "events:--mode events" \
-            "events_bound2:--mode events --bound 2" "ffnet:--net ff --bound 2" "amp_bf16:--amp-bf16" "fp16:--fp16" \
+            "events_bound2:--mode events --bound 2" "ffnet:--net ff --bound 2" "amp_bf16:--amp-bf16" "fp16:--fp16" "fp16_autocast:--fp16-autocast" \
             "noprefetch:--no-prefetch"; do
   name=${spec%%:*}; flags=${spec#*:}
   timeout 600 python bench.py --no-cpu-baseline --render-frames 0 --graph-leg-steps 0 --other-legs 0 $flags 2>&1 | tail -1 > $OUT/${TAG}_bench_$name.json
