@@ -99,6 +99,7 @@ def parse():
     ap.add_argument("--prof-all", action="store_true", help="hipEvent-time every kernel family, not just grid_encode")
     ap.add_argument("--other-legs", type=int, default=48,
                     help="steps of each extra leg (event step of configs[2], network_ff step, fp16=True step); 0 = skip")
+    ap.add_argument("--only-legs", default="", help="comma-separated tags of other_steps to run (default: all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--cpu-rays", type=int, default=256)
@@ -659,6 +660,8 @@ def main():
                                                                ("mlp32_fp32_exact_rgb", "linear", "rgb", args.bound, False, 0),
                                                                ("dropin_route_rgb", "linear", "rgb", args.bound, False, 0)):
             restore = []
+            if args.only_legs and tag not in args.only_legs.split(","):
+                continue
             try:
                 if tag == "mlp32_fp32_exact_rgb":
                     # the headline's step with the nn.Linear nets on v_mfma_f32_32x32x2_f32 (bit-comparable fmaf chains)
@@ -715,6 +718,8 @@ def main():
                                     "update_extra_state": "partial (iter_density >= 16)" if iter_density >= 16 else "full sweep"}
                 del m2, h2
             except Exception as e:          # a leg that breaks must not take the headline down with it
+                import traceback
+                traceback.print_exc(file=sys.stderr)
                 other_steps[tag] = {"error": repr(e)[:300]}
             finally:
                 for undo in reversed(restore):
