@@ -312,13 +312,6 @@ struct ChunkEntry {
 };
 constexpr uint32_t kLogCap = 64;                 // entries per ray; a ray that needs more is re-marched by the write pass
 constexpr uint32_t kLogOverflow = 0xffffffffu;
-// Run log (the one-thread-per-ray count pass and its wave continuation, further down): maximal runs of consecutive
-// emitted samples as (first lattice point, length)
-struct RunEntry {
-    float t_first;
-    uint32_t len;
-};
-constexpr uint32_t kRunCap = 64;                 // runs per ray; a ray with more is re-marched by the write pass
 
 template <bool WRITE, bool LOG = false, bool FAST = false>
 __device__ __forceinline__ uint32_t lattice_march(const RayCtx& c, float t0, float far, uint32_t limit, float* xyzs,
@@ -491,18 +484,17 @@ __device__ __forceinline__ ChunkGeo chunk_geometry(const RayCtx& c, const RayFix
     return g;
 }
 
-template <bool WRITE, int LOG>
+template <bool WRITE, bool LOG>
 __device__ __forceinline__ uint32_t lattice_march_fast(const RayCtx& c, const MarchTabs& tabs, float t0, float far,
                                                        uint32_t limit, float* xyzs, float* dirs, float* deltas,
-                                                       ChunkEntry* log, uint32_t* nlog, RunEntry* runlog = nullptr,
-                                                       uint32_t logged0 = 0) {
+                                                       ChunkEntry* log, uint32_t* nlog) {
     RayFixed rf;
     ray_fixed_init(rf, c);
     const int lane = lane_id();
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     float tt_pending = -__builtin_huge_valf();
     float last_t = t0;
-    uint32_t count = 0, logged = logged0;
+    uint32_t count = 0, logged = 0;
     if (t0 < far && limit > 0) {
         ChunkGeo A = chunk_geometry(c, rf, tabs, t0, far, lane);
         while (true) {
@@ -561,32 +553,19 @@ __device__ __forceinline__ uint32_t lattice_march_fast(const RayCtx& c, const Ma
                 }
                 last_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.t_next), top));
                 count += nemit;
-                if (LOG == 1) {
+                if (LOG) {
                     if (logged < kLogCap && lane == 0) {
                         log[logged].base = A.base;
                         log[logged].emit = emit;
                     }
                     logged++;
                 }
-                if (LOG == 2) {                              // the chunk's emitted lanes as runs (wave-uniform loop)
-                    unsigned long long m = emit;
-                    while (m) {
-                        const int s0 = __builtin_ctzll(m);
-                        const unsigned long long inv = ~(m >> s0);
-                        const int len = inv ? __builtin_ctzll(inv) : 64 - s0;
-                        const float tf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.ti), s0));
-                        if (logged < kRunCap && lane == 0) runlog[logged] = RunEntry{tf, (uint32_t)len};
-                        logged++;
-                        m = s0 + len >= 64 ? 0ull : (m >> (s0 + len)) << (s0 + len);
-                    }
-                }
             }
             if (!have_next || count >= limit) break;
             A = Bn;
         }
     }
-    if (LOG == 1 && lane == 0) *nlog = logged <= kLogCap ? logged : kLogOverflow;
-    if (LOG == 2 && lane == 0) *nlog = logged <= kRunCap ? logged : kLogOverflow;
+    if (LOG && lane == 0) *nlog = logged <= kLogCap ? logged : kLogOverflow;
     return count;
 }
 
@@ -733,7 +712,7 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
         if (occ_keys && !clip_to_occupied(c, occ_keys, far)) {
             if (lane_id() == 0) nlog[n] = 0;                                   // nothing to replay
         } else {
-            cnt = fast ? lattice_march_fast<false, 1>(c, tabs, t0, far, max_steps, nullptr, nullptr, nullptr,
+            cnt = fast ? lattice_march_fast<false, true>(c, tabs, t0, far, max_steps, nullptr, nullptr, nullptr,
                                                          log + (size_t)n * kLogCap, nlog + n)
                        : lattice_march<false, true, false>(c, t0, far, max_steps, nullptr, nullptr, nullptr,
                                                            log + (size_t)n * kLogCap, nlog + n);
@@ -1294,19 +1273,18 @@ __device__ __forceinline__ uint32_t march_one_ray_fast(const RayCtx& c, const Ra
 // the write pass stays one wavefront per ray and replays the runs with coalesced stores (the points of a run are
 // t_first + k * delta exactly inside a binade, as in the lattice marcher).  Same samples, offsets and counters, bit for
 // bit: the thread walks the reference's own loop.
-
-// rays a thread left unfinished (its iteration allowance ran out): [0] / [1] used by alternate calls, the continuation pass
-// of one call clears the other's counter (no memset launch)
-__device__ uint32_t g_cont_n[2] = {0u, 0u};
+struct RunEntry {
+    float t_first;
+    uint32_t len;
+};
+constexpr uint32_t kRunCap = 64;                 // runs per ray; a ray with more is re-marched by the write pass
 
 __global__ void __launch_bounds__(256) k_march_count_t(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
                                                        uint32_t N, uint32_t C, uint32_t H,
                                                        const float* __restrict__ nears, const float* __restrict__ fars,
                                                        int32_t* rays, uint32_t perturb, RunEntry* __restrict__ log,
-                                                       uint32_t* __restrict__ nlog, const int* __restrict__ occ_keys,
-                                                       uint32_t iter_cap, float* __restrict__ cont_t,
-                                                       uint32_t* __restrict__ cont_list, uint32_t parity) {
+                                                       uint32_t* __restrict__ nlog, const int* __restrict__ occ_keys) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     build_march_tabs(s_face, s_expand, H);
@@ -1319,19 +1297,14 @@ __global__ void __launch_bounds__(256) k_march_count_t(const float* __restrict__
     if (perturb) t = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t);     // contracted by the reference's compiler (:351)
     float far = fars[n];
     uint32_t cnt = 0, nruns = 0;
-    bool unfinished = false;
     if (!occ_keys || clip_to_occupied(c, occ_keys, far)) {
         RayFixed rf;
         ray_fixed_init(rf, c);
         RunEntry* lg = log + (size_t)n * kRunCap;
         const float dt = c.dt_min;
         float run_first = 0.0f;
-        uint32_t run_len = 0, it = 0;
+        uint32_t run_len = 0;
         while (t < far && cnt < max_steps) {
-            if (it++ >= iter_cap) {                     // a long ray: the wave continuation (k_march_count_c) takes it from t
-                unfinished = true;
-                break;
-            }
             float x, y, z, tt;
             if (eval_cell_fixed(c, rf, tabs, t, x, y, z, tt)) {
                 if (run_len == 0) run_first = t;
@@ -1354,51 +1327,6 @@ __global__ void __launch_bounds__(256) k_march_count_t(const float* __restrict__
     }
     nlog[n] = nruns <= kRunCap ? nruns : kLogOverflow;
     rays[(size_t)n * 3 + 2] = (int32_t)cnt;
-    // unfinished rays -> the continuation list (one atomic per wavefront)
-    const unsigned long long um = __ballot(unfinished);
-    if (um) {
-        const int lane = lane_id();
-        const int leader = __builtin_ctzll(um);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&g_cont_n[parity], (uint32_t)__popcll(um));
-        base = __shfl(base, leader, 64);
-        if (unfinished) {
-            cont_t[n] = t;
-            cont_list[base + (uint32_t)__popcll(um & (lane ? (~0ull >> (64 - lane)) : 0ull))] = n;
-        }
-    }
-}
-
-// The continuation: one wavefront per unfinished ray, the lattice marcher from where the thread stopped (a visited
-// lattice point: the chain from there on is the ray's own), its emitted lanes appended to the ray's run log.
-__global__ void __launch_bounds__(256) k_march_count_c(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                       const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
-                                                       uint32_t C, uint32_t H, const float* __restrict__ fars,
-                                                       int32_t* rays, RunEntry* __restrict__ log,
-                                                       uint32_t* __restrict__ nlog, const int* __restrict__ occ_keys,
-                                                       const float* __restrict__ cont_t,
-                                                       const uint32_t* __restrict__ cont_list, uint32_t parity) {
-    __shared__ float s_face[kTabH + 1];
-    __shared__ uint32_t s_expand[kTabH];
-    build_march_tabs(s_face, s_expand, H);
-    const MarchTabs tabs = {s_face, s_expand};
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_cont_n[parity ^ 1u] = 0u;          // the next call's counter
-    const uint32_t total = g_cont_n[parity];
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); i < total;
-         i += nw) {
-        const uint32_t n = __builtin_amdgcn_readfirstlane(cont_list[i]);
-        RayCtx c;
-        ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
-        float far = fars[n];
-        if (occ_keys) (void)clip_to_occupied(c, occ_keys, far);                    // (it passed the test in the first pass)
-        const uint32_t cnt0 = (uint32_t)rays[(size_t)n * 3 + 2];
-        const uint32_t nr0 = __builtin_amdgcn_readfirstlane(nlog[n]);
-        const uint32_t more = lattice_march_fast<false, 2>(c, tabs, cont_t[n], far, max_steps - cnt0, nullptr, nullptr,
-                                                           nullptr, nullptr, nlog + n, log + (size_t)n * kRunCap,
-                                                           nr0 == kLogOverflow ? kRunCap + 1u : nr0);
-        if (lane_id() == 0) rays[(size_t)n * 3 + 2] = (int32_t)(cnt0 + more);
-    }
 }
 
 // replay of a ray's runs by one wavefront: 64 consecutive lattice points per round while the progression holds
@@ -1541,7 +1469,7 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
     const size_t base = (size_t)n * n_step;
     uint32_t got;
     if (fast)
-        got = lattice_march_fast<true, 0>(c, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+        got = lattice_march_fast<true, false>(c, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
                                               deltas + base * 2, nullptr, nullptr);
     else
         got = lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
@@ -1805,9 +1733,6 @@ static inline bool march_uses_lattice(float dt_gamma, uint32_t max_steps, uint32
 // takes over from the wave-per-ray lattice once there are enough rays to keep every SIMD busy that way
 // (enerf_debug_march_thread_min_rays; count and write pass of a batch see the same N, hence the same choice)
 static uint32_t g_march_thread_min_rays = 65536u;
-// iterations (cells visited) a thread walks before it hands its ray to the wave continuation (k_march_count_c); 0 = never
-static uint32_t g_march_thread_iter_cap = 96u;
-static uint32_t g_march_cont_parity = 0u;
 static inline bool march_uses_threads(uint32_t N, uint32_t H) {
     return N >= g_march_thread_min_rays && H <= kTabH && (H & (H - 1u)) == 0u;
 }
@@ -1825,8 +1750,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
         const size_t log_bytes = march_log_bytes(N, H);
-        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 1024 +
-                                                  (march_uses_threads(N, H) ? (size_t)N * 8 : 0));
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 512);
         if (!ws) return ENERF_E_NOMEM;
         ChunkEntry* log = (ChunkEntry*)ws;
         uint32_t* nlog = (uint32_t*)(ws + log_bytes);
@@ -1852,20 +1776,10 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                 occ_keys = keys;
             }
         }
-        if (march_uses_threads(N, H)) {
-            // threads walk the first cells of every ray; what is still unfinished after g_march_thread_iter_cap of them
-            // -- the long rays that would otherwise set the pass's duration -- continues one wavefront per ray
-            float* cont_t = (float*)(ws + log_bytes + (((size_t)N * sizeof(uint32_t) + 255) & ~(size_t)255) + 256);
-            uint32_t* cont_list = (uint32_t*)(cont_t + N);
-            const uint32_t cap = g_march_thread_iter_cap ? g_march_thread_iter_cap : 0xffffffffu;
-            const uint32_t parity = g_march_cont_parity;
-            g_march_cont_parity ^= 1u;
+        if (march_uses_threads(N, H))
             k_march_count_t<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars,
-                                                           rays, perturb, (RunEntry*)ws, nlog, occ_keys, cap, cont_t,
-                                                           cont_list, parity);
-            k_march_count_c<<<4u * num_cus(), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, C, H, fars, rays,
-                                                           (RunEntry*)ws, nlog, occ_keys, cont_t, cont_list, parity);
-        } else
+                                                           rays, perturb, (RunEntry*)ws, nlog, occ_keys);
+        else
             k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
                 rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys);
     } else {
@@ -1893,8 +1807,7 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
     if (int e = workspace_family_enter(0, s)) return e;
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         const size_t log_bytes = march_log_bytes(N, H);
-        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 1024 +
-                                                  (march_uses_threads(N, H) ? (size_t)N * 8 : 0));
+        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 512);
         if (!ws) return ENERF_E_NOMEM;
         const ChunkEntry* log = (const ChunkEntry*)ws;
         const uint32_t* nlog = (const uint32_t*)(ws + log_bytes);
@@ -2108,12 +2021,6 @@ int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float
 int enerf_debug_march_thread_min_rays(uint32_t n) {
     const uint32_t prev = g_march_thread_min_rays;
     if (n) g_march_thread_min_rays = n;
-    return (int)prev;
-}
-
-int enerf_debug_march_thread_iter_cap(uint32_t n) {
-    const uint32_t prev = g_march_thread_iter_cap;
-    if (n != 0xffffffffu) g_march_thread_iter_cap = n;     // 0: threads walk every ray to its end
     return (int)prev;
 }
 

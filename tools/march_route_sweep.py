@@ -1,5 +1,5 @@
 """march_rays_train, fixed step: the wave-per-ray lattice marcher (chunk log) against the one-thread-per-ray walk (run
-log; "hybridK": threads for the first K cells of a ray, then one wavefront per unfinished ray) over the ray counts of the path -- count + scan, write, with and without the occupied-box test -- on the training
+log) over the ray counts of the path -- count + scan, write, with and without the occupied-box test -- on the training
 cameras (random pixels of one pose) and on a whole 640 x 480 frame (coherent rays).  Outputs of the two routes are compared
 bit for bit while they are timed.      gpurun -- 'python tools/march_route_sweep.py > gpurun_out/march_route_sweep.txt'"""
 import math
@@ -54,11 +54,9 @@ def main():
         M = N * 160
         outs = {}
         line = f"bound {bound} {kind:5s} {N:7d} rays:"
-        routes = [("wave", 0x7fffffff, 0), ("thread", 1, 0)] + [(f"hybrid{c}", 1, c) for c in (32, 64, 96, 160)]
-        for route, thr, cap in routes:
+        for route, thr in (("wave", 0x7fffffff), ("thread", 1)):
             lib.enerf_debug_march_thread_min_rays(thr)
-            lib.enerf_debug_march_thread_iter_cap(cap)
-            for box in ((0, 4) if route in ("wave", "thread") else (4,)):
+            for box in (0, 4):
                 rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
                 counter = torch.zeros(2, dtype=torch.int32, device=DEV)
                 xyzs, dirs, deltas = (torch.empty(M, 3, device=DEV), torch.empty(M, 3, device=DEV), torch.empty(M, 2, device=DEV))
@@ -81,7 +79,6 @@ def main():
         print(line + f"   ({ref[3]} samples, routes bit-identical)")
         del m
     lib.enerf_debug_march_thread_min_rays(65536)
-    lib.enerf_debug_march_thread_iter_cap(96)
 
 
 if __name__ == "__main__":
