@@ -84,7 +84,6 @@ SIGNATURES = {
     "enerf_amp_end": [_f32, _f32, _int, _vp],
     "enerf_amp_cancel": [],
     "enerf_debug_march_thread_min_rays": [_u32],
-    "enerf_debug_march_thread_points": [_u32],
     "enerf_event_loss_fwd_bwd": [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "enerf_event_pair_rays": [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _f32, _f32, _f32,
                               _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1279,11 +1279,6 @@ struct RunEntry {
 };
 constexpr uint32_t kRunCap = 64;                 // runs per ray; a ray with more is re-marched by the write pass
 
-// K: lattice points evaluated per trip of the loop -- t, t + dt, ..., the K - 1 points that follow if the first is occupied.
-// Their cell lookups are independent (the loads fly together), so a run of occupied cells advances K samples per memory
-// round trip instead of one; in empty space the extra evaluations are discarded.  The pass is bound by the latency of its
-// longest rays up to ~10^5 rays, which is where this pays; the sums t + dt are the reference's own sequence of additions.
-template <int K>
 __global__ void __launch_bounds__(256) k_march_count_t(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
                                                        uint32_t N, uint32_t C, uint32_t H,
@@ -1310,40 +1305,20 @@ __global__ void __launch_bounds__(256) k_march_count_t(const float* __restrict__
         float run_first = 0.0f;
         uint32_t run_len = 0;
         while (t < far && cnt < max_steps) {
-            float ts[K], tt[K];
-            bool occ[K];
-            ts[0] = t;
-#pragma unroll
-            for (int k = 1; k < K; k++) ts[k] = ts[k - 1] + dt;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                float x, y, z;
-                occ[k] = eval_cell_fixed(c, rf, tabs, ts[k], x, y, z, tt[k]);
-            }
-            bool advanced = false;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (advanced) break;
-                if (k > 0 && !(ts[k] < far && cnt < max_steps)) {       // the loop condition, for the points after the first
-                    t = ts[k];
-                    advanced = true;
-                    break;
+            float x, y, z, tt;
+            if (eval_cell_fixed(c, rf, tabs, t, x, y, z, tt)) {
+                if (run_len == 0) run_first = t;
+                run_len++;
+                cnt++;
+                t += dt;
+            } else {
+                if (run_len) {
+                    if (nruns < kRunCap) lg[nruns] = RunEntry{run_first, run_len};
+                    nruns++;
+                    run_len = 0;
                 }
-                if (occ[k]) {
-                    if (run_len == 0) run_first = ts[k];
-                    run_len++;
-                    cnt++;
-                } else {
-                    if (run_len) {
-                        if (nruns < kRunCap) lg[nruns] = RunEntry{run_first, run_len};
-                        nruns++;
-                        run_len = 0;
-                    }
-                    t = skip_empty(ts[k], tt[k], dt);
-                    advanced = true;
-                }
+                t = skip_empty(t, tt, dt);
             }
-            if (!advanced) t = ts[K - 1] + dt;
         }
         if (run_len) {
             if (nruns < kRunCap) lg[nruns] = RunEntry{run_first, run_len};
@@ -1758,7 +1733,6 @@ static inline bool march_uses_lattice(float dt_gamma, uint32_t max_steps, uint32
 // takes over from the wave-per-ray lattice once there are enough rays to keep every SIMD busy that way
 // (enerf_debug_march_thread_min_rays; count and write pass of a batch see the same N, hence the same choice)
 static uint32_t g_march_thread_min_rays = 65536u;
-static uint32_t g_march_thread_points = 4u;      // lattice points a thread evaluates per loop trip (1, 2 or 4)
 static inline bool march_uses_threads(uint32_t N, uint32_t H) {
     return N >= g_march_thread_min_rays && H <= kTabH && (H & (H - 1u)) == 0u;
 }
@@ -1802,15 +1776,10 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                 occ_keys = keys;
             }
         }
-        if (march_uses_threads(N, H)) {
-#define ENERF_MCT(KV)                                                                                                  \
-    k_march_count_t<KV><<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, \
-                                                       perturb, (RunEntry*)ws, nlog, occ_keys)
-            if (g_march_thread_points == 1) ENERF_MCT(1);
-            else if (g_march_thread_points == 2) ENERF_MCT(2);
-            else ENERF_MCT(4);
-#undef ENERF_MCT
-        } else
+        if (march_uses_threads(N, H))
+            k_march_count_t<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars,
+                                                           rays, perturb, (RunEntry*)ws, nlog, occ_keys);
+        else
             k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
                 rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys);
     } else {
@@ -2052,12 +2021,6 @@ int enerf_occupied_box_update(const uint8_t* grid, uint32_t C, uint32_t H, float
 int enerf_debug_march_thread_min_rays(uint32_t n) {
     const uint32_t prev = g_march_thread_min_rays;
     if (n) g_march_thread_min_rays = n;
-    return (int)prev;
-}
-
-int enerf_debug_march_thread_points(uint32_t k) {
-    const uint32_t prev = g_march_thread_points;
-    if (k == 1 || k == 2 || k == 4) g_march_thread_points = k;
     return (int)prev;
 }
 

@@ -494,9 +494,6 @@ int enerf_debug_march_clip(int on);
  * and a run log (instead of one wavefront per ray and a chunk log); 0 only reads.  Returns the previous value.  The
  * count and the write pass of a batch must see the same setting. */
 int enerf_debug_march_thread_min_rays(uint32_t n);
-/* tuning / test aid: lattice points a thread of that count pass evaluates per loop trip (1, 2 or 4; anything else only
- * reads).  Returns the previous value.  Same samples whatever the value. */
-int enerf_debug_march_thread_points(uint32_t k);
 /* Testing aid: 0 switches off the cross-stream ordering of the library's shared workspaces (a stream that is about to
  * use a kernel family's scratch waits for the family's previous user when that was another stream); 1 = default. */
 int enerf_debug_workspace_ordering(int on);

@@ -97,18 +97,15 @@ def test_polar_from_ray(rm):
 
 
 # ------------------------------------------------------------------ march_rays_train: rays/counter/samples bit-exact
-@pytest.fixture(params=["wave-per-ray", "thread-per-ray", "thread-per-ray-1-point"])
+@pytest.fixture(params=["wave-per-ray", "thread-per-ray"])
 def march_route(request):
     """Both fixed-step training marchers on every march_rays_train test: the wave-per-ray lattice marcher with its chunk
     log (what small batches take) and the one-thread-per-ray walk with its run log (what batches of 65 536+ rays take),
     forced through enerf_debug_march_thread_min_rays whatever the test's ray count."""
     from enerf_amd import _lib
-    prev = _lib.lib().enerf_debug_march_thread_min_rays(0x7fffffff if request.param == "wave-per-ray" else 1)
-    # (the thread marcher looks at 4 lattice points per loop trip by default; "-1-point" is the plain sequential walk)
-    prev_pts = _lib.lib().enerf_debug_march_thread_points(1 if request.param.endswith("1-point") else 4)
+    prev = _lib.lib().enerf_debug_march_thread_min_rays(1 if request.param == "thread-per-ray" else 0x7fffffff)
     yield request.param
     _lib.lib().enerf_debug_march_thread_min_rays(prev)
-    _lib.lib().enerf_debug_march_thread_points(prev_pts)
 
 
 def _gpu_march_train(rm, o, d, bits, bound, dt_gamma, C, M, nears, fars, perturb, max_steps=1024):

@@ -54,10 +54,9 @@ def main():
         M = N * 160
         outs = {}
         line = f"bound {bound} {kind:5s} {N:7d} rays:"
-        for route, thr, pts in (("wave", 0x7fffffff, 4), ("thread1", 1, 1), ("thread2", 1, 2), ("thread4", 1, 4)):
+        for route, thr in (("wave", 0x7fffffff), ("thread", 1)):
             lib.enerf_debug_march_thread_min_rays(thr)
-            lib.enerf_debug_march_thread_points(pts)
-            for box in (4,):
+            for box in (0, 4):
                 rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
                 counter = torch.zeros(2, dtype=torch.int32, device=DEV)
                 xyzs, dirs, deltas = (torch.empty(M, 3, device=DEV), torch.empty(M, 3, device=DEV), torch.empty(M, 2, device=DEV))
@@ -74,13 +73,12 @@ def main():
                 assert tot + 128 < M, (tot, M)
                 outs[(route, box)] = (rays.clone(), xyzs[:tot].clone(), deltas[:tot].clone(), tot)
                 line += f"  {route}{'+box' if box else ''}: c {tc:7.1f} w {tw:6.1f}"
-        ref = outs[("wave", 4)]
+        ref = outs[("wave", 0)]
         for k, v in outs.items():
             assert v[3] == ref[3] and torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]) and torch.equal(v[2], ref[2]), k
         print(line + f"   ({ref[3]} samples, routes bit-identical)")
         del m
     lib.enerf_debug_march_thread_min_rays(65536)
-    lib.enerf_debug_march_thread_points(4)
 
 
 if __name__ == "__main__":
