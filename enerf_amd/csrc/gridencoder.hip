@@ -743,11 +743,15 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
 // Pass B: persistent workgroups (one per CU: the tile takes 128 KiB of LDS) walk the record lists, finest level
 // first.  Sum the list's records into the LDS tile, add the non-zero part into the table (plain read-modify-write
 // when the tile has a single list, float atomics for replica lists), reset the list's cursor for the next call.
+// Owner range (data parallel, sharded tail; enerf_grid_owner_range): elements [own_lo, own_hi) of the flat table belong to
+// this rank.  Lists of tiles that lie wholly inside it are left alone -- they wait for k_grid_tile_adam, which sums them
+// in LDS as on one GPU -- and only the others are flushed into the dense gradient, for the reduce-scatter to carry away.
 template <int C>
 __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* __restrict__ offsets,
                                                                 float* __restrict__ grad_grid, uint32_t L, LevelTab tab,
                                                                 uint32_t min_tiles, const uint32_t* __restrict__ recs,
-                                                                uint32_t* __restrict__ cursors, uint32_t region) {
+                                                                uint32_t* __restrict__ cursors, uint32_t region,
+                                                                size_t own_lo = 0, size_t own_hi = 0) {
     __shared__ __attribute__((aligned(16))) double acc[kTileElems];
     __shared__ uint32_t s_n;
     constexpr uint32_t R = kTileElems / C;
@@ -767,6 +771,12 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
             rem -= plan.bins;
         }
         const uint32_t cap = region / plan.bins;
+        if (own_hi > own_lo) {
+            const uint32_t o0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - o0;
+            const uint32_t r0 = (list / plan.replicas) * R, nr = hs - r0 < R ? hs - r0 : R;
+            const size_t t_lo = ((size_t)o0 + r0) * C, t_hi = t_lo + (size_t)nr * C;
+            if (t_lo >= own_lo && t_hi <= own_hi) continue;             // mine: the optimizer pass consumes the list
+        }
         if (threadIdx.x == 0) {
             const uint32_t n = cursors[level * kMaxBins + list];
             s_n = n < cap ? n : cap;
@@ -876,7 +886,17 @@ __device__ __forceinline__ void amp_scalars(AdamScalars& a, float lr, uint32_t s
     a.inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, t)));
 }
 
-template <int C, bool AMP = false>
+// RANGE (enerf_grid_owner_range, the sharded data-parallel tail): Adam only on the elements [own_lo, own_hi) of the flat
+// table.  The dense gradient holds what the reduce-scatter delivered (the other ranks' share, already divided by the number
+// of ranks; plus this rank's own spilled / unbinned contributions); a tile wholly inside the range adds the sum of its own
+// record lists times rec_scale (1 / ranks) -- the one-GPU flush for this rank's slice; a tile the range cuts takes its
+// gradient from the dense buffer alone (pass B flushed its lists); everything outside is only cleared.
+struct OwnerRange {
+    size_t lo, hi;
+    float rec_scale;
+};
+
+template <int C, bool AMP = false, bool RANGE = false>
 __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* __restrict__ offsets, float* __restrict__ P,
                                                                  float* __restrict__ G, float* __restrict__ M,
                                                                  float* __restrict__ V, uint32_t L, uint32_t min_tiles,
@@ -884,7 +904,8 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                                                                  uint32_t* __restrict__ cursors, uint32_t region,
                                                                  uint32_t* __restrict__ overflow,
                                                                  uint32_t* __restrict__ other_overflow, AdamScalars ad,
-                                                                 SmallAdam small, AmpAdam amp = AmpAdam{}) {
+                                                                 SmallAdam small, AmpAdam amp = AmpAdam{},
+                                                                 OwnerRange own = OwnerRange{0, 0, 1.0f}) {
     __shared__ __attribute__((aligned(16))) double acc[kTileElems];
     __shared__ uint32_t s_n[64];
     constexpr uint32_t R = kTileElems / C;
@@ -915,9 +936,24 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
         const uint32_t row0 = tile * R;
         const uint32_t nrows = rows - row0 < R ? rows - row0 : R;
         const BinPlan plan = bin_plan(offsets, level, R, min_tiles);
-        const bool binned = have_records && plan.bins != 0;
-        const bool dense = !binned || spilled;
         const size_t base = ((size_t)off0 + row0) * C;          // level offsets are multiples of 8 rows: 16-byte aligned
+        uint32_t clip_lo = 0, clip_hi = nrows * C;              // RANGE: the tile's elements this rank updates
+        bool whole = true;
+        if (RANGE) {
+            const size_t t_hi = base + (size_t)nrows * C;
+            if (t_hi <= own.lo || base >= own.hi) {             // not mine: the contributions held here are spent
+                for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTileThreads * 4)
+                    *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
+            whole = base >= own.lo && t_hi <= own.hi;
+            if (!whole) {
+                clip_lo = own.lo > base ? (uint32_t)(own.lo - base) : 0u;
+                clip_hi = own.hi < t_hi ? (uint32_t)(own.hi - base) : nrows * C;
+            }
+        }
+        const bool binned = have_records && plan.bins != 0 && whole;
+        const bool dense = RANGE || !binned || spilled;
         // the tile's p / m / v (and dense gradient) are requested first: they travel while the records are summed
         constexpr int F = kTileElems / (4 * kTileThreads);
         // (no branch per piece: a short last tile re-requests its last piece, and the dense gradient is one
@@ -1000,10 +1036,15 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                     const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
                     const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
                     // (fp64 sum rounded once, then the dense part: what pass B + the dense buffer would have held)
-                    g4.x += (float)a0.x; g4.y += (float)a0.y; g4.z += (float)a1.x; g4.w += (float)a1.y;
+                    if (RANGE) {
+                        g4.x += (float)a0.x * own.rec_scale; g4.y += (float)a0.y * own.rec_scale;
+                        g4.z += (float)a1.x * own.rec_scale; g4.w += (float)a1.y * own.rec_scale;
+                    } else {
+                        g4.x += (float)a0.x; g4.y += (float)a0.y; g4.z += (float)a1.x; g4.w += (float)a1.y;
+                    }
                 }
                 if (AMP) { g4.x *= inv_scale; g4.y *= inv_scale; g4.z *= inv_scale; g4.w *= inv_scale; }
-                if (!AMP || !skip) {
+                if ((!AMP || !skip) && (!RANGE || (i >= clip_lo && i < clip_hi))) {
                     tile_adam1(p4[f].x, g4.x, m4[f].x, v4[f].x, ad);
                     tile_adam1(p4[f].y, g4.y, m4[f].y, v4[f].y, ad);
                     tile_adam1(p4[f].z, g4.z, m4[f].z, v4[f].z, ad);
@@ -1116,6 +1157,9 @@ struct PendingRecords {
     uint32_t region = 0, L = 0, C = 0, D = 0, min_tiles = 0;
 };
 static PendingRecords g_pending;
+// enerf_grid_owner_range: [lo, hi) elements of the flat table this rank owns (hi == lo: none set), records' scale
+static size_t g_own_lo = 0, g_own_hi = 0;
+static float g_own_scale = 1.0f;
 // device counters of records that did not fit their list: two, used by alternate sessions -- the flush of one session
 // clears the other's, so opening a session costs no memset launch
 static uint32_t* g_overflow = nullptr;
@@ -1186,6 +1230,9 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
                 if (flush_now)                                                                                   \
                     k_grid_bwd_tile<CC><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, \
                                                                            recs, cursors, region);               \
+                else if (g_own_hi > g_own_lo) /* sharded tail: everything outside this rank's slice is flushed now */ \
+                    k_grid_bwd_tile<CC><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, grad_emb, L, tab, min_tiles, \
+                                                                           recs, cursors, region, g_own_lo, g_own_hi); \
             }                                                                                                    \
         }                                                                                                        \
         if (calc)                                                                                                \
@@ -1315,6 +1362,18 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
                                          0u, 0u, stream);
 }
 
+// Sharded data-parallel tail: elements [lo, hi) of the flat table (multiples of 4) belong to this rank and `rec_scale`
+// (1 / ranks) weighs its own record lists against the averaged dense gradient.  While set (hi > lo), a deferred
+// enerf_grid_encode_backward_ex flushes every list outside the range into the dense gradient right away and
+// enerf_grid_adam_from_records(_ex) updates the range only (and clears the dense gradient everywhere).  lo == hi clears.
+int enerf_grid_owner_range(uint64_t lo, uint64_t hi, float rec_scale) {
+    if (hi < lo) ENERF_BADARG("grid_owner_range: hi < lo");
+    g_own_lo = (size_t)lo;
+    g_own_hi = (size_t)hi;
+    g_own_scale = hi > lo ? rec_scale : 1.0f;
+    return 0;
+}
+
 int enerf_grid_records_discard(enerf_stream_t stream) {
     // drop a pending deferred flush (the step that opened it failed before its optimizer pass): empty the lists
     if (g_pending.region != 0) {
@@ -1364,6 +1423,19 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
                                   : nullptr;
     const uint32_t min_tiles = region ? g_pending.min_tiles : 0u;
     ProfScope prof(ENERF_K_TABLE_ADAM, s);
+    if (g_own_hi > g_own_lo) {
+        // the sharded data-parallel tail: Adam on this rank's elements only (k_grid_tile_adam RANGE)
+        if (C != 2) ENERF_BADARG("grid_adam_from_records: an owner range serves C = 2 tables");
+        if (amp_state().scale) ENERF_BADARG("grid_adam_from_records: owner range and loss scaling do not combine");
+        if ((g_own_lo | g_own_hi) & 3u) ENERF_BADARG("grid_adam_from_records: owner range must be multiples of 4 elements");
+        k_grid_tile_adam<2, false, true><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(
+            offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{},
+            OwnerRange{g_own_lo, g_own_hi, g_own_scale});
+        if (g_pending.region != 0) g_session++;
+        g_pending = PendingRecords();
+        ENERF_LAUNCH_CHECK("grid_adam_from_records(range)");
+        return 0;
+    }
     const AmpState as = amp_state();
     if (as.scale) {
         // loss scaling armed (enerf_amp_begin): unscale, skip on a non-finite step, bias corrections from the device

@@ -101,9 +101,12 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     // ---- table backward (record lists) and the optimizer
     if (a->flags & 1u) {
         // data parallel: the gradient has to exist to be averaged -- the backward's own flush into the dense buffer
+        // (flags bit 1: the sharded tail with an owner range set -- enerf_grid_owner_range -- keeps this rank's own
+        //  slice as record lists for the optimizer pass and flushes the rest)
         STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,
                                            a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
-                                           ENERF_F32, 2, in_add, in_mul, 0, 0, s));
+                                           ENERF_F32, 2, in_add, in_mul, (a->flags & 2u) ? 1u : 0u, (a->flags & 2u) ? M : 0u,
+                                           s));
         goto done;
     }
     STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,

@@ -644,7 +644,7 @@ def _native_ctx(model, N, M, Nn, Mn, dev):
 
 
 def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_stream=None, loss_out=None, perturb=True,
-                      dt_gamma=0, max_steps=1024, raw=False):
+                      dt_gamma=0, max_steps=1024, raw=False, defer_dp=False):
     """One closed-form RGB step (loss = mean((image - target)^2), white background) through enerf_train_step_mse:
     render of this batch (marched ahead of time when the previous step asked for it) + backward + the optimizer, and the
     march of `next_rays` = (rays_o, rays_d) on `side_stream` behind the MLP backward.  -> blended image [N,3] (a buffer
@@ -699,7 +699,8 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             a.counter = pre["counter"].data_ptr() if SKIP_PADDING_ROWS else None
             a.target = target.contiguous().view(-1, 3).data_ptr()
             a.loss = None if loss_out is None else loss_out.data_ptr()
-            a.flags = 1 if raw else 0
+            # (bit 1: the sharded tail with an owner range set -- this rank's slice of the table stays as record lists)
+            a.flags = (3 if defer_dp else 1) if raw else 0
             # the next batch's march: kernels on the side stream, into the buffer set the current batch is NOT using
             nxt = key = None
             a.next_rays_o = None

@@ -56,6 +56,9 @@ class TrainHarness:
         self.comm_chunks = 4          # data parallel: pieces of the hash-table gradient all-reduce (0: one bucket + Adam)
         self.comm_mode = "allreduce"  # or "sharded": reduce-scatter -> Adam on this rank's slice -> all-gather
         self.comm_dtype = None        # torch.bfloat16: halve the table gradient's bytes on the wire (changes rounding)
+        # sharded tail: this rank's slice of the table keeps its own record lists for the optimizer pass (the one-GPU
+        # flush, csrc/gridencoder.hip OwnerRange) and only the rest of the gradient is made dense for the reduce-scatter
+        self.fused_sharded = True
         # the tail through the library's own RCCL communicator (csrc/dp_tail.hip: two C calls per step).  Opt-in: False =
         # the torch.distributed tail (the default: it is the one the world-size-2 tests cover), None = use the native one
         # when parallel.native_tail_init() succeeds (RCCL backend, every rank), True = likewise, decided already
@@ -467,6 +470,77 @@ class TrainHarness:
             p.grad = g.view_as(p)
         self.opt.step_now(only=small)
 
+    def _owner_range(self):
+        """(lo, hi, world) of this rank's slice of the flat table for the fused sharded tail, or None when that tail does
+        not apply (all-reduce tail, ragged shards, 16-bit wire format, an optimizer without the record-list pass)."""
+        import torch.distributed as dist
+        if not (self.fused_sharded and self.comm_mode == "sharded" and self.comm_dtype is None and self.avg is not None
+                and hasattr(self.opt, "step_grid_table") and not self.use_graphs
+                and dist.is_available() and dist.is_initialized()):
+            return None
+        emb = getattr(getattr(self.model, "encoder", None), "embeddings", None)
+        if emb is None or getattr(self.model.encoder, "level_dim", 0) != 2:
+            return None
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = emb.numel()
+        if n % world or (n // world) % 4:
+            return None
+        shard = n // world
+        return rank * shard, (rank + 1) * shard, world
+
+    def _finish_sharded_fused(self, own, issue_prefetch=None):
+        """The sharded tail with the one-GPU flush kept for this rank's own slice: the backward left the slice's tiles as
+        record lists and made only the rest of the gradient dense (enerf_grid_owner_range); the dense buffer is
+        reduce-scattered in place (this rank's slice receives the OTHER ranks' averaged share), the optimizer pass sums
+        its own lists in LDS on top of it (x 1 / ranks), updates the slice and clears the buffer, and the slices are
+        all-gathered in place.  Same update as _finish_sharded up to the order of the fp32 sums."""
+        import torch.distributed as dist
+        from . import _lib as L
+        from . import fused_network
+        m = self.model
+        lo, hi, world = own
+        g_emb, dw = self._raw_grads
+        self._raw_grads = None
+        emb = m.encoder.embeddings
+        if g_emb is None:
+            g_emb = emb.grad
+        else:
+            emb.grad = g_emb
+        nccl = dist.get_backend() == "nccl"
+        flat = g_emb.view(-1)
+        try:
+            w_dw = dist.all_reduce(dw, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
+            if nccl:                                          # in place: slice r of the buffer <- average of everybody's
+                work = dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.AVG, async_op=True)
+            else:                                             # gloo has no reduce-scatter
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            if issue_prefetch is not None:
+                issue_prefetch(background=False)
+            work.wait()
+            if not nccl:
+                flat[lo:hi].mul_(1.0 / world)
+            w_dw.wait()
+            if not nccl:
+                dw.mul_(1.0 / world)
+            small = fused_network.network_params(m)[1:]
+            for q, g in zip(small, fused_network.unpack_weight_grads(dw, getattr(m, "out_dim_color", 3),
+                                                                     fused_network.kind_of(m))):
+                q.grad = g.view_as(q)
+            enc = m.encoder
+            self.opt.step_grid_table(emb, enc.offsets, enc.level_dim, extra=small)      # (the owner range is still set)
+        finally:
+            L.lib().enerf_grid_owner_range(0, 0, 1.0)
+        self._cleared_grad = emb.grad                         # cleared everywhere by the optimizer pass
+        p = emb.data.view(-1)
+        if nccl:
+            dist.all_gather_into_tensor(p, p[lo:hi])          # in place: slice r of p <- rank r
+        else:
+            pieces = [torch.empty(hi - lo, dtype=p.dtype, device=p.device) for _ in range(world)]
+            dist.all_gather(pieces, p[lo:hi].contiguous())
+            for r, piece in enumerate(pieces):
+                if r * (hi - lo) != lo:
+                    p[r * (hi - lo):(r + 1) * (hi - lo)].copy_(piece)
+
     def _native_tail_ok(self):
         want = getattr(self, "native_tail", False)
         if want is False or getattr(self, "comm_dtype", None) is not None \
@@ -779,15 +853,24 @@ class TrainHarness:
                 self._side = torch.cuda.Stream()
             nxt = next_rays
         loss = self._loss_slot()
+        own = self._owner_range() if data_parallel else None
+        if own is not None:
+            from . import _lib as L
+            L.check(L.lib().enerf_grid_owner_range(own[0], own[1], 1.0 / own[2]), "grid_owner_range")
         try:
             out = fused_render.train_step_native(m, rays_o, rays_d, target, self.opt, next_rays=nxt,
                                                  side_stream=self._side, loss_out=loss, perturb=self.perturb,
-                                                 raw=data_parallel)
+                                                 raw=data_parallel, defer_dp=own is not None)
         except BaseException:
+            if own is not None:
+                L.lib().enerf_grid_owner_range(0, 0, 1.0)
             self._discard_pending_records()
             raise
         if data_parallel:
             self._raw_grads = (None, out[1])            # (the table's gradient sits in embeddings.grad)
+            if own is not None:
+                self._finish_sharded_fused(own, None)
+                return loss
             if self._native_tail_ok():
                 tail = self._finish_native
             else:
@@ -813,15 +896,25 @@ class TrainHarness:
         # optimizer's pass over the table sums them tile by tile in LDS (FusedAdam.step_grid_table)
         fuse_table = (self.fuse_table_adam and self.avg is None and hasattr(self.opt, "step_grid_table")
                       and not self.use_graphs)
+        own = self._owner_range() if chunked else None
+        if own is not None:
+            from . import _lib as L
+            L.check(L.lib().enerf_grid_owner_range(own[0], own[1], 1.0 / own[2]), "grid_owner_range")
         try:
             tail_side = side if (not late and self.prefetch_at == "mlp_backward") else None
             loss = self._manual_fwd_bwd(rays_o, rays_d, target,
                                         after_forward=None if (late or tail_side is not None) else side, raw=chunked,
-                                        defer_table=fuse_table, after_mlp_backward=tail_side, **render_kw)
+                                        defer_table=fuse_table or own is not None, after_mlp_backward=tail_side,
+                                        **render_kw)
         except BaseException:
+            if own is not None:
+                L.lib().enerf_grid_owner_range(0, 0, 1.0)
             self._discard_pending_records()
             raise
         if chunked:
+            if own is not None:
+                self._finish_sharded_fused(own, side if late else None)
+                return loss
             if self._native_tail_ok():
                 tail = self._finish_native
             else:

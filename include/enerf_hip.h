@@ -317,6 +317,15 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
                                     float lr, float beta1, float beta2, float eps, uint32_t step, uint32_t n_small,
                                     float* const* sp, const float* const* sg, float* const* sm, float* const* sv,
                                     const uint32_t* sn, const float* slr, const uint32_t* sstep, enerf_stream_t stream);
+/* Sharded data-parallel tail ("scaling risk (b)"): elements [lo, hi) of the flat table -- multiples of 4,
+ * this rank's slice of the reduce-scatter -- and `rec_scale` = 1 / ranks.  While a range is set (hi > lo):
+ *   enerf_grid_encode_backward_ex(flags bit 0) keeps the record lists of the tiles wholly inside the range pending and
+ *     flushes every other list into the dense gradient at once (that part travels through the reduce-scatter);
+ *   enerf_grid_adam_from_records(_ex) updates the range only: dense gradient (what the reduce-scatter delivered, averaged)
+ *     + rec_scale x this rank's own lists, summed in LDS as on one GPU; the dense gradient is cleared everywhere.
+ * lo == hi clears the range.  The caller reduce-scatters the dense gradient between the two calls and all-gathers the
+ * parameters after the second. */
+int enerf_grid_owner_range(uint64_t lo, uint64_t hi, float rec_scale);
 /* Abandon a pending deferred flush (error recovery: the record lists are emptied, nothing is applied). */
 int enerf_grid_records_discard(enerf_stream_t stream);
 

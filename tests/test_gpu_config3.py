@@ -85,12 +85,13 @@ def _rccl_worker(rank, world, port, out):
         # torch.distributed (one round trip per piece)
         for tag, dp, mode, native in (("single", 1, None, None), ("allreduce", 2, "allreduce", True),
                                       ("sharded", 2, "sharded", True), ("allreduce_torch", 2, "allreduce", False),
-                                      ("sharded_torch", 2, "sharded", False)):
+                                      ("sharded_torch", 2, "sharded", False), ("sharded_fused", 2, "sharded", False)):
             model = _model()
             h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=dp)   # dp = 2: the data-parallel tail runs
             if mode:
                 h.comm_mode = mode
                 h.native_tail = None if native else False
+                h.fused_sharded = tag == "sharded_fused"     # (the other sharded rows: the dense reduce-scatter tails)
             losses, counters = _run(h, data, 40)
             if native:
                 assert h.native_tail is True, "the native tail did not come up on RCCL"
@@ -108,7 +109,7 @@ def test_configs3_rank_shape_through_both_tails_on_rccl():
     mp.spawn(_rccl_worker, args=(1, _port(), out), nprocs=1, join=True)
     la, ca, pa, ma = out["single"]
     assert ca[:, 1].max() == RAYS_PER_RANK and ma > 0
-    for tag in ("allreduce", "sharded", "allreduce_torch", "sharded_torch"):
+    for tag in ("allreduce", "sharded", "allreduce_torch", "sharded_torch", "sharded_fused"):
         lb, cb, pb, mb = out[tag]
         assert np.array_equal(ca, cb) and ma == mb, tag
         assert np.abs(np.array(la) - np.array(lb)).max() <= 1e-4 * np.abs(la).max(), tag
@@ -130,10 +131,17 @@ def _gloo_worker(rank, world, port, mode, cold_steps, more_steps, out):
         model = _model()
         h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=world)
         h.perturb = False
-        h.comm_mode = mode
+        h.comm_mode = "sharded" if mode.startswith("sharded") else mode
+        h.fused_sharded = mode != "sharded_dense"         # "sharded": this rank's slice keeps its record lists (OwnerRange)
+        seen = []
+        if mode == "sharded":
+            inner = h._finish_sharded_fused
+            h._finish_sharded_fused = lambda *a, **k: (seen.append(1), inner(*a, **k))[1]
         l0, c0 = _run(h, data, cold_steps)
         p0, img0 = _params(model), _eval_image(model)
         l1, c1 = _run(h, data, more_steps, first=cold_steps)
+        if mode == "sharded":
+            assert len(seen) == cold_steps + more_steps, len(seen)      # every step went through the fused sharded tail
         out[(mode, rank)] = (l0, c0, p0, img0, l1, c1, _params(model), int(model.mean_count))
     finally:
         dist.destroy_process_group()
@@ -144,7 +152,7 @@ def test_configs3_two_ranks_of_8192_rays_equal_the_16384_ray_step():
     from enerf_amd.trainer import TrainHarness
     cold, more = 15, 25
     out = mp.Manager().dict()
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sharded_dense"):
         mp.spawn(_gloo_worker, args=(2, _port(), mode, cold, more, out), nprocs=2, join=True)
     # the whole batch in one process
     data = _data(4, 2 * RAYS_PER_RANK)
@@ -153,7 +161,7 @@ def test_configs3_two_ranks_of_8192_rays_equal_the_16384_ray_step():
     h.perturb = False
     ls, cs = _run(h, data, cold)
     ps, imgs = _params(model), _eval_image(model)
-    for mode in ("allreduce", "sharded"):
+    for mode in ("allreduce", "sharded", "sharded_dense"):
         (l0, c0, p0, i0, l1, c1, q0, m0), (lr1, cr1, p1, i1, lr2, cr2, q1, m1) = out[(mode, 0)], out[(mode, 1)]
         # replicas: identical weights after every window, one agreed sample budget
         assert all(torch.equal(p0[n], p1[n]) for n in p0) and all(torch.equal(q0[n], q1[n]) for n in q0), mode
@@ -168,8 +176,9 @@ def test_configs3_two_ranks_of_8192_rays_equal_the_16384_ray_step():
             assert float((a - p0[n]).abs().mean()) <= 1e-3 * float(a.abs().mean()), (mode, n)
         assert float((imgs - i0).abs().max()) <= 2e-3, mode
     # past the cold window (sample budget agreed by MAX all-reduce): both tails train the same model
-    qa, qb = out[("allreduce", 0)][6], out[("sharded", 0)][6]
-    for n, a in qa.items():
-        assert float((a - qb[n]).abs().mean()) <= 1e-3 * float(a.abs().mean()), n
-    la, lb = np.array(out[("allreduce", 0)][4]), np.array(out[("sharded", 0)][4])
-    assert np.isfinite(la).all() and np.abs(la - lb).max() <= 1e-3 * np.abs(la).max()
+    for other in ("sharded", "sharded_dense"):
+        qa, qb = out[("allreduce", 0)][6], out[(other, 0)][6]
+        for n, a in qa.items():
+            assert float((a - qb[n]).abs().mean()) <= 1e-3 * float(a.abs().mean()), (other, n)
+        la, lb = np.array(out[("allreduce", 0)][4]), np.array(out[(other, 0)][4])
+        assert np.isfinite(la).all() and np.abs(la - lb).max() <= 1e-3 * np.abs(la).max(), other

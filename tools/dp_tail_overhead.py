@@ -33,17 +33,24 @@ def main():
     dev = torch.device("cuda", 0)
     batches = bench.build_batches(8, a.rays, dev, 0, a.bound)
     # (native: csrc/dp_tail.hip on the library's own communicator; torch: torch.distributed, one round trip per piece)
-    configs = (("single process", 1, 4, None, None, "allreduce"),
-               ("torch tail, 1 piece", 2, 1, None, False, "allreduce"), ("torch tail, 4 pieces", 2, 4, None, False, "allreduce"),
-               ("torch tail, 8 pieces", 2, 8, None, False, "allreduce"), ("torch tail, sharded", 2, 4, None, False, "sharded"),
-               ("native tail, 1 piece", 2, 1, None, None, "allreduce"), ("native tail, 4 pieces", 2, 4, None, None, "allreduce"),
-               ("native tail, 8 pieces", 2, 8, None, None, "allreduce"), ("native tail, sharded", 2, 4, None, None, "sharded"),
-               ("torch tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16, False, "allreduce"))
-    for tag, dp, chunks, dtype, native, mode in (configs if a.only is None else configs[a.only:a.only + 1]):
+    # ("sharded, own slice fused": the default sharded tail -- this rank's slice of the table keeps its record lists for
+    #  the optimizer pass, TrainHarness._finish_sharded_fused; "dense": every tile made dense first, _finish_sharded)
+    configs = (("single process", 1, 4, None, None, "allreduce", True),
+               ("torch tail, 1 piece", 2, 1, None, False, "allreduce", True),
+               ("torch tail, 4 pieces", 2, 4, None, False, "allreduce", True),
+               ("torch tail, 8 pieces", 2, 8, None, False, "allreduce", True),
+               ("torch tail, sharded, own slice fused", 2, 4, None, False, "sharded", True),
+               ("torch tail, sharded, dense", 2, 4, None, False, "sharded", False),
+               ("native tail, 1 piece", 2, 1, None, None, "allreduce", True),
+               ("native tail, 4 pieces", 2, 4, None, None, "allreduce", True),
+               ("native tail, 8 pieces", 2, 8, None, None, "allreduce", True),
+               ("native tail, sharded, dense", 2, 4, None, None, "sharded", False),
+               ("torch tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16, False, "allreduce", True))
+    for tag, dp, chunks, dtype, native, mode, fused in (configs if a.only is None else configs[a.only:a.only + 1]):
         torch.manual_seed(0)
         model = NeRFNetwork(encoding="hashgrid", bound=a.bound, cuda_ray=True, out_dim_color=3).to(dev)
         h = TrainHarness(model, occupancy="synthetic", world=dp)
-        h.comm_chunks, h.comm_dtype, h.native_tail, h.comm_mode = chunks, dtype, native, mode
+        h.comm_chunks, h.comm_dtype, h.native_tail, h.comm_mode, h.fused_sharded = chunks, dtype, native, mode, fused
 
         def step(i):
             ro, rd, tg = batches[i % 8]
@@ -57,7 +64,7 @@ def main():
             step(i)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
-        print(f"{tag:28s} {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms/step   (host enqueue "
+        print(f"{tag:38s} {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms/step   (host enqueue "
               f"{(t1 - t0) / a.steps * 1e3:.3f})")
     dist.destroy_process_group()
 
