@@ -116,6 +116,9 @@ SIGNATURES = {
     "enerf_dp_world": [_c.POINTER(_int), _c.POINTER(_int)],
     "enerf_dp_shutdown": [],
     "enerf_dp_begin": [_int, _vp, _sz, _u32, _vp, _sz, _vp],
+    "enerf_dp_wait": [_vp],
+    "enerf_dp_allgather": [_vp, _vp],
+    "enerf_dp_probe": [],
     "enerf_dp_finish": [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _vp],
     "enerf_abi_version": [],
 }

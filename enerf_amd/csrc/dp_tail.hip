@@ -131,6 +131,24 @@ void clear_async(float* p, size_t n, hipStream_t s) {        // n and p are mult
     k_clear<<<512, 256, 0, s>>>(reinterpret_cast<float4*>(p), n / 4);
 }
 
+void release_stream_and_events() {
+    if (g_cs) {
+        (void)hipStreamDestroy(g_cs);
+        g_cs = nullptr;
+    }
+    hipEvent_t* single[] = {&g_ev_main, &g_ev_dw, &g_ev_gather};
+    for (hipEvent_t* e : single)
+        if (*e) {
+            (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+    for (uint32_t k = 0; k < kMaxPieces; k++)
+        if (g_ev_piece[k]) {
+            (void)hipEventDestroy(g_ev_piece[k]);
+            g_ev_piece[k] = nullptr;
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -140,6 +158,12 @@ int enerf_dp_unique_id(void* out, size_t bytes) {
     if (!out || bytes < sizeof(UniqueId)) ENERF_BADARG("dp_unique_id: need a buffer of %zu bytes", sizeof(UniqueId));
     if (int e = load_rccl()) return e;
     return check_rccl(g_rccl.get_unique_id((UniqueId*)out), "ncclGetUniqueId");
+}
+
+// 0 when librccl can be reached (what enerf_dp_unique_id does first; ranks other than 0 call this instead of minting an id)
+int enerf_dp_probe(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return load_rccl();
 }
 
 int enerf_dp_init(const void* unique_id, size_t bytes, int rank, int world) {
@@ -156,9 +180,13 @@ int enerf_dp_init(const void* unique_id, size_t bytes, int rank, int world) {
     if (he == hipSuccess) he = ev(&g_ev_dw);
     if (he == hipSuccess) he = ev(&g_ev_gather);
     for (uint32_t k = 0; k < kMaxPieces && he == hipSuccess; k++) he = ev(&g_ev_piece[k]);
-    if (int e = check_hip(he, "dp_init(events)")) return e;
+    if (int e = check_hip(he, "dp_init(events)")) {
+        release_stream_and_events();
+        return e;
+    }
     if (int e = check_rccl(g_rccl.comm_init_rank(&g_comm, world, id, rank), "ncclCommInitRank")) {
         g_comm = nullptr;
+        release_stream_and_events();
         return e;
     }
     g_rank = rank;
@@ -181,10 +209,7 @@ int enerf_dp_shutdown(void) {
         (void)g_rccl.comm_destroy(g_comm);
         g_comm = nullptr;
     }
-    if (g_cs) {
-        (void)hipStreamDestroy(g_cs);
-        g_cs = nullptr;
-    }
+    release_stream_and_events();
     g_pending = Pending();
     return 0;
 }
@@ -268,6 +293,36 @@ int enerf_dp_finish(float* p, float* m, float* v, float lr, float beta1, float b
     if (int e = check_hip(hipStreamWaitEvent(s, g_ev_dw, 0), "dp_finish(wait mlp)")) return e;
     ENERF_LAUNCH_CHECK("dp_finish");
     return 0;
+}
+
+// The sharded tail with the optimizer pass left to the caller (enerf_grid_owner_range + enerf_grid_adam_from_records_ex:
+// this rank's slice keeps its record lists): after enerf_dp_begin(mode 1, ...)
+//   enerf_dp_wait       `stream` waits for the reduce-scatter and for the MLP gradients' all-reduce -- the caller's
+//                       optimizer launch goes behind it;
+//   enerf_dp_allgather  the updated slices -> every replica's table (in place, on the collectives' stream behind what
+//                       `stream` holds so far), which `stream` then waits for; closes the step enerf_dp_begin opened.
+int enerf_dp_wait(enerf_stream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_comm || !g_pending.open) ENERF_BADARG("dp_wait: no enerf_dp_begin is pending");
+    hipStream_t s = (hipStream_t)stream;
+    for (uint32_t k = 0; k < g_pending.pieces; k++)
+        if (int e = check_hip(hipStreamWaitEvent(s, g_ev_piece[k], 0), "dp_wait(piece)")) return e;
+    return check_hip(hipStreamWaitEvent(s, g_ev_dw, 0), "dp_wait(mlp)");
+}
+
+int enerf_dp_allgather(float* p, enerf_stream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_comm || !g_pending.open) ENERF_BADARG("dp_allgather: no enerf_dp_begin is pending");
+    if (!p || g_pending.mode != 1) ENERF_BADARG("dp_allgather: needs the table and a sharded (mode 1) enerf_dp_begin");
+    hipStream_t s = (hipStream_t)stream;
+    const Pending pd = g_pending;
+    g_pending.open = false;
+    if (int e = check_hip(hipEventRecord(g_ev_main, s), "dp_allgather(record)")) return e;
+    if (int e = check_hip(hipStreamWaitEvent(g_cs, g_ev_main, 0), "dp_allgather(wait)")) return e;
+    if (int e = check_rccl(g_rccl.all_gather(p + pd.lo[0], p, pd.hi[0] - pd.lo[0], kFloat32, g_comm, g_cs), "ncclAllGather"))
+        return e;
+    if (int e = check_hip(hipEventRecord(g_ev_gather, g_cs), "dp_allgather(event)")) return e;
+    return check_hip(hipStreamWaitEvent(s, g_ev_gather, 0), "dp_allgather(wait gather)");
 }
 
 }  // extern "C"

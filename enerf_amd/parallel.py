@@ -49,7 +49,8 @@ def native_tail_init():
         rank, world = dist.get_rank(), dist.get_world_size()
         dev = torch.device("cuda", torch.cuda.current_device())
         host = (ctypes.c_char * 128)()
-        can = 1 if lib.enerf_dp_unique_id(host, 128) == 0 else 0          # (loads librccl; rank 0's id is the one used)
+        # the id is minted on rank 0 only (the others just check that librccl can be loaded: a second id would be thrown away)
+        can = 1 if (lib.enerf_dp_unique_id(host, 128) if rank == 0 else lib.enerf_dp_probe()) == 0 else 0
         flag = torch.tensor([can], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:

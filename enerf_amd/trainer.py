@@ -857,16 +857,22 @@ class TrainHarness:
         if own is not None:
             from . import _lib as L
             L.check(L.lib().enerf_grid_owner_range(own[0], own[1], 1.0 / own[2]), "grid_owner_range")
+        # (opted into the library's own communicator: the whole sharded tail is part of the one call)
+        native_dp = own is not None and self._native_tail_ok()
         try:
             out = fused_render.train_step_native(m, rays_o, rays_d, target, self.opt, next_rays=nxt,
                                                  side_stream=self._side, loss_out=loss, perturb=self.perturb,
-                                                 raw=data_parallel, defer_dp=own is not None)
+                                                 raw=data_parallel, defer_dp=own is not None, native_dp=native_dp)
         except BaseException:
             if own is not None:
                 L.lib().enerf_grid_owner_range(0, 0, 1.0)
             self._discard_pending_records()
             raise
         if data_parallel:
+            if native_dp:
+                L.lib().enerf_grid_owner_range(0, 0, 1.0)
+                self._cleared_grad = emb.grad
+                return loss
             self._raw_grads = (None, out[1])            # (the table's gradient sits in embeddings.grad)
             if own is not None:
                 self._finish_sharded_fused(own, None)

@@ -606,8 +606,16 @@ typedef struct enerf_train_step_args {
     const uint32_t* small_step;
     /* bit 0: data parallel -- the table's gradient is SUMMED INTO the dense buffer table_grad (grid_encode_backward's
      * own flush, no record lists left behind) and no optimizer runs: the caller averages table_grad and the buffers
-     * behind dwseg_* over the ranks (enerf_dp_begin / enerf_dp_finish) and steps the optimizer itself */
+     * behind dwseg_* over the ranks (enerf_dp_begin / enerf_dp_finish) and steps the optimizer itself.
+     * bit 1 (with bit 0, enerf_grid_owner_range set): the sharded tail that keeps this rank's slice as record lists -- the
+     * backward defers, flushing only the other slices into table_grad; the caller reduce-scatters, runs
+     * enerf_grid_adam_from_records_ex and all-gathers.
+     * bit 2 (with bits 0 and 1, enerf_dp_init done): that whole tail inside this call, on the library's communicator:
+     * enerf_dp_begin(1, table_grad, table_count, 1, dw_flat, dw_count) -> enerf_dp_wait -> the optimizer pass (table_* /
+     * small_* as without bit 0) -> enerf_dp_allgather(table). */
     uint32_t flags, reserved;
+    float* dw_flat;                     /* bit 2: the flat buffer behind dwseg_* and its length; elements of the table */
+    uint64_t dw_count, table_count;
 } enerf_train_step_args;
 int enerf_train_step_mse(const enerf_train_step_args* args);
 /* Development aid: host microseconds enerf_train_step_mse spends in each of its calls (in call order, 16 slots, averaged
@@ -703,6 +711,13 @@ int enerf_dp_world(int* rank, int* world);              /* (-1, 0) before enerf_
 int enerf_dp_shutdown(void);
 int enerf_dp_begin(int mode, float* table_grad, size_t n, uint32_t pieces, float* mlp_grad, size_t n_mlp,
                    enerf_stream_t stream);
+/* The sharded tail with the optimizer pass left to the caller (enerf_grid_owner_range + enerf_grid_adam_from_records_ex),
+ * after enerf_dp_begin(1, ...): enerf_dp_wait makes `stream` wait for the reduce-scatter and the MLP gradients'
+ * all-reduce; enerf_dp_allgather all-gathers the updated slices of `p` in place behind what `stream` holds, makes `stream`
+ * wait for it and closes the step.  enerf_dp_probe: 0 when librccl can be reached (ranks that do not mint the id). */
+int enerf_dp_wait(enerf_stream_t stream);
+int enerf_dp_allgather(float* p, enerf_stream_t stream);
+int enerf_dp_probe(void);
 int enerf_dp_finish(float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, uint32_t step,
                     enerf_stream_t stream);
 

@@ -45,6 +45,7 @@ def main():
                ("native tail, 4 pieces", 2, 4, None, None, "allreduce", True),
                ("native tail, 8 pieces", 2, 8, None, None, "allreduce", True),
                ("native tail, sharded, dense", 2, 4, None, None, "sharded", False),
+               ("native, sharded, own slice fused (1 call)", 2, 4, None, None, "sharded", True),
                ("torch tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16, False, "allreduce", True))
     for tag, dp, chunks, dtype, native, mode, fused in (configs if a.only is None else configs[a.only:a.only + 1]):
         torch.manual_seed(0)
@@ -64,7 +65,7 @@ def main():
             step(i)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
-        print(f"{tag:38s} {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms/step   (host enqueue "
+        print(f"{tag:42s} {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms/step   (host enqueue "
               f"{(t1 - t0) / a.steps * 1e3:.3f})")
     dist.destroy_process_group()
 
