@@ -46,7 +46,7 @@ typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, Comm, hipStream
 typedef int (*ReduceScatterFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, Comm, hipStream_t);
 typedef const char* (*GetErrorStringFn)(int);
-constexpr int kFloat32 = 7, kAvg = 4;
+constexpr int kFloat32 = 7, kAvg = 4, kSum = 0;
 constexpr uint32_t kMaxPieces = 16;
 
 struct Rccl {
@@ -219,13 +219,14 @@ int enerf_dp_begin(int mode, float* table_grad, size_t n, uint32_t pieces, float
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_comm) ENERF_BADARG("dp_begin: enerf_dp_init has not run");
     if (g_pending.open) ENERF_BADARG("dp_begin: the previous step's enerf_dp_finish has not run");
-    if (!table_grad || n == 0 || n % 4 || (mode != 0 && mode != 1)) ENERF_BADARG("dp_begin: bad arguments");
+    // mode 2: mode 1 with a SUM reduce-scatter (the caller's optimizer pass applies 1 / ranks: enerf_grid_owner_range)
+    if (!table_grad || n == 0 || n % 4 || mode < 0 || mode > 2) ENERF_BADARG("dp_begin: bad arguments");
     if (mode == 0 && (pieces < 1 || pieces > kMaxPieces)) ENERF_BADARG("dp_begin: 1..%u pieces", kMaxPieces);
-    if (mode == 1 && (n % (size_t)g_world || (n / (size_t)g_world) % 4))
+    if (mode >= 1 && (n % (size_t)g_world || (n / (size_t)g_world) % 4))
         ENERF_BADARG("dp_begin: the sharded tail needs the table to divide over the ranks in multiples of 4 elements");
     hipStream_t s = (hipStream_t)stream;
     Pending pd;
-    pd.mode = mode;
+    pd.mode = mode == 2 ? 1 : mode;
     pd.n = n;
     pd.g = table_grad;
     // the collectives come after everything the training stream holds so far (the backward that filled the buffers)
@@ -245,7 +246,8 @@ int enerf_dp_begin(int mode, float* table_grad, size_t n, uint32_t pieces, float
         pd.lo[0] = shard * (size_t)g_rank;
         pd.hi[0] = pd.lo[0] + shard;
         // in place: this rank's slice of the buffer receives the average of everybody's slice
-        if (int e = check_rccl(g_rccl.reduce_scatter(table_grad, table_grad + pd.lo[0], shard, kFloat32, kAvg, g_comm, g_cs),
+        if (int e = check_rccl(g_rccl.reduce_scatter(table_grad, table_grad + pd.lo[0], shard, kFloat32, mode == 2 ? kSum : kAvg,
+                                                     g_comm, g_cs),
                                "ncclReduceScatter"))
             return e;
         if (int e = check_hip(hipEventRecord(g_ev_piece[0], g_cs), "dp_begin(slice event)")) return e;

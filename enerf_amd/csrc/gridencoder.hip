@@ -887,10 +887,11 @@ __device__ __forceinline__ void amp_scalars(AdamScalars& a, float lr, uint32_t s
 }
 
 // RANGE (enerf_grid_owner_range, the sharded data-parallel tail): Adam only on the elements [own_lo, own_hi) of the flat
-// table.  The dense gradient holds what the reduce-scatter delivered (the other ranks' share, already divided by the number
-// of ranks; plus this rank's own spilled / unbinned contributions); a tile wholly inside the range adds the sum of its own
-// record lists times rec_scale (1 / ranks) -- the one-GPU flush for this rank's slice; a tile the range cuts takes its
-// gradient from the dense buffer alone (pass B flushed its lists); everything outside is only cleared.
+// table.  The dense gradient holds what the reduce-scatter (SUM) delivered: the other ranks' contributions, plus this
+// rank's own spilled / unbinned ones; a tile wholly inside the range adds the sum of its own record lists -- the one-GPU
+// flush for this rank's slice -- and the total is multiplied by rec_scale (1 / ranks: the average over the ranks); a tile
+// the range cuts takes its gradient from the dense buffer alone (pass B flushed its lists); everything outside is only
+// cleared.
 struct OwnerRange {
     size_t lo, hi;
     float rec_scale;
@@ -1036,13 +1037,9 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                     const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
                     const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
                     // (fp64 sum rounded once, then the dense part: what pass B + the dense buffer would have held)
-                    if (RANGE) {
-                        g4.x += (float)a0.x * own.rec_scale; g4.y += (float)a0.y * own.rec_scale;
-                        g4.z += (float)a1.x * own.rec_scale; g4.w += (float)a1.y * own.rec_scale;
-                    } else {
-                        g4.x += (float)a0.x; g4.y += (float)a0.y; g4.z += (float)a1.x; g4.w += (float)a1.y;
-                    }
+                    g4.x += (float)a0.x; g4.y += (float)a0.y; g4.z += (float)a1.x; g4.w += (float)a1.y;
                 }
+                if (RANGE) { g4.x *= own.rec_scale; g4.y *= own.rec_scale; g4.z *= own.rec_scale; g4.w *= own.rec_scale; }
                 if (AMP) { g4.x *= inv_scale; g4.y *= inv_scale; g4.z *= inv_scale; g4.w *= inv_scale; }
                 if ((!AMP || !skip) && (!RANGE || (i >= clip_lo && i < clip_hi))) {
                     tile_adam1(p4[f].x, g4.x, m4[f].x, v4[f].x, ad);
@@ -1363,7 +1360,7 @@ int enerf_grid_encode_backward(const void* grad, const float* inputs, const void
 }
 
 // Sharded data-parallel tail: elements [lo, hi) of the flat table (multiples of 4) belong to this rank and `rec_scale`
-// (1 / ranks) weighs its own record lists against the averaged dense gradient.  While set (hi > lo), a deferred
+// (1 / ranks) turns the summed gradient -- reduce-scattered dense part + its own record lists -- into the average.  While set (hi > lo), a deferred
 // enerf_grid_encode_backward_ex flushes every list outside the range into the dense gradient right away and
 // enerf_grid_adam_from_records(_ex) updates the range only (and clears the dense gradient everywhere).  lo == hi clears.
 int enerf_grid_owner_range(uint64_t lo, uint64_t hi, float rec_scale) {

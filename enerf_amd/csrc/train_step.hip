@@ -111,7 +111,7 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
             // bit 2: the rest of that tail from here, on the library's own communicator (csrc/dp_tail.hip): the other
             // slices' gradient leaves through the reduce-scatter, the optimizer pass runs on this rank's slice -- dense
             // share + its own lists, the MLP weights behind their all-reduce -- and the slices are all-gathered
-            STEP(enerf_dp_begin(1, a->table_grad, (size_t)a->table_count, 1, a->dw_flat, (size_t)a->dw_count, s));
+            STEP(enerf_dp_begin(2, a->table_grad, (size_t)a->table_count, 1, a->dw_flat, (size_t)a->dw_count, s));
             STEP(enerf_dp_wait(s));
             STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr,
                                                  a->beta1, a->beta2, a->eps, a->table_step, a->n_small, a->small_p,

@@ -491,9 +491,9 @@ class TrainHarness:
     def _finish_sharded_fused(self, own, issue_prefetch=None):
         """The sharded tail with the one-GPU flush kept for this rank's own slice: the backward left the slice's tiles as
         record lists and made only the rest of the gradient dense (enerf_grid_owner_range); the dense buffer is
-        reduce-scattered in place (this rank's slice receives the OTHER ranks' averaged share), the optimizer pass sums
-        its own lists in LDS on top of it (x 1 / ranks), updates the slice and clears the buffer, and the slices are
-        all-gathered in place.  Same update as _finish_sharded up to the order of the fp32 sums."""
+        reduce-scattered in place (SUM: this rank's slice receives the OTHER ranks' share), the optimizer pass sums its own
+        lists in LDS on top of it, divides by the number of ranks, updates the slice and clears the buffer, and the slices
+        are all-gathered in place.  Same update as _finish_sharded up to the order of the fp32 sums."""
         import torch.distributed as dist
         from . import _lib as L
         from . import fused_network
@@ -510,15 +510,15 @@ class TrainHarness:
         flat = g_emb.view(-1)
         try:
             w_dw = dist.all_reduce(dw, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
-            if nccl:                                          # in place: slice r of the buffer <- average of everybody's
-                work = dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.AVG, async_op=True)
+            # SUM, not AVG: the optimizer pass applies 1 / ranks to dense share + own lists together (and a one-rank world's
+            # in-place SUM is free where RCCL's AVG runs a scaling kernel over the 52 MB)
+            if nccl:                                          # in place: slice r of the buffer <- sum of everybody's
+                work = dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, async_op=True)
             else:                                             # gloo has no reduce-scatter
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
             if issue_prefetch is not None:
                 issue_prefetch(background=False)
             work.wait()
-            if not nccl:
-                flat[lo:hi].mul_(1.0 / world)
             w_dw.wait()
             if not nccl:
                 dw.mul_(1.0 / world)

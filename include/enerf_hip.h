@@ -321,8 +321,8 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
  * this rank's slice of the reduce-scatter -- and `rec_scale` = 1 / ranks.  While a range is set (hi > lo):
  *   enerf_grid_encode_backward_ex(flags bit 0) keeps the record lists of the tiles wholly inside the range pending and
  *     flushes every other list into the dense gradient at once (that part travels through the reduce-scatter);
- *   enerf_grid_adam_from_records(_ex) updates the range only: dense gradient (what the reduce-scatter delivered, averaged)
- *     + rec_scale x this rank's own lists, summed in LDS as on one GPU; the dense gradient is cleared everywhere.
+ *   enerf_grid_adam_from_records(_ex) updates the range only: rec_scale x (dense gradient -- what a SUM reduce-scatter
+ *     delivered -- + this rank's own lists, summed in LDS as on one GPU); the dense gradient is cleared everywhere.
  * lo == hi clears the range.  The caller reduce-scatters the dense gradient between the two calls and all-gathers the
  * parameters after the second. */
 int enerf_grid_owner_range(uint64_t lo, uint64_t hi, float rec_scale);
@@ -611,7 +611,7 @@ typedef struct enerf_train_step_args {
      * backward defers, flushing only the other slices into table_grad; the caller reduce-scatters, runs
      * enerf_grid_adam_from_records_ex and all-gathers.
      * bit 2 (with bits 0 and 1, enerf_dp_init done): that whole tail inside this call, on the library's communicator:
-     * enerf_dp_begin(1, table_grad, table_count, 1, dw_flat, dw_count) -> enerf_dp_wait -> the optimizer pass (table_* /
+     * enerf_dp_begin(2, table_grad, table_count, 1, dw_flat, dw_count) -> enerf_dp_wait -> the optimizer pass (table_* /
      * small_* as without bit 0) -> enerf_dp_allgather(table). */
     uint32_t flags, reserved;
     float* dw_flat;                     /* bit 2: the flat buffer behind dwseg_* and its length; elements of the table */

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--bound", type=int, default=3)
     ap.add_argument("--only", type=int, default=None, help="index of the one configuration to run (for profiling)")
+    ap.add_argument("--host-slots", action="store_true", help="print enerf_debug_step_timing's per-call host times")
     a = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.sched_setaffinity(0, set(range(8, 16)))          # as bench.py pins rank 0
@@ -60,11 +61,19 @@ def main():
         for i in range(32):
             step(i)
         torch.cuda.synchronize()
+        if a.host_slots:
+            from enerf_amd import _lib
+            _lib.lib().enerf_debug_step_timing(1, None)
         t0 = time.perf_counter()
         for i in range(32, 32 + a.steps):
             step(i)
         t1 = time.perf_counter()
         torch.cuda.synchronize()
+        if a.host_slots:
+            import ctypes
+            arr = (ctypes.c_double * 16)()
+            _lib.lib().enerf_debug_step_timing(0, arr)
+            print("   host us per library call inside the one-call step:", [round(v, 1) for v in arr])
         print(f"{tag:42s} {(time.perf_counter() - t0) / a.steps * 1e3:.3f} ms/step   (host enqueue "
               f"{(t1 - t0) / a.steps * 1e3:.3f})")
     dist.destroy_process_group()
