@@ -80,6 +80,7 @@ SIGNATURES = {
     "enerf_debug_march_wave_max_rays": [_u32],
     "enerf_debug_march_bg_blocks": [_u32],
     "enerf_debug_march_clip": [_int],
+    "enerf_march_rays_use_box": [_int],
     "enerf_grid_owner_range": [ctypes.c_uint64, ctypes.c_uint64, _f32],
     "enerf_amp_begin": [_vp, _vp, _vp, _vp],
     "enerf_amp_end": [_f32, _f32, _int, _vp],

@@ -1413,7 +1413,8 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
                                                     float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
                                                     uint32_t H, const uint8_t* __restrict__ grid,
                                                     const float* __restrict__ fars, float* xyzs, float* dirs,
-                                                    float* deltas, uint32_t perturb, uint32_t zero_rows_to) {
+                                                    float* deltas, uint32_t perturb, uint32_t zero_rows_to,
+                                                    const int* __restrict__ occ_keys) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     const bool fast = dt_gamma == 0.0f && march_fast_ok(H);
@@ -1429,14 +1430,18 @@ __global__ void __launch_bounds__(256) k_march_rays(uint32_t n_alive, uint32_t n
     if (perturb) t = fmaf(c.dt_min, pcg_first_float((uint64_t)n, (uint64_t)perturb), t);   // :744, contracted
     const size_t base = (size_t)n * n_step;
     uint32_t got;
+    // the occupied cells' box (as in the training count pass): no sample lies outside it, so the walk may stop at its far
+    // side -- or not start at all; the slots stay zero either way, which is what ends the ray in composite_rays
+    float far = fars[index];
+    if (occ_keys && !clip_to_occupied(c, occ_keys, far)) far = t;
     if (fast) {
         RayFixed rf;
         ray_fixed_init(rf, c);
         const MarchTabs tabs = {s_face, s_expand};
-        got = march_one_ray_fast<true>(c, rf, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+        got = march_one_ray_fast<true>(c, rf, tabs, t, far, n_step, xyzs + base * 3, dirs + base * 3,
                                        deltas + base * 2);
     } else {
-        got = march_one_ray<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+        got = march_one_ray<true>(c, t, far, n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
     }
     if (zero_rows_to && got < n_step)                          // the slots this ray did not fill (delta == 0: end)
         zero_rows(xyzs, dirs, deltas, (uint32_t)base + got, (uint32_t)base + n_step, 0, 1);
@@ -1451,7 +1456,7 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
                                                       float bound, uint32_t max_steps, uint32_t C, uint32_t H,
                                                       const uint8_t* __restrict__ grid, const float* __restrict__ fars,
                                                       float* xyzs, float* dirs, float* deltas, uint32_t perturb,
-                                                      uint32_t zero_rows_to) {
+                                                      uint32_t zero_rows_to, const int* __restrict__ occ_keys) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     const bool fast = march_fast_ok(H);
@@ -1468,11 +1473,13 @@ __global__ void __launch_bounds__(256) k_march_rays_w(uint32_t n_alive, uint32_t
     if (perturb) t = fmaf(c.dt_min, pcg_first_float((uint64_t)n, (uint64_t)perturb), t);   // :744, contracted
     const size_t base = (size_t)n * n_step;
     uint32_t got;
+    float far = fars[index];
+    if (occ_keys && !clip_to_occupied(c, occ_keys, far)) far = t;           // (see k_march_rays)
     if (fast)
-        got = lattice_march_fast<true, false>(c, tabs, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3,
+        got = lattice_march_fast<true, false>(c, tabs, t, far, n_step, xyzs + base * 3, dirs + base * 3,
                                               deltas + base * 2, nullptr, nullptr);
     else
-        got = lattice_march<true>(c, t, fars[index], n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
+        got = lattice_march<true>(c, t, far, n_step, xyzs + base * 3, dirs + base * 3, deltas + base * 2);
     got = __builtin_amdgcn_readfirstlane(got);
     if (zero_rows_to && got < n_step)
         zero_rows(xyzs, dirs, deltas, (uint32_t)base + got, (uint32_t)base + n_step, lane_id(), 64);
@@ -1694,6 +1701,7 @@ int enerf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t*
 
 static uint32_t g_march_bg_blocks = 0;
 static int g_march_clip = 1;        // enerf_debug_march_clip: test rays against the occupied cells' bounding box first
+static int g_infer_box = 0;         // enerf_march_rays_use_box: the inference march may trust the cached box
 // the bitfield the box in WS_AABB was last computed for (enerf_occupied_box_update)
 static const uint8_t* g_box_grid = nullptr;
 static uint32_t g_box_C = 0, g_box_H = 0;
@@ -2024,6 +2032,11 @@ int enerf_debug_march_thread_min_rays(uint32_t n) {
     return (int)prev;
 }
 
+int enerf_march_rays_use_box(int on) {
+    g_infer_box = on ? 1 : 0;
+    return 0;
+}
+
 int enerf_debug_march_clip(int on) {
     g_march_clip = on ? 1 : 0;
     return 0;
@@ -2062,16 +2075,32 @@ int enerf_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_a
     if (C == 0 || H < 2 || max_steps == 0) ENERF_BADARG("march_rays: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_INFER, s);
+    // the occupied cells' box: the cached one while the caller vouches for it (enerf_march_rays_use_box: a frame's rounds
+    // march one bitfield), else computed for this call when the round is large enough to repay two small launches
+    const int* occ_keys = nullptr;
+    if (g_march_clip && (H * H * H) % 8 == 0) {
+        if (g_infer_box && g_box_grid == grid && g_box_C == C && g_box_H == H && g_box_bound == bound) {
+            occ_keys = (const int*)workspace(WS_AABB, 6 * sizeof(int));
+        } else if (n_alive >= 32768u) {
+            if (int e = workspace_family_enter(0, s)) return e;
+            int* keys = (int*)workspace(WS_AABB_CALL, 64);
+            if (keys) {
+                k_aabb_init<<<1, 64, 0, s>>>(keys);
+                k_occupied_aabb<<<min(div_up(C * H * H * H / 8, 256), 2u * num_cus()), 256, 0, s>>>(grid, C, H, bound, keys);
+                occ_keys = keys;
+            }
+        }
+    }
     // Same samples either way (bit-identical).  One thread per ray wins while there are enough rays to fill the chip with
     // short loops; one wavefront per ray wins when rays are few or each must produce many samples.
     if (dt_gamma == 0.0f && (n_alive <= g_march_wave_max_rays || n_step >= g_march_wave_min_steps))
         k_march_rays_w<<<div_up(n_alive, 4), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
                                                           max_steps, C, H, grid, fars, xyzs, dirs, deltas, perturb,
-                                                          zero_rows_to);
+                                                          zero_rows_to, occ_keys);
     else
         k_march_rays<<<div_up(n_alive, 256), 256, 0, s>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
                                                           dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas,
-                                                          perturb, zero_rows_to);
+                                                          perturb, zero_rows_to, occ_keys);
     ENERF_LAUNCH_CHECK("march_rays");
     return 0;
 }

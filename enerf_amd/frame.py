@@ -89,6 +89,26 @@ def render_rounds(model, rays_o, rays_d, bg_color=1, perturb=False, dt_gamma=0, 
     survivors = torch.zeros(1, dtype=torch.int32, device=dev)
     widen = max(int(getattr(model, "infer_batch_mult", 1)), 1)
     n_alive, taken, cur = N, 0, 0
+    # every round marches the same bitfield: the library's box of the occupied cells (refreshed here if the bitfield
+    # changed) is vouched for once, and each round's walk stops at its far side
+    use_box = raymarching._DEVICE == "cuda" and rays_o.is_cuda
+    if use_box:
+        from . import _lib as L
+        from .fused_render import occupied_box_flag
+        use_box = bool(occupied_box_flag(model))
+        if use_box:
+            L.lib().enerf_march_rays_use_box(1)
+    try:
+        return _rounds_loop(model, rays_o, rays_d, bg_color, perturb, dt_gamma, max_steps, nears, fars, weights_sum, depth,
+                            image, alive, t_now, survivors, widen, N)
+    finally:
+        if use_box:
+            L.lib().enerf_march_rays_use_box(0)
+
+
+def _rounds_loop(model, rays_o, rays_d, bg_color, perturb, dt_gamma, max_steps, nears, fars, weights_sum, depth, image,
+                 alive, t_now, survivors, widen, N):
+    n_alive, taken, cur = N, 0, 0
     while taken < 1024 and n_alive > 0:
         n_step = max(min(widen * N // n_alive, 8 * widen), 1)
         xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive[cur], t_now[cur], rays_o, rays_d, model.bound,

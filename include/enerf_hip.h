@@ -499,6 +499,11 @@ int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
 int enerf_debug_march_wave_max_rays(uint32_t n);
 /* test / measurement aid: 0 switches off the occupied-box test (below) globally */
 int enerf_debug_march_clip(int on);
+/* While on, enerf_march_rays(_ex) trust the box enerf_occupied_box_update last computed when it was computed for the same
+ * bitfield pointer / C / H / bound (the caller vouches that the bitfield has not changed since: a frame's rounds); off
+ * (default), a round of 32 768+ rays computes the box for itself and smaller rounds march without it.  A ray emits no
+ * sample outside the box, so the walk stops at its far side: same samples, slots and termination. */
+int enerf_march_rays_use_box(int on);
 /* tuning / test aid: smallest ray count for which the fixed-step enerf_march_rays_train* counts with one thread per ray
  * and a run log (instead of one wavefront per ray and a chunk log); 0 only reads.  Returns the previous value.  The
  * count and the write pass of a batch must see the same setting. */
