@@ -82,6 +82,7 @@ SIGNATURES = {
     "enerf_debug_march_clip": [_int],
     "enerf_march_rays_use_box": [_int],
     "enerf_grid_owner_range": [ctypes.c_uint64, ctypes.c_uint64, _f32],
+    "enerf_ffmlp_recompute": [_int],
     "enerf_amp_begin": [_vp, _vp, _vp, _vp],
     "enerf_amp_end": [_f32, _f32, _int, _vp],
     "enerf_amp_cancel": [],

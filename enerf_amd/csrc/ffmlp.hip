@@ -18,6 +18,7 @@
 //    (deterministic; replaces the reference's per-layer split-K CUTLASS GEMMs on side streams).
 //  * fp32 accumulation everywhere (the reference accumulates in fp16).
 #include "ffmlp_common.h"
+#include "mlp32_common.h"
 
 using namespace enerf_ffmlp;
 
@@ -304,9 +305,51 @@ int run_bwd(const void* grad, const void* inputs, const void* weights, const voi
     return ffmlp_wgrad_launch(dtype, grad, inputs, fb, bb, B, input_dim, num_layers, grad_weights, s);
 }
 
+// ---- the recomputing data flow (mlp32s.hip through mlp32_common.h's ffmlp16_*): the training pair of entry points moves
+// 160 B per sample instead of ~1.4 KB -- `forward_buffer` / `backward_buffer` are scratch to every caller there is (the
+// reference's wrapper allocates them, hands them over and drops them: ffmlp/ffmlp.py:34-83), so they are left untouched.
+// Served: input_dim 32, two or three hidden layers (the two nets of nerf/network_ff.py), ReLU / no hidden activation, no
+// output activation.  enerf_ffmlp_recompute(0) brings the buffered kernels above back.
+int g_ffmlp_recompute = 1;
+
+bool lean_shape(uint32_t input_dim, uint32_t num_layers, uint32_t act, uint32_t out_act) {
+    return g_ffmlp_recompute && input_dim == 32 && (num_layers == 2 || num_layers == 3) && (act == 0 || act == 6) &&
+           out_act == 6;
+}
+uint32_t blob_elems(uint32_t num_layers) { return HID * (32 + HID * (num_layers - 1) + OUT); }
+
+template <typename E>
+__global__ void __launch_bounds__(256) k_w_to_f32(const E* __restrict__ w, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)w[i];
+}
+template <typename E>
+__global__ void __launch_bounds__(256) k_w_from_f32(const float* __restrict__ w, E* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (E)w[i];
+}
+// fp32 copy of the weight blob (and room for the fp32 weight gradients behind it)
+float* weights_f32(const void* weights, uint32_t n, int dtype, hipStream_t s) {
+    float* w32 = (float*)workspace(WS_FFMLP_W, sizeof(float) * 2 * (size_t)n);
+    if (!w32) return nullptr;
+    if (dtype == ENERF_BF16) k_w_to_f32<__bf16><<<div_up(n, 256), 256, 0, s>>>((const __bf16*)weights, w32, n);
+    else k_w_to_f32<_Float16><<<div_up(n, 256), 256, 0, s>>>((const _Float16*)weights, w32, n);
+    return w32;
+}
+
 }  // namespace
 
 extern "C" {
+
+// 1 (default): enerf_ffmlp_forward / enerf_ffmlp_backward recompute the hidden activations in the backward where the
+// shape allows (see lean_shape) and leave forward_buffer / backward_buffer untouched; 0: the buffered kernels (the
+// reference's data flow: ffmlp.cu:410-518,711-895).  Forward and backward of a batch must run under the same setting.
+// Returns the previous setting; a negative argument only queries.
+int enerf_ffmlp_recompute(int on) {
+    const int prev = g_ffmlp_recompute;
+    if (on >= 0) g_ffmlp_recompute = on != 0;
+    return prev;
+}
 
 int enerf_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                         uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
@@ -315,6 +358,15 @@ int enerf_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uin
     int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers, dtype);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (lean_shape(input_dim, num_layers, activation, output_activation)) {
+        if (int ew = workspace_family_enter(1, s)) return ew;
+        const float* w32 = weights_f32(weights, blob_elems(num_layers), dtype, s);
+        if (!w32) return ENERF_E_NOMEM;
+        rc = enerf_mlp32::ffmlp16_forward(dtype, inputs, w32, B, num_layers, activation, outputs, s);
+        if (rc) return rc;
+        ENERF_LAUNCH_CHECK("ffmlp_forward(recompute)");
+        return 0;
+    }
     ProfScope prof(ENERF_K_FFMLP_FWD, s);
     rc = dtype == ENERF_BF16
              ? run_fwd<__bf16, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, s)
@@ -351,6 +403,19 @@ int enerf_ffmlp_backward(const void* grad, const void* inputs, const void* weigh
     if (rc) return rc;
     if (activation == 2) ENERF_BADARG("ffmlp: sine activation has no backward (as in the reference)");
     hipStream_t s = (hipStream_t)stream;
+    if (lean_shape(input_dim, num_layers, activation, 6)) {
+        if (int ew = workspace_family_enter(1, s)) return ew;
+        const uint32_t n = blob_elems(num_layers);
+        float* w32 = weights_f32(weights, n, dtype, s);
+        if (!w32) return ENERF_E_NOMEM;
+        rc = enerf_mlp32::ffmlp16_backward(dtype, grad, inputs, w32, B, num_layers, activation,
+                                           calc_grad_inputs ? grad_inputs : nullptr, w32 + n, s);
+        if (rc) return rc;
+        if (dtype == ENERF_BF16) k_w_from_f32<__bf16><<<div_up(n, 256), 256, 0, s>>>(w32 + n, (__bf16*)grad_weights, n);
+        else k_w_from_f32<_Float16><<<div_up(n, 256), 256, 0, s>>>(w32 + n, (_Float16*)grad_weights, n);
+        ENERF_LAUNCH_CHECK("ffmlp_backward(recompute)");
+        return 0;
+    }
     ProfScope prof(ENERF_K_FFMLP_BWD, s);
     rc = dtype == ENERF_BF16
              ? run_bwd<__bf16>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, calc_grad_inputs != 0, backward_buffer, grad_inputs, grad_weights, dtype, s)

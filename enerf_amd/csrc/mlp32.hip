@@ -836,6 +836,7 @@ int g_precision = 1;                // enerf_mlp32_precision: 0 = fp32 MFMA (bit
                                     // 2 = bf16 operands (the FFMLP nets' arithmetic: one product, 16-bit roundings),
                                     // 3 = fp16 operands (the same kernels on IEEE half: the reference's fp16 regime)
 inline bool ops16() { return g_precision == 2 || g_precision == 3; }
+bool g_io16 = false;                // ffmlp16_forward / _backward: X, Y, dY, dX are 16-bit row-major tensors
 bool g_recompute = true;            // enerf_mlp32_recompute: the split backward recomputes the hidden activations
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
@@ -993,7 +994,7 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
         const bool store_fb = fb != nullptr && !(g_recompute && split_bwd_shape(num_hidden, out_dim, x_layout));
         (g_precision == 3 ? mlp32s_f16_launch_fwd : mlp32s_launch_fwd)(
             g_precision == 1 ? 3 : 1, num_hidden, store_fb, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
-            output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop());
+            output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop(), g_io16);
     } else if (sh_dirs) {
         const ShNorm4 nrm = make_sh_norm4();
         if (fb)
@@ -1140,7 +1141,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         (void)bb;
         (g_precision == 3 ? mlp32s_f16_launch_bwd : mlp32s_launch_bwd)(
             g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation, wgrid, s,
-            prof.start(), prof.stop(), g_recompute);
+            prof.start(), prof.stop(), g_recompute || g_io16, g_io16);
     } else if (fused) {
         (void)bb;
         if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }
@@ -1247,6 +1248,47 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
 }
 
 }  // extern "C"
+
+namespace enerf_mlp32 {
+
+// The reference's FFMLP entry points on this file's data flow (mlp32_common.h).  The arithmetic mode and the 16-bit I/O
+// flag are set for the duration of the call.
+int ffmlp16_forward(int dtype, const void* X, const float* W32, uint32_t B, uint32_t num_hidden, uint32_t activation,
+                    void* Y, hipStream_t s) {
+    if (num_hidden < 2 || num_hidden > 3) ENERF_BADARG("ffmlp16_forward: two or three hidden layers");
+    const int prev = g_precision;
+    g_precision = dtype == ENERF_BF16 ? 2 : 3;
+    g_io16 = true;
+    const int rc = mlp32_forward_impl(reinterpret_cast<const float*>(X), blob_src(W32, num_hidden), B, IN, 16, num_hidden,
+                                      activation, 6, nullptr, reinterpret_cast<float*>(Y), 0, 16, nullptr, nullptr,
+                                      (enerf_stream_t)s);
+    g_io16 = false;
+    g_precision = prev;
+    return rc;
+}
+
+int ffmlp16_backward(int dtype, const void* dY, const void* X, const float* W32, uint32_t B, uint32_t num_hidden,
+                     uint32_t activation, void* dX, float* dW32, hipStream_t s) {
+    if (num_hidden < 2 || num_hidden > 3) ENERF_BADARG("ffmlp16_backward: two or three hidden layers");
+    const WSrc w = blob_src(W32, num_hidden);
+    WDst d;
+    for (int k = 0; k < 4; k++) d.seg[k] = w.seg[k] ? dW32 + (w.seg[k] - W32) : nullptr;
+    d.w0_cols = IN;
+    d.nerf_perm = 0;
+    d.overwrite = 1;
+    const int prev = g_precision;
+    g_precision = dtype == ENERF_BF16 ? 2 : 3;
+    g_io16 = true;
+    const int rc = mlp32_backward_impl(reinterpret_cast<const float*>(dY), reinterpret_cast<const float*>(X), w, nullptr, B,
+                                       IN, 16, num_hidden, activation, nullptr, reinterpret_cast<float*>(dX), d, 0, 16,
+                                       nullptr, 0, nullptr, nullptr, 0, (enerf_stream_t)s);
+    g_io16 = false;
+    g_precision = prev;
+    return rc;
+}
+
+}  // namespace enerf_mlp32
+
 
 #ifdef ENERF_MLP_TIMING
 extern "C" int enerf_debug_mlp_phases(unsigned long long* out, int reset) {

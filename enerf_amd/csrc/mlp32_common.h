@@ -264,20 +264,28 @@ __device__ __forceinline__ void load_x(const float* __restrict__ X, uint32_t til
 void mlp32s_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X, const WSrc& W,
                        float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
                        uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s,
-                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool io16 = false);
 void mlp32s_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X, const WSrc& W,
                        const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim, uint32_t act,
                        uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
-                       bool recompute = false);
+                       bool recompute = false, bool io16 = false);
 
 // the same kernels with IEEE half operands (mlp32s_f16.hip; prec is 1 there: one product per operand pair)
 void mlp32s_f16_launch_fwd(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
                            const WSrc& W, float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
                            uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s,
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool io16 = false);
 void mlp32s_f16_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
                            const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
                            uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr,
-                           hipEvent_t ev_stop = nullptr, bool recompute = false);
+                           hipEvent_t ev_stop = nullptr, bool recompute = false, bool io16 = false);
+
+// The reference's FFMLP entry points on the data flow above (mlp32.hip; called by ffmlp.hip): 16-bit row-major X / Y /
+// dY / dX (dtype ENERF_BF16 or ENERF_F16), weights and weight gradients as fp32 blobs [W0 64x32 | Wh | Wout 16x64]; the
+// hidden activations are recomputed in the backward, nothing is stored between the two calls.  num_hidden = 2 or 3.
+int ffmlp16_forward(int dtype, const void* X, const float* W32, uint32_t B, uint32_t num_hidden, uint32_t activation,
+                    void* Y, hipStream_t s);
+int ffmlp16_backward(int dtype, const void* dY, const void* X, const float* W32, uint32_t B, uint32_t num_hidden,
+                     uint32_t activation, void* dX, float* dW32, hipStream_t s);
 
 }  // namespace enerf_mlp32

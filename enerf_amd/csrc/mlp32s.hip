@@ -156,6 +156,25 @@ __device__ __forceinline__ void flip_natural(const FragT<P>& f, bf16x8 selN, Fra
     }
 }
 
+// IO16 (the reference's FFMLP entry points, enerf_ffmlp_forward / _backward: row-major 16-bit tensors): a lane's 16 inputs
+// ARE its two first-layer operands as they lie in memory -- two 16-byte loads, no conversion -- and outputs / input
+// gradients leave as 16-bit values, four to an 8-byte store.
+__device__ __forceinline__ void load_x16(const void* __restrict__ X, uint32_t tile, int j, int h, uint32_t B, bf16x8 (&f)[2]) {
+    const size_t s = (size_t)tile * 32 + j;
+    const bool valid = s < B;
+    const size_t sc = valid ? s : (size_t)B - 1;
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const elem16*>(X) + sc * IN + 16 * h);
+    uint4 a = p[0], b = p[1];
+    if (!valid) a = b = make_uint4(0u, 0u, 0u, 0u);
+    f[0] = __builtin_bit_cast(bf16x8, a);
+    f[1] = __builtin_bit_cast(bf16x8, b);
+}
+__device__ __forceinline__ void store4_16(void* base, size_t elem, float a, float b, float c, float d) {
+    typedef elem16 e4 __attribute__((ext_vector_type(4)));
+    const e4 v = {(elem16)a, (elem16)b, (elem16)c, (elem16)d};
+    *reinterpret_cast<e4*>(reinterpret_cast<elem16*>(base) + elem) = v;
+}
+
 // Weight operands of the forward: in registers for the density-only sweeps (SIG: ~100 tiles per wavefront) and for bf16
 // operands; for split operands (P == 3) of a training / rendering batch they are kept in LDS in operand order instead
 // (k_mlp32s_bwd's scheme) -- the 96 / 128 registers they would take hold the kernel at two wavefronts per SIMD, and a
@@ -168,7 +187,7 @@ typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 #define k_mlp32s_bwd k_mlp32h_bwd
 #define k_mlp32s_mark k_mlp32h_mark
 #endif
-template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false, int P = 3>
+template <int NH, bool TRAIN, int XL, bool SIG = false, bool SH = false, int P = 3, bool IO16 = false>
 __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp32s_fwd(const float* __restrict__ X, WSrc W,
                                                     float* __restrict__ fb, float* __restrict__ Y, uint32_t B,
                                                     uint32_t out_dim, uint32_t act, uint32_t out_act, uint32_t y_stride,
@@ -177,10 +196,15 @@ __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
+    static_assert(!IO16 || (P == 1 && XL == 0 && !SIG && !SH && !TRAIN), "16-bit I/O: bf16 / fp16 operands, row-major, plain");
     float x[16];
+    bf16x8 xraw[2];
     {
         const uint32_t tile0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (tile0 < Bp / 32) load_x<XL>(X, tile0, j, h, B, Bp, x);
+        if (tile0 < Bp / 32) {
+            if constexpr (IO16) load_x16(X, tile0, j, h, B, xraw);
+            else load_x<XL>(X, tile0, j, h, B, Bp, x);
+        }
     }
     stage_rot(wl, W, NH, out_dim);
 
@@ -284,7 +308,10 @@ __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp
         const size_t s = (size_t)tile * 32 + j;
         const bool valid = s < B;
         if (WL) asm volatile("" ::: "memory");             // the operand reads stay inside the loop
-        if (!SIG && tile != gw) load_x<XL>(X, tile, j, h, B, Bp, x);
+        if (!SIG && tile != gw) {
+            if constexpr (IO16) load_x16(X, tile, j, h, B, xraw);
+            else load_x<XL>(X, tile, j, h, B, Bp, x);
+        }
         float dir0 = 0.0f, dir1 = 0.0f, dir2 = 0.0f;
         if (SH && valid) {
             dir0 = sh_dirs[s * 3]; dir1 = sh_dirs[s * 3 + 1]; dir2 = sh_dirs[s * 3 + 2];
@@ -292,10 +319,14 @@ __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp
         Frag xf[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            float v[8];
+            if constexpr (IO16) {
+                xf[t].hi = xraw[t];
+            } else {
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = x[8 * t + e];
-            xf[t] = split8<P>(v);
+                for (int e = 0; e < 8; e++) v[e] = x[8 * t + e];
+                xf[t] = split8<P>(v);
+            }
         }
         if (SIG && tile + nw < ntiles) load_x<XL>(X, tile + nw, j, h, B, Bp, x);
         f32x16 a[2];
@@ -348,7 +379,18 @@ __global__ void __launch_bounds__(256, fwd_weights_in_lds(SIG, P) ? 3 : 1) k_mlp
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
             for (int t = 0; t < 2; t++) o = mmap(WO(ib, t), af[ib][t], o);
-        if (valid) {
+        if (IO16) {
+            // rows of out_dim <= 16 values: registers 0..3 -> columns 4h .. 4h+3, registers 4..7 -> columns 8 + 4h ..
+            if (valid) {
+#pragma unroll
+                for (int g4 = 0; g4 < 2; g4++) {
+                    const uint32_t c0 = (uint32_t)(8 * g4 + 4 * h);
+                    if (c0 < out_dim)
+                        store4_16(Y, s * y_stride + c0, out_act_fwd(o[4 * g4], out_act), out_act_fwd(o[4 * g4 + 1], out_act),
+                                  out_act_fwd(o[4 * g4 + 2], out_act), out_act_fwd(o[4 * g4 + 3], out_act));
+                }
+            }
+        } else if (valid) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t r = (uint32_t)nrow(q, h);
@@ -389,11 +431,12 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 // and read by the backward -- at the 133 k-sample training batch that buffer was two thirds of the MLP kernels' HBM
 // traffic.  X arrives once, in the forward's operand layout; its transpose for the first layer's weight gradient is a
 // flip by the matrix pipe like every other tile's.  The forward-order weight operands join the others in LDS.
-template <int NH, int XL, int P = 3, bool RC = false>
+template <int NH, int XL, int P = 3, bool RC = false, bool IO16 = false>
 __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* __restrict__ X, WSrc W,
                                                     const float* __restrict__ fb, float* __restrict__ dX,
                                                     float* __restrict__ partial, uint32_t B, uint32_t out_dim,
                                                     uint32_t act) {
+    static_assert(!IO16 || (P == 1 && XL == 0 && RC), "16-bit I/O: bf16 / fp16 operands, row-major, recomputing");
     constexpr uint32_t NW_MAX = HID * IN + (NH - 1) * HID * HID + 16 * HID;
     constexpr bool WL = NH > 1 || RC;                                  // weight operands from LDS
     constexpr int NFRAG_T = 2 + 4 + 8 * (NH - 1);                      // transposed operands (dgrad)
@@ -535,7 +578,8 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const uint32_t o = (uint32_t)(8 * h + e), oc = o < out_dim ? o : out_dim - 1;
-            dy_raw[e] = dys.dY[sc * dys.stride + oc];
+            if constexpr (IO16) dy_raw[e] = (float)reinterpret_cast<const elem16*>(dys.dY)[sc * dys.stride + oc];
+            else dy_raw[e] = dys.dY[sc * dys.stride + oc];
             ys_raw[e] = dys.y_sig ? dys.y_sig[sc * dys.y_sig_stride + oc] : 0.0f;
         }
         if (dys.dsigma) {
@@ -554,7 +598,12 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
         for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + sn) * HID, ib, h, fwl[l][ib]);
     };
     float xfw[16];                                     // RC: X in the forward's operand layout (load_x), a tile ahead
+    bf16x8 xraw[2];                                    // IO16: the same as the operands themselves
     auto request_x = [&](uint32_t t) {
+        if constexpr (IO16) {
+            load_x16(X, t, j, h, B, xraw);
+            return;
+        }
         if constexpr (RC) {
             load_x<XL>(X, t, j, h, B, Bp, xfw);
             return;
@@ -586,7 +635,12 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
         if (WL) asm volatile("" ::: "memory");        // the operand reads stay in the loop (hoisted, they are 112 registers)
         if (tile >= nreal) {
             if (dX) {
-                if (XL == 0) {
+                if (IO16) {
+                    if (valid) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) store4_16(dX, s * IN + 8 * gq + 4 * h, 0.f, 0.f, 0.f, 0.f);
+                    }
+                } else if (XL == 0) {
                     if (valid) {
 #pragma unroll
                         for (int gq = 0; gq < 4; gq++)
@@ -607,10 +661,14 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
         if constexpr (RC) {
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                float v[8];
+                if constexpr (IO16) {
+                    xop[t].hi = xraw[t];
+                } else {
+                    float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = xfw[8 * t + e];
-                xop[t] = split8<P>(v);
+                    for (int e = 0; e < 8; e++) v[e] = xfw[8 * t + e];
+                    xop[t] = split8<P>(v);
+                }
             }
             request_x(tnext);
             // the forward, instruction for instruction (k_mlp32s_fwd): same operands, same order of the products
@@ -756,7 +814,13 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             for (int ob = 0; ob < 2; ob++)
 #pragma unroll
                 for (int t = 0; t < 2; t++) d = mmap(WI(ob, t), gf[ob][t], d);
-            if (XL == 0) {
+            if (IO16) {
+                if (valid) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        store4_16(dX, s * IN + 8 * gq + 4 * h, d[4 * gq], d[4 * gq + 1], d[4 * gq + 2], d[4 * gq + 3]);
+                }
+            } else if (XL == 0) {
                 if (valid) {
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++)
@@ -821,7 +885,7 @@ __global__ void k_mlp32s_mark() {}
 void MLP32S_LAUNCH_FWD(int prec, uint32_t num_hidden, bool train, uint32_t x_layout, bool sigma_only, const float* X,
                        const WSrc& W, float* fb, float* Y, uint32_t B, uint32_t out_dim, uint32_t act, uint32_t out_act,
                        uint32_t y_stride, float* y0_exp, const float* sh_dirs, uint32_t grid, size_t lds, hipStream_t s,
-                       hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       hipEvent_t ev_start, hipEvent_t ev_stop, bool io16) {
     // timed launches (enerf_prof_*): the interval runs between two kernel-attached stop events -- a one-wavefront marker
     // right before the kernel, and the kernel itself -- i.e. the kernel's own dispatch-to-end, as for grid_encode_forward
     if (ev_start) hipExtLaunchKernelGGL(k_mlp32s_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);
@@ -837,6 +901,9 @@ void MLP32S_LAUNCH_FWD(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
         else S_FWD(NHV, TR, XLV, SIGV, SHV, 1);          \
     } while (0)
 #endif
+#define S_FWD_IO(NHV)                                                                                                       \
+    hipExtLaunchKernelGGL((k_mlp32s_fwd<NHV, false, 0, false, false, 1, true>), dim3(grid), dim3(256), lds, s, nullptr, ev_stop, \
+                          0, X, W, fb, Y, B, out_dim, act, out_act, y_stride, y0_exp, sh_dirs, nrm)
 #define S_FWD_XL(NHV, TR)                                   \
     do {                                                    \
         if (x_layout == 0) S_FWD_P(NHV, TR, 0, false, false); \
@@ -848,7 +915,10 @@ void MLP32S_LAUNCH_FWD(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
         else S_FWD_XL(NHV, false);      \
     } while (0)
     const ShNorm4 nrm = sh_dirs ? make_sh_norm4() : ShNorm4{};
-    if (sh_dirs) {                       // level-major input, the SH encoding into columns 16..31 of the output rows
+    if (io16) {                          // the FFMLP entry points: 16-bit row-major X / Y, two or three hidden layers
+        if (num_hidden == 2) S_FWD_IO(2);
+        else S_FWD_IO(3);
+    } else if (sh_dirs) {                // level-major input, the SH encoding into columns 16..31 of the output rows
         if (num_hidden == 1) {
             if (train) S_FWD_P(1, true, 1, false, true);
             else S_FWD_P(1, false, 1, false, true);
@@ -866,6 +936,7 @@ void MLP32S_LAUNCH_FWD(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
         S_FWD_TR(3);
     }
 #undef S_FWD_TR
+#undef S_FWD_IO
 #undef S_FWD_XL
 #undef S_FWD_P
 #undef S_FWD
@@ -874,8 +945,17 @@ void MLP32S_LAUNCH_FWD(int prec, uint32_t num_hidden, bool train, uint32_t x_lay
 void MLP32S_LAUNCH_BWD(int prec, uint32_t num_hidden, uint32_t x_layout, const DySource& dys, const float* X,
                        const WSrc& W, const float* fb, float* dX, float* partial, uint32_t B, uint32_t out_dim,
                        uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
-                       bool recompute) {
+                       bool recompute, bool io16) {
     if (ev_start) hipExtLaunchKernelGGL(k_mlp32s_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);
+    if (io16) {                          // the FFMLP entry points: 16-bit row-major X / dY / dX, recomputing
+        if (num_hidden == 2)
+            hipExtLaunchKernelGGL((k_mlp32s_bwd<2, 0, 1, true, true>), dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, dys, X,
+                                  W, fb, dX, partial, B, out_dim, act);
+        else
+            hipExtLaunchKernelGGL((k_mlp32s_bwd<3, 0, 1, true, true>), dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, dys, X,
+                                  W, fb, dX, partial, B, out_dim, act);
+        return;
+    }
 #define S_BWD(NHV, XLV, PV, RCV)                                                                                         \
     hipExtLaunchKernelGGL((k_mlp32s_bwd<NHV, XLV, PV, RCV>), dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, dys, X, W, fb, \
                           dX, partial, B, out_dim, act)

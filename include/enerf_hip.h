@@ -369,6 +369,13 @@ int enerf_ffmlp_backward(const void* grad, const void* inputs, const void* weigh
                          int calc_grad_inputs, void* backward_buffer, void* grad_inputs, void* grad_weights,
                          int dtype, enerf_stream_t stream);
 
+/* 1 (default): enerf_ffmlp_forward / enerf_ffmlp_backward take the recomputing data flow where the shape allows (input_dim
+ * 32, two or three hidden layers -- the two nets of nerf/network_ff.py --, ReLU / no hidden activation, no output
+ * activation): the backward recomputes the hidden activations from the inputs (bit-identical to the forward's) and
+ * `forward_buffer` / `backward_buffer` -- scratch to the reference's wrapper, ffmlp/ffmlp.py:34-83 -- are neither written nor
+ * read: 160 B per sample instead of ~1.4 KB through HBM.  0: the buffered kernels (ffmlp.cu:410-518,711-895's data flow).
+ * Forward and backward of a batch must run under the same setting.  Returns the previous setting; < 0 only queries. */
+int enerf_ffmlp_recompute(int on);
 /* ffmlp.cu:723-743: the reference (re)creates its split-K side streams here.  This implementation reduces weight
  * gradients inside the fused backward kernel, so these only (re)size the fp32 partial-sum workspace. */
 int enerf_allocate_splitk(size_t size);

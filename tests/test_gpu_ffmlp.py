@@ -25,9 +25,72 @@ def _ulp_tol(ref, dtype, n_ulp=2.0):
     return n_ulp * eps * np.maximum(np.abs(ref), 1e-3 if dtype == torch.bfloat16 else 1e-4)
 
 
+@pytest.fixture
+def buffered_ffmlp():
+    """The reference's data flow for enerf_ffmlp_forward / _backward (forward_buffer / backward_buffer written and read);
+    the default since round 4 recomputes the hidden activations in the backward and leaves both buffers alone."""
+    from enerf_amd import _lib
+    prev = _lib.lib().enerf_ffmlp_recompute(0)
+    yield
+    _lib.lib().enerf_ffmlp_recompute(prev)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k,B", [(2, 256), (3, 640), (2, 100 * 128), (3, 128)])
+def test_ffmlp_recomputing_entry_points_vs_oracle(dtype, k, B):
+    """enerf_ffmlp_forward / _backward on the recomputing data flow (the default for the two nets of nerf/network_ff.py:
+    input_dim 32, two / three hidden layers): outputs, input gradients and weight gradients against the oracle's rounded
+    FFMLP, `forward_buffer` / `backward_buffer` untouched, and the same results as the buffered kernels'."""
+    from enerf_amd import _lib
+    from enerf_amd.backends import _ffmlp as ff
+    assert _lib.lib().enerf_ffmlp_recompute(-1) == 1
+    i = 32
+    rnd = 1 if dtype == torch.bfloat16 else 2
+    W, x, g = _mk(i, k, B, 300 + k)
+    Wd = torch.from_numpy(W).to(DEV).to(dtype)
+    xd = torch.from_numpy(x).to(DEV).to(dtype)
+    gd = torch.from_numpy(g).to(DEV).to(dtype)
+    Wr, xr, gr = Wd.float().cpu().numpy(), xd.float().cpu().numpy(), gd.float().cpu().numpy()
+    out_ref, fb_ref = O.ffmlp_forward(xr, Wr, i, 16, 64, k, 0, 6, rnd=rnd)
+    gi_ref, gw_ref, _ = O.ffmlp_backward(gr, xr, Wr, fb_ref, i, 16, 64, k, 0, True, rnd=rnd)
+
+    def run():
+        fb = torch.full((k, B, 64), 7.0, device=DEV, dtype=dtype)
+        bb = torch.full((k, B, 64), 7.0, device=DEV, dtype=dtype)
+        out = torch.empty(B, 16, device=DEV, dtype=dtype)
+        gi = torch.zeros(B, i, device=DEV, dtype=dtype)
+        gw = torch.zeros_like(Wd)
+        ff.ffmlp_forward(xd, Wd, B, i, 16, 64, k, 0, 6, fb, out)
+        ff.ffmlp_backward(gd, xd, Wd, fb, B, i, 16, 64, k, 0, 6, True, bb, gi, gw)
+        return out, gi, gw, fb, bb
+    out, gi, gw, fb, bb = run()
+    assert float((fb - 7.0).abs().max()) == 0.0 and float((bb - 7.0).abs().max()) == 0.0       # neither written
+    o = out.float().cpu().numpy()
+    assert (np.abs(o - out_ref) <= _ulp_tol(out_ref, dtype, 4)).mean() > 0.995 and np.abs(o - out_ref).max() < 0.06
+    gi_ = gi.float().cpu().numpy()
+    assert (np.abs(gi_ - gi_ref) <= _ulp_tol(gi_ref, dtype, 4)).mean() > 0.985
+    gw_ = gw.float().cpu().numpy()
+    scale = np.abs(gw_ref).max()
+    assert np.abs(gw_ - gw_ref).max() < 0.02 * scale
+    np.testing.assert_allclose(gw_, gw_ref, rtol=0.05, atol=0.01 * scale)
+    # the buffered kernels on the same tensors: same outputs (both round every layer to 16 bits at the same points)
+    prev = _lib.lib().enerf_ffmlp_recompute(0)
+    try:
+        out_b, gi_b, gw_b, fb_b, _ = run()
+    finally:
+        _lib.lib().enerf_ffmlp_recompute(prev)
+    assert float((fb_b - 7.0).abs().max()) > 0.0
+    assert (np.abs(o - out_b.float().cpu().numpy()) <= _ulp_tol(out_ref, dtype, 2)).mean() > 0.999
+    assert np.abs(gw_ - gw_b.float().cpu().numpy()).max() < 0.02 * scale
+    # without grad_inputs
+    gw2 = torch.zeros_like(Wd)
+    ff.ffmlp_backward(gd, xd, Wd, fb, B, i, 16, 64, k, 0, 6, False, bb, torch.zeros(1, device=DEV, dtype=dtype), gw2)
+    assert torch.equal(gw2, gw)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("i,k,B", [(32, 2, 256), (32, 3, 640), (16, 2, 128), (64, 4, 384)])
-def test_ffmlp_forward_inference_backward_vs_oracle(dtype, i, k, B):
+def test_ffmlp_forward_inference_backward_vs_oracle(dtype, i, k, B, buffered_ffmlp):
     from enerf_amd.backends import _ffmlp as ff
     rnd = 1 if dtype == torch.bfloat16 else 2
     W, x, g = _mk(i, k, B, 100 + i + k)
@@ -74,7 +137,7 @@ def test_ffmlp_forward_inference_backward_vs_oracle(dtype, i, k, B):
 
 
 @pytest.mark.parametrize("act", [1, 3, 4, 5, 6])
-def test_ffmlp_other_activations(act):
+def test_ffmlp_other_activations(act, buffered_ffmlp):
     from enerf_amd.backends import _ffmlp as ff
     i, k, B, dtype = 32, 2, 128, torch.bfloat16
     W, x, g = _mk(i, k, B, 7)
