@@ -47,12 +47,19 @@ def main():
                 gi = torch.zeros(B, 32, device=dev, dtype=dtype)
                 gw = torch.zeros_like(W)
                 t_bwd = timeit(lambda: ff.ffmlp_backward(g, x, W, fb, B, 32, 16, 64, k, 0, 6, True, bb, gi, gw))
+                # the reference's data flow (forward_buffer / backward_buffer written and read back) beside the default
+                prev = L.lib().enerf_ffmlp_recompute(0)
+                t_fwd_b = timeit(lambda: ff.ffmlp_forward(x, W, B, 32, 16, 64, k, 0, 6, fb, out))
+                t_bwd_b = timeit(lambda: ff.ffmlp_backward(g, x, W, fb, B, 32, 16, 64, k, 0, 6, True, bb, gi, gw))
+                L.lib().enerf_ffmlp_recompute(prev)
                 by_inf = B * (64 + 32)
                 by_fwd = B * (64 + 32 + k * 128)
                 print(f"{str(dtype)[6:]:9s} B={B:8d} {name}: inference {t_inf*1e3:7.1f} us "
                       f"({flops/t_inf/1e9:7.1f} TFLOP/s = {flops/t_inf/1e9/2500*100:4.1f}% of 2.5 PF, "
                       f"{by_inf/t_inf/1e6:6.0f} GB/s) | train fwd {t_fwd*1e3:7.1f} us ({by_fwd/t_fwd/1e6:6.0f} GB/s) | "
-                      f"bwd {t_bwd*1e3:7.1f} us ({3*flops/t_bwd/1e9:6.1f} TFLOP/s useful)")
+                      f"bwd {t_bwd*1e3:7.1f} us ({3*flops/t_bwd/1e9:6.1f} TFLOP/s useful) | buffered flow: fwd "
+                      f"{t_fwd_b*1e3:7.1f} us, bwd {t_bwd_b*1e3:7.1f} us ({B*(64+32+k*128)/t_fwd_b/1e6:5.0f} / "
+                      f"{B*(2*k*128+k*128+64+64+32)/t_bwd_b/1e6:5.0f} GB/s)")
     # fused fp32 MLP
     lib = L.lib()
     for B in ((a.batch,) if a.batch else (131072, 2 * 1024 * 1024)):
