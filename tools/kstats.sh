@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp
 for N in 16 80; do
   rm -rf /tmp/ks_$N
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$N -o s -- python $R/bench.py --no-cpu-baseline --render-frames 0 --graph-leg-steps 0 --probe-steps 0 --steps $N --warmup 16 "$@" > $R/gpurun_out/kstats_$N.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$N -o s -- python $R/bench.py --no-cpu-baseline --render-frames 0 --graph-leg-steps 0 --probe-steps 0 --other-legs 0 --strong-rays 0 --steps $N --warmup 16 "$@" > $R/gpurun_out/kstats_$N.log 2>&1
   find /tmp/ks_$N -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/kstats_$N.csv \;
 done
 python - <<PY

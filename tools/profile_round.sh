@@ -13,7 +13,7 @@ rm -rf /tmp/p_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-forma
 find /tmp/p_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
 
 # live hipEvent timing vs rocprofv3 on the same launches: a run whose timed region is the tail of the process
-rm -rf /tmp/p_agree; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_agree -o a -- $BENCH --render-frames 0 --graph-leg-steps 0 --probe-steps 0 --other-legs 0 > $OUT/bench_under_trace.log 2>&1
+rm -rf /tmp/p_agree; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_agree -o a -- $BENCH --render-frames 0 --graph-leg-steps 0 --probe-steps 0 --other-legs 0 --strong-rays 0 > $OUT/bench_under_trace.log 2>&1
 python $R/tools/agree.py $(find /tmp/p_agree -name "*kernel_trace.csv") $OUT/bench_under_trace.log $OUT/${TAG}_hipevent_vs_rocprof.json
 
 for C in FETCH_SIZE WRITE_SIZE; do

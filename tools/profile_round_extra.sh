@@ -12,7 +12,7 @@ for spec in "1024rays:--rays 1024" "16384rays:--rays 16384" "65536rays:--rays 65
             "events_bound2:--mode events --bound 2" "ffnet:--net ff --bound 2" "amp_bf16:--amp-bf16" "fp16:--fp16" "fp16_autocast:--fp16-autocast" \
             "noprefetch:--no-prefetch"; do
   name=${spec%%:*}; flags=${spec#*:}
-  timeout 600 python bench.py --no-cpu-baseline --render-frames 0 --graph-leg-steps 0 --other-legs 0 $flags 2>&1 | tail -1 > $OUT/${TAG}_bench_$name.json
+  timeout 600 python bench.py --no-cpu-baseline --render-frames 0 --graph-leg-steps 0 --other-legs 0 --strong-rays 0 $flags 2>&1 | tail -1 > $OUT/${TAG}_bench_$name.json
 done
 # split-bf16 MLP kernels: accuracy of both arithmetic modes, kernel times, SQ counters
 timeout 300 python tools/diag_mlp32_split.py --B 5000 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_mlp32_accuracy.txt
