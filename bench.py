@@ -720,7 +720,7 @@ def main():
             except Exception as e:          # a leg that breaks must not take the headline down with it
                 import traceback
                 traceback.print_exc(file=sys.stderr)
-                other_steps[tag] = {"error": repr(e)[:300]}
+                other_steps[tag] = {"error": repr(e)[:300], "where": traceback.format_exc()[-700:]}
             finally:
                 for undo in reversed(restore):
                     undo()
