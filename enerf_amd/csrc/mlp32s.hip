@@ -450,9 +450,33 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
     __shared__ __attribute__((aligned(16))) float lds[NRED * NW_MAX];   // staged weights (+ operands), then the waves' dW sums
     float* wl = lds;
     const uint32_t NW = blob_size(NH, out_dim);
-    stage(wl, W, NW);
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const int wid = threadIdx.x >> 6;
+    // RC: the forward-order operands (k_mlp32s_fwd's w0 / wh) come straight from the weights in global memory -- rows
+    // across lanes is a 32-way bank conflict in the staged (un-rotated) copy -- each built by the wave that stores it
+    // (fragment f by wave f % 4).  Their strided loads are requested here, BEFORE the staging, and travel beside it.
+    constexpr int NRC_W = RC ? (4 + 8 * (NH - 1)) / 4 : 1;
+    float rc_raw[NRC_W][8];
+    if constexpr (RC) {
+#pragma unroll
+        for (int k = 0; k < NRC_W; k++) {
+            const int idx = 4 * k + ((wid - NFRAG_T) & 3);                 // fragment NFRAG_T + idx is this wave's
+            if (idx < 4) {
+                const int ob = idx >> 1, t = idx & 1;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int c = w0_col((uint32_t)kmap<XL>(8 * t + e, h), W.nerf_perm);
+                    rc_raw[k][e] = c < 0 ? 0.0f : W.seg[0][(size_t)(32 * ob + j) * W.w0_cols + (c < 0 ? 0 : c)];
+                }
+            } else {
+                const int q = idx - 4, l = q >> 3, ob = (q >> 2) & 1, ib = (q >> 1) & 1, t = q & 1;
+                const float* row = W.seg[1 + l] + (size_t)(32 * ob + j) * HID + 32 * ib;
+#pragma unroll
+                for (int e = 0; e < 8; e++) rc_raw[k][e] = row[nrow(8 * t + e, h)];
+            }
+        }
+    }
+    stage(wl, W, NW);
     const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
     const uint32_t Bp = (B + 31u) & ~31u;
     u32x4v* fr = reinterpret_cast<u32x4v*>(lds + NW_MAX);
@@ -507,40 +531,14 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
                     if (WL) put(6 + ((l * 2 + ib) * 2 + ob) * 2 + t, whT[l][ib][ob][t]);
                 }
     if constexpr (RC) {
-        // forward operands (k_mlp32s_fwd's w0 / wh), each built by the wave that stores it, straight from the weights in
-        // global memory: rows across lanes is a 32-way bank conflict in the staged (un-rotated) copy
+        // forward operands (k_mlp32s_fwd's w0 / wh): the values were requested before the staging (rc_raw above)
 #pragma unroll
-        for (int ob = 0; ob < 2; ob++)
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int f = NFRAG_T + 2 * ob + t;
-                if ((f & 3) == wid) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int c = w0_col((uint32_t)kmap<XL>(8 * t + e, h), W.nerf_perm);
-                        v[e] = c < 0 ? 0.0f : W.seg[0][(size_t)(32 * ob + j) * W.w0_cols + c];
-                    }
-                    put(f, split8<P>(v));
-                }
-            }
-#pragma unroll
-        for (int l = 0; l < NH - 1; l++)
-#pragma unroll
-            for (int ob = 0; ob < 2; ob++)
-#pragma unroll
-                for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const int f = NFRAG_T + 4 + ((l * 2 + ob) * 2 + ib) * 2 + t;
-                        if ((f & 3) == wid) {
-                            const float* row = W.seg[1 + l] + (size_t)(32 * ob + j) * HID + 32 * ib;
-                            float v[8];
-#pragma unroll
-                            for (int e = 0; e < 8; e++) v[e] = row[nrow(8 * t + e, h)];
-                            put(f, split8<P>(v));
-                        }
-                    }
+        for (int k = 0; k < NRC_W; k++) {
+            const int f = NFRAG_T + 4 * k + ((wid - NFRAG_T) & 3);
+            const Frag w = split8<P>(rc_raw[k]);
+            fr[(FRQ * f) * 64 + lane] = __builtin_bit_cast(u32x4v, w.hi);
+            if constexpr (P == 3) fr[(FRQ * f + 1) * 64 + lane] = __builtin_bit_cast(u32x4v, w.lo);
+        }
     }
     if (WL) __syncthreads();
     auto W0F = [&](int ob, int t) -> Frag { return get(NFRAG_T + 2 * ob + t); };
