@@ -1556,12 +1556,32 @@ __global__ void __launch_bounds__(256) k_composite_rays_frame(const float* __res
     while (step < count && !done) {
         float ps[PF], pd0[PF], pd1[PF], pc0[PF], pc1[PF], pc2[PF];
         const uint32_t nb = count - step < (uint32_t)PF ? count - step : (uint32_t)PF;
+        if (nb == (uint32_t)PF) {
+            // a whole group: 12 sixteen-byte loads (dword-aligned is all gfx950 asks of them) instead of 48 four-byte ones --
+            // every lane walks its own segment, so each load instruction is 64 separate line look-ups either way
+            const float4 s0 = *reinterpret_cast<const float4*>(s), s1 = *reinterpret_cast<const float4*>(s + 4);
+            ps[0] = s0.x; ps[1] = s0.y; ps[2] = s0.z; ps[3] = s0.w; ps[4] = s1.x; ps[5] = s1.y; ps[6] = s1.z; ps[7] = s1.w;
 #pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const uint32_t kk = (uint32_t)k < nb ? (uint32_t)k : nb - 1;
-            ps[k] = s[kk];
-            pd0[k] = dl[kk * 2]; pd1[k] = dl[kk * 2 + 1];
-            pc0[k] = c[kk * 3]; pc1[k] = c[kk * 3 + 1]; pc2[k] = c[kk * 3 + 2];
+            for (int q = 0; q < 4; q++) {
+                const float4 v = *reinterpret_cast<const float4*>(dl + 4 * q);
+                pd0[2 * q] = v.x; pd1[2 * q] = v.y; pd0[2 * q + 1] = v.z; pd1[2 * q + 1] = v.w;
+            }
+            float cc[24];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float4 v = *reinterpret_cast<const float4*>(c + 4 * q);
+                cc[4 * q] = v.x; cc[4 * q + 1] = v.y; cc[4 * q + 2] = v.z; cc[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < PF; k++) { pc0[k] = cc[3 * k]; pc1[k] = cc[3 * k + 1]; pc2[k] = cc[3 * k + 2]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const uint32_t kk = (uint32_t)k < nb ? (uint32_t)k : nb - 1;
+                ps[k] = s[kk];
+                pd0[k] = dl[kk * 2]; pd1[k] = dl[kk * 2 + 1];
+                pc0[k] = c[kk * 3]; pc1[k] = c[kk * 3 + 1]; pc2[k] = c[kk * 3 + 2];
+            }
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
