@@ -305,8 +305,11 @@ def test_fused_ff_network_training_node_matches_op_by_op_route(monkeypatch, n):
     assert float(wc[2048 + 8192 + 3 * 64:].abs().max()) == 0.0
 
 
-def test_network_ff_training_step_takes_the_closed_form_path():
-    """TrainHarness drives network_ff through the same closed-form step as the nn.Linear nets (march -> grid -> fused MLPs
+@pytest.mark.parametrize("fp16", [False, True])
+def test_network_ff_training_step_takes_the_closed_form_path(fp16):
+    """(fp16=True: the shipped configs' regime on network_ff -- fp16 operands for both FFMLP nets, the three-hidden-layer
+    backward included, under the device-side GradScaler.)
+    TrainHarness drives network_ff through the same closed-form step as the nn.Linear nets (march -> grid -> fused MLPs
     -> composite + MSE gradient -> fused MLP backward -> table records -> one optimizer launch): the loss falls, the
     table gradient is never materialised, and the FFMLP master weights are what Adam updates."""
     from enerf_amd import fused_render
@@ -315,7 +318,8 @@ def test_network_ff_training_step_takes_the_closed_form_path():
     from test_gpu_training import _batches
     torch.manual_seed(0)
     model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to(DEV)
-    h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+    h = TrainHarness(model, lr=1e-2, occupancy="synthetic", fp16=fp16)
+    assert h.amp_f16 == fp16
     data = _batches(8, 2048, 2)
     assert h._manual_ok(data[0][0], data[0][1], data[0][2], {})
     w0 = model.sigma_net.weights.detach().clone()
@@ -329,5 +333,7 @@ def test_network_ff_training_step_takes_the_closed_form_path():
         fused_render.train_step_mse, fused_render.train_step_native = orig, orig_native
     assert len(calls) == 120
     assert np.isfinite(losses).all() and np.mean(losses[-8:]) < 0.5 * np.mean(losses[:8]), (losses[:4], losses[-4:])
-    assert float((model.sigma_net.weights - w0).abs().max()) > 1e-3
+    assert float((model.sigma_net.weights.detach() - w0).abs().max()) > 1e-3
     assert model.mean_count > 0
+    if fp16:
+        assert float(h.scaler.get_scale()) >= 256.0 and h.amp_skipped_steps() <= 10
