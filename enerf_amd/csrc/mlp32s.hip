@@ -476,9 +476,74 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             }
         }
     }
+    const uint32_t Bp = (B + 31u) & ~31u;
+    const uint32_t ntiles = Bp / 32;
+    const uint32_t nreal = valid_tiles(W, B, ntiles);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
+    // (the first tile's requests go out here, before the weights are staged: they travel during the set-up)
+    // as in the fp32 kernel: everything a tile reads from global memory is requested for the wave's NEXT tile where the
+    // current tile has used it for the last time, branch-free, into the same registers
+    float dy_raw[8], ys_raw[8], ds_raw = 0.0f, h0_raw = 0.0f;
+    f32x16 fwl[NH][2];
+    float xT[16];                                      // X^T: lane (input column j, h) holds samples nrow(q, h)
+    auto request_out = [&](uint32_t t) {
+        const size_t sn = (size_t)t * 32 + j;
+        const size_t sc = sn < B ? sn : (size_t)B - 1;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t o = (uint32_t)(8 * h + e), oc = o < out_dim ? o : out_dim - 1;
+            if constexpr (IO16) dy_raw[e] = (float)reinterpret_cast<const elem16*>(dys.dY)[sc * dys.stride + oc];
+            else dy_raw[e] = dys.dY[sc * dys.stride + oc];
+            ys_raw[e] = dys.y_sig ? dys.y_sig[sc * dys.y_sig_stride + oc] : 0.0f;
+        }
+        if (dys.dsigma) {
+            ds_raw = dys.dsigma[sc];
+            h0_raw = dys.h0[sc * dys.h0_stride];
+        }
+        if constexpr (!RC) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)(NH - 1) * Bp + sn) * HID, ib, h, fwl[NH - 1][ib]);
+        }
+    };
+    auto request_hidden = [&](uint32_t t, int l) {
+        if constexpr (RC) return;
+        const size_t sn = (size_t)t * 32 + j;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + sn) * HID, ib, h, fwl[l][ib]);
+    };
+    float xfw[16];                                     // RC: X in the forward's operand layout (load_x), a tile ahead
+    bf16x8 xraw[2];                                    // IO16: the same as the operands themselves
+    auto request_x = [&](uint32_t t) {
+        if constexpr (IO16) {
+            load_x16(X, t, j, h, B, xraw);
+            return;
+        }
+        if constexpr (RC) {
+            load_x<XL>(X, t, j, h, B, Bp, xfw);
+            return;
+        }
+        const size_t t0 = (size_t)t * 32;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const size_t row = t0 + nrow(q, h);
+            if (XL == 0) {
+                const size_t rc = row < B ? row : (size_t)B - 1;
+                xT[q] = X[rc * IN + j];
+            } else {
+                xT[q] = X[((size_t)(j >> 1) * Bp + row) * 2 + (j & 1)];     // pad rows of a level-major X hold zeros
+            }
+        }
+    };
+    {
+        const uint32_t t0 = gw < ntiles ? gw : ntiles - 1;
+        request_out(t0);
+#pragma unroll
+        for (int l = NH - 2; l >= 0; l--) request_hidden(t0, l);
+        request_x(t0);
+    }
     stage(wl, W, NW);
     const float* wout = wl + HID * IN + (NH - 1) * HID * HID;
-    const uint32_t Bp = (B + 31u) & ~31u;
     u32x4v* fr = reinterpret_cast<u32x4v*>(lds + NW_MAX);
     auto put = [&](int f, const Frag& w) {                             // built by every wave, stored by wave f % 4
         if ((f & 3) == wid) {
@@ -561,70 +626,6 @@ __global__ void __launch_bounds__(256) k_mlp32s_bwd(DySource dys, const float* _
             for (int b = 0; b < 2; b++) awh[l][a][b] = (f32x16)(0.0f);
     }
 
-    const uint32_t ntiles = Bp / 32;
-    const uint32_t nreal = valid_tiles(W, B, ntiles);
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wid;
-    const uint32_t nw = gridDim.x * (blockDim.x >> 6);
-    // as in the fp32 kernel: everything a tile reads from global memory is requested for the wave's NEXT tile where the
-    // current tile has used it for the last time, branch-free, into the same registers
-    float dy_raw[8], ys_raw[8], ds_raw = 0.0f, h0_raw = 0.0f;
-    f32x16 fwl[NH][2];
-    float xT[16];                                      // X^T: lane (input column j, h) holds samples nrow(q, h)
-    auto request_out = [&](uint32_t t) {
-        const size_t sn = (size_t)t * 32 + j;
-        const size_t sc = sn < B ? sn : (size_t)B - 1;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t o = (uint32_t)(8 * h + e), oc = o < out_dim ? o : out_dim - 1;
-            if constexpr (IO16) dy_raw[e] = (float)reinterpret_cast<const elem16*>(dys.dY)[sc * dys.stride + oc];
-            else dy_raw[e] = dys.dY[sc * dys.stride + oc];
-            ys_raw[e] = dys.y_sig ? dys.y_sig[sc * dys.y_sig_stride + oc] : 0.0f;
-        }
-        if (dys.dsigma) {
-            ds_raw = dys.dsigma[sc];
-            h0_raw = dys.h0[sc * dys.h0_stride];
-        }
-        if constexpr (!RC) {
-#pragma unroll
-            for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)(NH - 1) * Bp + sn) * HID, ib, h, fwl[NH - 1][ib]);
-        }
-    };
-    auto request_hidden = [&](uint32_t t, int l) {
-        if constexpr (RC) return;
-        const size_t sn = (size_t)t * 32 + j;
-#pragma unroll
-        for (int ib = 0; ib < 2; ib++) load_tile_fb(fb + ((size_t)l * Bp + sn) * HID, ib, h, fwl[l][ib]);
-    };
-    float xfw[16];                                     // RC: X in the forward's operand layout (load_x), a tile ahead
-    bf16x8 xraw[2];                                    // IO16: the same as the operands themselves
-    auto request_x = [&](uint32_t t) {
-        if constexpr (IO16) {
-            load_x16(X, t, j, h, B, xraw);
-            return;
-        }
-        if constexpr (RC) {
-            load_x<XL>(X, t, j, h, B, Bp, xfw);
-            return;
-        }
-        const size_t t0 = (size_t)t * 32;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const size_t row = t0 + nrow(q, h);
-            if (XL == 0) {
-                const size_t rc = row < B ? row : (size_t)B - 1;
-                xT[q] = X[rc * IN + j];
-            } else {
-                xT[q] = X[((size_t)(j >> 1) * Bp + row) * 2 + (j & 1)];     // pad rows of a level-major X hold zeros
-            }
-        }
-    };
-    {
-        const uint32_t t0 = gw < ntiles ? gw : ntiles - 1;
-        request_out(t0);
-#pragma unroll
-        for (int l = NH - 2; l >= 0; l--) request_hidden(t0, l);
-        request_x(t0);
-    }
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const uint32_t tnext = tile + nw < nreal ? tile + nw : tile;
         const size_t s0 = (size_t)tile * 32;
