@@ -36,7 +36,6 @@ from .fused_mlp import pad32
 ENABLED = True
 
 
-_arch_ok = {}      # id(net) -> (weak check key, bool): the architecture part of `supported` does not change per call
 
 
 def _architecture_kind(net):
@@ -73,13 +72,16 @@ def _architecture_kind(net):
 
 
 def kind_of(net):
-    """Architecture served by this module ("linear" / "ff") or None; cached per (net, embeddings parameter)."""
+    """Architecture served by this module ("linear" / "ff") or None; cached ON the net (with its embeddings parameter as
+    the check key).  (It used to live in a module-level dict keyed by id(net): a model built right after another was
+    deleted can get the same id -- and the same id for its embeddings -- and then inherited the dead model's kind: a
+    network.py model was taken for a network_ff one, once in a few runs of bench.py's legs.)"""
     enc = net._modules.get("encoder")
     emb = enc._parameters.get("embeddings") if enc is not None else None
     key = (id(emb), emb.dtype) if emb is not None else (0, None)
-    hit = _arch_ok.get(id(net))
+    hit = net.__dict__.get("_fused_kind")
     if hit is None or hit[0] != key:
-        hit = _arch_ok[id(net)] = (key, _architecture_kind(net))
+        hit = net.__dict__["_fused_kind"] = (key, _architecture_kind(net))
     return hit[1]
 
 

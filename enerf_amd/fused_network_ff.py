@@ -11,7 +11,6 @@ from .fused_mlp import pad32
 
 ENABLED = True
 _DTYPES = {torch.bfloat16: 2, torch.float16: 1}
-_ARCH = {}
 
 
 def _architecture_supported(net):
@@ -40,10 +39,10 @@ def supported(net, x, d):
     if torch.is_grad_enabled() and (net.training or x.requires_grad or d.requires_grad
                                     or any(p.requires_grad for p in net.parameters())):
         return False                                   # someone may want a gradient: the autograd route serves it
-    key = id(net)
-    if key not in _ARCH:
-        _ARCH[key] = _architecture_supported(net)
-    return _ARCH[key]
+    ok = net.__dict__.get("_ffnerf_arch_ok")           # (cached on the net, not by id(net): ids are reused after a delete)
+    if ok is None:
+        ok = net.__dict__["_ffnerf_arch_ok"] = _architecture_supported(net)
+    return ok
 
 
 @torch.no_grad()

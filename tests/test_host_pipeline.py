@@ -19,3 +19,25 @@ def test_event_loss_with_grads_host_route_matches_autograd():
         assert torch.equal(delta, ref_delta.detach()) and float(loss) == float(ref_loss)
         assert torch.equal(g1, torch.zeros_like(a) if r1 is None else r1)
         assert torch.equal(g2, torch.zeros_like(b) if r2 is None else r2)
+
+
+def test_architecture_caches_do_not_outlive_their_model():
+    """The fused routes cache "which architecture is this model" -- on the model.  Keyed by id(model) in a module-level
+    dict (as it was), a network.py model built right after a network_ff one was deleted could inherit the dead model's
+    entry when the allocator handed out the same addresses: bench.py's legs hit it once in a few runs."""
+    import gc
+    from enerf_amd import fused_network
+    from enerf_amd.network import NeRFNetwork as Linear
+    from enerf_amd.network_ff import NeRFNetwork as FF
+    for _ in range(8):
+        a = FF(encoding="hashgrid", encoding_dir="sphere_harmonics", bound=1, cuda_ray=False)
+        ka = fused_network.kind_of(a)
+        ia = id(a)
+        del a
+        gc.collect()
+        b = Linear(encoding="hashgrid", encoding_dir="sphere_harmonics", bound=1, cuda_ray=False, out_dim_color=3)
+        assert ka == "ff" and fused_network.kind_of(b) == "linear", (ka, fused_network.kind_of(b), ia == id(b))
+        assert "_fused_kind" in b.__dict__                            # the verdict lives on THIS model
+        assert not hasattr(fused_network, "_arch_ok")
+        del b
+        gc.collect()
