@@ -78,6 +78,23 @@ template <>
 __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
+// results[ch] += w * grid[i + ch] and results_grad[ch] += w * (grid[r + ch] - grid[l + ch]) as the reference's types make
+// them (gridencoder.cu:136,163,186,210: `scalar_t results[C]`, float w).  fp32 table: one contracted multiply-add.
+// at::Half table: the float product is converted to Half for Half's operator+=, which adds in float and rounds again;
+// the difference of two table entries is a Half.  `acc` holds the running Half as a float.  Bit for bit the
+// reference's kernel (tests/test_gpu_ref_gridencoder.py).
+__device__ __forceinline__ float acc_feat(float acc, float w, float g) { return fmaf(w, g, acc); }
+__device__ __forceinline__ float acc_feat(float acc, float w, __half g) {
+    // (the float product must exist: left alone, the compiler folds multiply + conversion into v_fma_mixlo_f16, which
+    //  rounds the exact product to half ONCE -- one entry in 8000 then differs from the reference's by a half ulp)
+    float p = w * __half2float(g);
+    asm volatile("" : "+v"(p));
+    return __half2float(__float2half(acc + __half2float(__float2half(p))));
+}
+__device__ __forceinline__ float acc_diff(float acc, float w, float r, float l) { return fmaf(w, r - l, acc); }
+__device__ __forceinline__ float acc_diff(float acc, float w, __half r, __half l) {
+    return acc_feat(acc, w, __float2half(__half2float(r) - __half2float(l)));
+}
 
 template <int D>
 __device__ __forceinline__ uint32_t fast_hash(const uint32_t (&p)[D]) {
@@ -335,7 +352,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {
 #pragma unroll
-        for (int c = 0; c < C; c++) res[c] = fmaf(w[idx], to_f(f[idx].v[c]), res[c]);
+        for (int c = 0; c < C; c++) res[c] = acc_feat(res[c], w[idx], f[idx].v[c]);
     }
     Feat<T, C> o;
 #pragma unroll
@@ -368,7 +385,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
                 pgl[gd] = pos_grid[gd] + 1;
                 const Feat<T, C> fr_ = rows[grid_row<D>(geom, pgl)];
 #pragma unroll
-                for (int c = 0; c < C; c++) rg[c] = fmaf(wi, to_f(fr_.v[c]) - to_f(fl_.v[c]), rg[c]);
+                for (int c = 0; c < C; c++) rg[c] = acc_diff(rg[c], wi, fr_.v[c], fl_.v[c]);
             }
 #pragma unroll
             for (int c = 0; c < C; c++) jac[gd * C + c] = from_f<T>(rg[c]);
@@ -1086,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ gr
                                               : grad_layout == 1 ? ((size_t)b * L + l) * C
                                                                  : ((size_t)l * ((B + 31u) & ~31u) + b) * C);
 #pragma unroll
-        for (int c = 0; c < C; c++) result = fmaf(to_f(g[c]), to_f(jac[((size_t)l * D + d) * C + c]), result);
+        for (int c = 0; c < C; c++) result = acc_feat(result, to_f(g[c]), jac[((size_t)l * D + d) * C + c]);   // (Half * Half: the product of two halves is exact in float)
     }
     grad_inputs[t] = from_f<T>(result);
 }

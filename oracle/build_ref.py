@@ -1,6 +1,6 @@
 """oracle/_ref: the reference's OWN native kernels, built for gfx950.  TEST INFRASTRUCTURE ONLY.
 
-What this is.  `raymarching/src/raymarching.cu` and `shencoder/src/shencoder.cu` (with
+What this is.  `raymarching/src/raymarching.cu`, `shencoder/src/shencoder.cu` and `gridencoder/src/gridencoder.cu` (with
 their `bindings.cpp` / headers / `pcg32.h`) are plain CUDA C++ without warp intrinsics, textures or third-party
 libraries.  This image's PyTorch is a ROCm build, and a ROCm PyTorch carries the source translator its extension builder
 applies to every `CUDAExtension` (`torch.utils.hipify`): it is the step the reference's own `setup.py` would run on this
@@ -17,8 +17,24 @@ machine.  The recipe below does that step by hand and nothing else:
      product's `_raymarching`).  The scratch directory is deleted; only the `.so` files stay, git-ignored, and travel to
      the GPU box with the tree.
 
-`gridencoder` and `ffmlp` are NOT built (UNBUILDABLE below: a half2 atomicAdd HIP does not declare; the empty CUTLASS
-submodule and `nvcuda::wmma`).  No stand-ins are written -- they stay on the second statements DESIGN.md section 2 lists.
+`gridencoder` needs ONE MORE API SPELLING than PyTorch's translator knows (RESPELL below; rounds 1-3 left the module
+unbuilt over it).  CUDA overloads `atomicAdd` for `__half*` / `__half2*`; ROCm 7.2 gives the same two operations the name
+`unsafeAtomicAdd` (hip/amd_detail/amd_hip_fp16.h:882,910) and declares no `atomicAdd` for them, so `gridencoder.cu`
+stops at two call sites -- its `at::Half` helper ("never used, just for compatability", gridencoder.cu:24-26) and the
+packed-half branch of the backward kernel (gridencoder.cu:301) -- that every instantiation must compile and only an
+`at::Half` table ever executes.  Step 2b respells exactly those two calls in the scratch copy, the way step 2 respells
+`cudaStream_t`: call name only, arguments untouched, the count of rewritten sites asserted.  What that does and does
+not touch, so that a reader can weigh it:
+  * `kernel_grid` (the forward -- this repository's roofline kernel), `kernel_input_backward`, the index / hash / scale
+    arithmetic and the fp32 branch of `kernel_grid_backward` (`atomicAdd(float*, float)`, which HIP does declare) are
+    compiled exactly as hipify leaves them;
+  * nothing is added: no header, no function, no macro, no library.  The two operations are ROCm's own.
+Tests that rest on this build say so (tests/test_gpu_ref_gridencoder.py, the grid_* arrays of
+tests/golden/ref_kernels_gfx950.npz); the builder-written second statements of the grid (fp64 torch grid, linear-field
+reproduction) stay in the suite beside them.
+
+`ffmlp` is NOT built (UNBUILDABLE below: the empty CUTLASS submodule and `nvcuda::wmma`).  No stand-ins are written -- it
+stays on the second statements DESIGN.md section 2 lists.
 
 Who may use the result: tests (`tests/test_gpu_ref_kernels.py` compares the product's HIP kernels and the C oracle with
 these kernels on the same GPU, same inputs), `oracle/mint_ref_gpu.py` (writes small input / output fixtures of the
@@ -40,14 +56,20 @@ MODULES = {
     # module directory under the reference -> (translation units, extension name)
     "raymarching": (["raymarching.cu", "bindings.cpp"], "_ref_raymarching"),
     "shencoder": (["shencoder.cu", "bindings.cpp"], "_ref_shencoder"),
+    "gridencoder": (["gridencoder.cu", "bindings.cpp"], "_ref_gridencoder"),
+}
+# API spellings PyTorch's hipify does not carry (see the module docstring): translation unit -> ((CUDA spelling, ROCm
+# spelling, number of sites that must be found), ...).  Call names only.
+RESPELL = {
+    ("gridencoder", "gridencoder.cu"): (
+        ("atomicAdd(reinterpret_cast<__half*>(", "unsafeAtomicAdd(reinterpret_cast<__half*>(", 1),
+        ("atomicAdd((__half2*)", "unsafeAtomicAdd((__half2*)", 1),
+    ),
 }
 
 
 # Tried with the same recipe and NOT buildable without writing something the image lacks (so: not built, no stand-ins):
 UNBUILDABLE = {
-    "gridencoder": "gridencoder.cu:301 calls atomicAdd(__half2*, __half2) in a branch that every instantiation compiles "
-                   "(AT_DISPATCH_FLOATING_TYPES_AND_HALF); ROCm 7.2's headers declare only unsafeAtomicAdd(__half2*, "
-                   "__half2) (hip/amd_detail/amd_hip_fp16.h:882) -- hipcc: 'no matching function for call to atomicAdd'",
     "ffmlp": "needs the CUTLASS submodule (empty directory, commit not recorded) and nvcuda::wmma (mma.h)",
 }
 
@@ -104,6 +126,13 @@ def build(verbose: bool = False) -> list:
             objs = []
             for u in units:
                 hip = res[os.path.join(work, u)].hipified_path or os.path.join(work, u)
+                for cuda_name, rocm_name, sites in RESPELL.get((mod, u), ()):             # step 2b
+                    text = open(hip).read()
+                    if text.count(cuda_name) != sites:
+                        raise RuntimeError(f"{mod}/{u}: expected {sites} site(s) of '{cuda_name}', found "
+                                           f"{text.count(cuda_name)} -- the reference changed; not guessing")
+                    with open(hip, "w") as f:
+                        f.write(text.replace(cuda_name, rocm_name))
                 obj = os.path.join(scratch, os.path.basename(hip) + ".o")
                 cmd = [hipcc, "-x", "hip", "-c", hip, "-o", obj, f"-DTORCH_EXTENSION_NAME={name}", f"-I{work}"] \
                     + inc + common

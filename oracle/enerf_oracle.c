@@ -511,9 +511,17 @@ static inline uint32_t orc_get_grid_index(uint32_t D, uint32_t C, uint32_t gridt
     return (index % hashmap_size) * C + ch;
 }
 
-/* per-level constants: gridencoder.cu:124-126 (fp32 exp2f / ceil) */
+/* per-level constants: gridencoder.cu:124-126 (fp32 exp2f / ceil).
+ * The reference evaluates exp2f ON THE DEVICE, i.e. with the platform's libm: CUDA's, or -- oracle/_ref on gfx950 --
+ * ROCm's, which is within 1 ulp of glibc's but not always equal to it (measured: level 11 of the bound-2 table).
+ * orc_grid_scale_nudge(level, k) lets a test say "the reference's exp2f was k ulp away at this level" (k = -1, 0, +1)
+ * and then demand bit-equality; product and oracle use glibc's value. */
+static int g_scale_nudge[64];
+void orc_grid_scale_nudge(uint32_t level, int ulps) { if (level < 64) g_scale_nudge[level] = ulps; }
 void orc_grid_level_params(uint32_t level, float S, uint32_t H, float* scale, uint32_t* resolution) {
-    const float sc = exp2f(level * S) * H - 1.0f;
+    float e = exp2f(level * S);
+    if (level < 64 && g_scale_nudge[level] != 0) e = nextafterf(e, g_scale_nudge[level] > 0 ? INFINITY : -INFINITY);
+    const float sc = e * H - 1.0f;
     *scale = sc;
     *resolution = (uint32_t)ceil(sc) + 1;
 }

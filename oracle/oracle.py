@@ -3,6 +3,7 @@
 TEST INFRASTRUCTURE ONLY -- nothing in enerf_amd/ may import this module.
 Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -37,6 +38,7 @@ _SIGS = {
     "orc_composite_rays": [_u32, _u32, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p],
     "orc_compact_rays": [_u32, _i32p, _i32p, _f32p, _f32p, _i32p],
     "orc_grid_level_params": [_u32, _f32, _u32, _f32p, _u32p],
+    "orc_grid_scale_nudge": [_u32, _int],
     "orc_grid_encode_forward": [_f32p, _f32p, _i32p, _f32p, _u32, _u32, _u32, _u32, _f32, _u32, _int, _f32p, _u32],
     "orc_grid_encode_backward": [_f32p, _f32p, _f32p, _i32p, _f32p, _u32, _u32, _u32, _u32, _f32, _u32,
                                  _int, _f32p, _f32p, _u32],
@@ -215,6 +217,17 @@ def grid_level_params(level, S, H):
     res = np.zeros(1, np.uint32)
     lib().orc_grid_level_params(level, S, H, _p(sc, _f32p), _p(res, _u32p))
     return float(sc[0]), int(res[0])
+
+
+@contextlib.contextmanager
+def grid_exp2f_nudged(level, ulps):
+    """Inside: level `level` uses exp2f(level * S) moved by `ulps` (+-1) ulp -- a platform libm whose exp2f is not glibc's
+    (see orc_grid_level_params).  For tests against the reference's kernels only."""
+    lib().orc_grid_scale_nudge(level, ulps)
+    try:
+        yield
+    finally:
+        lib().orc_grid_scale_nudge(level, 0)
 
 
 def grid_offsets(input_dim=3, num_levels=16, level_dim=2, per_level_scale=2.0, base_resolution=16,

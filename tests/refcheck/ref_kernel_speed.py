@@ -1,4 +1,4 @@
-"""The reference's own kernels (oracle/_ref: raymarching.cu / shencoder.cu built for gfx950 with default flags) timed beside
+"""The reference's own kernels (oracle/_ref: raymarching.cu / shencoder.cu / gridencoder.cu built for gfx950 with default flags) timed beside
 this library's kernels on the same MI355X, same inputs, BASELINE shapes.  TEST INFRASTRUCTURE (it lives under tests/ because it
 runs the checker's kernels): the product never loads oracle/_ref.  Both sides are called through their pybind modules (same signatures), hipEvents around 20
 back-to-back launches after 3 warm-ups; outputs are the ones tests/test_gpu_ref_kernels.py proves equal.
@@ -104,6 +104,34 @@ def main():
         for i, k in enumerate(("sh_fwd", "sh_fwd+jac", "sh_bwd")):
             print(f"sh degree 4, {B} dirs: {k:10s} reference {out['reference'][i]:9.1f}   this library {out['this'][i]:9.1f}   "
                   f"x{out['reference'][i] / out['this'][i]:5.2f}")
+    # grid encoder (gridencoder.cu, see oracle/build_ref.py for how it is built): BASELINE's bound-3 table; points as the
+    # training step has them (consecutive samples of 4096 rays) and uniformly random ones (no locality at all)
+    ref_ge = br.load("gridencoder")
+    offsets, pls = O.grid_offsets(desired_resolution=2048 * 3)
+    S = float(np.log2(pls)); L = 16; Cf = 2
+    g = torch.Generator(device=DEV).manual_seed(3)
+    emb = (torch.rand(int(offsets[-1]), Cf, device=DEV, generator=g) * 2 - 1) * 1e-4
+    co = cu(offsets)
+    for B, kind in ((133120, "ray-ordered"), (133120, "random"), (2097152, "ray-ordered"), (2097152, "random")):
+        if kind == "random":
+            x = torch.rand(B, 3, device=DEV, generator=g)
+        else:
+            K = 65 if B == 133120 else 64
+            R = B // K
+            o = torch.rand(R, 1, 3, device=DEV, generator=g) * 0.4 + 0.3
+            d = torch.nn.functional.normalize(torch.randn(R, 1, 3, device=DEV, generator=g), dim=-1)
+            t = (torch.arange(K, device=DEV)[None, :, None] + torch.rand(R, 1, 1, device=DEV, generator=g)) / 1024
+            x = (o + d * t).clamp(0, 1).reshape(-1, 3)[:B].contiguous()
+        gr = torch.randn(L, B, Cf, device=DEV, generator=g)
+        dummy = torch.empty(1, device=DEV)
+        out = {}
+        for name, ge in (("reference", ref_ge), ("this", prod["_gridencoder"])):
+            y = torch.empty(L, B, Cf, device=DEV); gemb = torch.zeros_like(emb)
+            out[name] = (timeit(lambda: ge.grid_encode_forward(x, emb, co, y, B, 3, Cf, L, S, 16, False, dummy, 0)),
+                         timeit(lambda: ge.grid_encode_backward(gr, x, emb, co, gemb, B, 3, Cf, L, S, 16, False, dummy, dummy, 0)))
+        for i, k in enumerate(("grid_fwd", "grid_bwd")):
+            print(f"grid L16 F2 T2^19 bound 3, {B} {kind} points: {k:9s} reference {out['reference'][i]:9.1f}   this library "
+                  f"{out['this'][i]:9.1f}   x{out['reference'][i] / out['this'][i]:5.2f}")
 
 
 if __name__ == "__main__":
