@@ -18,9 +18,11 @@
  * reference kernel -- bit for bit for the marchers -- on the GPU box
  * (tests/test_gpu_ref_kernels.py) and against arrays those kernels wrote
  * (tests/golden/ref_kernels_gfx950.npz, tests/test_oracle_vs_ref_kernels_golden.py).
- * STILL UNPINNED against the reference's native code: grid_encode_* and ffmlp_*
- * (gridencoder.cu / ffmlp.cu cannot be built in this image, see build_ref.py);
- * they rest on (b) and (c).
+ * Since round 4 also grid_encode_* (gridencoder.cu, built with two half-atomic call
+ * names respelled, build_ref.py): forward and Jacobian bit for bit
+ * (tests/test_gpu_ref_gridencoder.py, tests/golden/ref_gridencoder_gfx950.npz).
+ * STILL UNPINNED against the reference's native code: ffmlp_* (ffmlp.cu cannot be
+ * built in this image, see build_ref.py); it rests on (b) and (c).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference).  Floating-point convention: nvcc contracts a*b+c into FMA by

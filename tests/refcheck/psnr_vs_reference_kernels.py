@@ -1,5 +1,6 @@
-"""tools/psnr_ab.py with route B on the reference's OWN ray-marching / compositing / SH kernels (oracle/_ref, built by
-oracle/build_ref.py).  TEST INFRASTRUCTURE: it lives under tests/ because it runs the checker's kernels.
+"""tools/psnr_ab.py with route B on the reference's OWN ray-marching / compositing / SH / grid-encoder kernels (oracle/_ref,
+built by oracle/build_ref.py): with its nn.Linear nets and torch.optim.Adam, route B is then the reference's native code end
+to end.  ENERF_PSNR_REF_GRID=0 keeps route B's grid encoder on this library (the round-3 experiment).  TEST INFRASTRUCTURE: it lives under tests/ because it runs the checker's kernels.
     python -B tests/refcheck/psnr_vs_reference_kernels.py [steps] [seeds] [out.json] [first_seed]"""
 import os
 import runpy
@@ -10,4 +11,6 @@ sys.path.insert(0, ROOT)
 from oracle import build_ref  # noqa: E402
 
 backends = (build_ref.load("raymarching"), build_ref.load("shencoder"))
+if os.environ.get("ENERF_PSNR_REF_GRID", "1") == "1":
+    backends += (build_ref.load("gridencoder"),)
 runpy.run_path(os.path.join(ROOT, "tools", "psnr_ab.py"), init_globals={"ROUTE_B_BACKENDS": backends}, run_name="__main__")

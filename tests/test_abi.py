@@ -100,6 +100,10 @@ def test_reference_kernel_build_recipe_is_declared():
     """oracle/build_ref.py: which reference modules are built for gfx950 as the GPU tests' cross-check, which are not and
     why (no compute here: the recipe needs /root/reference to build and a GPU to run)."""
     from oracle import build_ref as br
-    assert set(br.MODULES) == {"raymarching", "shencoder"} and set(br.UNBUILDABLE) == {"gridencoder", "ffmlp"}
+    assert set(br.MODULES) == {"raymarching", "shencoder", "gridencoder"} and set(br.UNBUILDABLE) == {"ffmlp"}
+    # the one thing the recipe changes beyond PyTorch's translator: two call NAMES, both in at::Half-only code
+    assert {k: [(a, b) for a, b, _ in v] for k, v in br.RESPELL.items()} == {("gridencoder", "gridencoder.cu"): [
+        ("atomicAdd(reinterpret_cast<__half*>(", "unsafeAtomicAdd(reinterpret_cast<__half*>("),
+        ("atomicAdd((__half2*)", "unsafeAtomicAdd((__half2*)")]}
     assert all(name.startswith("_ref_") for _, name in br.MODULES.values())
     assert isinstance(br.built(), list)

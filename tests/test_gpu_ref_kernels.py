@@ -2,9 +2,8 @@
 oracle/build_ref.py -- the translator that ships inside this image's PyTorch + hipcc, nothing written by us) against the C
 oracle and against the product's kernels, same inputs.  This is what pins the oracle's marcher to the reference itself
 (rows a1-a11, a15 of SURVEY.md section 8): before it, `march_rays_train` / `march_rays` had only builder-written second
-statements.  `gridencoder.cu` does not build here (HIP 7.2 declares no `atomicAdd(__half2*, __half2)`; its half path is
-instantiated unconditionally) and `ffmlp` needs CUTLASS + nvcuda::wmma: no stand-ins were written, they stay on the pins
-DESIGN.md section 2 lists.
+statements.  `gridencoder.cu` has its own file (tests/test_gpu_ref_gridencoder.py; built since round 4, the recipe says
+how); `ffmlp` needs CUTLASS + nvcuda::wmma: no stand-in was written, it stays on the pins DESIGN.md section 2 lists.
 
 The reference's marcher hands out sample rows and ray-table rows by atomicAdd, so WHICH rows a ray gets differs from run to
 run; every comparison below is per ray (the table sorted by its ray index, each ray's samples read from its own offset).
@@ -32,7 +31,7 @@ def ref():
     from oracle import build_ref as br
     br.build()
     try:
-        return {"rm": br.load("raymarching"), "sh": br.load("shencoder")}
+        return {"rm": br.load("raymarching"), "sh": br.load("shencoder"), "ge": br.load("gridencoder")}
     except ImportError as e:                                     # never built: /root/reference is not on this machine
         pytest.skip(f"oracle/_ref not built: {e}")
 
@@ -383,13 +382,16 @@ def test_config4_frame_on_the_reference_inference_kernels_equals_the_whole_frame
     assert float(image.std()) > 0.01 and float((image - 1).abs().max()) > 0.1       # a real picture, not the background
 
 
-def test_training_render_on_the_reference_kernels_equals_the_fused_product_render(ref, monkeypatch):
+@pytest.mark.parametrize("reference_grid", [False, True])
+def test_training_render_on_the_reference_kernels_equals_the_fused_product_render(ref, monkeypatch, reference_grid):
     """BASELINE configs[1] end to end (4096 rays, bound 3, jitter on): a training render + backward with the reference-shaped
-    wrappers bound to the REFERENCE's raymarching and SH modules (op by op, autograd; the hash grid and the nn.Linear nets on
-    this library -- gridencoder.cu cannot be built here) against the product's fused route (one render node, closed
-    backward, split-bf16 MLP kernels): sample counters bit-exact, image 1e-4, every parameter's gradient to the bars of the
-    product's own route-equivalence tests."""
-    import enerf_amd.raymarching as rmod, enerf_amd.shencoder as smod
+    wrappers bound to the REFERENCE's raymarching and SH modules (op by op, autograd) against the product's fused route (one
+    render node, closed backward, split-bf16 MLP kernels): sample counters bit-exact, image 1e-4, every parameter's gradient
+    to the bars of the product's own route-equivalence tests.  reference_grid=True binds the reference's grid encoder as
+    well (gridencoder.cu, oracle/build_ref.py): with the nn.Linear nets on torch's GEMMs -- what nerf/network.py runs on --
+    every native instruction of that route is then the reference's or PyTorch's; False keeps the grid on this library (the
+    round-3 form of the test)."""
+    import enerf_amd.raymarching as rmod, enerf_amd.shencoder as smod, enerf_amd.gridencoder as gmod
     from enerf_amd import fused_network, fused_render, density_update
     from enerf_amd.network import NeRFNetwork
     bound = 3
@@ -400,6 +402,8 @@ def test_training_render_on_the_reference_kernels_equals_the_fused_product_rende
         with monkeypatch.context() as mp:
             if on_reference:
                 mp.setattr(rmod, "_backend", ref["rm"]); mp.setattr(smod, "_backend", ref["sh"])
+                if reference_grid:
+                    mp.setattr(gmod, "_backend", ref["ge"]); mp.setattr(gmod, "_layout_support", {})
                 mp.setattr(fused_render, "ENABLED", False); mp.setattr(fused_network, "ENABLED", False)
                 mp.setattr(density_update, "ENABLED", False)
             torch.manual_seed(0)

@@ -34,15 +34,19 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 out_path = sys.argv[3] if len(sys.argv) > 3 else None
 first_seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-# ROUTE_B_BACKENDS = (raymarching module, shencoder module): set by tests/refcheck/psnr_vs_reference_kernels.py, which runs this
-# file with the reference's own kernels bound to route B's wrappers (this tool itself never touches oracle/)
+# ROUTE_B_BACKENDS = (raymarching module, shencoder module[, gridencoder module]): set by
+# tests/refcheck/psnr_vs_reference_kernels.py, which runs this file with the reference's own kernels bound to route B's
+# wrappers (this tool itself never touches oracle/).  With all three, route B is the reference's native code end to end:
+# its nets are nn.Linear (torch's GEMMs, as in the reference's nerf/network.py), its optimizer torch.optim.Adam.
 _ref = globals().get("ROUTE_B_BACKENDS")
 ref_kernels = _ref is not None
 _own = None
 if ref_kernels:
     import enerf_amd.raymarching as _rmod
     import enerf_amd.shencoder as _smod
-    _own = (_rmod._backend, _smod._backend)
+    import enerf_amd.gridencoder as _gmod
+    _own = (_rmod._backend, _smod._backend, _gmod._backend)
+    _ref = tuple(_ref) + (_gmod._backend,) * (3 - len(_ref))
 SHUFFLE = os.environ.get("ENERF_PSNR_SHUFFLE", "0") == "1"
 # ENERF_PSNR_NO_DROPS=1: the sample budget of both routes is three times the mean count of the window, so that no ray is
 # ever dropped for lack of room (which rays a budget drops is the one thing the two marchers do differently: the reference
@@ -56,7 +60,7 @@ def run(route, seed):
     fused = route == "A"
     fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = fused
     if _own is not None:
-        _rmod._backend, _smod._backend = _own if fused else _ref
+        _rmod._backend, _smod._backend, _gmod._backend = _own if fused else _ref
     torch.manual_seed(seed)
     model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).cuda()
     h = TrainHarness(model, lr=1e-2, occupancy="learned")
@@ -120,14 +124,14 @@ for seed in range(first_seed, first_seed + seeds):
         print(route, seed, round(r["psnr_db"], 3), flush=True)
 fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = True
 if _own is not None:
-    _rmod._backend, _smod._backend = _own
+    _rmod._backend, _smod._backend, _gmod._backend = _own
 mean = {k: sum(r["psnr_db"] for r in rows if r["route"] == k) / seeds for k in ("A", "B")}
 spread = {k: max(r["psnr_db"] for r in rows if r["route"] == k) - min(r["psnr_db"] for r in rows if r["route"] == k)
           for k in ("A", "B")}
 diffs = [a["psnr_db"] - b["psnr_db"] for a, b in zip(rows[0::2], rows[1::2])]           # paired by seed
 dmean = sum(diffs) / len(diffs)
 dstd = (sum((d - dmean) ** 2 for d in diffs) / max(len(diffs) - 1, 1)) ** 0.5
-summary = {"steps": steps, "seeds": seeds, "rays_reshuffled_per_use": SHUFFLE, "no_budget_drops": NO_DROPS, "route_B_kernels": "reference raymarching.cu + shencoder.cu (oracle/_ref)" if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
+summary = {"steps": steps, "seeds": seeds, "rays_reshuffled_per_use": SHUFFLE, "no_budget_drops": NO_DROPS, "route_B_kernels": ("reference raymarching.cu + shencoder.cu" + (" + gridencoder.cu" if _ref[2] is not _own[2] else "") + " (oracle/_ref)") if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
            "A_minus_B_db": dmean, "paired_std_db": dstd, "standard_error_db": dstd / len(diffs) ** 0.5,
            "runs": rows}
 print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
