@@ -58,6 +58,9 @@ MODULES = {
     "shencoder": (["shencoder.cu", "bindings.cpp"], "_ref_shencoder"),
     "gridencoder": (["gridencoder.cu", "bindings.cpp"], "_ref_gridencoder"),
 }
+# (Tried: the same module with -munsafe-fp-atomics -- no change, 2490 vs 2497 us for the training batch's backward: hipcc
+#  already emits global_atomic_add_f32 for `atomicAdd(float*, float)` on gfx950; the kernel is slow because it issues one
+#  memory-side atomic per corner and channel, 34 M per step at the ~14-21 G/s those sustain.)
 # API spellings PyTorch's hipify does not carry (see the module docstring): translation unit -> ((CUDA spelling, ROCm
 # spelling, number of sites that must be found), ...).  Call names only.
 RESPELL = {

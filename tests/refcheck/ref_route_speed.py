@@ -4,11 +4,13 @@ under tests/ because it runs oracle/_ref).
 
   reference kernels : `run_cuda` op by op through the reference-shaped autograd Functions with `_backend` = oracle/_ref's
                       _ref_raymarching / _ref_gridencoder / _ref_shencoder (raymarching.cu, gridencoder.cu, shencoder.cu built
-                      for gfx950 by oracle/build_ref.py), nn.Linear nets (torch's GEMMs, as nerf/network.py has them),
-                      F.mse_loss + autograd, the Python update_extra_state (nerf/renderer.py:472-560), torch.optim.Adam.
-                      Everything native on this route is the reference's or PyTorch's; the Python above it is this
-                      repository's restatement of nerf/renderer.py (same calls in the same order).
-  drop-in           : the same route with `_backend` = this library's pybind modules (bench.py's `dropin_route_rgb`).
+                      for gfx950 by oracle/build_ref.py), the nn.Linear nets as the plain Linear / ReLU loop on torch's GEMMs
+                      (`fused_mlp.ENABLED = False`: what nerf/network.py runs on), F.mse_loss + autograd, the Python
+                      update_extra_state (nerf/renderer.py:472-560), torch.optim.Adam.  Everything native on this route is
+                      the reference's or PyTorch's; the Python above it is this repository's restatement of
+                      nerf/renderer.py (same calls in the same order).
+  drop-in           : that route with `_backend` = this library's pybind modules and its nets on this library's MLP kernels
+                      behind autograd (bench.py's `dropin_route_rgb`).
   product           : what bench.py's headline times.
 
     gpurun -- 'python tests/refcheck/ref_route_speed.py > gpurun_out/ref_route_speed.txt'
@@ -28,7 +30,7 @@ from oracle import build_ref as br  # noqa: E402
 import enerf_amd.raymarching as rmod  # noqa: E402
 import enerf_amd.gridencoder as gmod  # noqa: E402
 import enerf_amd.shencoder as smod  # noqa: E402
-from enerf_amd import ext as ext_pkg, fused_network as fn_, fused_render as fr_, density_update as du_  # noqa: E402
+from enerf_amd import ext as ext_pkg, fused_mlp as fm_, fused_network as fn_, fused_render as fr_, density_update as du_  # noqa: E402
 from enerf_amd.network import NeRFNetwork  # noqa: E402
 from enerf_amd.trainer import TrainHarness  # noqa: E402
 
@@ -39,8 +41,9 @@ def run(kind, batches, dev):
     own = (rmod._backend, gmod._backend, smod._backend)
     try:
         if kind != "product":
-            if kind == "reference kernels":
+            if kind.startswith("reference kernels"):
                 mods = [br.load(n) for n in ("raymarching", "gridencoder", "shencoder")]
+                fm_.ENABLED = False
             else:
                 ext_pkg.activate()
                 mods = [importlib.import_module(n) for n in ("_raymarching", "_gridencoder", "_shencoder")]
@@ -72,7 +75,7 @@ def run(kind, batches, dev):
     finally:
         rmod._backend, gmod._backend, smod._backend = own
         gmod._layout_support = {}
-        fr_.ENABLED = fn_.ENABLED = du_.ENABLED = True
+        fr_.ENABLED = fn_.ENABLED = du_.ENABLED = fm_.ENABLED = True
 
 
 def main():

@@ -392,7 +392,7 @@ def test_training_render_on_the_reference_kernels_equals_the_fused_product_rende
     every native instruction of that route is then the reference's or PyTorch's; False keeps the grid on this library (the
     round-3 form of the test)."""
     import enerf_amd.raymarching as rmod, enerf_amd.shencoder as smod, enerf_amd.gridencoder as gmod
-    from enerf_amd import fused_network, fused_render, density_update
+    from enerf_amd import fused_mlp, fused_network, fused_render, density_update
     from enerf_amd.network import NeRFNetwork
     bound = 3
     bits = O.packbits(synthetic_density_grid(bound, H).reshape(-1), 0.01)
@@ -404,6 +404,7 @@ def test_training_render_on_the_reference_kernels_equals_the_fused_product_rende
                 mp.setattr(rmod, "_backend", ref["rm"]); mp.setattr(smod, "_backend", ref["sh"])
                 if reference_grid:
                     mp.setattr(gmod, "_backend", ref["ge"]); mp.setattr(gmod, "_layout_support", {})
+                    mp.setattr(fused_mlp, "ENABLED", False)       # the nets: nn.Linear / ReLU on torch's GEMMs
                 mp.setattr(fused_render, "ENABLED", False); mp.setattr(fused_network, "ENABLED", False)
                 mp.setattr(density_update, "ENABLED", False)
             torch.manual_seed(0)

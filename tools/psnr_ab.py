@@ -25,7 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from enerf_amd import density_update, fused_network, fused_render  # noqa: E402
+from enerf_amd import density_update, fused_mlp, fused_network, fused_render  # noqa: E402
 from enerf_amd.network import NeRFNetwork  # noqa: E402
 from enerf_amd.trainer import TrainHarness  # noqa: E402
 from test_gpu_training import _batches  # noqa: E402
@@ -59,6 +59,9 @@ held = _batches(1, 16384, 2, seed=77)[0]
 def run(route, seed):
     fused = route == "A"
     fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = fused
+    # route B entirely on the reference's native code (three backends given): its nets as the plain Linear / ReLU loop on
+    # torch's GEMMs too; otherwise route B's nn.Linear nets run on this library's MLP kernels behind autograd
+    fused_mlp.ENABLED = fused or not (_own is not None and _ref[2] is not _own[2])
     if _own is not None:
         _rmod._backend, _smod._backend, _gmod._backend = _own if fused else _ref
     torch.manual_seed(seed)
@@ -122,7 +125,7 @@ for seed in range(first_seed, first_seed + seeds):
         r = run(route, seed)
         rows.append(r)
         print(route, seed, round(r["psnr_db"], 3), flush=True)
-fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = True
+fused_render.ENABLED = fused_network.ENABLED = density_update.ENABLED = fused_mlp.ENABLED = True
 if _own is not None:
     _rmod._backend, _smod._backend, _gmod._backend = _own
 mean = {k: sum(r["psnr_db"] for r in rows if r["route"] == k) / seeds for k in ("A", "B")}
@@ -131,7 +134,7 @@ spread = {k: max(r["psnr_db"] for r in rows if r["route"] == k) - min(r["psnr_db
 diffs = [a["psnr_db"] - b["psnr_db"] for a, b in zip(rows[0::2], rows[1::2])]           # paired by seed
 dmean = sum(diffs) / len(diffs)
 dstd = (sum((d - dmean) ** 2 for d in diffs) / max(len(diffs) - 1, 1)) ** 0.5
-summary = {"steps": steps, "seeds": seeds, "rays_reshuffled_per_use": SHUFFLE, "no_budget_drops": NO_DROPS, "route_B_kernels": ("reference raymarching.cu + shencoder.cu" + (" + gridencoder.cu" if _ref[2] is not _own[2] else "") + " (oracle/_ref)") if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
+summary = {"steps": steps, "seeds": seeds, "rays_reshuffled_per_use": SHUFFLE, "no_budget_drops": NO_DROPS, "route_B_kernels": ("reference raymarching.cu + shencoder.cu" + (" + gridencoder.cu, nets on torch's GEMMs" if _ref[2] is not _own[2] else "") + " (oracle/_ref)") if ref_kernels else "this library", "mean_psnr_db": mean, "seed_spread_db": spread,
            "A_minus_B_db": dmean, "paired_std_db": dstd, "standard_error_db": dstd / len(diffs) ** 0.5,
            "runs": rows}
 print(json.dumps({k: v for k, v in summary.items() if k != "runs"}))
