@@ -20,6 +20,8 @@ Extra objects on that line:
                 the step after the 16 full density sweeps, the exact-fp32 MFMA arithmetic (enerf_mlp32_precision(0)) and
                 `dropin_route_rgb`: the reference-shaped run_cuda op by op through the four pybind modules with autograd
                 and torch.optim.Adam -- what an unmodified nerf/renderer.py:281-342 gets from this library
+  gpu_reference_route  read from profiles/, NOT measured here: the same step on the reference's own kernels built for gfx950
+                (tests/refcheck/ref_route_speed.py; bench.py may not touch oracle/)
   strong        BASELINE configs[3]: 65 536 rays per step over all ranks, timed like the main region
   comm_tuning   N > 1: measured ms/step per cut of the table-gradient all-reduce and per placement of the next batch's
                 march (TrainHarness.tune_comm, untimed, before the warm-up) with the choices made, and the step time the
@@ -46,6 +48,22 @@ MLP_LINEAR_FLOP_FWD = 18688       # nn.Linear nets, sigma 6144 +
 MLP_LINEAR_FLOP_STEP = 56064      # forward + dgrad + wgrad = 3 x forward
 FFMLP_FLOP_FWD = 36864            # FFMLP nets (padded dims), sigma 14336 + colour 22528
 PMC_FILE = "profiles/r04_pmc_hbm_bench.json"
+REF_ROUTE_FILE = "profiles/r04_ref_route_speed.txt"
+
+
+def reference_route_on_file():
+    """NOT measured by this run (bench.py may not touch oracle/): the configs[1] training step on the reference's OWN native
+    code on an MI355X -- its raymarching.cu / gridencoder.cu / shencoder.cu built for gfx950 (oracle/build_ref.py), nn.Linear
+    on torch's GEMMs, autograd, torch.optim.Adam -- as tests/refcheck/ref_route_speed.py last wrote it to profiles/.  The GPU
+    baseline beside `cpu_baseline`; None when the file is absent."""
+    try:
+        rows = [json.loads(line) for line in open(os.path.join(ROOT, REF_ROUTE_FILE)) if line.startswith("{")]
+        ref = next(r for r in rows if r["route"] == "reference kernels")
+        return {"ms_per_step": ref["ms_per_step"], "rays_per_sec": ref["rays_per_sec"], "steps": ref["steps"],
+                "source": REF_ROUTE_FILE + " (tests/refcheck/ref_route_speed.py on an MI355X; not this run)",
+                "same_script_product_ms_per_step": next(r for r in rows if r["route"] == "product")["ms_per_step"]}
+    except Exception:
+        return None
 TABLE_OPT_BYTES_PER_PARAM = 24     # Adam over the table: p, m, v read + written, 4 B each
 
 
@@ -924,6 +942,7 @@ def main():
             "kernels": kernels,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "gpu_reference_route": reference_route_on_file(),
         }
         print(json.dumps(out))
     if world > 1:
