@@ -1,3 +1,10 @@
+"""at::Half tables: the product's grid kernels beside the reference's (oracle/_ref/_ref_gridencoder) level by level, and which
+arithmetic each side's Half accumulation follows -- (a) forward / Jacobian: equal entries per level (1.0 since the product
+pins the float product: hipcc folds multiply + convert into v_fma_mixlo_f16, which rounds once); (b) grad_inputs: the
+reference AS BUILT contracts Half's multiply-add into v_fma_f16 (99.99 % of its entries equal that emulation), its source
+rounds the product first (what the product does, 100 %).  TEST INFRASTRUCTURE.
+    gpurun -- 'python tests/refcheck/half_diag.py'
+"""
 import sys, os, importlib
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
