@@ -141,10 +141,12 @@ def mark_untrained(model, poses, intrinsic):
 # comparator of tests/test_gpu_density_update.py.  Semantics: SURVEY.md 3.4 and Appendix A ("Renderer/network glue").
 
 def _all_cells(H, dev):
-    """Integer coordinates of every grid cell, x fastest (x-neighbours are adjacent rows of every hash-grid level, so a
-    sweep in this order gathers coalesced), and their Morton indices."""
+    """Integer coordinates of every grid cell in the reference's order (nerf/renderer.py:489-496: meshgrid 'ij' over x, y,
+    z, flattened -- z fastest) and their Morton indices.  The order decides which draw of torch's random stream jitters
+    which cell: with it, this route reproduces the reference's update_extra_state bit for bit on the same stream
+    (tests/test_host_cuda_ray_vs_reference.py)."""
     ax = torch.arange(H, dtype=torch.int32, device=dev)
-    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    xx, yy, zz = torch.meshgrid(ax, ax, ax, indexing="ij")
     coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
     return coords, _rm.morton3D(coords).long()
 
@@ -154,33 +156,35 @@ def _jittered_density(model, coords, cas):
     H = model.grid_size
     extent = min(2 ** cas, model.bound)
     half_cell = extent / H
-    centre = (2 * coords.float() / (H - 1) - 1) * (extent - half_cell)
-    pts = centre + (torch.rand_like(centre) * 2 - 1) * half_cell
+    pts = (2 * coords.float() / (H - 1) - 1) * (extent - half_cell)
+    pts += (torch.rand_like(pts) * 2 - 1) * half_cell                 # (in place, as renderer.py:507 has it)
     return _sigmas(model, pts) * (model.density_scale * 0.003383)
 
 
 @torch.no_grad()
-def update_torch(model, decay=0.95, chunk=1 << 21):
-    """update_extra_state op by op.  First 16 calls: every cell of every cascade is re-evaluated; afterwards, per
-    cascade, H^3/4 uniformly drawn cells plus H^3/4 draws (with replacement) from the cells whose density is positive.
-    Then: grid <- max(grid * decay, new) where both are valid (>= 0; -1 marks untrained cells), mean of the clamped
-    grid, bitfield at min(mean, density_thresh), sample budget from the step counters."""
+def update_torch(model, decay=0.95):
+    """update_extra_state op by op, in the reference's order of cells, cascades and random draws (renderer.py:472-560; H =
+    128 is one block of its S = 128 split).  First 16 calls: every cell of every cascade is re-evaluated; afterwards, per
+    cascade, H^3/4 uniformly drawn cells followed by H^3/4 draws (with replacement) from the cells whose density is
+    positive.  Then: grid <- max(grid * decay, new) where both are valid (>= 0; -1 marks untrained cells), mean of the
+    clamped grid, bitfield at min(mean, density_thresh), sample budget from the step counters."""
     H, C = model.grid_size, model.cascade
     dev = model.density_grid.device
     fresh = torch.full_like(model.density_grid, -1.0)
     if model.iter_density < 16:
         coords, cells = _all_cells(H, dev)
         for cas in range(C):
-            for a in range(0, cells.shape[0], chunk):
-                fresh[cas, cells[a:a + chunk]] = _jittered_density(model, coords[a:a + chunk], cas)
+            fresh[cas, cells] = _jittered_density(model, coords, cas)
     else:
         n = H ** 3 // 4
         for cas in range(C):
-            uniform = _rm.morton3D(torch.randint(0, H, (n, 3), device=dev)).long()
+            coords = torch.randint(0, H, (n, 3), device=dev)
+            uniform = _rm.morton3D(coords).long()
             occupied = torch.nonzero(model.density_grid[cas] > 0).squeeze(-1)
             drawn = occupied[torch.randint(0, occupied.shape[0], [n], dtype=torch.long, device=dev)]
-            cells = torch.sort(torch.cat([uniform, drawn]))[0]          # Morton order: same cells, local gathers
-            fresh[cas, cells] = _jittered_density(model, _rm.morton3D_invert(cells), cas)
+            cells = torch.cat([uniform, drawn], dim=0)
+            coords = torch.cat([coords, _rm.morton3D_invert(drawn)], dim=0)
+            fresh[cas, cells] = _jittered_density(model, coords, cas)
 
     both = (model.density_grid >= 0) & (fresh >= 0)
     model.density_grid[both] = torch.maximum(model.density_grid[both] * decay, fresh[both])

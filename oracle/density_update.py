@@ -8,10 +8,13 @@
   mean_count         :555-558             int(sum(step_counter[:total_step, 0]) / total_step)
   untrained_cells    :408-469             mark_untrained_grid: cells no camera frustum (widened by two half-cells) sees
 
-Parity status: "unpinned" against a run of the reference itself -- update_extra_state lives inside NeRFRenderer and needs
-the reference's CUDA raymarching extension (morton3D, packbits) to execute; these functions transcribe its tensor
-expressions.  Which cells are drawn (torch.randint / rand_like) is random in the reference and only checked in
-distribution by the tests.
+Parity status: these functions transcribe the method's tensor expressions; they are not themselves run against the
+reference.  What IS (round 4): the reference's own NeRFRenderer.update_extra_state / mark_untrained_grid, executed on CPU
+over this oracle (oracle/make_golden.py gold_cuda_ray -> tests/golden/ref_cuda_ray.npz), pin enerf_amd's plain-tensor
+route (density_update.update_torch / mark_untrained_torch) bit for bit on the same torch random stream
+(tests/test_host_cuda_ray_vs_reference.py); the device-side passes are compared with that route and with these functions
+on the GPU (tests/test_gpu_density_update.py): which cells a device-side update draws comes from its own counter-based
+generator and is checked in distribution.
 """
 import numpy as np
 

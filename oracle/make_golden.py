@@ -531,6 +531,115 @@ def gold_checkpoint():
          **{"p_" + k.replace(".", "_"): v for k, v in model.state_dict().items() if k.endswith(".weight")})
 
 
+def _summary(t):
+    """A large state tensor as data small enough to keep: sha256 of its bytes, sum, and a strided sample."""
+    import hashlib
+    a = np.ascontiguousarray(t.detach().cpu().numpy())
+    flat = a.reshape(-1)
+    return {"sha256": np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8),
+            "sum": np.float64(flat.astype(np.float64).sum()), "sample": flat[:: max(1, flat.size // 4096)][:4096].copy()}
+
+
+def gold_cuda_ray():
+    """The reference's cuda_ray path END TO END in its own Python: NeRFRenderer.mark_untrained_grid, update_extra_state
+    (full sweep and partial update), run_cuda in training (forward + backward through its raymarching autograd Functions)
+    and the inference round loop -- nerf/renderer.py:281-560 and raymarching/raymarching.py, BOTH the reference's files,
+    executed on CPU: `_raymarching` is the C oracle behind the reference's binding signatures (oracle/backend.py) and the
+    wrappers' unconditional `.cuda()` moves are made no-ops for the duration of this function (torch.Tensor.cuda patched,
+    nothing in /root/reference is touched).  What the fixture pins: enerf_amd's restatement of that Python -- renderer,
+    sampler, the plain-tensor density update, the ten raymarching wrappers -- driven the same way over the same oracle
+    (tests/test_host_cuda_ray_vs_reference.py), and through it the device-side passes the GPU tests compare with that route."""
+    from . import backend as ob
+    keep_rm = sys.modules.pop("raymarching", None)
+    keep_cuda = torch.Tensor.cuda
+    sys.modules["_raymarching"] = ob.as_module("_raymarching", ob.raymarching_backend)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        import importlib
+        import raymarching
+        assert raymarching.__file__.startswith(ref_import.REFERENCE), raymarching.__file__
+        import nerf.renderer as rr
+        importlib.reload(rr)                               # bind the real package in place of the facade
+        import nerf.network as rn
+        importlib.reload(rn)
+        torch.manual_seed(0)
+        model = rn.NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3)
+        det_fill_([p for n, p in model.named_parameters() if "embeddings" not in n], 71, -0.35, 0.35)
+        det_fill_([model.encoder.embeddings], 72, -1.0, 1.0)
+        z = {}
+        # --- mark_untrained_grid: three cameras looking at the origin
+        poses = []
+        for k, (ax, ay) in enumerate(((0.0, 0.0), (0.6, 0.3), (-0.5, 0.9))):
+            cz, sz = np.cos(ax), np.sin(ax); cy, sy = np.cos(ay), np.sin(ay)
+            R = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cz, -sz], [0, sz, cz]])
+            T = np.eye(4, dtype=np.float32); T[:3, :3] = R; T[:3, 3] = R @ np.array([0, 0, -2.5 + 0.4 * k])
+            poses.append(T)
+        poses = np.stack(poses).astype(np.float32)
+        intrinsic = np.array([60.0, 60.0, 32.0, 24.0], np.float32)
+        model.mark_untrained_grid(poses, intrinsic)
+        z["poses"], z["intrinsic"] = poses, intrinsic
+        z["untrained_count"] = np.int64((model.density_grid == -1).sum())
+        for k, v in _summary(model.density_grid).items():
+            z["untrained_grid_" + k] = v
+        # --- update_extra_state: two full sweeps, then a partial update; the random draws come from torch's global CPU stream
+        model.train()
+        torch.manual_seed(123)
+        threads = torch.get_num_threads()
+        for tag in ("full1", "full2", "partial"):
+            if tag == "partial":
+                model.iter_density = 16
+                # `tmp_grid[cas, indices] = sigmas` with repeated indices (cells drawn twice): which write stays depends on
+                # how index_put_ splits the work over threads (and is undefined on a GPU); one thread = the last one
+                torch.set_num_threads(1)
+            model.local_step = 3
+            model.step_counter.zero_()
+            model.step_counter[:3, 0] = torch.tensor([1000, 1200, 1100], dtype=torch.int32)
+            model.update_extra_state()
+            for k, v in _summary(model.density_grid).items():
+                z[f"{tag}_grid_{k}"] = v
+            for k, v in _summary(model.density_bitfield).items():
+                z[f"{tag}_bits_{k}"] = v
+            z[f"{tag}_mean_density"] = np.float64(model.mean_density)
+            z[f"{tag}_mean_count"] = np.int64(model.mean_count)
+            z[f"{tag}_iter_density"] = np.int64(model.iter_density)
+        torch.set_num_threads(threads)
+        # --- run_cuda, training: two steps (the second one takes the first one's slot of the step counter ring)
+        o, d = _rays(40, 73, 2)
+        z["rays_o"], z["rays_d"] = o, d
+        for step, (perturb, force, gamma) in enumerate(((True, False, 0.0), (False, True, 1.0 / 256))):
+            model.zero_grad()
+            out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25), perturb=perturb, force_all_rays=force,
+                               dt_gamma=gamma, max_steps=256)
+            loss = (out["image"] ** 2).sum() + 0.1 * out["depth"].sum()
+            loss.backward()
+            z[f"train{step}_image"], z[f"train{step}_depth"] = out["image"], out["depth"]
+            z[f"train{step}_g_sigma0"] = model.sigma_net[0].weight.grad.clone()
+            z[f"train{step}_g_color2"] = model.color_net[2].weight.grad.clone()
+            g = model.encoder.embeddings.grad
+            z[f"train{step}_g_emb_abs_sum"] = np.float64(g.abs().double().sum())
+            z[f"train{step}_g_emb_l0"] = g[:4920].clone()
+            z[f"train{step}_step_counter"] = model.step_counter[:4].clone()
+            z[f"train{step}_local_step"] = np.int64(model.local_step)
+        # --- run_cuda, inference: the round loop (march_rays / composite_rays / compact_rays)
+        model.eval()
+        with torch.no_grad():
+            for tag, gamma in (("infer", 0.0), ("infer_gamma", 1.0 / 128)):
+                out = model.render(o, d, staged=False, bg_color=None, perturb=False, dt_gamma=gamma, max_steps=256)
+                z[f"{tag}_image"], z[f"{tag}_depth"] = out["image"], out["depth"]
+        save("ref_cuda_ray", **z)
+    finally:
+        torch.Tensor.cuda = keep_cuda
+        sys.modules.pop("_raymarching", None)
+        sys.modules.pop("raymarching", None)
+        if keep_rm is not None:
+            sys.modules["raymarching"] = keep_rm
+        import importlib
+        import nerf.renderer as rr
+        importlib.reload(rr)
+        import nerf.network as rn
+        importlib.reload(rn)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -542,7 +651,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_no_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint]
+            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

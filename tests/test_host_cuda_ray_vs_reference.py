@@ -1,0 +1,91 @@
+"""enerf_amd's restatement of the reference's cuda_ray Python -- NeRFRenderer.mark_untrained_grid, update_extra_state (full
+sweep and partial update), run_cuda in training (forward + backward through the raymarching autograd Functions) and the
+inference round loop -- against tests/golden/ref_cuda_ray.npz: what the REFERENCE's own nerf/renderer.py and
+raymarching/raymarching.py computed, executed on CPU over the C oracle (oracle/make_golden.py: gold_cuda_ray; both files
+are the reference's, `_raymarching` is the oracle behind the reference's binding signatures).  Here the same sequence runs
+through enerf_amd/renderer.py, sampler.py, density_update.py's plain-tensor passes and enerf_amd/raymarching.py over the
+same oracle: state tensors must be bit-identical (same arithmetic, same torch random stream), images and gradients equal to
+float round-off.  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from util import golden, det_fill_
+
+
+def _check_summary(z, prefix, t, exact=True):
+    a = np.ascontiguousarray(t.detach().cpu().numpy())
+    flat = a.reshape(-1)
+    sample = flat[:: max(1, flat.size // 4096)][:4096]
+    if exact:
+        assert np.array_equal(sample, z[prefix + "_sample"]), prefix
+        assert hashlib.sha256(a.tobytes()).digest() == z[prefix + "_sha256"].tobytes(), prefix
+    else:
+        np.testing.assert_allclose(sample, z[prefix + "_sample"], rtol=1e-5, atol=1e-7, err_msg=prefix)
+    np.testing.assert_allclose(flat.astype(np.float64).sum(), float(z[prefix + "_sum"]), rtol=1e-6, err_msg=prefix)
+
+
+@pytest.fixture(scope="module")
+def z():
+    return golden("ref_cuda_ray")
+
+
+def _model():
+    from enerf_amd.network import NeRFNetwork
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3)
+    det_fill_([p for n, p in model.named_parameters() if "embeddings" not in n], 71, -0.35, 0.35)
+    det_fill_([model.encoder.embeddings], 72, -1.0, 1.0)
+    return model
+
+
+def test_cuda_ray_path_reproduces_the_reference_python(z, cpu_oracle_backend):
+    model = _model()
+    # mark_untrained_grid (nerf/renderer.py:408-469)
+    model.mark_untrained_grid(z["poses"], z["intrinsic"])
+    assert int((model.density_grid == -1).sum()) == int(z["untrained_count"])
+    _check_summary(z, "untrained_grid", model.density_grid)
+    # update_extra_state (:472-560): two full sweeps, one partial update, torch's global CPU random stream
+    model.train()
+    torch.manual_seed(123)
+    threads = torch.get_num_threads()
+    for tag in ("full1", "full2", "partial"):
+        if tag == "partial":
+            model.iter_density = 16
+            torch.set_num_threads(1)          # cells drawn twice: one thread makes "the last write stays" of index_put_ hold
+        model.local_step = 3
+        model.step_counter.zero_()
+        model.step_counter[:3, 0] = torch.tensor([1000, 1200, 1100], dtype=torch.int32)
+        model.update_extra_state()
+        _check_summary(z, f"{tag}_grid", model.density_grid)
+        _check_summary(z, f"{tag}_bits", model.density_bitfield)
+        assert float(model.mean_density) == float(z[f"{tag}_mean_density"]), tag
+        assert int(model.mean_count) == int(z[f"{tag}_mean_count"]) and int(model.iter_density) == int(z[f"{tag}_iter_density"])
+    torch.set_num_threads(threads)
+    # run_cuda, training (:281-330): jittered without force_all_rays, then dt_gamma with force_all_rays
+    o, d = torch.from_numpy(z["rays_o"]), torch.from_numpy(z["rays_d"])
+    for step, (perturb, force, gamma) in enumerate(((True, False, 0.0), (False, True, 1.0 / 256))):
+        model.zero_grad()
+        out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25), perturb=perturb, force_all_rays=force,
+                           dt_gamma=gamma, max_steps=256)
+        loss = (out["image"] ** 2).sum() + 0.1 * out["depth"].sum()
+        loss.backward()
+        assert torch.equal(model.step_counter[:4].cpu(), torch.from_numpy(z[f"train{step}_step_counter"])), step
+        assert int(model.local_step) == int(z[f"train{step}_local_step"])
+        np.testing.assert_allclose(out["image"].detach().numpy(), z[f"train{step}_image"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out["depth"].detach().numpy(), z[f"train{step}_depth"], rtol=1e-5, atol=1e-6)
+        for name, g in (("g_sigma0", model.sigma_net[0].weight.grad), ("g_color2", model.color_net[2].weight.grad),
+                        ("g_emb_l0", model.encoder.embeddings.grad[:4920])):
+            ref = z[f"train{step}_{name}"]
+            np.testing.assert_allclose(g.numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=f"{step} {name}")
+        np.testing.assert_allclose(float(model.encoder.embeddings.grad.abs().double().sum()),
+                                   float(z[f"train{step}_g_emb_abs_sum"]), rtol=1e-5)
+    # run_cuda, inference (:330-380): the round loop
+    model.eval()
+    with torch.no_grad():
+        for tag, gamma in (("infer", 0.0), ("infer_gamma", 1.0 / 128)):
+            out = model.render(o, d, staged=False, bg_color=None, perturb=False, dt_gamma=gamma, max_steps=256)
+            np.testing.assert_allclose(out["image"].numpy(), z[f"{tag}_image"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(out["depth"].numpy(), z[f"{tag}_depth"], rtol=1e-5, atol=1e-6)
