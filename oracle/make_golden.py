@@ -620,6 +620,42 @@ def gold_cuda_ray():
             z[f"train{step}_g_emb_l0"] = g[:4920].clone()
             z[f"train{step}_step_counter"] = model.step_counter[:4].clone()
             z[f"train{step}_local_step"] = np.int64(model.local_step)
+        # --- Trainer.train_step_events (nerf/utils.py:482-573) on this model: two event renders + the frame render, luma /
+        # lin-log / C_thres 0.2; its background is drawn from torch's stream
+        import argparse as ap
+        import nerf.utils as ru
+        importlib.reload(ru)
+        t = ru.Trainer.__new__(ru.Trainer)
+        t.device = torch.device("cpu")
+        t.out_dim_color = 3
+        t.use_luma, t.linlog, t.C_thres, t.event_only = 1, 1, 0.2, 0
+        t.log_implicit_C_thres = False
+        t.negative_event_sampling = False
+        t.weight_loss_rgb = 1.0
+        t.epoch, t.epoch_start_noEvLoss = 1, 0
+        t.criterion = torch.nn.MSELoss(reduction="none")
+        t.opt = ap.Namespace()
+        t.model = model
+        o1, d1 = _rays(32, 74, 2)
+        o2, d2 = o1 + 0.02, torch.nn.functional.normalize(d1 + 0.015, dim=-1)
+        of, df = _rays(32, 75, 2)
+        g = torch.Generator().manual_seed(76)
+        data = {"images": torch.rand(1, 32, 3, generator=g), "rays_evs_o1": o1, "rays_evs_d1": d1, "rays_evs_o2": o2,
+                "rays_evs_d2": d2, "pols": torch.sign(torch.rand(1, 32, generator=g) - 0.5), "rays_o": of, "rays_d": df}
+        model.zero_grad()
+        torch.manual_seed(321)
+        delta, gt_pol, loss, _, losses = t.train_step_events(data)
+        loss.backward()
+        for k, v in data.items():
+            z["ev_" + k] = v
+        z["ev_loss"], z["ev_delta"] = loss, delta
+        z["ev_loss_evs"], z["ev_loss_frames"] = losses["loss_evs"], losses["loss_frames"]
+        z["ev_g_sigma0"] = model.sigma_net[0].weight.grad.clone()
+        z["ev_g_color2"] = model.color_net[2].weight.grad.clone()
+        z["ev_g_emb_abs_sum"] = np.float64(model.encoder.embeddings.grad.abs().double().sum())
+        z["ev_g_emb_l0"] = model.encoder.embeddings.grad[:4920].clone()
+        z["ev_step_counter"] = model.step_counter[:6].clone()
+        z["ev_local_step"] = np.int64(model.local_step)
         # --- run_cuda, inference: the round loop (march_rays / composite_rays / compact_rays)
         model.eval()
         with torch.no_grad():
@@ -638,6 +674,8 @@ def gold_cuda_ray():
         importlib.reload(rr)
         import nerf.network as rn
         importlib.reload(rn)
+        import nerf.utils as ru
+        importlib.reload(ru)
 
 
 def main():

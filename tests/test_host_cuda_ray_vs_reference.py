@@ -1,6 +1,6 @@
 """enerf_amd's restatement of the reference's cuda_ray Python -- NeRFRenderer.mark_untrained_grid, update_extra_state (full
-sweep and partial update), run_cuda in training (forward + backward through the raymarching autograd Functions) and the
-inference round loop -- against tests/golden/ref_cuda_ray.npz: what the REFERENCE's own nerf/renderer.py and
+sweep and partial update), run_cuda in training (forward + backward through the raymarching autograd Functions),
+Trainer.train_step_events over the real model and the inference round loop -- against tests/golden/ref_cuda_ray.npz: what the REFERENCE's own nerf/renderer.py and
 raymarching/raymarching.py computed, executed on CPU over the C oracle (oracle/make_golden.py: gold_cuda_ray; both files
 are the reference's, `_raymarching` is the oracle behind the reference's binding signatures).  Here the same sequence runs
 through enerf_amd/renderer.py, sampler.py, density_update.py's plain-tensor passes and enerf_amd/raymarching.py over the
@@ -82,6 +82,25 @@ def test_cuda_ray_path_reproduces_the_reference_python(z, cpu_oracle_backend):
             np.testing.assert_allclose(g.numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=f"{step} {name}")
         np.testing.assert_allclose(float(model.encoder.embeddings.grad.abs().double().sum()),
                                    float(z[f"train{step}_g_emb_abs_sum"]), rtol=1e-5)
+    # Trainer.train_step_events (nerf/utils.py:482-573) over this model: two event renders and the frame render
+    from enerf_amd.events import EventOptions, train_step_events
+    data = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("ev_") and k[3:] in
+            ("images", "rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols", "rays_o", "rays_d")}
+    opt = EventOptions(use_luma=True, linlog=True, C_thres=0.2, event_only=False)
+    model.zero_grad()
+    torch.manual_seed(321)
+    loss, delta = train_step_events(model, data, opt)
+    loss.backward()
+    assert torch.equal(model.step_counter[:6].cpu(), torch.from_numpy(z["ev_step_counter"]))
+    assert int(model.local_step) == int(z["ev_local_step"])
+    np.testing.assert_allclose(float(loss.detach()), float(z["ev_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(delta.detach().numpy(), z["ev_delta"], rtol=1e-4, atol=1e-5)
+    for name, g in (("g_sigma0", model.sigma_net[0].weight.grad), ("g_color2", model.color_net[2].weight.grad),
+                    ("g_emb_l0", model.encoder.embeddings.grad[:4920])):
+        ref = z[f"ev_{name}"]
+        np.testing.assert_allclose(g.numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=f"events {name}")
+    np.testing.assert_allclose(float(model.encoder.embeddings.grad.abs().double().sum()), float(z["ev_g_emb_abs_sum"]),
+                               rtol=1e-5)
     # run_cuda, inference (:330-380): the round loop
     model.eval()
     with torch.no_grad():
