@@ -1,0 +1,106 @@
+"""The PRODUCT on the GPU against what the reference's own Python computed (tests/golden/ref_cuda_ray.npz: nerf/renderer.py +
+raymarching/raymarching.py run on CPU over the C oracle, oracle/make_golden.py gold_cuda_ray): the model's occupancy state is
+brought to the fixture's by the restated update on CPU (bit for bit, tests/test_host_cuda_ray_vs_reference.py -- the GPU
+cannot replay torch's CPU random stream), then the model moves to the GPU and the fixture's two training renders, its event
+step and its inference renders run on the product's own routes (fused render node, closed backward, split-bf16 or fp32 MFMA
+networks, whole-frame inference pass): sample counters bit-exact -- incl. the first step's budget of 1152 rows that most rays
+do not fit into (the `>=` drop rule) --, images and depths 1e-4, gradients to the bars of the route-equivalence tests."""
+import numpy as np
+import pytest
+import torch
+
+from util import golden, det_fill_
+
+pytestmark = pytest.mark.gpu
+
+
+def _bring_to_fixture_state(z, monkeypatch):
+    from oracle import backend as ob
+    import enerf_amd.raymarching as rm, enerf_amd.gridencoder as ge, enerf_amd.shencoder as sh
+    from enerf_amd.network import NeRFNetwork
+    with monkeypatch.context() as mp:
+        mp.setattr(rm, "_backend", ob.raymarching_backend); mp.setattr(rm, "_DEVICE", "cpu")
+        mp.setattr(ge, "_backend", ob.gridencoder_backend); mp.setattr(sh, "_backend", ob.shencoder_backend)
+        torch.manual_seed(0)
+        model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3)
+        det_fill_([p for n, p in model.named_parameters() if "embeddings" not in n], 71, -0.35, 0.35)
+        det_fill_([model.encoder.embeddings], 72, -1.0, 1.0)
+        model.mark_untrained_grid(z["poses"], z["intrinsic"])
+        model.train()
+        torch.manual_seed(123)
+        threads = torch.get_num_threads()
+        for tag in ("full1", "full2", "partial"):
+            if tag == "partial":
+                model.iter_density = 16
+                torch.set_num_threads(1)
+            model.local_step = 3
+            model.step_counter.zero_()
+            model.step_counter[:3, 0] = torch.tensor([1000, 1200, 1100], dtype=torch.int32)
+            model.update_extra_state()
+        torch.set_num_threads(threads)
+        assert float(model.mean_density) == float(z["partial_mean_density"])        # the fixture's state, exactly
+    return model
+
+
+def _grad_check(model, z, prefix, tol=2e-3):
+    for name, g in (("g_sigma0", model.sigma_net[0].weight.grad), ("g_color2", model.color_net[2].weight.grad),
+                    ("g_emb_l0", model.encoder.embeddings.grad[:4920])):
+        ref = z[f"{prefix}_{name}"]
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(g.detach().cpu().numpy() - ref).max())
+        print(f"{prefix} {name}: max err / max |grad| = {err / scale:.2e}")
+        assert err < tol * scale, (prefix, name, err / scale)
+    got = float(model.encoder.embeddings.grad.abs().double().sum())
+    assert abs(got - float(z[f"{prefix}_g_emb_abs_sum"])) < 1e-3 * float(z[f"{prefix}_g_emb_abs_sum"])
+
+
+def test_product_on_the_gpu_reproduces_the_reference_python(monkeypatch, mlp32_mode):
+    z = golden("ref_cuda_ray")
+    model = _bring_to_fixture_state(z, monkeypatch).cuda()
+    dev = "cuda"
+    o, d = torch.from_numpy(z["rays_o"]).to(dev), torch.from_numpy(z["rays_d"]).to(dev)
+    for step, (perturb, force, gamma) in enumerate(((True, False, 0.0), (False, True, 1.0 / 256))):
+        model.zero_grad()
+        out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25, device=dev), perturb=perturb,
+                           force_all_rays=force, dt_gamma=gamma, max_steps=256)
+        loss = (out["image"] ** 2).sum() + 0.1 * out["depth"].sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(model.step_counter[:4].cpu(), torch.from_numpy(z[f"train{step}_step_counter"])), step
+        assert int(model.local_step) == int(z[f"train{step}_local_step"])
+        np.testing.assert_allclose(out["image"].detach().cpu().numpy(), z[f"train{step}_image"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), z[f"train{step}_depth"], rtol=1e-4, atol=2e-5)
+        _grad_check(model, z, f"train{step}")
+    from enerf_amd.events import EventOptions, train_step_events
+    data = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("ev_") and k[3:] in
+            ("images", "rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols", "rays_o", "rays_d")}
+    opt = EventOptions(use_luma=True, linlog=True, C_thres=0.2, event_only=False)
+    model.zero_grad()
+    torch.manual_seed(321)
+    bg = torch.rand((1, 1, 3)).to(dev)                              # the reference's host-side draw (nerf/utils.py:487)
+    loss, delta = train_step_events(model, data, opt, bg_color=bg)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(model.step_counter[:6].cpu(), torch.from_numpy(z["ev_step_counter"]))
+    assert int(model.local_step) == int(z["ev_local_step"])
+    np.testing.assert_allclose(float(loss.detach()), float(z["ev_loss"]), rtol=2e-4)
+    np.testing.assert_allclose(delta.detach().cpu().numpy(), z["ev_delta"], rtol=1e-3, atol=2e-4)
+    # (the event loss differentiates a DIFFERENCE of two renders of nearly the same rays: the gradient is what is left of
+    #  two contributions ~40x its size that cancel, and so is its error -- 5.5e-3 of the largest entry in split-bf16 mode)
+    _grad_check(model, z, "ev", tol=2e-2 if mlp32_mode == "split-bf16" else 5e-3)
+    # inference: the reference's round schedule (renderer.py:330-380) on the product's kernels must reproduce the fixture;
+    # the whole-frame pass (the default: one march, one compositing pass) differs where the schedule itself shows -- a ray
+    # still alive when the global step counter reaches max_steps has been handed up to 7 samples more than max_steps by
+    # the last round (n_step grows to 8 as rays finish), and max_steps is only 256 here
+    from enerf_amd import frame
+    model.eval()
+    with torch.no_grad():
+        for tag, gamma in (("infer", 0.0), ("infer_gamma", 1.0 / 128)):
+            monkeypatch.setattr(frame, "FRAME_ENABLED", False)
+            out = model.render(o, d, staged=False, bg_color=None, perturb=False, dt_gamma=gamma, max_steps=256)
+            np.testing.assert_allclose(out["image"].cpu().numpy(), z[f"{tag}_image"], rtol=1e-4, atol=2e-5)
+            np.testing.assert_allclose(out["depth"].cpu().numpy(), z[f"{tag}_depth"], rtol=1e-4, atol=2e-5)
+            monkeypatch.setattr(frame, "FRAME_ENABLED", True)
+            whole = model.render(o, d, staged=False, bg_color=None, perturb=False, dt_gamma=gamma, max_steps=256)
+            diff = (whole["image"] - out["image"]).abs().amax(-1).reshape(-1)
+            assert int((diff > 1e-4).sum()) <= 4 and float(diff.max()) < 5e-3, (tag, diff)
