@@ -678,6 +678,89 @@ def gold_cuda_ray():
         importlib.reload(ru)
 
 
+def gold_collate():
+    """EventNeRFDataset.collate (nerf/provider.py:1364-1480) -- the reference's own method -- on a dataset object whose
+    tables are filled in by hand: the constructor reads image folders, pose files and event containers from disk
+    (:1107-1260), so the per-pixel event tables come from oracle/event_collate.group_events, this repository's line-by-line
+    transcription of the constructor's grouping loop (:1147-1199; checked against a brute-force definition, NOT pinned
+    here).  What the fixture pins is everything collate does per step: the successor filter, the random window end, the
+    polarity sum, the un-accumulated variant, scipy's Slerp / cubic pose interpolation at the event times, get_event_rays,
+    and the no-event entries.  numpy's global draws are recorded as they are made, so that the restatement is fed the same."""
+    from scipy.interpolate import interp1d
+    from scipy.spatial.transform import Rotation as R, Slerp
+    import nerf.provider as rp
+    from . import event_collate as EC
+    rng = np.random.default_rng(81)
+    Hs, Ws, n = 12, 16, 900
+    ev = np.stack([rng.integers(0, Ws, n), rng.integers(0, Hs, n), np.sort(rng.uniform(1e6, 9e7, n)),
+                   rng.choice([-1.0, 1.0], n)], axis=1).astype(np.float32)
+    g = EC.group_events(ev)
+    K = 24
+    ts = np.linspace(0.0, 1e8, K)
+    rots = R.from_euler("xyz", np.stack([0.3 * np.sin(np.arange(K) * 0.4), 0.2 * np.cos(np.arange(K) * 0.3),
+                                         0.05 * np.arange(K)], axis=1))
+    trans = np.stack([0.1 * np.arange(K), np.sin(np.arange(K) * 0.5), 0.3 * np.cos(np.arange(K) * 0.2)], axis=1)
+    z = {"events": ev, "pose_ts": ts, "pose_R": rots.as_matrix(), "pose_t": trans}
+    for tag, accumulate, acc_max, negative in (("acc", True, 0, False), ("acc_max3", True, 3, False),
+                                               ("single", False, 0, False), ("acc_noev", True, 0, True)):
+        ds = rp.EventNeRFDataset.__new__(rp.EventNeRFDataset)
+        ds.frame_idxs = [7]
+        ds.accumulate_evs, ds.batch_size_evs, ds.acc_max_num_evs = accumulate, 64, acc_max
+        ds.num_evs = {7: len(g["events"])}
+        ds.idx_no_successor = {7: g["idx_no_successor"]}
+        ds.num_successor_evs = {7: g["num_successor_evs"]}
+        ds.xy_numEvs_Idx = {7: g["xy_numEvs_Idx"]}
+        ds.events = {7: torch.from_numpy(g["events"])}
+        ds.precompute_evs_poses = False
+        ds.rot_interpolator = Slerp(ts, rots)
+        ds.trans_interpolator = interp1d(x=ts, y=trans, axis=0, kind="cubic", bounds_error=True)
+        ds.device = torch.device("cpu")
+        ds.intrinsics_evs = np.array([14.0, 13.0, 8.0, 6.0])
+        ds.intrinsics = np.array([14.0, 13.0, 8.0, 6.0])
+        ds.poses = torch.eye(4).unsqueeze(0)
+        ds.error_map = None
+        ds.H, ds.W, ds.num_rays = Hs, Ws, 16
+        ds.training = True
+        ds.images = torch.from_numpy(rng.random((1, Hs, Ws, 3)).astype(np.float32))
+        z["images"] = ds.images if "images" not in z else z["images"]
+        ds.negative_event_sampling = negative
+        if negative:
+            coords = [torch.from_numpy(np.stack([rng.integers(0, Ws, 30), rng.integers(0, Hs, 30)], axis=1).astype(np.float32))
+                      for _ in range(3)]
+            ds.no_evs = {7: {"coords": coords, "tss_bds": {"N_ev_chunks": [3], "start_time_us": [2e3, 3.2e4, 6.2e4],
+                                                            "end_time_us": [3.2e4, 6.2e4, 9.2e4]}}}
+            z[tag + "_noev_coords"] = np.stack([c.numpy() for c in coords])
+        drawn = {"randint": [], "rand": [], "choice": [], "random": []}
+        keep = (np.random.randint, np.random.rand, np.random.choice, np.random.random)
+
+        def rec(name, fn):
+            def wrapped(*a, **k):
+                r = fn(*a, **k)
+                drawn[name].append(np.array(r, copy=True))
+                return r
+            return wrapped
+        np.random.seed(82)
+        torch.manual_seed(83)
+        np.random.randint, np.random.rand = rec("randint", keep[0]), rec("rand", keep[1])
+        np.random.choice, np.random.random = rec("choice", keep[2]), rec("random", keep[3])
+        try:
+            out = ds.collate([0])
+        finally:
+            np.random.randint, np.random.rand, np.random.choice, np.random.random = keep
+        for k in ("rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols", "rays_o", "rays_d", "images"):
+            z[f"{tag}_{k}"] = out[k]
+        z[f"{tag}_frame_images"] = ds.images
+        if negative:
+            for k in ("rays_no_evs_o1", "rays_no_evs_d1", "rays_no_evs_o2", "rays_no_evs_d2"):
+                z[f"{tag}_{k}"] = out[k]
+        for name, lst in drawn.items():
+            if lst:
+                z[f"{tag}_draw_{name}_first"] = np.asarray(lst[0])
+                rest = [np.asarray(v).reshape(-1) for v in lst[1:]]
+                z[f"{tag}_draw_{name}_rest"] = np.concatenate(rest) if rest else np.zeros(0)
+    save("ref_collate", **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -689,7 +772,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_no_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray]
+            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue
