@@ -678,6 +678,107 @@ def gold_cuda_ray():
         importlib.reload(ru)
 
 
+def gold_train_epoch():
+    """The reference's OWN training loop -- Trainer.train_one_epoch (nerf/utils.py:920-1015): update_extra_state every 16
+    global steps, zero_grad, train_step_events (two run_cuda renders), GradScaler (disabled: fp32), Adam(betas=(0.9, 0.99),
+    eps=1e-15) (main_nerf.py:211), LambdaLR stepped every step -- for 18 steps of event training on a cuda_ray hash-grid
+    model, executed on CPU over the C oracle as gold_cuda_ray does (the reference's renderer.py and raymarching.py).  Stored:
+    the data of every step, every step's loss, the learning rates, the sample budget and counters at the end, slices of the
+    parameters after the epoch.  The Trainer object is made with __new__ and given what the loop reads."""
+    from . import backend as ob
+    keep_rm = sys.modules.pop("raymarching", None)
+    keep_cuda = torch.Tensor.cuda
+    sys.modules["_raymarching"] = ob.as_module("_raymarching", ob.raymarching_backend)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import importlib
+    try:
+        import raymarching
+        assert raymarching.__file__.startswith(ref_import.REFERENCE), raymarching.__file__
+        import nerf.renderer as rr
+        importlib.reload(rr)
+        import nerf.network as rn
+        importlib.reload(rn)
+        import nerf.utils as ru
+        importlib.reload(ru)
+        import argparse as ap
+        torch.manual_seed(0)
+        model = rn.NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3)
+        det_fill_([p for n, p in model.named_parameters() if "embeddings" not in n], 101, -0.35, 0.35)
+        det_fill_([model.encoder.embeddings], 102, -0.5, 0.5)
+        steps, N = 18, 24
+        g = torch.Generator().manual_seed(103)
+        batches = []
+        for i in range(steps):
+            o1, d1 = _rays(N, 200 + i, 2)
+            batches.append({"images": torch.rand(1, N, 3, generator=g), "rays_evs_o1": o1, "rays_evs_d1": d1,
+                            "rays_evs_o2": o1 + 0.02, "rays_evs_d2": torch.nn.functional.normalize(d1 + 0.015, dim=-1),
+                            "pols": torch.sign(torch.rand(1, N, generator=g) - 0.5), "rays_o": o1, "rays_d": d1})
+
+        class Loader(list):
+            batch_size = 1
+        t = ru.Trainer.__new__(ru.Trainer)
+        t.log = lambda *a, **k: None
+        t.model, t.device = model, torch.device("cpu")
+        t.optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+        t.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(t.optimizer, lambda it: 0.1 ** min(it / 30, 1))
+        t.scheduler_update_every_step = True
+        t.scaler = torch.cuda.amp.GradScaler(enabled=False)
+        t.fp16 = False
+        t.ema = None
+        t.epoch, t.global_step, t.local_rank, t.world_size = 1, 0, 0, 1
+        t.report_metric_at_train = False
+        t.use_tensorboardX = False
+        t.eval_interval = 0
+        t.stats = {"loss": []}
+        t.use_events = True
+        t.out_dim_color = 3
+        t.use_luma, t.linlog, t.C_thres, t.event_only = 1, 1, 0.2, 1
+        t.log_implicit_C_thres = False
+        t.negative_event_sampling = False
+        t.weight_loss_rgb = 1.0
+        t.epoch_start_noEvLoss = 0
+        t.criterion = torch.nn.MSELoss(reduction="none")
+        t.opt = ap.Namespace()
+        losses, lrs = [], []
+        inner = t.train_step_events
+
+        def recording(data):
+            out = inner(data)
+            losses.append(out[2].detach().clone())
+            lrs.append(t.optimizer.param_groups[0]["lr"])
+            return out
+        t.train_step_events = recording
+        torch.manual_seed(777)
+        t.train_one_epoch(Loader(batches))
+        z = {"steps": np.int64(steps), "losses": torch.stack(losses), "lrs": np.asarray(lrs, np.float64),
+             "final_lr": np.float64(t.optimizer.param_groups[0]["lr"]), "mean_count": np.int64(model.mean_count),
+             "iter_density": np.int64(model.iter_density), "model_local_step": np.int64(model.local_step),
+             "step_counter": model.step_counter.clone(), "mean_density": np.float64(model.mean_density),
+             "epoch_loss": np.float64(t.stats["loss"][0])}
+        for i, b in enumerate(batches):
+            for k in ("images", "rays_evs_o1", "rays_evs_d1", "pols"):
+                z[f"b{i}_{k}"] = b[k]
+        sd = model.state_dict()
+        z["p_sigma0"] = sd["sigma_net.0.weight"]
+        z["p_color2"] = sd["color_net.2.weight"]
+        z["p_emb_l0"] = sd["encoder.embeddings"][:4920]
+        for k, v in _summary(model.density_bitfield).items():
+            z["bits_" + k] = v
+        save("ref_train_epoch", **z)
+    finally:
+        torch.Tensor.cuda = keep_cuda
+        sys.modules.pop("_raymarching", None)
+        sys.modules.pop("raymarching", None)
+        if keep_rm is not None:
+            sys.modules["raymarching"] = keep_rm
+        import nerf.renderer as rr
+        importlib.reload(rr)
+        import nerf.network as rn
+        importlib.reload(rn)
+        import nerf.utils as ru
+        importlib.reload(ru)
+
+
 def gold_collate():
     """EventNeRFDataset.collate (nerf/provider.py:1364-1480) -- the reference's own method -- on a dataset object whose
     tables are filled in by hand: the constructor reads image folders, pose files and event containers from disk
@@ -772,7 +873,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_no_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate]
+            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate, gold_train_epoch]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

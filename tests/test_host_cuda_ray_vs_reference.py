@@ -108,3 +108,42 @@ def test_cuda_ray_path_reproduces_the_reference_python(z, cpu_oracle_backend):
             out = model.render(o, d, staged=False, bg_color=None, perturb=False, dt_gamma=gamma, max_steps=256)
             np.testing.assert_allclose(out["image"].numpy(), z[f"{tag}_image"], rtol=1e-5, atol=1e-6)
             np.testing.assert_allclose(out["depth"].numpy(), z[f"{tag}_depth"], rtol=1e-5, atol=1e-6)
+
+
+def test_training_epoch_reproduces_the_reference_trainer(cpu_oracle_backend):
+    """tests/golden/ref_train_epoch.npz: the reference's OWN Trainer.train_one_epoch (nerf/utils.py:920-1015) -- 18 steps of
+    event training on a cuda_ray hash-grid model, update_extra_state at global steps 0 and 16, Adam + LambdaLR stepped every
+    step -- run on CPU over the oracle (oracle/make_golden.py: gold_train_epoch).  TrainHarness.step_events driven with the
+    same batches on the same torch random stream: every step's loss, the learning rates, the sample budget, the counters,
+    the bitfield and the parameters after the epoch."""
+    from enerf_amd.events import EventOptions
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    z = golden("ref_train_epoch")
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3)
+    det_fill_([p for n, p in model.named_parameters() if "embeddings" not in n], 101, -0.35, 0.35)
+    det_fill_([model.encoder.embeddings], 102, -0.5, 0.5)
+    h = TrainHarness(model, lr=1e-2, occupancy="learned", optimizer=torch.optim.Adam)
+    h.set_lr_scheduler(lambda o: torch.optim.lr_scheduler.LambdaLR(o, lambda it: 0.1 ** min(it / 30, 1)))
+    opt = EventOptions(use_luma=True, linlog=True, C_thres=0.2, event_only=True)
+    torch.manual_seed(777)
+    losses, lrs = [], []
+    for i in range(int(z["steps"])):
+        o1, d1 = torch.from_numpy(z[f"b{i}_rays_evs_o1"]), torch.from_numpy(z[f"b{i}_rays_evs_d1"])
+        data = {"images": torch.from_numpy(z[f"b{i}_images"]), "rays_evs_o1": o1, "rays_evs_d1": d1, "rays_evs_o2": o1 + 0.02,
+                "rays_evs_d2": torch.nn.functional.normalize(d1 + 0.015, dim=-1), "pols": torch.from_numpy(z[f"b{i}_pols"])}
+        lrs.append(h.opt.param_groups[0]["lr"])
+        losses.append(float(h.step_events(data, opt)))
+    np.testing.assert_allclose(lrs, z["lrs"], rtol=1e-12)
+    np.testing.assert_allclose(h.opt.param_groups[0]["lr"], float(z["final_lr"]), rtol=1e-12)
+    np.testing.assert_allclose(losses, z["losses"], rtol=2e-5)
+    assert int(model.mean_count) == int(z["mean_count"]) and int(model.iter_density) == int(z["iter_density"])
+    assert int(model.local_step) == int(z["model_local_step"])
+    assert torch.equal(model.step_counter.cpu(), torch.from_numpy(z["step_counter"]))
+    np.testing.assert_allclose(float(model.mean_density), float(z["mean_density"]), rtol=1e-5)
+    sd = model.state_dict()
+    for name, key in (("p_sigma0", "sigma_net.0.weight"), ("p_color2", "color_net.2.weight")):
+        np.testing.assert_allclose(sd[key].numpy(), z[name], rtol=1e-4, atol=1e-6, err_msg=name)
+    np.testing.assert_allclose(sd["encoder.embeddings"][:4920].numpy(), z["p_emb_l0"], rtol=1e-4, atol=1e-6)
+    _check_summary(z, "bits", model.density_bitfield, exact=False)
