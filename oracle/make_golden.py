@@ -779,6 +779,67 @@ def gold_train_epoch():
         importlib.reload(ru)
 
 
+def gold_event_readers():
+    """The reference's event readers run on containers made here: EventSlicer (utils/event_utils.py:223-383) over a dict
+    that answers like the h5 file it expects ('events/{p,x,y,t}', 'ms_to_idx', 't_offset'), its millisecond index from the
+    reference's compute_ms_to_idx (:389-408), windows incl. the edge cases; and load_contiguous_evs_batches_esim_ns
+    (nerf/provider.py:27-82) over a directory of .npy event files written to /tmp."""
+    import tempfile
+    from utils.event_utils import EventSlicer, compute_ms_to_idx
+    import nerf.provider as rp
+    rng = np.random.default_rng(111)
+    n = 4000
+    t = np.sort(rng.integers(0, 60_000, n)).astype(np.int64)          # microseconds: duplicates, empty milliseconds
+    t[1000:1040] = t[1000]                                             # a run of equal stamps
+    t = np.sort(t)
+    x, y = rng.integers(0, 64, n).astype(np.int16), rng.integers(0, 48, n).astype(np.int16)
+    p = rng.integers(0, 2, n).astype(np.int8)
+    ms_to_idx = compute_ms_to_idx(t * 1000)                            # the function takes nanoseconds
+    z = {"t_us": t, "x": x, "y": y, "p": p, "ms_to_idx": ms_to_idx}
+    for tag, off in (("plain", 0), ("offset", 1_234_567)):
+        h5 = {"events/p": p, "events/x": x, "events/y": y, "events/t": t, "ms_to_idx": ms_to_idx}
+        if off:
+            h5["t_offset"] = np.array(off)
+        sl = EventSlicer(h5)
+        z[f"{tag}_t_final"] = np.int64(sl.get_final_time_us())
+        wins = [(0, 1), (0, 1000), (999, 1001), (1500, 4321), (int(t[1000]), int(t[1000]) + 1), (int(t[1000]) - 1, int(t[1000])),
+                (30_000, 30_500), (58_000, 59_000), (59_000, 60_000), (59_500, 61_000), (10, 59_999)]
+        wins += [tuple(sorted(rng.integers(0, 59_000, 2).tolist())) for _ in range(24)]
+        wins = [(a + off, b + off) for a, b in wins if a < b]
+        res = []
+        for a, b in wins:
+            ev = sl.get_events(a, b)
+            if ev is None:
+                res.append((-1, -1, -1, -1))
+            else:
+                res.append((ev["t"].size, int(ev["t"][0]) if ev["t"].size else -1, int(ev["t"][-1]) if ev["t"].size else -1,
+                            int(ev["x"].astype(np.int64).sum() + 7 * ev["y"].astype(np.int64).sum() + 13 * ev["p"].astype(np.int64).sum())))
+        z[f"{tag}_windows"] = np.asarray(wins, np.int64)
+        z[f"{tag}_results"] = np.asarray(res, np.int64)
+    # esim event directories
+    with tempfile.TemporaryDirectory(prefix="enerf_esim_", dir="/tmp") as d:
+        files = []
+        t0 = 0
+        for k in range(7):
+            m = int(rng.integers(20, 60))
+            ts = np.sort(rng.integers(t0, t0 + 10_000_000, m)).astype(np.float64)
+            t0 += 10_000_000
+            # a fifth column the loader must drop; polarities -1 / +1 (the reference's own {0, 1} -> {-1, +1} mapping
+            # multiplies four-column batches by a five-entry mask, utils/event_utils.py:144-145, and cannot run)
+            ev = np.stack([rng.integers(0, 64, m), rng.integers(0, 48, m), ts, rng.integers(0, 2, m) * 2 - 1,
+                           rng.integers(0, 9, m)], axis=1).astype(np.float64)
+            np.save(os.path.join(d, f"{k:06d}.npy"), ev)
+            files.append(ev)
+        for tag, idxs in (("esim_a", [0, 2, 3, 6]), ("esim_b", [1, 4]), ("esim_c", [5])):
+            out = rp.load_contiguous_evs_batches_esim_ns(d, idxs, hwf=(48, 64, 1.0))
+            z[f"{tag}_idxs"] = np.asarray(idxs, np.int64)
+            z[f"{tag}_sizes"] = np.asarray([len(b) for b in out], np.int64)
+            z[f"{tag}_cat"] = np.concatenate([np.asarray(b, np.float64) for b in out])
+        for k, ev in enumerate(files):
+            z[f"esim_file{k}"] = ev
+    save("ref_event_readers", **z)
+
+
 def gold_collate():
     """EventNeRFDataset.collate (nerf/provider.py:1364-1480) -- the reference's own method -- on a dataset object whose
     tables are filled in by hand: the constructor reads image folders, pose files and event containers from disk
@@ -873,7 +934,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_no_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate, gold_train_epoch]
+            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate, gold_train_epoch, gold_event_readers]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue
