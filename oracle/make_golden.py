@@ -678,6 +678,65 @@ def gold_cuda_ray():
         importlib.reload(ru)
 
 
+def gold_cuda_ray_ff():
+    """nerf/network_ff.py (hash grid + SH + two FFMLP nets) on the cuda_ray path of the reference's own renderer.py /
+    raymarching.py, on CPU over the oracle (as gold_cuda_ray; `_ffmlp` is the oracle's rounded-half FFMLP behind the
+    reference's ffmlp.py): one update_extra_state, a jittered training render with backward, an inference render."""
+    from . import backend as ob
+    keep_rm = sys.modules.pop("raymarching", None)
+    keep_cuda = torch.Tensor.cuda
+    sys.modules["_raymarching"] = ob.as_module("_raymarching", ob.raymarching_backend)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import importlib
+    try:
+        import raymarching
+        assert raymarching.__file__.startswith(ref_import.REFERENCE), raymarching.__file__
+        import nerf.renderer as rr
+        importlib.reload(rr)
+        import nerf.network_ff as rn
+        importlib.reload(rn)
+        torch.manual_seed(0)
+        model = rn.NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True)
+        det_fill_([model.encoder.embeddings], 121, -1.0, 1.0)
+        det_fill_([model.sigma_net.weights], 122, -0.3, 0.3)
+        det_fill_([model.color_net.weights], 123, -0.3, 0.3)
+        z = {}
+        model.train()
+        torch.manual_seed(124)
+        model.update_extra_state()
+        for k, v in _summary(model.density_bitfield).items():
+            z["bits_" + k] = v
+        z["mean_density"] = np.float64(model.mean_density)
+        o, d = _rays(32, 125, 2)
+        z["rays_o"], z["rays_d"] = o, d
+        model.zero_grad()
+        out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25), perturb=True, force_all_rays=True,
+                           max_steps=128)
+        loss = (out["image"].float() ** 2).sum() + 0.1 * out["depth"].float().sum()
+        loss.backward()
+        z["train_image"], z["train_depth"] = out["image"].float(), out["depth"].float()
+        z["g_sigma_w"] = model.sigma_net.weights.grad.float().clone()
+        z["g_color_w"] = model.color_net.weights.grad.float().clone()
+        z["g_emb_abs_sum"] = np.float64(model.encoder.embeddings.grad.abs().double().sum())
+        z["g_emb_l0"] = model.encoder.embeddings.grad[:4920].float().clone()
+        z["step_counter"] = model.step_counter[:2].clone()
+        model.eval()
+        with torch.no_grad():
+            out = model.render(o, d, staged=False, bg_color=None, perturb=False, max_steps=128)
+        z["infer_image"], z["infer_depth"] = out["image"].float(), out["depth"].float()
+        save("ref_cuda_ray_ff", **z)
+    finally:
+        torch.Tensor.cuda = keep_cuda
+        sys.modules.pop("_raymarching", None)
+        sys.modules.pop("raymarching", None)
+        if keep_rm is not None:
+            sys.modules["raymarching"] = keep_rm
+        import nerf.renderer as rr
+        importlib.reload(rr)
+        import nerf.network_ff as rn
+        importlib.reload(rn)
+
+
 def gold_train_epoch():
     """The reference's OWN training loop -- Trainer.train_one_epoch (nerf/utils.py:920-1015): update_extra_state every 16
     global steps, zero_grad, train_step_events (two run_cuda renders), GradScaler (disabled: fp32), Adam(betas=(0.9, 0.99),
@@ -934,7 +993,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = [gold_grid_wrapper, gold_sh_wrapper, gold_ffmlp_wrapper, gold_network, gold_network_ff,
             gold_composite_vs_run, gold_events, gold_no_events, gold_misc, gold_sh_literals, gold_near_far_from_bound,
-            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate, gold_train_epoch, gold_event_readers]
+            gold_binding_signatures, gold_state_dict_schema, gold_config0, gold_checkpoint, gold_cuda_ray, gold_collate, gold_train_epoch, gold_event_readers, gold_cuda_ray_ff]
     for j in jobs:
         if a.only and a.only not in j.__name__:
             continue

@@ -147,3 +147,43 @@ def test_training_epoch_reproduces_the_reference_trainer(cpu_oracle_backend):
         np.testing.assert_allclose(sd[key].numpy(), z[name], rtol=1e-4, atol=1e-6, err_msg=name)
     np.testing.assert_allclose(sd["encoder.embeddings"][:4920].numpy(), z["p_emb_l0"], rtol=1e-4, atol=1e-6)
     _check_summary(z, "bits", model.density_bitfield, exact=False)
+
+
+def _ff_model():
+    from enerf_amd.network_ff import NeRFNetwork
+    torch.manual_seed(0)
+    model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True)
+    det_fill_([model.encoder.embeddings], 121, -1.0, 1.0)
+    det_fill_([model.sigma_net.weights], 122, -0.3, 0.3)
+    det_fill_([model.color_net.weights], 123, -0.3, 0.3)
+    return model
+
+
+def test_network_ff_on_the_cuda_ray_path_reproduces_the_reference_python(cpu_oracle_backend):
+    """tests/golden/ref_cuda_ray_ff.npz (gold_cuda_ray_ff): nerf/network_ff.py -- hash grid, SH, two FFMLP nets through the
+    reference's ffmlp.py over the oracle's rounded-half FFMLP -- rendered and differentiated by the reference's renderer.py /
+    raymarching.py on CPU.  enerf_amd/network_ff.py + ffmlp.py + the restated renderer over the same oracle."""
+    z = golden("ref_cuda_ray_ff")
+    model = _ff_model()
+    model.train()
+    torch.manual_seed(124)
+    model.update_extra_state()
+    _check_summary(z, "bits", model.density_bitfield)
+    assert float(model.mean_density) == float(z["mean_density"])
+    o, d = torch.from_numpy(z["rays_o"]), torch.from_numpy(z["rays_d"])
+    model.zero_grad()
+    out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25), perturb=True, force_all_rays=True, max_steps=128)
+    loss = (out["image"].float() ** 2).sum() + 0.1 * out["depth"].float().sum()
+    loss.backward()
+    assert torch.equal(model.step_counter[:2].cpu(), torch.from_numpy(z["step_counter"]))
+    np.testing.assert_allclose(out["image"].detach().float().numpy(), z["train_image"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["depth"].detach().float().numpy(), z["train_depth"], rtol=1e-5, atol=1e-6)
+    for name, g in (("g_sigma_w", model.sigma_net.weights.grad), ("g_color_w", model.color_net.weights.grad),
+                    ("g_emb_l0", model.encoder.embeddings.grad[:4920])):
+        ref = z[name]
+        np.testing.assert_allclose(g.float().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=name)
+    model.eval()
+    with torch.no_grad():
+        out = model.render(o, d, staged=False, bg_color=None, perturb=False, max_steps=128)
+    np.testing.assert_allclose(out["image"].float().numpy(), z["infer_image"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["depth"].float().numpy(), z["infer_depth"], rtol=1e-5, atol=1e-6)
