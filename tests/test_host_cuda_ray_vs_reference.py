@@ -61,7 +61,8 @@ def test_cuda_ray_path_reproduces_the_reference_python(z, cpu_oracle_backend):
         model.update_extra_state()
         _check_summary(z, f"{tag}_grid", model.density_grid)
         _check_summary(z, f"{tag}_bits", model.density_bitfield)
-        assert float(model.mean_density) == float(z[f"{tag}_mean_density"]), tag
+        # (torch.mean's summation order follows the host's thread count: the last digits may differ on another machine)
+        np.testing.assert_allclose(float(model.mean_density), float(z[f"{tag}_mean_density"]), rtol=1e-6, err_msg=tag)
         assert int(model.mean_count) == int(z[f"{tag}_mean_count"]) and int(model.iter_density) == int(z[f"{tag}_iter_density"])
     torch.set_num_threads(threads)
     # run_cuda, training (:281-330): jittered without force_all_rays, then dt_gamma with force_all_rays
@@ -169,7 +170,7 @@ def test_network_ff_on_the_cuda_ray_path_reproduces_the_reference_python(cpu_ora
     torch.manual_seed(124)
     model.update_extra_state()
     _check_summary(z, "bits", model.density_bitfield)
-    assert float(model.mean_density) == float(z["mean_density"])
+    np.testing.assert_allclose(float(model.mean_density), float(z["mean_density"]), rtol=1e-6)
     o, d = torch.from_numpy(z["rays_o"]), torch.from_numpy(z["rays_d"])
     model.zero_grad()
     out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25), perturb=True, force_all_rays=True, max_steps=128)
