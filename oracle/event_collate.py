@@ -12,12 +12,12 @@
                                                   sorted uniform times, scipy Slerp / cubic interp1d poses, get_event_rays
                                                   (draws passed in)
 
-Parity status: collate_pairs / collate_single / no_event_rays -- everything EventNeRFDataset.collate does per step -- are
-pinned (round 4) by the reference's OWN collate run on a dataset object filled in by hand, numpy's draws recorded
-(oracle/make_golden.py gold_collate -> tests/golden/ref_collate.npz, tests/test_collate_vs_reference.py: the product's CPU
-and device routes reproduce it, ends and polarity sums exactly, rays to 1e-5).  group_events / no_event_tables restate code
-that lives inline in the constructor, which reads dataset files from disk: a line-by-line transcription checked against an
-independent brute-force definition in tests/test_event_sampler.py, "unpinned" against a run of the reference.
+Parity status: pinned (round 4) by the reference's OWN EventNeRFDataset, constructed and collated with only its file
+reading stubbed and numpy's draws recorded (oracle/make_golden.py gold_collate -> tests/golden/ref_collate.npz,
+tests/test_collate_vs_reference.py): the product's tables equal the constructor's grouping loop entry for entry, its
+no-event tables the loader's, its CPU and device routes reproduce collate -- ends and polarity sums exactly, rays to 1e-5.
+These functions remain the line-by-line transcription the product is ALSO compared with (tests/test_event_sampler.py, with
+an independent brute-force definition beside them).
 """
 import numpy as np
 

@@ -900,85 +900,114 @@ def gold_event_readers():
 
 
 def gold_collate():
-    """EventNeRFDataset.collate (nerf/provider.py:1364-1480) -- the reference's own method -- on a dataset object whose
-    tables are filled in by hand: the constructor reads image folders, pose files and event containers from disk
-    (:1107-1260), so the per-pixel event tables come from oracle/event_collate.group_events, this repository's line-by-line
-    transcription of the constructor's grouping loop (:1147-1199; checked against a brute-force definition, NOT pinned
-    here).  What the fixture pins is everything collate does per step: the successor filter, the random window end, the
-    polarity sum, the un-accumulated variant, scipy's Slerp / cubic pose interpolation at the event times, get_event_rays,
-    and the no-event entries.  numpy's global draws are recorded as they are made, so that the restatement is fed the same."""
-    from scipy.interpolate import interp1d
-    from scipy.spatial.transform import Rotation as R, Slerp
+    """EventNeRFDataset -- the reference's own class (nerf/provider.py:1105-1500) -- CONSTRUCTED and collated here.  What is
+    stubbed is its input/output only: the parent's __init__ (image folders, pose files: :430-700) is replaced by one that
+    sets the attributes it would leave behind, `load_event_data_esim` (the .npy reader) hands over event batches made
+    here, the pose plot is a no-op.  Everything else is the reference's code: load_events_at_frame_idxs' no-event tables
+    (:1283-1351), the constructor's per-pixel grouping loop (:1147-1199), the interpolators, and collate (:1364-1480) --
+    successor filter, random window end, polarity sum, the un-accumulated variant, scipy's Slerp / cubic pose interpolation
+    at the event times, get_event_rays, the no-event entries.  numpy's global draws are recorded as they are made, so that
+    the restatement can be fed the same."""
+    import argparse as ap
+    from scipy.spatial.transform import Rotation as R
     import nerf.provider as rp
-    from . import event_collate as EC
     rng = np.random.default_rng(81)
     Hs, Ws, n = 12, 16, 900
     ev = np.stack([rng.integers(0, Ws, n), rng.integers(0, Hs, n), np.sort(rng.uniform(1e6, 9e7, n)),
-                   rng.choice([-1.0, 1.0], n)], axis=1).astype(np.float32)
-    g = EC.group_events(ev)
+                   rng.choice([-1.0, 1.0], n)], axis=1).astype(np.float64)
+    ev2 = ev.copy()
+    ev2[:, 2] += 9e7                                                     # a second batch: only its first stamp is used (:1270)
     K = 24
-    ts = np.linspace(0.0, 1e8, K)
+    ts = np.linspace(0.0, 2e8, K)
     rots = R.from_euler("xyz", np.stack([0.3 * np.sin(np.arange(K) * 0.4), 0.2 * np.cos(np.arange(K) * 0.3),
                                          0.05 * np.arange(K)], axis=1))
     trans = np.stack([0.1 * np.arange(K), np.sin(np.arange(K) * 0.5), 0.3 * np.cos(np.arange(K) * 0.2)], axis=1)
-    z = {"events": ev, "pose_ts": ts, "pose_R": rots.as_matrix(), "pose_t": trans}
-    for tag, accumulate, acc_max, negative in (("acc", True, 0, False), ("acc_max3", True, 3, False),
-                                               ("single", False, 0, False), ("acc_noev", True, 0, True)):
-        ds = rp.EventNeRFDataset.__new__(rp.EventNeRFDataset)
-        ds.frame_idxs = [7]
-        ds.accumulate_evs, ds.batch_size_evs, ds.acc_max_num_evs = accumulate, 64, acc_max
-        ds.num_evs = {7: len(g["events"])}
-        ds.idx_no_successor = {7: g["idx_no_successor"]}
-        ds.num_successor_evs = {7: g["num_successor_evs"]}
-        ds.xy_numEvs_Idx = {7: g["xy_numEvs_Idx"]}
-        ds.events = {7: torch.from_numpy(g["events"])}
-        ds.precompute_evs_poses = False
-        ds.rot_interpolator = Slerp(ts, rots)
-        ds.trans_interpolator = interp1d(x=ts, y=trans, axis=0, kind="cubic", bounds_error=True)
-        ds.device = torch.device("cpu")
-        ds.intrinsics_evs = np.array([14.0, 13.0, 8.0, 6.0])
-        ds.intrinsics = np.array([14.0, 13.0, 8.0, 6.0])
-        ds.poses = torch.eye(4).unsqueeze(0)
-        ds.error_map = None
-        ds.H, ds.W, ds.num_rays = Hs, Ws, 16
-        ds.training = True
-        ds.images = torch.from_numpy(rng.random((1, Hs, Ws, 3)).astype(np.float32))
-        z["images"] = ds.images if "images" not in z else z["images"]
-        ds.negative_event_sampling = negative
-        if negative:
-            coords = [torch.from_numpy(np.stack([rng.integers(0, Ws, 30), rng.integers(0, Hs, 30)], axis=1).astype(np.float32))
-                      for _ in range(3)]
-            ds.no_evs = {7: {"coords": coords, "tss_bds": {"N_ev_chunks": [3], "start_time_us": [2e3, 3.2e4, 6.2e4],
-                                                            "end_time_us": [3.2e4, 6.2e4, 9.2e4]}}}
-            z[tag + "_noev_coords"] = np.stack([c.numpy() for c in coords])
-        drawn = {"randint": [], "rand": [], "choice": [], "random": []}
-        keep = (np.random.randint, np.random.rand, np.random.choice, np.random.random)
+    poses_hf = []
+    for k in range(K):
+        T = np.zeros((3, 4)); T[:, :3] = rots[k].as_matrix(); T[:, 3] = trans[k]
+        poses_hf.append({"ts_ns": ts[k], "pose_c2w": T})
+    z = {"events": ev.astype(np.float32), "events_next_first_ns": np.float64(ev2[0, 2]), "pose_ts": ts,
+         "pose_R": rots.as_matrix(), "pose_t": trans}
+    frames = torch.from_numpy(rng.random((2, Hs, Ws, 3)).astype(np.float32))
+    z["frame_images"] = frames
 
-        def rec(name, fn):
-            def wrapped(*a, **k):
-                r = fn(*a, **k)
-                drawn[name].append(np.array(r, copy=True))
-                return r
-            return wrapped
-        np.random.seed(82)
-        torch.manual_seed(83)
-        np.random.randint, np.random.rand = rec("randint", keep[0]), rec("rand", keep[1])
-        np.random.choice, np.random.random = rec("choice", keep[2]), rec("random", keep[3])
-        try:
+    def parent_init(self, opt, device, type="train", downscale=1, n_test=10, select_frames=None):
+        self.opt, self.device, self.type, self.training = opt, device, type, True
+        self.frame_idxs = np.asarray([7, 9])
+        self.poses_hf = poses_hf
+        self.workspace = "/tmp"
+        self.images_corrupted = False
+        self.negative_event_sampling = opt.negative_event_sampling
+        self.acc_max_num_evs = opt.acc_max_num_evs
+        self.precompute_evs_poses = opt.precompute_evs_poses
+        self.H, self.W, self.H_ev, self.W_ev = Hs, Ws, Hs, Ws
+        self.intrinsics = np.array([14.0, 13.0, 8.0, 6.0])
+        self.intrinsics_evs = np.array([14.0, 13.0, 8.0, 6.0])
+        self.poses = torch.eye(4).unsqueeze(0).repeat(2, 1, 1)
+        self.images = frames
+        self.error_map = None
+        self.num_rays = 16
+        self.hotpixs = None
+    keep = (rp.NGPDataset.__init__, rp.load_event_data_esim, rp.plotting_poses_hf)
+    rp.NGPDataset.__init__ = parent_init
+    rp.load_event_data_esim = lambda path, idxs, hwf=None, img_folder="images": [ev.copy(), ev2.copy()]
+    rp.plotting_poses_hf = lambda *a, **k: None
+    np_keep = (np.random.randint, np.random.rand, np.random.choice, np.random.random)
+    try:
+        for tag, accumulate, acc_max, negative in (("acc", True, 0, False), ("acc_max3", True, 3, False),
+                                                   ("single", False, 0, False), ("acc_noev", True, 0, True)):
+            drawn = {"randint": [], "rand": [], "choice": [], "random": []}
+
+            def rec(name, fn):
+                def wrapped(*a, **k):
+                    r = fn(*a, **k)
+                    drawn[name].append(np.array(r, copy=True))
+                    return r
+                return wrapped
+            np.random.randint, np.random.rand = rec("randint", np_keep[0]), rec("rand", np_keep[1])
+            np.random.choice, np.random.random = rec("choice", np_keep[2]), rec("random", np_keep[3])
+            opt = ap.Namespace(accumulate_evs=accumulate, batch_size_evs=64, out_dim_color=3, datadir="/nonexistent",
+                               mode="esim", negative_event_sampling=negative, acc_max_num_evs=acc_max,
+                               precompute_evs_poses=False)
+            np.random.seed(80)
+            ds = rp.EventNeRFDataset(opt, torch.device("cpu"))
+            if tag == "acc":            # the tables the constructor built for frame 7 (the grouping loop, :1147-1199)
+                z["tab_events"] = ds.events[7]
+                z["tab_xy_numEvs_Idx"] = np.asarray(ds.xy_numEvs_Idx[7], np.int64)
+                z["tab_idx_no_successor"] = np.asarray(ds.idx_no_successor[7], np.int64)
+                z["tab_num_successor_evs"] = np.asarray(ds.num_successor_evs[7], np.int64)
+                z["tab_num_evs"] = np.int64(ds.num_evs[7])
+            if negative:                # the no-event tables of frame 7 (:1283-1351) and the choices that thinned them
+                ne = ds.no_evs[7]
+                z["noev_n_chunks"] = np.int64(ne["tss_bds"]["N_ev_chunks"][0])
+                z["noev_start_us"] = np.asarray(ne["tss_bds"]["start_time_us"], np.float64)
+                z["noev_end_us"] = np.asarray(ne["tss_bds"]["end_time_us"], np.float64)
+                for j, c in enumerate(ne["coords"]):
+                    z[f"noev_coords{j}"] = c
+                nch = int(z["noev_n_chunks"])
+                for j in range(nch):
+                    z[f"noev_choice{j}"] = np.asarray(drawn["choice"][j], np.int64)
+                for name in drawn:
+                    drawn[name] = []
+                drawn_ctor_done = True
+            for name in drawn:
+                drawn[name] = []
+            np.random.seed(82)
+            torch.manual_seed(83)
             out = ds.collate([0])
-        finally:
-            np.random.randint, np.random.rand, np.random.choice, np.random.random = keep
-        for k in ("rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols", "rays_o", "rays_d", "images"):
-            z[f"{tag}_{k}"] = out[k]
-        z[f"{tag}_frame_images"] = ds.images
-        if negative:
-            for k in ("rays_no_evs_o1", "rays_no_evs_d1", "rays_no_evs_o2", "rays_no_evs_d2"):
+            for k in ("rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols", "rays_o", "rays_d", "images"):
                 z[f"{tag}_{k}"] = out[k]
-        for name, lst in drawn.items():
-            if lst:
-                z[f"{tag}_draw_{name}_first"] = np.asarray(lst[0])
-                rest = [np.asarray(v).reshape(-1) for v in lst[1:]]
-                z[f"{tag}_draw_{name}_rest"] = np.concatenate(rest) if rest else np.zeros(0)
+            if negative:
+                for k in ("rays_no_evs_o1", "rays_no_evs_d1", "rays_no_evs_o2", "rays_no_evs_d2"):
+                    z[f"{tag}_{k}"] = out[k]
+            for name, lst in drawn.items():
+                if lst:
+                    z[f"{tag}_draw_{name}_first"] = np.asarray(lst[0])
+                    rest = [np.asarray(v).reshape(-1) for v in lst[1:]]
+                    z[f"{tag}_draw_{name}_rest"] = np.concatenate(rest) if rest else np.zeros(0)
+    finally:
+        rp.NGPDataset.__init__, rp.load_event_data_esim, rp.plotting_poses_hf = keep
+        np.random.randint, np.random.rand, np.random.choice, np.random.random = np_keep
     save("ref_collate", **z)
 
 

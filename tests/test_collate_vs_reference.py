@@ -1,7 +1,7 @@
-"""enerf_amd's event-pair sampling against the reference's OWN EventNeRFDataset.collate (nerf/provider.py:1364-1480), run by
-oracle/make_golden.py: gold_collate on a dataset object filled in by hand (its constructor reads dataset files; the
-per-pixel tables come from oracle/event_collate.group_events -- NOT pinned by this fixture) with numpy's global draws
-recorded: tests/golden/ref_collate.npz.  The same draws go into event_sampler.sample_event_pairs / no_event_rays / PoseTrack /
+"""enerf_amd's event-pair sampling against the reference's OWN EventNeRFDataset (nerf/provider.py:1105-1500), constructed and
+collated by oracle/make_golden.py: gold_collate with only its input/output stubbed (the parent's file-reading __init__, the
+.npy reader, the pose plot): the constructor's per-pixel grouping loop, the no-event tables of load_events_at_frame_idxs and
+collate are the reference's code, numpy's global draws recorded: tests/golden/ref_collate.npz.  The same draws go into event_sampler.sample_event_pairs / no_event_rays / PoseTrack /
 get_event_rays on the CPU, and -- marked gpu -- into the one-launch device route (csrc/event_pairs.hip): pair ends and
 polarity sums exact, rays to 1e-5."""
 import numpy as np
@@ -23,6 +23,40 @@ def _tables_and_track(z, dev="cpu"):
     from enerf_amd.pose_interp import PoseTrack
     t = build_event_tables(torch.from_numpy(z["events"]).to(dev))
     return t, PoseTrack(z["pose_ts"], z["pose_R"], z["pose_t"], device=dev)
+
+
+def test_event_tables_equal_the_reference_constructor(z):
+    """The grouping loop of the constructor (:1147-1199): events sorted by time, grouped per pixel in first-occurrence
+    order, pixels with one event dropped; per-pixel counts and offsets, the last event of every pixel, successors."""
+    t, _ = _tables_and_track(z)
+    assert np.array_equal(t["events"].numpy(), z["tab_events"])
+    assert np.array_equal(t["num_at_xy"].numpy(), z["tab_xy_numEvs_Idx"][:, 0])
+    assert np.array_equal(t["first_at_xy"].numpy(), z["tab_xy_numEvs_Idx"][:, 1])
+    assert np.array_equal(t["no_successor"].nonzero().flatten().numpy(), z["tab_idx_no_successor"])
+    assert np.array_equal(t["num_successor"].numpy(), z["tab_num_successor_evs"])
+    assert t["events"].shape[0] == int(z["tab_num_evs"])
+
+
+def test_no_event_tables_equal_the_reference_loader(z):
+    """load_events_at_frame_idxs' no-event tables (:1283-1351): chunks of ~20 ms between this batch's first stamp and the
+    next batch's, the pixels without an event per chunk, thinned to 1 / N by np.random.choice (the recorded draws)."""
+    from enerf_amd.event_sampler import build_no_event_tables
+    ev = z["events"].astype(np.float64)
+    start_us, end_us = 1e-3 * ev[0, 2], 1e-3 * float(z["events_next_first_ns"])
+    n = int(z["noev_n_chunks"])
+    out = build_no_event_tables(torch.from_numpy(ev), 12, 16, start_us, end_us,
+                                keep=lambda j, cand: z[f"noev_choice{j}"] - 1)       # the reference numbers pixels from 1
+    assert out["N_ev_chunks"] == n
+    np.testing.assert_allclose(out["start_time_us"], z["noev_start_us"], rtol=1e-6)   # (the reference keeps them as fp32)
+    np.testing.assert_allclose(out["end_time_us"], z["noev_end_us"], rtol=1e-6)
+    for j in range(n):
+        assert np.array_equal(out["coords"][j].numpy(), z[f"noev_coords{j}"]), j
+    # and the candidates the reference drew from are the ones the restatement lists: every recorded choice is a candidate
+    seen = []
+    build_no_event_tables(torch.from_numpy(ev), 12, 16, start_us, end_us,
+                          keep=lambda j, cand: (seen.append(cand.numpy()), cand[:0])[1])
+    for j in range(n):
+        assert np.all(np.isin(z[f"noev_choice{j}"] - 1, seen[j])) and len(z[f"noev_choice{j}"]) == int(len(seen[j]) / n)
 
 
 def _u_end(t, starts, ends, acc_max):
@@ -74,8 +108,10 @@ def test_no_event_rays_equal_the_reference_collate(z):
     rest = z[f"{tag}_draw_randint_rest"]
     chunk, idx = int(rest[64]), rest[65:65 + 32].astype(np.int64)         # after the 64 window ends: the chunk, then 32 pixels
     u = z[f"{tag}_draw_random_first"]                                      # np.random.random((32, 2))
-    coords = [torch.from_numpy(c) for c in z[f"{tag}_noev_coords"]]
-    no_evs = {"coords": coords, "N_ev_chunks": 3, "start_time_us": [2e3, 3.2e4, 6.2e4], "end_time_us": [3.2e4, 6.2e4, 9.2e4]}
+    n = int(z["noev_n_chunks"])
+    coords = [torch.from_numpy(z[f"noev_coords{j}"]) for j in range(n)]
+    no_evs = {"coords": coords, "N_ev_chunks": n, "start_time_us": z["noev_start_us"].tolist(),
+              "end_time_us": z["noev_end_us"].tolist()}
     r = no_event_rays(no_evs, track, INTR, 64, draws={"chunk": chunk, "idx": torch.from_numpy(idx), "u": torch.from_numpy(u)})
     for k in ("rays_no_evs_o1", "rays_no_evs_d1", "rays_no_evs_o2", "rays_no_evs_d2"):
         np.testing.assert_allclose(r[k].numpy(), z[f"{tag}_{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
