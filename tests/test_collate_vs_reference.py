@@ -131,3 +131,16 @@ def test_device_launch_equals_the_reference_collate(z, tag, acc_max):
     assert np.array_equal(r["pols"].cpu().numpy(), z[f"{tag}_pols"])
     for k in ("rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2"):
         np.testing.assert_allclose(r[k].cpu().numpy(), z[f"{tag}_{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_frame_rays_of_collate_equal_the_reference(z):
+    """The frame entries of the same collate call (:1414-1416, :1488-1493): get_rays with 16 pixels drawn from torch's
+    stream, the frame's colours gathered at them."""
+    from enerf_amd.events import get_rays
+    torch.manual_seed(83)
+    r = get_rays(torch.eye(4).unsqueeze(0), INTR, 12, 16, 16)
+    np.testing.assert_allclose(r["rays_o"].numpy(), z["acc_rays_o"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r["rays_d"].numpy(), z["acc_rays_d"], rtol=1e-6, atol=1e-7)
+    images = torch.from_numpy(z["frame_images"])[[0]]
+    got = torch.gather(images.view(1, -1, 3), 1, torch.stack(3 * [r["inds"]], -1))
+    assert np.array_equal(got.numpy(), z["acc_images"])
