@@ -56,6 +56,48 @@ def _grad_check(model, z, prefix, tol=2e-3):
     assert abs(got - float(z[f"{prefix}_g_emb_abs_sum"])) < 1e-3 * float(z[f"{prefix}_g_emb_abs_sum"])
 
 
+def test_drop_in_modules_on_the_gpu_reproduce_the_reference_python(monkeypatch):
+    """The boundary as the reference uses it: the restated renderer op by op over the pybind11 modules _raymarching /
+    _gridencoder / _shencoder (enerf_amd/ext -- what an unmodified nerf/renderer.py imports), every fused route off, the
+    nets as the plain nn.Linear loop on torch's GEMMs, autograd: the same fixture, fp32 throughout."""
+    import importlib
+    import sys
+    import enerf_amd.raymarching as rmod, enerf_amd.gridencoder as gmod, enerf_amd.shencoder as smod
+    from enerf_amd import ext as ext_pkg, fused_mlp, fused_network, fused_render, density_update, frame
+    from enerf_amd.ext import build as eb
+    z = golden("ref_cuda_ray")
+    model = _bring_to_fixture_state(z, monkeypatch).cuda()
+    eb.build(verbose=False)
+    ext_pkg.activate()
+    mods = [importlib.import_module(n) for n in ("_raymarching", "_gridencoder", "_shencoder")]
+    try:
+        for obj, name, val in ((rmod, "_backend", mods[0]), (gmod, "_backend", mods[1]), (smod, "_backend", mods[2]),
+                               (gmod, "_layout_support", {}), (fused_render, "ENABLED", False), (fused_network, "ENABLED", False),
+                               (density_update, "ENABLED", False), (fused_mlp, "ENABLED", False), (frame, "FRAME_ENABLED", False)):
+            monkeypatch.setattr(obj, name, val)
+        dev = "cuda"
+        o, d = torch.from_numpy(z["rays_o"]).to(dev), torch.from_numpy(z["rays_d"]).to(dev)
+        for step, (perturb, force, gamma) in enumerate(((True, False, 0.0), (False, True, 1.0 / 256))):
+            model.zero_grad()
+            out = model.render(o, d, staged=False, bg_color=torch.full((3,), 0.25, device=dev), perturb=perturb,
+                               force_all_rays=force, dt_gamma=gamma, max_steps=256)
+            ((out["image"] ** 2).sum() + 0.1 * out["depth"].sum()).backward()
+            torch.cuda.synchronize()
+            assert torch.equal(model.step_counter[:4].cpu(), torch.from_numpy(z[f"train{step}_step_counter"])), step
+            np.testing.assert_allclose(out["image"].detach().cpu().numpy(), z[f"train{step}_image"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), z[f"train{step}_depth"], rtol=1e-4, atol=1e-5)
+            _grad_check(model, z, f"train{step}", tol=2e-4)
+        model.eval()
+        with torch.no_grad():
+            for tag, gamma in (("infer", 0.0), ("infer_gamma", 1.0 / 128)):
+                out = model.render(o, d, staged=False, bg_color=None, perturb=False, dt_gamma=gamma, max_steps=256)
+                np.testing.assert_allclose(out["image"].cpu().numpy(), z[f"{tag}_image"], rtol=1e-4, atol=2e-5)
+                np.testing.assert_allclose(out["depth"].cpu().numpy(), z[f"{tag}_depth"], rtol=1e-4, atol=2e-5)
+    finally:
+        for n in ext_pkg.MODULES:
+            sys.modules.pop(n, None)
+
+
 def test_product_on_the_gpu_reproduces_the_reference_python(monkeypatch, mlp32_mode):
     z = golden("ref_cuda_ray")
     model = _bring_to_fixture_state(z, monkeypatch).cuda()
