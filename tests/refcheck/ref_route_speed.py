@@ -82,7 +82,8 @@ def main():
     dev = torch.device("cuda", 0)
     os.sched_setaffinity(0, set(range(8, 16)))
     batches = bench.build_batches(8, RAYS, dev, 0, BOUND)
-    rows = [run(k, batches, dev) for k in ("reference kernels", "drop-in", "product")]
+    only = os.environ.get("REF_ROUTE_ONLY")                   # one route only (for a rocprofv3 --stats run of it)
+    rows = [run(k, batches, dev) for k in ("reference kernels", "drop-in", "product") if only in (None, k)]
     ref = rows[0]["ms_per_step"]
     for r in rows:
         r["speedup_vs_reference_kernels"] = ref / r["ms_per_step"]
