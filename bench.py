@@ -141,6 +141,8 @@ def parse():
                     help="only the launch plumbing: rendezvous, barrier, MAX all-reduce, rank 0 prints one JSON line; no "
                          "compute, no GPU needed (tests/test_bench_launch.py drives `--gpus 2 --backend gloo` through it)")
     ap.add_argument("--force-device", type=int, default=None, help="put every rank on this device index")
+    ap.add_argument("--mlp-exact", action="store_true",
+                    help="development: the main region on the exact-fp32 MFMA kernels (enerf_mlp32_precision(0))")
     return ap.parse_args()
 
 
@@ -352,6 +354,8 @@ def main():
     from enerf_amd.trainer import TrainHarness
     from enerf_amd.events import EventOptions
 
+    if args.mlp_exact:
+        _lib.lib().enerf_mlp32_precision(0)
     if args.march_bg_blocks:
         _lib.lib().enerf_debug_march_bg_blocks(args.march_bg_blocks)
     if args.no_march_clip:

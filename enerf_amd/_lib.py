@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libenerf_hip.so")
+if os.environ.get("ENERF_LIB_PATH"):          # development aid: an A/B build of the same sources (tools/dev)
+    LIB_PATH = os.environ["ENERF_LIB_PATH"]
 
 _c = ctypes
 _vp, _u32, _f32, _int, _sz = _c.c_void_p, _c.c_uint32, _c.c_float, _c.c_int, _c.c_size_t
@@ -123,6 +125,10 @@ SIGNATURES = {
     "enerf_dp_probe": [],
     "enerf_dp_finish": [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _vp],
     "enerf_abi_version": [],
+    "enerf_nerf_mlp_available": [],
+    "enerf_debug_nerf_mlp_fused": [_int],
+    "enerf_nerf_mlp_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
+    "enerf_nerf_mlp_backward": [_vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp],
 }
 
 F32, F16, BF16 = 0, 1, 2

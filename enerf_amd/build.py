@@ -15,18 +15,19 @@ LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libenerf_hip.so")
 SOURCES = ["runtime.hip", "raymarching.hip", "gridencoder.hip", "shencoder.hip", "ffmlp.hip", "ffmlp_wgrad.hip",
-           "mlp32.hip", "mlp32s.hip", "mlp32s_f16.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "dp_tail.hip", "train_step.hip"]
+           "mlp32.hip", "mlp32s.hip", "mlp32s_f16.hip", "nerf_mlp.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "dp_tail.hip", "train_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 # Per-file extras.  ffmlp.hip (forward + dgrad) keeps its MFMA accumulators in arch VGPRs: every accumulator is
 # post-processed by VALU code (activation, 16-bit conversion) right away, and the default AGPR form costs a
 # v_accvgpr_read/write pair per element.  The weight-gradient kernels hold up to 192 accumulator registers and need
 # the AGPR half of the register file, so they live in their own translation unit without the flag.
-EXTRA = {"ffmlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "mlp32s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-         "mlp32s_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# (ENERF_MFMA_VGPR_FORM arms csrc/mfma_guard.h: that form lets a zero-initialised MFMA's result land on its operands)
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DENERF_MFMA_VGPR_FORM"]
+EXTRA = {"ffmlp.hip": _VGPR_FORM, "mlp32s.hip": _VGPR_FORM, "mlp32s_f16.hip": _VGPR_FORM, "nerf_mlp.hip": _VGPR_FORM}
 # development aid: extra -D flags for every file (e.g. ENERF_DEFINES="-DENERF_BIN_TIMING" python -m enerf_amd.build --force)
 FLAGS += os.environ.get("ENERF_DEFINES", "").split()
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ffmlp_common.h"), os.path.join(CSRC, "mlp32_common.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ffmlp_common.h"), os.path.join(CSRC, "mlp32_common.h"), os.path.join(CSRC, "mlp32s_ops.h"), os.path.join(CSRC, "mfma_guard.h"),
            os.path.join(_HERE, "..", "include", "enerf_hip.h")]
 
 

@@ -81,18 +81,49 @@ def _warn(what, err):
                   f"Trainer.load_checkpoint does, nerf/utils.py:1396-1415)")
 
 
+def _numpy_scalar_globals():
+    """What pickling a numpy scalar (np.float64(3.1)) refers to: the scalar constructor, the dtype class and its
+    instances' types.  Names moved between numpy 1.x and 2.x; whatever exists is listed."""
+    import numpy as np
+    out = [np.dtype, np.float64, np.float32, np.int64, np.int32, np.bool_]
+    for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+        try:
+            out.append(getattr(__import__(mod, fromlist=["scalar"]), "scalar"))
+        except Exception:                       # noqa: BLE001
+            pass
+    for name in ("Float64DType", "Float32DType", "Int64DType", "Int32DType", "BoolDType"):
+        t = getattr(getattr(np, "dtypes", None), name, None)
+        if t is not None:
+            out.append(t)
+    return out
+
+
 def load_checkpoint(harness, checkpoint, model_only=False, map_location=None, trusted=False):
     """`checkpoint`: a path / file object, or an already loaded dict.  Mirrors Trainer.load_checkpoint: a bare
     state_dict is accepted; the model loads non-strictly and the (missing, unexpected) key lists are returned; the
     sample budget and mean density follow when the model marches on the occupancy grid; optimizer / scheduler / scaler
     are restored when present and wanted, and -- as in the reference (nerf/utils.py:1396-1415) -- one of those failing
     to load is a warning, not an error.
-    Files are read with `weights_only=True` (the reference-format dict is tensors, numbers, strings, lists and dicts: it
-    loads that way, whoever wrote it); `trusted=True` allows the full unpickler for a file that holds more."""
+    Files are read with `weights_only=True`, with numpy's scalar reconstruction allow-listed: the reference-format dict
+    is tensors, numbers, strings, lists and dicts, plus -- when the run kept a metric instead of the loss
+    (`use_loss_as_metric=False`, nerf/utils.py:275-281,1278-1280) -- `numpy.float64` values of `PSNRMeter.measure()` in
+    `stats['results']` / `stats['best_result']`.  A file that holds anything else fails with a hint; `trusted=True`
+    allows the full unpickler for it."""
     m = harness.model
     if not isinstance(checkpoint, dict):
         dev = map_location or next(m.parameters()).device
-        checkpoint = torch.load(checkpoint, map_location=dev, weights_only=not trusted)
+        if trusted:
+            checkpoint = torch.load(checkpoint, map_location=dev, weights_only=False)
+        else:
+            import pickle
+            try:
+                with torch.serialization.safe_globals(_numpy_scalar_globals()):
+                    checkpoint = torch.load(checkpoint, map_location=dev, weights_only=True)
+            except pickle.UnpicklingError as e:
+                raise pickle.UnpicklingError(
+                    f"{e}\n[enerf_amd.checkpoint] the file holds objects outside the weights-only allow-list (tensors, "
+                    f"numbers, strings, containers, numpy scalars); if you trust its origin, load it with "
+                    f"load_checkpoint(..., trusted=True)") from e
     if "model" not in checkpoint:
         m.load_state_dict(checkpoint)
         return [], []

@@ -71,7 +71,7 @@ uint32_t num_cus();                    // compute units of the current device (2
 int workspace_family_enter(int family, hipStream_t s);
 // process-wide session state belongs to the first device that used it: != 0 (error set) when another device is current
 int single_device_guard(const char* what);
-enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_AABB = 7, WS_AABB_CALL = 8, WS_FFMLP_W = 9, WS_SLOTS = 10 };
+enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_AABB = 7, WS_AABB_CALL = 8, WS_FFMLP_W = 9, WS_NERF_FRAGS = 10, WS_NERF_PART = 11, WS_SLOTS = 12 };
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 

@@ -2,6 +2,7 @@
 // accumulators in arch VGPRs) and ffmlp_wgrad.hip (weight gradients, accumulators in AGPRs).  See ffmlp.hip for the
 // design notes.
 #pragma once
+#include "mfma_guard.h"
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -24,11 +25,16 @@ template <typename E> struct V;
 template <> struct V<__bf16> { using x8 = bf16x8; using x4 = bf16x4; };
 template <> struct V<_Float16> { using x8 = f16x8; using x4 = f16x4; };
 
+// (ENERF_MFMA_GUARD: mfma_guard.h -- a zero-initialised MFMA's result must not land on its own operands)
 __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    ENERF_MFMA_GUARD(d, a, b, c);
+    return d;
 }
 __device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    ENERF_MFMA_GUARD(d, a, b, c);
+    return d;
 }
 
 #define K_ACT 10.0f

@@ -777,10 +777,12 @@ struct ReduceJob {
     const float* partial;
     uint32_t nblocks, NW;
     WDst dst;
+    uint32_t stride;          // floats between two workgroups' partial sums (0: NW)
 };
 
 __device__ __forceinline__ void reduce_w_body(const float* __restrict__ partial, uint32_t nblocks, uint32_t NW,
-                                              const WDst& gw, uint32_t blk, uint32_t* found_inf) {
+                                              const WDst& gw, uint32_t blk, uint32_t* found_inf, uint32_t stride = 0) {
+    const size_t ST = stride ? stride : NW;
     // 64 weights per workgroup; each of the 16 waves sums every 16th partial block with four independent chains
     // (fixed order), then the waves' sums are combined in a fixed order: deterministic.
     __shared__ float acc[16][64];
@@ -790,12 +792,12 @@ __device__ __forceinline__ void reduce_w_body(const float* __restrict__ partial,
     if (i < NW) {
         uint32_t b = part;
         for (; b + 48 < nblocks; b += 64) {
-            s0 += partial[(size_t)b * NW + i];
-            s1 += partial[(size_t)(b + 16) * NW + i];
-            s2 += partial[(size_t)(b + 32) * NW + i];
-            s3 += partial[(size_t)(b + 48) * NW + i];
+            s0 += partial[(size_t)b * ST + i];
+            s1 += partial[(size_t)(b + 16) * ST + i];
+            s2 += partial[(size_t)(b + 32) * ST + i];
+            s3 += partial[(size_t)(b + 48) * ST + i];
         }
-        for (; b < nblocks; b += 16) s0 += partial[(size_t)b * NW + i];
+        for (; b < nblocks; b += 16) s0 += partial[(size_t)b * ST + i];
     }
     acc[part][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -818,8 +820,8 @@ __global__ void __launch_bounds__(1024) k_mlp32_reduce_w(const float* __restrict
 // two networks' weight gradients in one launch (the first job was left pending by enerf_mlp32_defer_reduce)
 __global__ void __launch_bounds__(1024) k_mlp32_reduce_w2(ReduceJob a, ReduceJob b, uint32_t* found_inf) {
     const uint32_t na = (a.NW + 63u) / 64u;
-    if (blockIdx.x < na) reduce_w_body(a.partial, a.nblocks, a.NW, a.dst, blockIdx.x, found_inf);
-    else reduce_w_body(b.partial, b.nblocks, b.NW, b.dst, blockIdx.x - na, found_inf);
+    if (blockIdx.x < na) reduce_w_body(a.partial, a.nblocks, a.NW, a.dst, blockIdx.x, found_inf, a.stride);
+    else reduce_w_body(b.partial, b.nblocks, b.NW, b.dst, blockIdx.x - na, found_inf, b.stride);
 }
 
 static const int32_t* g_valid_rows = nullptr;      // enerf_mlp32_valid_rows
@@ -838,6 +840,9 @@ int g_precision = 1;                // enerf_mlp32_precision: 0 = fp32 MFMA (bit
 inline bool ops16() { return g_precision == 2 || g_precision == 3; }
 bool g_io16 = false;                // ffmlp16_forward / _backward: X, Y, dY, dX are 16-bit row-major tensors
 bool g_recompute = true;            // enerf_mlp32_recompute: the split backward recomputes the hidden activations
+// three hidden layers (the FFMLP colour net on 16-bit operands) recompute whatever the switch says: mlp32s.hip has no
+// activation-loading instance of that shape
+inline bool recompute_for(uint32_t num_hidden) { return g_recompute || num_hidden == 3; }
 uint32_t g_wgrad_blocks = 0;        // 0: 768 workgroups for one hidden layer, 512 otherwise (measured optimum)
 
 uint32_t g_fwd_blocks = 0;          // 0: default cap of the forward grid
@@ -991,7 +996,7 @@ static int mlp32_forward_impl(const float* X, WSrc W, uint32_t B, uint32_t in_di
     const bool sigma_only = num_hidden == 1 && !fb && !Y && y0_exp && x_layout == 1;
     if (g_precision != 0) {
         // (a training forward whose backward recomputes the activations is the inference kernel)
-        const bool store_fb = fb != nullptr && !(g_recompute && split_bwd_shape(num_hidden, out_dim, x_layout));
+        const bool store_fb = fb != nullptr && !(recompute_for(num_hidden) && split_bwd_shape(num_hidden, out_dim, x_layout));
         (g_precision == 3 ? mlp32s_f16_launch_fwd : mlp32s_launch_fwd)(
             g_precision == 1 ? 3 : 1, num_hidden, store_fb, x_layout, sigma_only, X, W, fb, Y, B, out_dim, activation,
             output_activation, y_stride, y0_exp, sh_dirs, grid, lds, s, prof.start(), prof.stop(), g_io16);
@@ -1141,7 +1146,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         (void)bb;
         (g_precision == 3 ? mlp32s_f16_launch_bwd : mlp32s_launch_bwd)(
             g_precision == 1 ? 3 : 1, num_hidden, x_layout, dys, X, W, fb, dX, partial, B, out_dim, activation, wgrid, s,
-            prof.start(), prof.stop(), g_recompute || g_io16, g_io16);
+            prof.start(), prof.stop(), recompute_for(num_hidden) || g_io16, g_io16);
     } else if (fused) {
         (void)bb;
         if (num_hidden == 1) { if (x_layout == 0) MLP32_BF2(1, 0); else MLP32_BF2(1, 1); }
@@ -1155,7 +1160,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
 #undef MLP32_BWD2
 #undef MLP32_BA
     if (defer) {
-        g_pending = ReduceJob{partial, wgrid, NW, dW};
+        g_pending = ReduceJob{partial, wgrid, NW, dW, 0};
         g_have_pending = true;
     } else {
         // enerf_mlp32_signal_next_reduce: the reduce launch carries the signal event as its stop event -- a
@@ -1176,13 +1181,141 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
         if (g_have_pending) {
             g_have_pending = false;
             hipExtLaunchKernelGGL(k_mlp32_reduce_w2, dim3(div_up(g_pending.NW, 64) + div_up(NW, 64)), dim3(1024), 0, s,
-                                  nullptr, sig, 0, g_pending, ReduceJob{partial, wgrid, NW, dW}, amp_state().found_inf);
+                                  nullptr, sig, 0, g_pending, ReduceJob{partial, wgrid, NW, dW, 0}, amp_state().found_inf);
         } else {
             hipExtLaunchKernelGGL(k_mlp32_reduce_w, dim3(div_up(NW, 64)), dim3(1024), 0, s, nullptr, sig, 0, partial,
                                   wgrid, NW, dW, amp_state().found_inf);
         }
     }
     ENERF_LAUNCH_CHECK("mlp32_backward");
+    return 0;
+}
+
+// ---- nerf/network.py's two nets as one launch per direction (csrc/nerf_mlp.hip) -------------------------------------
+static bool g_nerf_fused = true;                 // enerf_debug_nerf_mlp_fused
+static const float* g_nerf_built[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+static uint32_t g_nerf_built_cols = 0, g_nerf_built_out = 0;
+static uint64_t g_nerf_built_gen = 0;
+
+// 1 when enerf_nerf_mlp_forward / _backward serve the process's current arithmetic (split-bf16, recomputing backward)
+int enerf_nerf_mlp_available(void) { return (g_nerf_fused && g_precision == 1 && g_recompute && g_fused_bwd) ? 1 : 0; }
+// testing aid: 0 = callers that ask enerf_nerf_mlp_available() fall back to one launch per net; returns the previous value
+int enerf_debug_nerf_mlp_fused(int on) {
+    const int prev = g_nerf_fused ? 1 : 0;
+    if (on >= 0) g_nerf_fused = on != 0;
+    return prev;
+}
+
+static int nerf_args_ok(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
+                        const char* what) {
+    if (!wseg_s || !wseg_c || !wseg_s[0] || !wseg_s[3] || !wseg_c[0] || !wseg_c[1] || !wseg_c[3]) {
+        set_error("%s: weight segments {first layer, hidden 0, -, output layer} of both nets are required", what);
+        return ENERF_E_BADARG;
+    }
+    if (w0_cols_c != 31 && w0_cols_c != 32) {
+        set_error("%s: the colour net's first-layer rows are 31 (or 32, padded) floats [SH 16 | geo_feat 15]", what);
+        return ENERF_E_BADARG;
+    }
+    if (out_c == 0 || out_c > 16) {
+        set_error("%s: colour outputs must be in [1, 16], got %u", what, out_c);
+        return ENERF_E_BADARG;
+    }
+    if (g_precision != 1) {
+        set_error("%s: serves the split-bf16 arithmetic (enerf_mlp32_precision 1) only; ask enerf_nerf_mlp_available()", what);
+        return ENERF_E_BADARG;
+    }
+    return 0;
+}
+
+// the operand fragments of the five matrices (flags bit 0: the caller vouches that they were built for these very
+// weights -- same pointers, values unchanged since -- by an earlier call; anything else rebuilds them: one 44-wave launch)
+static uint32_t* nerf_frags(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
+                            uint32_t flags, hipStream_t s) {
+    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfFragBytes);
+    if (!frags) return nullptr;
+    const float* w[5] = {wseg_s[0], wseg_s[3], wseg_c[0], wseg_c[1], wseg_c[3]};
+    bool same = (flags & 1u) && g_nerf_built_cols == w0_cols_c && g_nerf_built_out == out_c &&
+                g_nerf_built_gen == workspace_generation();
+    for (int k = 0; k < 5; k++) same = same && g_nerf_built[k] == w[k];
+    if (!same) {
+        nerf_launch_frags(w[0], w[1], w[2], w[3], w[4], w0_cols_c, out_c, frags, s);
+        for (int k = 0; k < 5; k++) g_nerf_built[k] = w[k];
+        g_nerf_built_cols = w0_cols_c;
+        g_nerf_built_out = out_c;
+        g_nerf_built_gen = workspace_generation();
+    }
+    return frags;
+}
+
+// feats [16, Bp, 2] (grid_encode_forward's level-major layout 2), dirs [B, 3] -> sigma [B] = exp(h0), rgb [B, out_c] =
+// sigmoid(colour net([h0 | geo_feat | SH(dirs)])).  Honours enerf_mlp32_valid_rows.
+int enerf_nerf_mlp_forward(const float* feats, const float* dirs, const float* const* wseg_s, const float* const* wseg_c,
+                           uint32_t w0_cols_c, uint32_t B, uint32_t out_c, float* sigma, float* rgb, uint32_t flags,
+                           enerf_stream_t stream) {
+    if (B == 0) return 0;
+    if (int e = nerf_args_ok(wseg_s, wseg_c, w0_cols_c, out_c, "nerf_mlp_forward")) return e;
+    if (!feats || !dirs || !sigma || !rgb) ENERF_BADARG("nerf_mlp_forward: feats, dirs, sigma and rgb are required");
+    if (int eg = single_device_guard("nerf_mlp_forward")) return eg;
+    hipStream_t s = (hipStream_t)stream;
+    if (int ew = workspace_family_enter(1, s)) return ew;
+    uint32_t* frags = nerf_frags(wseg_s, wseg_c, w0_cols_c, out_c, flags, s);
+    if (!frags) return ENERF_E_NOMEM;
+    ProfScope prof(ENERF_K_FFMLP_FWD, s, true);
+    prof.units((double)B);
+    nerf_launch_fwd(feats, dirs, frags, sigma, rgb, B, out_c, g_valid_rows, g_valid_base, g_valid_cap,
+                    pgrid(B, g_fwd_blocks ? g_fwd_blocks : 768), s, prof.start(), prof.stop());
+    ENERF_LAUNCH_CHECK("nerf_mlp_forward");
+    return 0;
+}
+
+// Gradients of both nets' weights (dwseg_*: overwritten when `overwrite`, else added to) and of feats (dfeat [16, Bp, 2])
+// given g_rgb [B, out_c], g_sigma [B] (multiplied by sigma_scale on the fly) and the forward's rgb.  Honours
+// enerf_mlp32_valid_rows and enerf_mlp32_signal_next_reduce (the reduce launch carries the signal).
+int enerf_nerf_mlp_backward(const float* g_rgb, const float* g_sigma, float sigma_scale, const float* feats,
+                            const float* dirs, const float* rgb, const float* const* wseg_s, const float* const* wseg_c,
+                            float* const* dwseg_s, float* const* dwseg_c, uint32_t w0_cols_c, uint32_t overwrite,
+                            uint32_t B, uint32_t out_c, float* dfeat, uint32_t flags, enerf_stream_t stream) {
+    if (B == 0) return 0;
+    if (int e = nerf_args_ok(wseg_s, wseg_c, w0_cols_c, out_c, "nerf_mlp_backward")) return e;
+    if (!dwseg_s || !dwseg_c || !dwseg_s[0] || !dwseg_s[3] || !dwseg_c[0] || !dwseg_c[1] || !dwseg_c[3])
+        ENERF_BADARG("nerf_mlp_backward: gradient segments of both nets are required");
+    if (!g_rgb || !g_sigma || !feats || !dirs || !rgb || !dfeat)
+        ENERF_BADARG("nerf_mlp_backward: g_rgb, g_sigma, feats, dirs, rgb and dfeat are required");
+    if (int eg = single_device_guard("nerf_mlp_backward")) return eg;
+    hipStream_t s = (hipStream_t)stream;
+    if (int ew = workspace_family_enter(1, s)) return ew;
+    uint32_t* frags = nerf_frags(wseg_s, wseg_c, w0_cols_c, out_c, flags, s);
+    if (!frags) return ENERF_E_NOMEM;
+    const uint32_t grid = pgrid(B, g_bwd_blocks ? g_bwd_blocks : 256);
+    float* partial = (float*)workspace(WS_NERF_PART, sizeof(float) * (size_t)grid * kNerfPartialStride);
+    if (!partial) return ENERF_E_NOMEM;
+    {
+        ProfScope prof(ENERF_K_FFMLP_BWD, s, true);
+        prof.units((double)B);
+        nerf_launch_bwd(feats, dirs, g_rgb, rgb, g_sigma, sigma_scale, frags, dfeat, partial, B, out_c, g_valid_rows,
+                        g_valid_base, g_valid_cap, grid, s, prof.start(), prof.stop());
+    }
+    WDst ds, dc;
+    for (int k = 0; k < 4; k++) {
+        ds.seg[k] = (k == 0 || k == 3) ? dwseg_s[k] : nullptr;
+        dc.seg[k] = (k == 0 || k == 1 || k == 3) ? dwseg_c[k] : nullptr;
+    }
+    ds.w0_cols = IN; ds.nerf_perm = 0; ds.overwrite = overwrite;
+    dc.w0_cols = w0_cols_c; dc.nerf_perm = 1; dc.overwrite = overwrite;
+    hipEvent_t sig = nullptr;
+    if (g_signal_armed) {
+        g_signal_armed = false;
+        if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming) != hipSuccess)
+            g_signal_event = nullptr;
+        sig = g_signal_event;
+        g_signal_recorded = sig != nullptr;
+    }
+    const uint32_t nw_c = HID * IN + HID * HID + out_c * HID;
+    ProfScope prof_reduce(ENERF_K_MLP_REDUCE, s);
+    hipExtLaunchKernelGGL(k_mlp32_reduce_w2, dim3(div_up(kNerfSigmaWords, 64) + div_up(nw_c, 64)), dim3(1024), 0, s, nullptr,
+                          sig, 0, ReduceJob{partial, grid, kNerfSigmaWords, ds, kNerfPartialStride},
+                          ReduceJob{partial + kNerfSigmaWords, grid, nw_c, dc, kNerfPartialStride}, amp_state().found_inf);
+    ENERF_LAUNCH_CHECK("nerf_mlp_backward");
     return 0;
 }
 

@@ -280,6 +280,22 @@ void mlp32s_f16_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, con
                            uint32_t act, uint32_t grid, hipStream_t s, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr, bool recompute = false, bool io16 = false);
 
+// nerf_mlp.hip: sigma + colour net of nerf/network.py as one launch per direction (split-bf16).  `frags`: 44 operand
+// fragments of 2 KiB built by nerf_launch_frags from the five weight matrices; `partial`: grid x kNerfPartialStride floats
+// of per-workgroup weight-gradient sums, [sigma blob 3072 | colour blob 6144 + 64 out_c] each.
+constexpr uint32_t kNerfFragBytes = 44 * 2048;
+constexpr uint32_t kNerfPartialStride = (HID * IN + 16 * HID) + (HID * IN + HID * HID + 16 * HID);
+constexpr uint32_t kNerfSigmaWords = HID * IN + 16 * HID;
+void nerf_launch_frags(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
+                       uint32_t w0_cols, uint32_t out_c, uint32_t* frags, hipStream_t s);
+void nerf_launch_fwd(const float* X, const float* dirs, const uint32_t* frags, float* sigma, float* rgb, uint32_t B,
+                     uint32_t out_c, const int32_t* valid_rows, uint32_t valid_base, uint32_t valid_cap, uint32_t grid,
+                     hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void nerf_launch_bwd(const float* X, const float* dirs, const float* g_rgb, const float* rgb, const float* g_sigma,
+                     float sigma_scale, const uint32_t* frags, float* dX, float* partial, uint32_t B, uint32_t out_c,
+                     const int32_t* valid_rows, uint32_t valid_base, uint32_t valid_cap, uint32_t grid, hipStream_t s,
+                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // The reference's FFMLP entry points on the data flow above (mlp32.hip; called by ffmlp.hip): 16-bit row-major X / Y /
 // dY / dX (dtype ENERF_BF16 or ENERF_F16), weights and weight gradients as fp32 blobs [W0 64x32 | Wh | Wout 16x64]; the
 // hidden activations are recomputed in the backward, nothing is stored between the two calls.  num_hidden = 2 or 3.

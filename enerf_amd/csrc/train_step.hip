@@ -38,7 +38,7 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     int prev_prec = -1;
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
-    bool rows_set = false, defer_set = false, signal_set = false;
+    bool rows_set = false, defer_set = false, signal_set = false, fused_mlp = false;
     int slot = 0;
     auto t_prev = std::chrono::steady_clock::now();
     if (g_host_timing) g_host_steps++;
@@ -60,10 +60,17 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         enerf_mlp32_valid_rows(a->counter);
         rows_set = true;
     }
-    STEP(enerf_mlp32_forward_p(a->feats, a->wseg_s, 32, 0, M, 32, 16, a->nh_s, 0, 6, a->fb_s, a->h32, 1, 32, a->sigma,
-                               a->dirs, s));
-    STEP(enerf_mlp32_forward_p(a->h32, a->wseg_c, a->w0_cols_c, 1, M, 32, a->out_c, a->nh_c, 0, 3, a->fb_c, a->rgb, 0, 0,
-                               nullptr, nullptr, s));
+    // (both nets as one launch each way when the arithmetic is the split-bf16 default: csrc/nerf_mlp.hip)
+    fused_mlp = a->nh_s == 1 && a->nh_c == 2 && enerf_nerf_mlp_available() != 0;
+    if (fused_mlp) {
+        STEP(enerf_nerf_mlp_forward(a->feats, a->dirs, a->wseg_s, a->wseg_c, a->w0_cols_c, M, a->out_c, a->sigma, a->rgb, 0, s));
+        if (g_host_timing) slot++;
+    } else {
+        STEP(enerf_mlp32_forward_p(a->feats, a->wseg_s, 32, 0, M, 32, 16, a->nh_s, 0, 6, a->fb_s, a->h32, 1, 32, a->sigma,
+                                   a->dirs, s));
+        STEP(enerf_mlp32_forward_p(a->h32, a->wseg_c, a->w0_cols_c, 1, M, 32, a->out_c, a->nh_c, 0, 3, a->fb_c, a->rgb, 0, 0,
+                                   nullptr, nullptr, s));
+    }
     // ---- compositing forward + loss gradient + compositing backward
     STEP(enerf_composite_rays_train_fwd_bwd_mse(a->sigma, a->rgb, a->deltas, a->rays, M, N, a->weights_sum, a->image,
                                                 nullptr, 0, a->bg_scalar, a->out_image, a->target, a->grad_scale,
@@ -73,14 +80,20 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         enerf_mlp32_signal_next_reduce(1);
         signal_set = true;
     }
-    enerf_mlp32_defer_reduce(1);
-    defer_set = true;
-    STEP(enerf_mlp32_backward_p(a->g_rgbs, a->h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, 1, a->fb_c, M, 32, a->out_c,
-                                a->nh_c, 0, nullptr, a->dx32, 0, 0, a->rgb, a->out_c, nullptr, nullptr, 0, s));
-    STEP(enerf_mlp32_backward_p(a->dx32, a->feats, a->wseg_s, a->dwseg_s, 32, 0, 1, a->fb_s, M, 32, 16, a->nh_s, 0, nullptr,
-                                a->dfeat, 1, 32, nullptr, 0, a->g_sigmas, a->h32, 32, s));
-    enerf_mlp32_defer_reduce(0);
-    defer_set = false;
+    if (fused_mlp) {
+        STEP(enerf_nerf_mlp_backward(a->g_rgbs, a->g_sigmas, 1.0f, a->feats, a->dirs, a->rgb, a->wseg_s, a->wseg_c,
+                                     a->dwseg_s, a->dwseg_c, a->w0_cols_c, 1, M, a->out_c, a->dfeat, 1, s));
+        if (g_host_timing) slot++;
+    } else {
+        enerf_mlp32_defer_reduce(1);
+        defer_set = true;
+        STEP(enerf_mlp32_backward_p(a->g_rgbs, a->h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, 1, a->fb_c, M, 32, a->out_c,
+                                    a->nh_c, 0, nullptr, a->dx32, 0, 0, a->rgb, a->out_c, nullptr, nullptr, 0, s));
+        STEP(enerf_mlp32_backward_p(a->dx32, a->feats, a->wseg_s, a->dwseg_s, 32, 0, 1, a->fb_s, M, 32, 16, a->nh_s, 0,
+                                    nullptr, a->dfeat, 1, 32, nullptr, 0, a->g_sigmas, a->h32, 32, s));
+        enerf_mlp32_defer_reduce(0);
+        defer_set = false;
+    }
     if (rows_set) {
         enerf_mlp32_valid_rows(nullptr);
         rows_set = false;
@@ -153,6 +166,7 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     bool rows_set = false, defer_set = false, signal_set = false;
     const bool march_next = r0.next_rays_o != nullptr || r1.next_rays_o != nullptr;
     const bool skip = r0.counter != nullptr && r1.counter != nullptr;
+    const bool fused_mlp = a->nh_s == 1 && a->nh_c == 2 && enerf_nerf_mlp_available() != 0;
 #define STEP(call)           \
     do {                     \
         rc = (call);         \
@@ -164,10 +178,15 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         enerf_mlp32_valid_rows_ex(r1.counter, M, M);         // real rows: the first render's M + min(counter_2, M)
         rows_set = true;
     }
-    STEP(enerf_mlp32_forward_p(a->m_feats, a->wseg_s, 32, 0, M2, 32, 16, a->nh_s, 0, 6, a->m_fb_s, a->m_h32, 1, 32,
-                               a->m_sigma, r0.dirs, s));
-    STEP(enerf_mlp32_forward_p(a->m_h32, a->wseg_c, a->w0_cols_c, 1, M2, 32, a->out_c, a->nh_c, 0, 3, a->m_fb_c, a->m_rgb, 0,
-                               0, nullptr, nullptr, s));
+    if (fused_mlp) {
+        STEP(enerf_nerf_mlp_forward(a->m_feats, r0.dirs, a->wseg_s, a->wseg_c, a->w0_cols_c, M2, a->out_c, a->m_sigma,
+                                    a->m_rgb, 0, s));
+    } else {
+        STEP(enerf_mlp32_forward_p(a->m_feats, a->wseg_s, 32, 0, M2, 32, 16, a->nh_s, 0, 6, a->m_fb_s, a->m_h32, 1, 32,
+                                   a->m_sigma, r0.dirs, s));
+        STEP(enerf_mlp32_forward_p(a->m_h32, a->wseg_c, a->w0_cols_c, 1, M2, 32, a->out_c, a->nh_c, 0, 3, a->m_fb_c, a->m_rgb,
+                                   0, 0, nullptr, nullptr, s));
+    }
     if (rows_set) {
         enerf_mlp32_valid_rows(nullptr);
         rows_set = false;
@@ -196,14 +215,19 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         enerf_mlp32_signal_next_reduce(1);
         signal_set = true;
     }
-    enerf_mlp32_defer_reduce(1);
-    defer_set = true;
-    STEP(enerf_mlp32_backward_p(a->m_g_rgbs, a->m_h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, 1u, a->m_fb_c, M2, 32, a->out_c,
-                                a->nh_c, 0, nullptr, a->m_dx32, 0, 0, a->m_rgb, a->out_c, nullptr, nullptr, 0, s));
-    STEP(enerf_mlp32_backward_p(a->m_dx32, a->m_feats, a->wseg_s, a->dwseg_s, 32, 0, 1u, a->m_fb_s, M2, 32, 16, a->nh_s, 0,
-                                nullptr, a->m_dfeat, 1, 32, nullptr, 0, a->m_g_sigmas, a->m_h32, 32, s));
-    enerf_mlp32_defer_reduce(0);
-    defer_set = false;
+    if (fused_mlp) {
+        STEP(enerf_nerf_mlp_backward(a->m_g_rgbs, a->m_g_sigmas, 1.0f, a->m_feats, r0.dirs, a->m_rgb, a->wseg_s, a->wseg_c,
+                                     a->dwseg_s, a->dwseg_c, a->w0_cols_c, 1u, M2, a->out_c, a->m_dfeat, 1, s));
+    } else {
+        enerf_mlp32_defer_reduce(1);
+        defer_set = true;
+        STEP(enerf_mlp32_backward_p(a->m_g_rgbs, a->m_h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, 1u, a->m_fb_c, M2, 32,
+                                    a->out_c, a->nh_c, 0, nullptr, a->m_dx32, 0, 0, a->m_rgb, a->out_c, nullptr, nullptr, 0, s));
+        STEP(enerf_mlp32_backward_p(a->m_dx32, a->m_feats, a->wseg_s, a->dwseg_s, 32, 0, 1u, a->m_fb_s, M2, 32, 16, a->nh_s, 0,
+                                    nullptr, a->m_dfeat, 1, 32, nullptr, 0, a->m_g_sigmas, a->m_h32, 32, s));
+        enerf_mlp32_defer_reduce(0);
+        defer_set = false;
+    }
     if (rows_set) {
         enerf_mlp32_valid_rows(nullptr);
         rows_set = false;
@@ -258,6 +282,7 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
     int rc = 0;
     bool rows_set = false, defer_set = false, signal_set = false;
     const bool march_next = a->r[0].next_rays_o != nullptr || a->r[1].next_rays_o != nullptr;
+    const bool fused_mlp = a->nh_s == 1 && a->nh_c == 2 && enerf_nerf_mlp_available() != 0;
 #define STEP(call)           \
     do {                     \
         rc = (call);         \
@@ -272,10 +297,15 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
             enerf_mlp32_valid_rows(r.counter);
             rows_set = true;
         }
-        STEP(enerf_mlp32_forward_p(r.feats, a->wseg_s, 32, 0, r.M, 32, 16, a->nh_s, 0, 6, r.fb_s, r.h32, 1, 32, r.sigma,
-                                   r.dirs, s));
-        STEP(enerf_mlp32_forward_p(r.h32, a->wseg_c, a->w0_cols_c, 1, r.M, 32, a->out_c, a->nh_c, 0, 3, r.fb_c, r.rgb, 0, 0,
-                                   nullptr, nullptr, s));
+        if (fused_mlp) {
+            STEP(enerf_nerf_mlp_forward(r.feats, r.dirs, a->wseg_s, a->wseg_c, a->w0_cols_c, r.M, a->out_c, r.sigma, r.rgb,
+                                        k == 0 ? 0u : 1u, s));
+        } else {
+            STEP(enerf_mlp32_forward_p(r.feats, a->wseg_s, 32, 0, r.M, 32, 16, a->nh_s, 0, 6, r.fb_s, r.h32, 1, 32, r.sigma,
+                                       r.dirs, s));
+            STEP(enerf_mlp32_forward_p(r.h32, a->wseg_c, a->w0_cols_c, 1, r.M, 32, a->out_c, a->nh_c, 0, 3, r.fb_c, r.rgb, 0,
+                                       0, nullptr, nullptr, s));
+        }
         if (rows_set) {
             enerf_mlp32_valid_rows(nullptr);
             rows_set = false;
@@ -300,15 +330,20 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
             enerf_mlp32_signal_next_reduce(1);
             signal_set = true;
         }
-        enerf_mlp32_defer_reduce(1);
-        defer_set = true;
         const uint32_t overwrite = k == 0 ? 1u : 0u;
-        STEP(enerf_mlp32_backward_p(r.g_rgbs, r.h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, overwrite, r.fb_c, r.M, 32,
-                                    a->out_c, a->nh_c, 0, nullptr, r.dx32, 0, 0, r.rgb, a->out_c, nullptr, nullptr, 0, s));
-        STEP(enerf_mlp32_backward_p(r.dx32, r.feats, a->wseg_s, a->dwseg_s, 32, 0, overwrite, r.fb_s, r.M, 32, 16, a->nh_s, 0,
-                                    nullptr, r.dfeat, 1, 32, nullptr, 0, r.g_sigmas, r.h32, 32, s));
-        enerf_mlp32_defer_reduce(0);
-        defer_set = false;
+        if (fused_mlp) {
+            STEP(enerf_nerf_mlp_backward(r.g_rgbs, r.g_sigmas, 1.0f, r.feats, r.dirs, r.rgb, a->wseg_s, a->wseg_c, a->dwseg_s,
+                                         a->dwseg_c, a->w0_cols_c, overwrite, r.M, a->out_c, r.dfeat, 1, s));
+        } else {
+            enerf_mlp32_defer_reduce(1);
+            defer_set = true;
+            STEP(enerf_mlp32_backward_p(r.g_rgbs, r.h32, a->wseg_c, a->dwseg_c, a->w0_cols_c, 1, overwrite, r.fb_c, r.M, 32,
+                                        a->out_c, a->nh_c, 0, nullptr, r.dx32, 0, 0, r.rgb, a->out_c, nullptr, nullptr, 0, s));
+            STEP(enerf_mlp32_backward_p(r.dx32, r.feats, a->wseg_s, a->dwseg_s, 32, 0, overwrite, r.fb_s, r.M, 32, 16, a->nh_s,
+                                        0, nullptr, r.dfeat, 1, 32, nullptr, 0, r.g_sigmas, r.h32, 32, s));
+            enerf_mlp32_defer_reduce(0);
+            defer_set = false;
+        }
         if (rows_set) {
             enerf_mlp32_valid_rows(nullptr);
             rows_set = false;

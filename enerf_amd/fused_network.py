@@ -168,33 +168,42 @@ def nerf_forward(x, d, cfg, train, embeddings, offsets, *weights, out=None, vali
     _gb.grid_encode_forward(x, emb, offsets, feats, B, 3, 2, 16, S, base_resolution, False, feats, gridtype,
                             layout=2, affine=affine)
     stream = L.stream_handle()
-    h32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
     # the MLP kernels stage the weights straight from the parameters (the colour net's first-layer column order
     # [SH | geo_feat (| pad)] -> [0 | geo_feat | SH] is applied on the way into LDS): nothing is packed per step
     seg_s, seg_c = _weight_segments(kind, weights)
     nh_s, nh_c = arch["nh_s"], arch["nh_c"]
-    fb_s = torch.empty(nh_s, Bp, 64, dtype=torch.float32, device=dev) if train else None
+    h32 = fb_s = fb_c = None
+    fused = False
     if valid_rows is not None:
         lib.enerf_mlp32_valid_rows(valid_rows.data_ptr())
     try:
         with _precision(arch["prec"]):
-            # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
-            L.check(lib.enerf_mlp32_forward_p(feats.data_ptr(), seg_s, 32, 0, B, 32, 16, nh_s, 0, 6,
-                                              fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32, sigma.data_ptr(),
-                                              d.data_ptr(), stream), "mlp32_forward_p(sigma)")
-            # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
-            fb_c = torch.empty(nh_c, Bp, 64, dtype=torch.float32, device=dev) if train else None
-            L.check(lib.enerf_mlp32_forward_p(h32.data_ptr(), seg_c, arch["w0c"], 1, B, 32, out_c, nh_c, 0, 3,
-                                              fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, None,
-                                              stream), "mlp32_forward_p(color)")
+            # nerf/network.py's nets in the split-bf16 default: both as ONE launch (csrc/nerf_mlp.hip) -- the sigma net's
+            # outputs and the SH basis reach the colour net in registers, no [B, 32] hand-over tensor
+            fused = kind == "linear" and out_c <= 16 and bool(lib.enerf_nerf_mlp_available())
+            if fused:
+                L.check(lib.enerf_nerf_mlp_forward(feats.data_ptr(), d.data_ptr(), seg_s, seg_c, arch["w0c"], B, out_c,
+                                                   sigma.data_ptr(), rgb.data_ptr(), 0, stream), "nerf_mlp_forward")
+            else:
+                h32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
+                fb_s = torch.empty(nh_s, Bp, 64, dtype=torch.float32, device=dev) if train else None
+                # the sigma kernel also fills the SH columns 16..31 of h32 from the directions (no separate encoder launch)
+                L.check(lib.enerf_mlp32_forward_p(feats.data_ptr(), seg_s, 32, 0, B, 32, 16, nh_s, 0, 6,
+                                                  fb_s.data_ptr() if train else None, h32.data_ptr(), 1, 32,
+                                                  sigma.data_ptr(), d.data_ptr(), stream), "mlp32_forward_p(sigma)")
+                # (colour net input columns: [raw density (zero weight) | geo_feat 15 | SH 16])
+                fb_c = torch.empty(nh_c, Bp, 64, dtype=torch.float32, device=dev) if train else None
+                L.check(lib.enerf_mlp32_forward_p(h32.data_ptr(), seg_c, arch["w0c"], 1, B, 32, out_c, nh_c, 0, 3,
+                                                  fb_c.data_ptr() if train else None, rgb.data_ptr(), 0, 0, None, None,
+                                                  stream), "mlp32_forward_p(color)")
     finally:                                 # the row count is per call: never left behind for another model's launch
         if valid_rows is not None:
             lib.enerf_mlp32_valid_rows(None)
     saved = None
     if train:
-        saved = dict(x=x, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, seg_s=seg_s, seg_c=seg_c,
-                     weights=weights, rgb=rgb, B=B, S=S, H=base_resolution, gridtype=gridtype, kind=kind, arch=arch,
-                     affine=affine, out_c=out_c, param=embeddings, valid_rows=valid_rows)
+        saved = dict(x=x, d=d, emb=emb, offsets=offsets, feats=feats, h32=h32, fb_s=fb_s, fb_c=fb_c, seg_s=seg_s,
+                     seg_c=seg_c, weights=weights, rgb=rgb, B=B, S=S, H=base_resolution, gridtype=gridtype, kind=kind,
+                     arch=arch, affine=affine, out_c=out_c, param=embeddings, valid_rows=valid_rows, fused=fused)
     return sigma, rgb, saved
 
 
@@ -246,30 +255,38 @@ def nerf_backward(sv, g_sigma, g_rgb, sigma_scale=1.0, raw=False, owner=False, d
     dev = sv["x"].device
     lib = L.lib()
     stream = L.stream_handle()
-    if sigma_scale != 1.0:
+    fused = bool(sv.get("fused"))
+    if sigma_scale != 1.0 and not fused:
         g_sigma = g_sigma * sigma_scale
     # weight gradients: written (not accumulated) by the backward's reduce pass, straight in parameter order
     dw, (dseg_s, dseg_c) = _grad_segments(kind, dev, out_c)
-    # (scratch of the unfused dgrad / wgrad kernels only: the fused backward never touches it)
-    bb_c = torch.empty(nh_c if kind == "linear" else 0, Bp, 64, dtype=torch.float32, device=dev)
-    dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
+    dfeat = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
     if sv.get("valid_rows") is not None:     # the forward skipped the budget's padding rows: so must the backward
         lib.enerf_mlp32_valid_rows(sv["valid_rows"].data_ptr())
     if after_mlp is not None:                # its side stream waits for the reduce launch's own completion signal
         lib.enerf_mlp32_signal_next_reduce(1)
     try:
         with _precision(arch["prec"]):
-            lib.enerf_mlp32_defer_reduce(1)      # the colour net's dW partial sums are reduced by the sigma net's launch
-            L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, arch["w0c"], 1,
-                                               1, sv["fb_c"].data_ptr(), B, 32, out_c, nh_c, 0, bb_c.data_ptr(),
-                                               dx32.data_ptr(), 0, 0, sv["rgb"].data_ptr(), out_c, None, None, 0, stream),
-                    "mlp32_backward_p(color)")
-            bb_s = torch.empty(nh_s if kind == "linear" else 0, Bp, 64, dtype=torch.float32, device=dev)
-            dfeat = torch.empty(16, Bp, 2, dtype=torch.float32, device=dev)
-            L.check(lib.enerf_mlp32_backward_p(dx32.data_ptr(), sv["feats"].data_ptr(), sv["seg_s"], dseg_s, 32, 0, 1,
-                                               sv["fb_s"].data_ptr(), B, 32, 16, nh_s, 0, bb_s.data_ptr(), dfeat.data_ptr(),
-                                               1, 32, None, 0, g_sigma.data_ptr(), sv["h32"].data_ptr(), 32, stream),
-                    "mlp32_backward_p(sigma)")
+            if fused:
+                # (the forward of this very step built the operand fragments from these weights: flags = 1)
+                L.check(lib.enerf_nerf_mlp_backward(g_rgb.data_ptr(), g_sigma.data_ptr(), float(sigma_scale),
+                                                    sv["feats"].data_ptr(), sv["d"].data_ptr(), sv["rgb"].data_ptr(),
+                                                    sv["seg_s"], sv["seg_c"], dseg_s, dseg_c, arch["w0c"], 1, B, out_c,
+                                                    dfeat.data_ptr(), 1, stream), "nerf_mlp_backward")
+            else:
+                # (scratch of the unfused dgrad / wgrad kernels only: the fused backward never touches it)
+                bb_c = torch.empty(nh_c if kind == "linear" else 0, Bp, 64, dtype=torch.float32, device=dev)
+                dx32 = torch.empty(B, 32, dtype=torch.float32, device=dev)
+                lib.enerf_mlp32_defer_reduce(1)      # the colour net's dW partial sums are reduced by the sigma net's launch
+                L.check(lib.enerf_mlp32_backward_p(g_rgb.data_ptr(), sv["h32"].data_ptr(), sv["seg_c"], dseg_c, arch["w0c"],
+                                                   1, 1, sv["fb_c"].data_ptr(), B, 32, out_c, nh_c, 0, bb_c.data_ptr(),
+                                                   dx32.data_ptr(), 0, 0, sv["rgb"].data_ptr(), out_c, None, None, 0,
+                                                   stream), "mlp32_backward_p(color)")
+                bb_s = torch.empty(nh_s if kind == "linear" else 0, Bp, 64, dtype=torch.float32, device=dev)
+                L.check(lib.enerf_mlp32_backward_p(dx32.data_ptr(), sv["feats"].data_ptr(), sv["seg_s"], dseg_s, 32, 0, 1,
+                                                   sv["fb_s"].data_ptr(), B, 32, 16, nh_s, 0, bb_s.data_ptr(),
+                                                   dfeat.data_ptr(), 1, 32, None, 0, g_sigma.data_ptr(),
+                                                   sv["h32"].data_ptr(), 32, stream), "mlp32_backward_p(sigma)")
     finally:
         lib.enerf_mlp32_defer_reduce(0)
         lib.enerf_mlp32_signal_next_reduce(0)

@@ -162,6 +162,11 @@ class TrainHarness:
         optimizer's own `step` counts them, its bias corrections do not.  One 4-byte read-back."""
         return int(self._amp_words[1]) if self._amp_words is not None else 0
 
+    def _amp_closed_form_ok(self):
+        """Decided per step (graph replay, an attached averager and `fuse_table_adam` can all change after __init__): what
+        the device-side GradScaler protocol cannot serve takes the autocast route with the same scaler instead of raising."""
+        return not self.use_graphs and self.avg is None and bool(self.fuse_table_adam)
+
     def _amp_step(self, fn, *args, **kw):
         """One step under the device-side GradScaler protocol (include/enerf_hip.h: enerf_amp_begin / enerf_amp_end)."""
         from . import _lib as L
@@ -945,7 +950,7 @@ class TrainHarness:
         if self.amp_bf16 or self.amp_f16:
             prev = self._amp_scope()
             try:
-                if self.amp_f16 and self._manual_ok(rays_o, rays_d, target, render_kw):
+                if self.amp_f16 and self._amp_closed_form_ok() and self._manual_ok(rays_o, rays_d, target, render_kw):
                     loss = self._amp_step(self._step_rgb, rays_o, rays_d, target, next_rays, **render_kw)
                 elif self.amp_f16:              # a step the closed form does not serve: the autocast route, same scaler
                     self.fp16 = True
@@ -1018,7 +1023,7 @@ class TrainHarness:
         if self.amp_bf16 or self.amp_f16:
             prev = self._amp_scope()
             try:
-                if self.amp_f16 and opt.event_only and self._events_manual_ok(data, opt):
+                if self.amp_f16 and self._amp_closed_form_ok() and opt.event_only and self._events_manual_ok(data, opt):
                     loss = self._amp_step(self._step_events, data, opt, next_data)
                 elif self.amp_f16:
                     self.fp16 = True

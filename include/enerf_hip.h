@@ -422,6 +422,31 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
                            uint32_t y_sigmoid_stride, const float* dsigma, const float* h0, uint32_t h0_stride,
                            enerf_stream_t stream);
 
+/* The two networks of nerf/network.py:104-132 as ONE launch per direction (csrc/nerf_mlp.hip; replaces the
+ * sigma_net / color_net loops and the torch glue between them, nerf/network.py:108-130):
+ *   h = sigma_net(feats);  sigma = exp(h[0]);  rgb = sigmoid(color_net([SH4(dirs) | h[1:16]]))
+ * feats: the grid encoder's level-major fp32 output [16, Bp, 2] (enerf_grid_encode_forward, out_layout 2; Bp = B rounded
+ * up to 32, pad rows zero), dirs [B,3]; wseg_s = {sigma_net[0].weight [64,32], NULL, NULL, sigma_net[1].weight [16,64]},
+ * wseg_c = {color_net[0].weight [64,w0_cols_c] with memory columns [SH 16 | geo_feat 15], color_net[1].weight [64,64],
+ * NULL, color_net[2].weight [out_c,64]}; sigma [B], rgb [B,out_c] (out_c <= 16).  The sigma net's 16 outputs never leave
+ * the registers: they are the first half of the colour net's input as they stand, the SH basis is evaluated in registers.
+ * Arithmetic: split-bf16 (enerf_mlp32_precision 1) -- enerf_nerf_mlp_available() says whether the process's current
+ * arithmetic is served (callers fall back to enerf_mlp32_*_p otherwise).  Both calls honour enerf_mlp32_valid_rows; the
+ * backward recomputes both forwards, honours enerf_mlp32_signal_next_reduce and writes (overwrite != 0) or adds the weight
+ * gradients through dwseg_* (same shapes as wseg_*), the feature gradient level-major into dfeat [16, Bp, 2] (pad rows
+ * zero: ready for enerf_grid_encode_backward with grad_layout 2).  g_sigma is multiplied by sigma_scale on the fly.
+ * flags bit 0: the operand fragments an earlier call built from these very weight tensors are still current (no
+ * optimizer step since) -- skips the 44-wavefront rebuild. */
+int enerf_nerf_mlp_available(void);
+int enerf_debug_nerf_mlp_fused(int on);
+int enerf_nerf_mlp_forward(const float* feats, const float* dirs, const float* const* wseg_s, const float* const* wseg_c,
+                           uint32_t w0_cols_c, uint32_t B, uint32_t out_c, float* sigma, float* rgb, uint32_t flags,
+                           enerf_stream_t stream);
+int enerf_nerf_mlp_backward(const float* g_rgb, const float* g_sigma, float sigma_scale, const float* feats,
+                            const float* dirs, const float* rgb, const float* const* wseg_s, const float* const* wseg_c,
+                            float* const* dwseg_s, float* const* dwseg_c, uint32_t w0_cols_c, uint32_t overwrite,
+                            uint32_t B, uint32_t out_c, float* dfeat, uint32_t flags, enerf_stream_t stream);
+
 /* enerf_mlp32_forward that also writes the degree-4 SH encoding of sh_dirs [B,3] (shencoder.cu:27-128) into columns
  * 16..31 of each row of Y: for the sigma net of nerf/network.py, whose output row is the colour net's input row
  * (num_hidden 1, level-major X, out_dim <= 16, y_stride >= 32).  sh_dirs == NULL: plain enerf_mlp32_forward. */
@@ -470,7 +495,8 @@ int enerf_mlp32_precision(int mode);
  * instruction sequence (bit-identical values and ReLU masks) and the training forward does not store them -- `fb` is
  * then neither written nor read (two thirds of these kernels' HBM traffic at the training batch).  0: the forward
  * stores them and the backward loads them (the reference's data flow, ffmlp.cu:711-895 / autograd's saved tensors).
- * Forward and backward of a batch must run under the same setting.  Returns the previous setting (NOT a status);
+ * Forward and backward of a batch must run under the same setting.  Nets with three hidden layers (16-bit operands) recompute
+ * under either setting.  Returns the previous setting (NOT a status);
  * a negative `on` only queries. */
 int enerf_mlp32_recompute(int on);
 /* Testing aid: 1 (default) lets enerf_mlp32_backward use its fused dgrad + wgrad kernel (num_hidden <= 2; `bb` is then

@@ -435,3 +435,68 @@ def test_backward_recomputing_the_activations_is_bit_identical_to_loading_them(m
     finally:
         lib.enerf_mlp32_recompute(prev_rc)
         lib.enerf_mlp32_precision(prev_mode)
+
+
+@pytest.mark.parametrize("N,out_c", [(1, 3), (33, 1), (4097, 3), (70001, 3), (2048, 7)])
+def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
+    """csrc/nerf_mlp.hip (sigma + colour net of nerf/network.py:104-132 as one launch per direction, split-bf16) against
+    the one-launch-per-net kernels it replaces and against an fp64 nn.Linear loop: the same arithmetic up to the summation
+    order inside the colour net's first layer, so the bars are the split-bf16 ones of this file."""
+    from enerf_amd import _lib, fused_network as fn
+    from enerf_amd.network import NeRFNetwork
+    lib = _lib.lib()
+    if precision == 1.0:
+        assert lib.enerf_nerf_mlp_available() == 0          # the exact-fp32 arithmetic keeps the one-net kernels
+        return
+    assert lib.enerf_nerf_mlp_available() == 1
+    torch.manual_seed(5)
+    m = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=out_c).to(DEV)
+    m.encoder.embeddings.data.uniform_(-1, 1)
+    x = torch.rand(N, 3, device=DEV) * 4 - 2
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=DEV), dim=-1)
+    gs, gc = torch.randn(N, device=DEV), torch.randn(N, out_c, device=DEV)
+    params = fn.network_params(m)
+    cfg, offs = fn.network_cfg(m), fn.encoder_offsets(m)
+
+    def run(fused, scale=1.0, valid=None):
+        prev = lib.enerf_debug_nerf_mlp_fused(1 if fused else 0)
+        try:
+            sigma, rgb, sv = fn.nerf_forward(x, d, cfg, True, params[0], offs, *params[1:], valid_rows=valid)
+            assert bool(sv["fused"]) == fused
+            g = fn.nerf_backward(sv, gs, gc, sigma_scale=scale)
+        finally:
+            lib.enerf_debug_nerf_mlp_fused(prev)
+        return sigma, rgb, g
+
+    s1, c1, g1 = run(True)
+    s0, c0, g0 = run(False)
+    assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-6)).max()) < 2e-5
+    assert float((c1 - c0).abs().max()) < 2e-6
+    for a, b in zip(g1, g0):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
+    # the fp64 loop
+    with torch.no_grad():
+        ws = [p.double() for p in params[1:]]
+        feat = m.encoder(x, bound=m.bound).double()
+        h = torch.relu(feat @ ws[0].t()) @ ws[1].t()
+        sh = m.encoder_dir(d).double()
+        hc = torch.relu(torch.relu(torch.cat([sh, h[:, 1:]], dim=1) @ ws[2].t()) @ ws[3].t()) @ ws[4].t()
+        assert float(((s1.double() - torch.exp(h[:, 0])).abs() / torch.exp(h[:, 0]).clamp(min=1e-6)).max()) < 1e-4
+        assert float((c1.double() - torch.sigmoid(hc)).abs().max()) < 2e-5
+    # density_scale on the fly, and the sample budget's padding rows skipped by both directions
+    if N >= 2048:
+        _, _, g2 = run(True, scale=0.25)
+        _, _, g3 = run(False, scale=0.25)
+        for a, b in zip(g2, g3):
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
+        real = N - 700
+        cnt = torch.tensor([real, 0], dtype=torch.int32, device=DEV)
+        gs[real:] = 0
+        gc[real:] = 0
+        s4, c4, g4 = run(True, valid=cnt)
+        s5, c5, g5 = run(False, valid=cnt)
+        assert float(((s4 - s5).abs() / s5.abs().clamp(min=1e-6))[:real].max()) < 2e-5
+        assert float((c4 - c5).abs()[:real].max()) < 2e-6
+        for a, b in zip(g4, g5):
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9

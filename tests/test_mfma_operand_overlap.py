@@ -1,0 +1,29 @@
+"""No 32x32 MFMA of the translation units built with -amdgpu-mfma-vgpr-form may write its result over its own SrcA / SrcB
+(csrc/mfma_guard.h: the compiler's untied VGPR form of a zero-initialised MFMA lacks the early-clobber; the hardware then
+computes some samples of a tile with half-read operands when the matrix pipe is contended -- intermittent, small, and
+invisible to every test that runs one workgroup per CU).  The device code is compiled to assembly here (hipcc cross-compiles
+without a GPU) and scanned by tools/mfma_overlap.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.parametrize("src", ["nerf_mlp.hip", "mlp32s.hip", "mlp32s_f16.hip", "ffmlp.hip"])
+def test_no_mfma_result_lands_on_its_operands(src, tmp_path):
+    from enerf_amd import build
+    flags = [f for f in build.FLAGS if f not in ("-fPIC",)] + build.EXTRA.get(src, [])
+    assert "-amdgpu-mfma-vgpr-form" in flags, f"{src} is no longer built in the VGPR form: drop it from this test"
+    out = tmp_path / (src + ".s")
+    subprocess.check_call([build._hipcc()] + flags + ["-S", "--cuda-device-only", os.path.join(build.CSRC, src), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_overlap.py"), str(out)], capture_output=True,
+                         text=True, check=True).stdout
+    rows = [ln for ln in res.splitlines() if " mfma " in ln]
+    assert rows, "no MFMA found: the scan is looking at the wrong thing"
+    bad = [ln for ln in rows if not ln.rstrip().endswith("overlapping 0")]
+    assert not bad, "MFMA results overlapping SrcA / SrcB:\n" + "\n".join(bad[:10])
