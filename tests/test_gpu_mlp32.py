@@ -428,7 +428,9 @@ def test_backward_recomputing_the_activations_is_bit_identical_to_loading_them(m
                     "bwd")
             torch.cuda.synchronize()
             res[rc] = (Y, dX, dW, fb)
-        assert bool((res[1][3] == 7.0).all()) and not bool((res[0][3][:B * 64] == 7.0).all())
+        # (three hidden layers recompute under either setting since round 5: the activation-loading instance of that shape
+        #  was retired, csrc/mfma_guard.h -- its forward buffer is never written)
+        assert bool((res[1][3] == 7.0).all()) and (nh == 3) == bool((res[0][3][:B * 64] == 7.0).all())
         for a, b, what in zip(res[0][:3], res[1][:3], ("Y", "dX", "dW")):
             assert torch.equal(a, b), what
         assert float(res[1][2].abs().max()) > 0 and float(res[1][1].abs().max()) > 0
@@ -468,13 +470,16 @@ def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
             lib.enerf_debug_nerf_mlp_fused(prev)
         return sigma, rgb, g
 
+    # (gradients: a hidden unit whose pre-activation sits within a round-off of zero can fall on either side of its ReLU
+    #  under the other summation order, which moves one sample's terms -- the bar of the fused-node test above)
+    gtol = (5e-4 if N > 10000 else 5e-5) * 2
     s1, c1, g1 = run(True)
     s0, c0, g0 = run(False)
     assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-6)).max()) < 2e-5
     assert float((c1 - c0).abs().max()) < 2e-6
     for a, b in zip(g1, g0):
         assert a.shape == b.shape
-        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
+        assert float((a - b).abs().max()) <= gtol * float(b.abs().max()) + 1e-9
     # the fp64 loop
     with torch.no_grad():
         ws = [p.double() for p in params[1:]]
@@ -489,7 +494,7 @@ def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
         _, _, g2 = run(True, scale=0.25)
         _, _, g3 = run(False, scale=0.25)
         for a, b in zip(g2, g3):
-            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
+            assert float((a - b).abs().max()) <= gtol * float(b.abs().max()) + 1e-9
         real = N - 700
         cnt = torch.tensor([real, 0], dtype=torch.int32, device=DEV)
         gs[real:] = 0
@@ -499,4 +504,4 @@ def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
         assert float(((s4 - s5).abs() / s5.abs().clamp(min=1e-6))[:real].max()) < 2e-5
         assert float((c4 - c5).abs()[:real].max()) < 2e-6
         for a, b in zip(g4, g5):
-            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
+            assert float((a - b).abs().max()) <= gtol * float(b.abs().max()) + 1e-9
