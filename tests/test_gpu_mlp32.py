@@ -470,16 +470,22 @@ def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
             lib.enerf_debug_nerf_mlp_fused(prev)
         return sigma, rgb, g
 
-    # (gradients: a hidden unit whose pre-activation sits within a round-off of zero can fall on either side of its ReLU
-    #  under the other summation order, which moves one sample's terms -- the bar of the fused-node test above)
-    gtol = (5e-4 if N > 10000 else 5e-5) * 2
+    # gradients: a hidden unit whose pre-activation sits within a round-off of zero falls on either side of its ReLU under
+    # the other summation order of the colour net's first layer, which moves that one sample's terms (|g| |a| of ONE of the
+    # N samples, against sums of N of them): a handful of entries may move by that much, everything else is round-off
+    def grads_agree(ga, gb):
+        for a, b in zip(ga, gb):
+            assert a.shape == b.shape
+            err, top = (a - b).abs(), float(b.abs().max())
+            assert float(err.max()) <= 4e-3 * top + 1e-9, (float(err.max()), top)
+            # (one flipped unit moves a whole row / column of a 64-wide matrix: a few of them are 10 % of its entries)
+            assert float((err > 1e-4 * top).float().mean()) <= 0.2, float((err > 1e-4 * top).float().mean())
+            assert float((err > 1e-3 * top).float().mean()) <= 0.01, float((err > 1e-3 * top).float().mean())
     s1, c1, g1 = run(True)
     s0, c0, g0 = run(False)
     assert float(((s1 - s0).abs() / s0.abs().clamp(min=1e-6)).max()) < 2e-5
     assert float((c1 - c0).abs().max()) < 2e-6
-    for a, b in zip(g1, g0):
-        assert a.shape == b.shape
-        assert float((a - b).abs().max()) <= gtol * float(b.abs().max()) + 1e-9
+    grads_agree(g1, g0)
     # the fp64 loop
     with torch.no_grad():
         ws = [p.double() for p in params[1:]]
@@ -493,8 +499,7 @@ def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
     if N >= 2048:
         _, _, g2 = run(True, scale=0.25)
         _, _, g3 = run(False, scale=0.25)
-        for a, b in zip(g2, g3):
-            assert float((a - b).abs().max()) <= gtol * float(b.abs().max()) + 1e-9
+        grads_agree(g2, g3)
         real = N - 700
         cnt = torch.tensor([real, 0], dtype=torch.int32, device=DEV)
         gs[real:] = 0
@@ -503,5 +508,37 @@ def test_both_nets_in_one_launch_match_one_launch_per_net(N, out_c, precision):
         s5, c5, g5 = run(False, valid=cnt)
         assert float(((s4 - s5).abs() / s5.abs().clamp(min=1e-6))[:real].max()) < 2e-5
         assert float((c4 - c5).abs()[:real].max()) < 2e-6
-        for a, b in zip(g4, g5):
-            assert float((a - b).abs().max()) <= gtol * float(b.abs().max()) + 1e-9
+        grads_agree(g4, g5)
+
+
+def test_both_nets_in_one_launch_are_bit_stable_from_run_to_run(precision):
+    """csrc/nerf_mlp.hip, soak: the same batch through forward and backward 60 times -- every output bit-identical to the
+    first run's.  (Round 5: with two or three workgroups of the forward kernel on a CU a few per cent of the later workgroups'
+    tiles came out with wrong colours for samples 16..31, different rows every launch; the kernel now takes a CU for itself.
+    This test is what would notice a relapse: 4160 tiles, i.e. more workgroups than CUs.)"""
+    from enerf_amd import _lib, fused_network as fn
+    from enerf_amd.network import NeRFNetwork
+    lib = _lib.lib()
+    if not lib.enerf_nerf_mlp_available():
+        pytest.skip("split-bf16 only")
+    N = 133000
+    torch.manual_seed(2)
+    m = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(DEV)
+    m.encoder.embeddings.data.uniform_(-1, 1)
+    x = torch.rand(N, 3, device=DEV) * 6 - 3
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=DEV), dim=-1)
+    gs, gc = torch.randn(N, device=DEV), torch.randn(N, 3, device=DEV)
+    params = fn.network_params(m)
+    cfg, offs = fn.network_cfg(m), fn.encoder_offsets(m)
+
+    def step():
+        s, c, sv = fn.nerf_forward(x, d, cfg, True, params[0], offs, *params[1:])
+        assert sv["fused"]
+        g_emb, dw = fn.nerf_backward(sv, gs, gc, raw=True)
+        return s, c, dw
+
+    first = step()
+    for it in range(60):
+        again = step()
+        for a, b, what in zip(again, first, ("sigma", "rgb", "dW")):
+            assert torch.equal(a, b), (it, what, int((a != b).sum()))
