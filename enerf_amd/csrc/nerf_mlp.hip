@@ -161,7 +161,11 @@ __device__ __forceinline__ void copy_frags(u32x4n* __restrict__ fr, const uint32
 // builds alike, while the one-net kernels of mlp32s.hip at the same residency and every build of this kernel at one
 // workgroup per CU are bit-stable over hundreds of launches.  The cause was not found in this round (it is not the operand
 // overlap of mfma_guard.h, which was fixed first and made the second workgroup safe but not the third); until it is, the
-// kernel does not share a SIMD.  tests/test_gpu_mlp32.py soaks both kernels for run-to-run bit-stability.
+// kernel does not share a SIMD with anything (NERF_WHOLE_SIMD below; the backward needs 149 KiB of LDS and ~480 registers
+// anyway).  tests/test_gpu_mlp32.py soaks both kernels for run-to-run bit-stability.
+// the wave's allocation is the SIMD's whole register file (256 + 256): no wavefront of ANY kernel shares the SIMD -- the
+// next batch's march runs on a second stream beside this library's step
+#define NERF_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
 constexpr uint32_t kFwdLdsWords = 21 * 1024;              // 84 KiB: two workgroups do not fit a CU's 160 KiB
 __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ X, const float* __restrict__ dirs,
                                                    const uint32_t* __restrict__ frags, float* __restrict__ sigma,
@@ -169,8 +173,7 @@ __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ X, c
                                                    ShNorm4 nrm) {
     static_assert(NF_FWD * kFragWords <= kFwdLdsWords, "LDS");
     __shared__ __attribute__((aligned(16))) uint32_t lds[kFwdLdsWords];
-    // (a register beyond the first 256 of the wave's allocation: no second wavefront fits the SIMD's 512)
-    asm volatile("v_accvgpr_write_b32 a140, 0" ::: "a140");
+    NERF_WHOLE_SIMD();
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -314,6 +317,7 @@ __global__ void __launch_bounds__(256) k_nerf_bwd(NerfBwdArgs a, const uint32_t*
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBwdLdsWords];       // operands (then the dW sums), selectors, stashes
     static_assert(NF_BWD * kFragWords >= 2 * P_STRIDE, "the two sum regions reuse the operand area");
     static_assert(kBwdLdsWords * 4 <= 160 * 1024, "LDS");
+    NERF_WHOLE_SIMD();
     typedef FragT<3> Frag;
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const int wid = threadIdx.x >> 6;
