@@ -114,7 +114,8 @@ def test_product_on_the_gpu_reproduces_the_reference_python(monkeypatch, mlp32_m
         assert int(model.local_step) == int(z[f"train{step}_local_step"])
         np.testing.assert_allclose(out["image"].detach().cpu().numpy(), z[f"train{step}_image"], rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), z[f"train{step}_depth"], rtol=1e-4, atol=2e-5)
-        _grad_check(model, z, f"train{step}")
+        # (bars = 3x what round 5 measured: fp32 MFMA 2.6e-6 .. 4.0e-6, split-bf16 3.5e-6 .. 2.2e-4 of the largest entry)
+        _grad_check(model, z, f"train{step}", tol=7e-4 if mlp32_mode == "split-bf16" else 1.5e-5)
     from enerf_amd.events import EventOptions, train_step_events
     data = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("ev_") and k[3:] in
             ("images", "rays_evs_o1", "rays_evs_d1", "rays_evs_o2", "rays_evs_d2", "pols", "rays_o", "rays_d")}
@@ -130,8 +131,10 @@ def test_product_on_the_gpu_reproduces_the_reference_python(monkeypatch, mlp32_m
     np.testing.assert_allclose(float(loss.detach()), float(z["ev_loss"]), rtol=2e-4)
     np.testing.assert_allclose(delta.detach().cpu().numpy(), z["ev_delta"], rtol=1e-3, atol=2e-4)
     # (the event loss differentiates a DIFFERENCE of two renders of nearly the same rays: the gradient is what is left of
-    #  two contributions ~40x its size that cancel, and so is its error -- 5.5e-3 of the largest entry in split-bf16 mode)
-    _grad_check(model, z, "ev", tol=2e-2 if mlp32_mode == "split-bf16" else 5e-3)
+    #  two contributions ~40x its size that cancel, and so is its error -- measured 5.5e-3 of the largest entry in split-bf16
+    #  mode, 4.4e-6 on the fp32 MFMA kernels; bars = 3x that.  The per-entry bound of this cancellation, from the oracle's own
+    #  fp64 terms with knife-edge samples counted, is tests/test_gpu_baseline_configs.py's configs[2] step at full size.)
+    _grad_check(model, z, "ev", tol=1.7e-2 if mlp32_mode == "split-bf16" else 1.5e-5)
     # inference: the reference's round schedule (renderer.py:330-380) on the product's kernels must reproduce the fixture;
     # the whole-frame pass (the default: one march, one compositing pass) differs where the schedule itself shows -- a ray
     # still alive when the global step counter reaches max_steps has been handed up to 7 samples more than max_steps by
@@ -182,15 +185,20 @@ def test_network_ff_product_on_the_gpu_against_the_reference_python(monkeypatch)
     assert torch.equal(model.step_counter[:2].cpu(), torch.from_numpy(z["step_counter"]))
     err = float((out["image"].detach().float().cpu() - torch.from_numpy(z["train_image"])).abs().max())
     print(f"network_ff image: max |diff| {err:.2e}")
-    assert err < 3e-3
+    assert err < 2e-3                                          # (3x the 6.1e-4 measured)
     np.testing.assert_allclose(out["depth"].detach().float().cpu().numpy(), z["train_depth"], rtol=2e-2, atol=2e-3)
     for name, g in (("g_sigma_w", model.sigma_net.weights.grad), ("g_color_w", model.color_net.weights.grad),
                     ("g_emb_l0", model.encoder.embeddings.grad[:4920])):
         ref = z[name]
         e = float(np.abs(g.detach().float().cpu().numpy().reshape(ref.shape) - ref).max()) / float(np.abs(ref).max())
         print(f"network_ff {name}: max err / max |grad| = {e:.2e}")
-        assert e < 6e-2, (name, e)
+        # 3x what was measured (2.4e-3, 3.8e-3, 2.4e-2).  The table's coarsest level is the loosest because every one of its
+        # rows sums several hundred per-sample feature gradients, each the back-propagation through two nets of bf16
+        # operands (2^-8 per product, against the fixture's half: 2^-11) with the signs of a cancelling sum
+        assert e < {"g_sigma_w": 8e-3, "g_color_w": 1.2e-2, "g_emb_l0": 7e-2}[name], (name, e)
     model.eval()
     with torch.no_grad():
         out = model.render(o, d, staged=False, bg_color=None, perturb=False, max_steps=128)
-    assert float((out["image"].float().cpu() - torch.from_numpy(z["infer_image"])).abs().max()) < 1e-2
+    ierr = float((out["image"].float().cpu() - torch.from_numpy(z["infer_image"])).abs().max())
+    print(f"network_ff inference image: max |diff| {ierr:.2e}")
+    assert ierr < 1e-2

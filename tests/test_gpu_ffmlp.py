@@ -337,3 +337,35 @@ def test_network_ff_training_step_takes_the_closed_form_path(fp16):
     assert model.mean_count > 0
     if fp16:
         assert float(h.scaler.get_scale()) >= 256.0 and h.amp_skipped_steps() <= 10
+
+
+@pytest.mark.parametrize("route", ["network_ff fused inference", "network_ff op by op", "network.py, one launch per net"])
+def test_mfma_kernels_are_bit_stable_from_run_to_run(monkeypatch, route):
+    """Soak for every MFMA forward kernel that shares its SIMDs with other wavefronts (several workgroups per CU): the same
+    400 000 rows 40 times, every output bit-identical to the first run's.  Round 5 found two ways for such kernels to be
+    right on most launches only -- an MFMA result allocated over its own operands (csrc/mfma_guard.h, which these kernels
+    carried since round 3) and whatever made csrc/nerf_mlp.hip's forward unstable at more than one workgroup per CU; a test
+    that compares with a reference at 1e-4 on one launch sees neither."""
+    from enerf_amd import _lib, fused_network, fused_network_ff
+    n = 400000
+    torch.manual_seed(3)
+    if route.startswith("network_ff"):
+        from enerf_amd.network_ff import NeRFNetwork
+        monkeypatch.setattr(fused_network_ff, "ENABLED", "fused" in route)
+    else:
+        from enerf_amd.network import NeRFNetwork
+        prev = _lib.lib().enerf_debug_nerf_mlp_fused(0)
+    try:
+        net = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True).to(DEV).eval()
+        net.encoder.embeddings.data.uniform_(-1.0, 1.0)
+        x = (torch.rand(n, 3, device=DEV) * 2 - 1) * 2
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=-1)
+        with torch.no_grad():
+            s0, c0 = net(x, d)
+            assert float(c0.float().std()) > 1e-3
+            for it in range(40):
+                s1, c1 = net(x, d)
+                assert torch.equal(s1, s0) and torch.equal(c1, c0), (route, it, int((s1 != s0).sum()), int((c1 != c0).any(dim=1).sum()))
+    finally:
+        if not route.startswith("network_ff"):
+            _lib.lib().enerf_debug_nerf_mlp_fused(prev)
