@@ -445,9 +445,7 @@ def main():
                            "chosen_tail": harness.comm_mode,
                            "prefetch_at_ms_per_step": harness.tuned["prefetch_at_ms_per_step"],
                            "chosen_prefetch_at": harness.prefetch_at,
-                           "native_tail_ms_per_step": harness.tuned.get("native_tail_ms_per_step"),
-                           "torch_distributed_tail_ms_per_step": harness.tuned.get("torch_distributed_tail_ms_per_step"),
-                           "chosen_native_tail": harness.tuned.get("native_tail")}
+                           }
             if harness.comm_dtype is None:      # reported only: what the opt-in 16-bit wire format would give here
                 comm_tuning["bf16_wire_ms_per_step"] = harness.probe_comm_dtype(one_step, torch.bfloat16)
         # the tuning steps must not change what the timed region holds: back to step 0 of the density-grid schedule
@@ -759,7 +757,7 @@ def main():
             torch.manual_seed(0)
             m3 = NeRFNetwork(encoding="hashgrid", bound=args.bound, cuda_ray=True, out_dim_color=3).to(device)
             h3 = TrainHarness(m3, occupancy="synthetic", world=world)
-            for k in ("prefetch", "early_budget", "prefetch_at", "comm_dtype", "comm_chunks", "comm_mode", "native_tail"):
+            for k in ("prefetch", "early_budget", "prefetch_at", "comm_dtype", "comm_chunks", "comm_mode"):
                 setattr(h3, k, getattr(harness, k))
             parallel.broadcast_state(m3)
             b3 = build_batches(4, rays_s, device, rank, args.bound)
@@ -798,7 +796,7 @@ def main():
                       "train_ray_samples_per_sec": smp / ts,
                       "host_enqueue_ms_per_step": (ts_enq - ts0) / args.strong_steps * 1e3,
                       "includes_update_extra_state_steps": sum(1 for i in range(20, 20 + args.strong_steps) if i % 16 == 0),
-                      "tail": (h3.comm_mode + (" native" if h3.native_tail else " torch.distributed")) if world > 1 else None}
+                      "tail": (h3.comm_mode + " torch.distributed") if world > 1 else None}
             del m3, h3, b3
         except Exception as e:                  # the headline must survive a leg that breaks
             strong = {"error": repr(e)[:300]}
@@ -951,7 +949,6 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
-        parallel.native_tail_shutdown()
         dist.destroy_process_group()
 
 

@@ -115,15 +115,6 @@ SIGNATURES = {
     "enerf_train_step_mse": [_vp],
     "enerf_train_step_events": [_vp],
     "enerf_debug_step_timing": [_int, _c.POINTER(_c.c_double)],
-    "enerf_dp_unique_id": [_vp, _sz],
-    "enerf_dp_init": [_vp, _sz, _int, _int],
-    "enerf_dp_world": [_c.POINTER(_int), _c.POINTER(_int)],
-    "enerf_dp_shutdown": [],
-    "enerf_dp_begin": [_int, _vp, _sz, _u32, _vp, _sz, _vp],
-    "enerf_dp_wait": [_vp],
-    "enerf_dp_allgather": [_vp, _vp],
-    "enerf_dp_probe": [],
-    "enerf_dp_finish": [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32, _vp],
     "enerf_abi_version": [],
     "enerf_nerf_mlp_available": [],
     "enerf_debug_nerf_mlp_fused": [_int],

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libenerf_hip.so")
 SOURCES = ["runtime.hip", "raymarching.hip", "gridencoder.hip", "shencoder.hip", "ffmlp.hip", "ffmlp_wgrad.hip",
-           "mlp32.hip", "mlp32s.hip", "mlp32s_f16.hip", "nerf_mlp.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "dp_tail.hip", "train_step.hip"]
+           "mlp32.hip", "mlp32s.hip", "mlp32s_f16.hip", "nerf_mlp.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "train_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 # Per-file extras.  ffmlp.hip (forward + dgrad) keeps its MFMA accumulators in arch VGPRs: every accumulator is

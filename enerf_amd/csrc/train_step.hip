@@ -120,18 +120,6 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
                                            a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
                                            ENERF_F32, 2, in_add, in_mul, (a->flags & 2u) ? 1u : 0u, (a->flags & 2u) ? M : 0u,
                                            s));
-        if ((a->flags & 6u) == 6u) {
-            // bit 2: the rest of that tail from here, on the library's own communicator (csrc/dp_tail.hip): the other
-            // slices' gradient leaves through the reduce-scatter, the optimizer pass runs on this rank's slice -- dense
-            // share + its own lists, the MLP weights behind their all-reduce -- and the slices are all-gathered
-            STEP(enerf_dp_begin(2, a->table_grad, (size_t)a->table_count, 1, a->dw_flat, (size_t)a->dw_count, s));
-            STEP(enerf_dp_wait(s));
-            STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr,
-                                                 a->beta1, a->beta2, a->eps, a->table_step, a->n_small, a->small_p,
-                                                 a->small_g, a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step,
-                                                 s));
-            STEP(enerf_dp_allgather(a->table, s));
-        }
         goto done;
     }
     STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,

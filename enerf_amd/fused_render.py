@@ -557,8 +557,7 @@ class _StepArgs(_ct.Structure):          # enerf_train_step_args (include/enerf_
                 + [(n, _f32c) for n in ("lr", "beta1", "beta2", "eps")]
                 + [("table_step", _u32), ("n_small", _u32)]
                 + [(n, _vp) for n in ("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step")]
-                + [("flags", _u32), ("reserved", _u32), ("dw_flat", _vp), ("dw_count", _ct.c_uint64),
-                   ("table_count", _ct.c_uint64)])
+                + [("flags", _u32), ("reserved", _u32)])
 
 
 COLD_NATIVE = True            # the one-call step also serves the window before the first sample budget (see cold_capacity)
@@ -645,7 +644,7 @@ def _native_ctx(model, N, M, Nn, Mn, dev):
 
 
 def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_stream=None, loss_out=None, perturb=True,
-                      dt_gamma=0, max_steps=1024, raw=False, defer_dp=False, native_dp=False):
+                      dt_gamma=0, max_steps=1024, raw=False, defer_dp=False):
     """One closed-form RGB step (loss = mean((image - target)^2), white background) through enerf_train_step_mse:
     render of this batch (marched ahead of time when the previous step asked for it) + backward + the optimizer, and the
     march of `next_rays` = (rays_o, rays_d) on `side_stream` behind the MLP backward.  -> blended image [N,3] (a buffer
@@ -701,7 +700,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             a.target = target.contiguous().view(-1, 3).data_ptr()
             a.loss = None if loss_out is None else loss_out.data_ptr()
             # (bit 1: the sharded tail with an owner range set -- this rank's slice of the table stays as record lists)
-            a.flags = ((7 if native_dp else 3) if defer_dp else 1) if raw else 0
+            a.flags = (3 if defer_dp else 1) if raw else 0
             # the next batch's march: kernels on the side stream, into the buffer set the current batch is NOT using
             nxt = key = None
             a.next_rays_o = None
@@ -726,9 +725,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                     setattr(a, "next_" + name, nxt[name].data_ptr())
                 key = (no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps))
             a.table_grad = emb.grad.data_ptr()
-            if native_dp:
-                a.dw_flat, a.dw_count, a.table_count = ctx["dw"].data_ptr(), ctx["dw"].numel(), emb.numel()
-            if raw and not native_dp:
+            if raw:
                 a.n_small = 0
                 ctx["plan"] = None                  # (a later optimizer-carrying step rebuilds its arrays)
             else:
@@ -758,7 +755,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
         if nxt is not None:
             which = nxt.pop("_which")
             ctx["flip"] = which ^ 1              # (the set the next call looks at first is the one this stage does not use)
-        if not raw or native_dp:
+        if not raw:
             a.lr, a.beta1, a.beta2, a.eps, a.table_step = ctx["plan"]()
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
@@ -787,7 +784,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                 nxt["ready"].record(side_stream)
             stash[key] = nxt
             model._last_march_event = (nxt["ready"], side_stream)
-        if not raw or native_dp:
+        if not raw:
             views = ctx.get("grad_views")
             if views is None:
                 views = ctx["grad_views"] = [g.view_as(p) for p, g in zip(weights, grads)]

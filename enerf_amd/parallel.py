@@ -30,50 +30,6 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
-_NATIVE = {"state": None}          # None: not tried; True / False: the library's own communicator exists / cannot
-
-
-def native_tail_init():
-    """Give the library its own RCCL communicator over this process group's ranks (csrc/dp_tail.hip: the data-parallel
-    tail of a step as two C calls instead of a dozen torch.distributed round trips).  Collective: every rank of the
-    group must call it.  -> True when every rank has one; False (and nothing left behind) on gloo, without a GPU, or
-    when any rank could not -- the harness then keeps the torch.distributed tail."""
-    if _NATIVE["state"] is not None:
-        return _NATIVE["state"]
-    ok = False
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and torch.cuda.is_available() \
-            and os.environ.get("ENERF_DP_NATIVE", "1") != "0":
-        import ctypes
-        from . import _lib as L
-        lib = L.lib()
-        rank, world = dist.get_rank(), dist.get_world_size()
-        dev = torch.device("cuda", torch.cuda.current_device())
-        host = (ctypes.c_char * 128)()
-        # the id is minted on rank 0 only (the others just check that librccl can be loaded: a second id would be thrown away)
-        can = 1 if (lib.enerf_dp_unique_id(host, 128) if rank == 0 else lib.enerf_dp_probe()) == 0 else 0
-        flag = torch.tensor([can], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            ident = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
-            dist.broadcast(ident, src=0)
-            blob = bytes(ident.cpu().numpy().tobytes())
-            rc = lib.enerf_dp_init(blob, 128, rank, world)
-            flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item()) == 1
-            if not ok:
-                lib.enerf_dp_shutdown()
-    _NATIVE["state"] = ok
-    return ok
-
-
-def native_tail_shutdown():
-    if _NATIVE["state"]:
-        from . import _lib as L
-        L.lib().enerf_dp_shutdown()
-    _NATIVE["state"] = None
-
-
 def shard_range(n, rank, world):
     """Contiguous slice [lo, hi) of n rays owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(n, world)

@@ -59,10 +59,6 @@ class TrainHarness:
         # sharded tail: this rank's slice of the table keeps its own record lists for the optimizer pass (the one-GPU
         # flush, csrc/gridencoder.hip OwnerRange) and only the rest of the gradient is made dense for the reduce-scatter
         self.fused_sharded = True
-        # the tail through the library's own RCCL communicator (csrc/dp_tail.hip: two C calls per step).  Opt-in: False =
-        # the torch.distributed tail (the default: it is the one the world-size-2 tests cover), None = use the native one
-        # when parallel.native_tail_init() succeeds (RCCL backend, every rank), True = likewise, decided already
-        self.native_tail = False
         # where the next batch's march is released on the side stream: once the "forward" is queued (runs beside the
         # MLP backward), once the MLP backward is ("mlp_backward": runs beside the hash table's backward and the
         # optimizer -- the MFMA kernels, one register-filling wavefront per SIMD, then have the CUs to themselves:
@@ -487,6 +483,11 @@ class TrainHarness:
         if emb is None or getattr(self.model.encoder, "level_dim", 0) != 2:
             return None
         world, rank = dist.get_world_size(), dist.get_rank()
+        # measurement aid (tools/dp_tail_overhead.py): a one-rank world that OWNS only 1 / N of the table, i.e. pays an
+        # N-rank world's dense route for the other (N - 1) / N (the collectives degenerate; nothing is averaged)
+        pretend = int(getattr(self, "pretend_world", 0) or 0)
+        if pretend > 1 and world == 1:
+            world = pretend
         n = emb.numel()
         if n % world or (n // world) % 4:
             return None
@@ -517,8 +518,10 @@ class TrainHarness:
             w_dw = dist.all_reduce(dw, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, async_op=True)
             # SUM, not AVG: the optimizer pass applies 1 / ranks to dense share + own lists together (and a one-rank world's
             # in-place SUM is free where RCCL's AVG runs a scaling kernel over the 52 MB)
+            real = dist.get_world_size() == world             # (False: tools/dp_tail_overhead.py's pretend world)
             if nccl:                                          # in place: slice r of the buffer <- sum of everybody's
-                work = dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, async_op=True)
+                work = dist.reduce_scatter_tensor(flat[lo:hi], flat if real else flat[lo:hi], op=dist.ReduceOp.SUM,
+                                                  async_op=True)
             else:                                             # gloo has no reduce-scatter
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
             if issue_prefetch is not None:
@@ -538,67 +541,13 @@ class TrainHarness:
         self._cleared_grad = emb.grad                         # cleared everywhere by the optimizer pass
         p = emb.data.view(-1)
         if nccl:
-            dist.all_gather_into_tensor(p, p[lo:hi])          # in place: slice r of p <- rank r
+            dist.all_gather_into_tensor(p if real else p[lo:hi], p[lo:hi])          # in place: slice r of p <- rank r
         else:
             pieces = [torch.empty(hi - lo, dtype=p.dtype, device=p.device) for _ in range(world)]
             dist.all_gather(pieces, p[lo:hi].contiguous())
             for r, piece in enumerate(pieces):
                 if r * (hi - lo) != lo:
                     p[r * (hi - lo):(r + 1) * (hi - lo)].copy_(piece)
-
-    def _native_tail_ok(self):
-        want = getattr(self, "native_tail", False)
-        if want is False or getattr(self, "comm_dtype", None) is not None \
-                or not hasattr(getattr(self, "opt", None), "step_now"):
-            return False
-        from . import parallel
-        ok = parallel.native_tail_init()
-        if want is None:
-            self.native_tail = ok
-        return ok
-
-    def _finish_native(self, issue_prefetch=None):
-        """Both data-parallel tails through csrc/dp_tail.hip: enerf_dp_begin queues the collectives (all-reduce of the
-        table gradient in `comm_chunks` pieces, or its reduce-scatter; the flat MLP gradient buffer's all-reduce) on the
-        library's communicator and returns; the next batch's march is issued underneath them; enerf_dp_finish queues Adam
-        per piece / on this rank's slice (+ the all-gather of the updated slices) on the training stream.  Same
-        collectives, same arithmetic and the same order as _finish_distributed / _finish_sharded; what changes is that
-        the host spends two ctypes calls on it instead of a torch.distributed round trip per piece."""
-        import torch.distributed as dist
-        from . import _lib as L
-        from . import fused_network
-        m = self.model
-        g_emb, dw = self._raw_grads
-        self._raw_grads = None
-        emb = m.encoder.embeddings
-        if g_emb is None:
-            g_emb = emb.grad
-        else:
-            emb.grad = g_emb
-        world = dist.get_world_size()
-        n = g_emb.numel()
-        sharded = self.comm_mode == "sharded" and n % world == 0 and (n // world) % 4 == 0
-        st = self.opt.state[emb]
-        if not st:
-            st["step"] = 0
-            st["exp_avg"] = torch.zeros_like(emb, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(emb, memory_format=torch.preserve_format)
-        st["step"] += 1
-        group = next(g for g in self.opt.param_groups if any(q is emb for q in g["params"]))
-        lib, stream = L.lib(), L.stream_handle()
-        L.check(lib.enerf_dp_begin(1 if sharded else 0, g_emb.data_ptr(), n, max(1, min(16, int(self.comm_chunks))),
-                                   dw.data_ptr(), dw.numel(), stream), "dp_begin")
-        if issue_prefetch is not None:
-            issue_prefetch(background=False)                  # marches while the gradients are on the wire
-        b1, b2 = group["betas"]
-        L.check(lib.enerf_dp_finish(emb.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                    float(group["lr"]), b1, b2, float(group["eps"]), int(st["step"]), stream), "dp_finish")
-        self._cleared_grad = emb.grad
-        small = fused_network.network_params(m)[1:]
-        for q, g in zip(small, fused_network.unpack_weight_grads(dw, getattr(m, "out_dim_color", 3),
-                                                                 fused_network.kind_of(m))):
-            q.grad = g.view_as(q)
-        self.opt.step_now(only=small)
 
     @staticmethod
     def _discard_pending_records():
@@ -762,32 +711,8 @@ class TrainHarness:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             placements[at] = float(dt.item()) / window * 1e3
         self.prefetch_at = min(placements, key=placements.get)
-        # everything above ran on the library's own communicator when it exists; one window on the torch.distributed
-        # tail with the same settings decides between the two (and puts the difference on record)
-        native_ms = python_ms = None
-        if self._native_tail_ok():
-            native_ms = placements[self.prefetch_at]
-            self.native_tail = False
-            if self.comm_mode == "sharded":
-                self.gather_sharded_optimizer_state()
-            for n in range(2):
-                sync()
-                dist.barrier()
-                t0 = time.perf_counter()
-                for _ in range(window):
-                    step_fn(i)
-                    i += 1
-                sync()
-                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                python_ms = float(dt.item()) / window * 1e3
-            if self.comm_mode == "sharded":
-                self.gather_sharded_optimizer_state()
-            self.native_tail = native_ms <= python_ms
         self.tuned = {"chunks_ms_per_step": dict(timings), "sharded_ms_per_step": sharded_ms,
-                      "mode": self.comm_mode, "prefetch_at_ms_per_step": placements,
-                      "native_tail_ms_per_step": native_ms, "torch_distributed_tail_ms_per_step": python_ms,
-                      "native_tail": bool(getattr(self, "native_tail", False))}
+                      "mode": self.comm_mode, "prefetch_at_ms_per_step": placements}
         return timings
 
     def probe_comm_dtype(self, step_fn, dtype=torch.bfloat16, window=None, first_step=0):
@@ -862,30 +787,21 @@ class TrainHarness:
         if own is not None:
             from . import _lib as L
             L.check(L.lib().enerf_grid_owner_range(own[0], own[1], 1.0 / own[2]), "grid_owner_range")
-        # (opted into the library's own communicator: the whole sharded tail is part of the one call)
-        native_dp = own is not None and self._native_tail_ok()
         try:
             out = fused_render.train_step_native(m, rays_o, rays_d, target, self.opt, next_rays=nxt,
                                                  side_stream=self._side, loss_out=loss, perturb=self.perturb,
-                                                 raw=data_parallel, defer_dp=own is not None, native_dp=native_dp)
+                                                 raw=data_parallel, defer_dp=own is not None)
         except BaseException:
             if own is not None:
                 L.lib().enerf_grid_owner_range(0, 0, 1.0)
             self._discard_pending_records()
             raise
         if data_parallel:
-            if native_dp:
-                L.lib().enerf_grid_owner_range(0, 0, 1.0)
-                self._cleared_grad = emb.grad
-                return loss
             self._raw_grads = (None, out[1])            # (the table's gradient sits in embeddings.grad)
             if own is not None:
                 self._finish_sharded_fused(own, None)
                 return loss
-            if self._native_tail_ok():
-                tail = self._finish_native
-            else:
-                tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
+            tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
             tail(None)                                  # the next batch's march is already queued (behind the MLP backward)
             return loss
         self._cleared_grad = emb.grad
@@ -926,10 +842,7 @@ class TrainHarness:
             if own is not None:
                 self._finish_sharded_fused(own, side if late else None)
                 return loss
-            if self._native_tail_ok():
-                tail = self._finish_native
-            else:
-                tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
+            tail = self._finish_sharded if self.comm_mode == "sharded" else self._finish_distributed
             tail(side if late else None)
             return loss
         self._reduce_grads(None if side is not None else next_rays)

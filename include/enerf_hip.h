@@ -644,16 +644,12 @@ typedef struct enerf_train_step_args {
     const uint32_t* small_step;
     /* bit 0: data parallel -- the table's gradient is SUMMED INTO the dense buffer table_grad (grid_encode_backward's
      * own flush, no record lists left behind) and no optimizer runs: the caller averages table_grad and the buffers
-     * behind dwseg_* over the ranks (enerf_dp_begin / enerf_dp_finish) and steps the optimizer itself.
+     * behind dwseg_* over the ranks (torch.distributed over RCCL: enerf_amd/trainer.py) and steps the optimizer itself.
      * bit 1 (with bit 0, enerf_grid_owner_range set): the sharded tail that keeps this rank's slice as record lists -- the
      * backward defers, flushing only the other slices into table_grad; the caller reduce-scatters, runs
      * enerf_grid_adam_from_records_ex and all-gathers.
-     * bit 2 (with bits 0 and 1, enerf_dp_init done): that whole tail inside this call, on the library's communicator:
-     * enerf_dp_begin(2, table_grad, table_count, 1, dw_flat, dw_count) -> enerf_dp_wait -> the optimizer pass (table_* /
-     * small_* as without bit 0) -> enerf_dp_allgather(table). */
+     * (ABI 2: bit 2 and the three fields behind it -- the tail on the library's own RCCL communicator -- are gone.) */
     uint32_t flags, reserved;
-    float* dw_flat;                     /* bit 2: the flat buffer behind dwseg_* and its length; elements of the table */
-    uint64_t dw_count, table_count;
 } enerf_train_step_args;
 int enerf_train_step_mse(const enerf_train_step_args* args);
 /* Development aid: host microseconds enerf_train_step_mse spends in each of its calls (in call order, 16 slots, averaged
@@ -726,38 +722,6 @@ typedef struct enerf_event_step_args {
     float *m_feats, *m_h32, *m_fb_s, *m_fb_c, *m_sigma, *m_rgb, *m_g_sigmas, *m_g_rgbs, *m_dx32, *m_dfeat;
 } enerf_event_step_args;
 int enerf_train_step_events(const enerf_event_step_args* args);
-
-/* ------------------------------------------------------------------ data-parallel tail (not in the reference,
- * whose Trainer wraps the model in DistributedDataParallel: nerf/utils.py:353-355)
- * One process per GPU; rays shard over the ranks, and the step's only exchange is the average of the hash-table gradient
- * and of the MLP weight gradients before Adam.  The library owns an RCCL communicator and a stream for it: the unique id
- * is minted on rank 0 (enerf_dp_unique_id: 128 bytes) and handed to every rank's enerf_dp_init by the caller
- * (e.g. a torch.distributed broadcast).  Per step:
- *   enerf_dp_begin(mode, table_grad, n, pieces, mlp_grad, n_mlp, stream): queue the collectives behind everything `stream`
- *     holds so far and return.  mode 0: all-reduce (AVG) of table_grad[0..n) in `pieces` pieces (1..16) ; mode 1:
- *     reduce-scatter (AVG), this rank keeping slice [rank * n / world, (rank + 1) * n / world) (n must divide, in multiples
- *     of 4); then the all-reduce (AVG) of mlp_grad[0..n_mlp) (may be NULL).
- *   enerf_dp_finish(p, m, v, lr, beta1, beta2, eps, step, stream): on `stream`, Adam (torch.optim.Adam's update, as
- *     enerf_adam_step_multi) on each piece of the table as its collective lands, the gradients cleared by the same pass;
- *     mode 1: on this rank's slice only, the other slices' gradients cleared and the updated slices all-gathered in place
- *     into every replica's table.  `stream` ends up waiting for the MLP gradients' all-reduce too: what the caller queues
- *     next sees averaged mlp_grad and the updated table.
- * Work queued on `stream` between the two calls runs underneath the collectives. */
-int enerf_dp_unique_id(void* out, size_t bytes);
-int enerf_dp_init(const void* unique_id, size_t bytes, int rank, int world);
-int enerf_dp_world(int* rank, int* world);              /* (-1, 0) before enerf_dp_init */
-int enerf_dp_shutdown(void);
-int enerf_dp_begin(int mode, float* table_grad, size_t n, uint32_t pieces, float* mlp_grad, size_t n_mlp,
-                   enerf_stream_t stream);
-/* The sharded tail with the optimizer pass left to the caller (enerf_grid_owner_range + enerf_grid_adam_from_records_ex),
- * after enerf_dp_begin(1, ...): enerf_dp_wait makes `stream` wait for the reduce-scatter and the MLP gradients'
- * all-reduce; enerf_dp_allgather all-gathers the updated slices of `p` in place behind what `stream` holds, makes `stream`
- * wait for it and closes the step.  enerf_dp_probe: 0 when librccl can be reached (ranks that do not mint the id). */
-int enerf_dp_wait(enerf_stream_t stream);
-int enerf_dp_allgather(float* p, enerf_stream_t stream);
-int enerf_dp_probe(void);
-int enerf_dp_finish(float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, uint32_t step,
-                    enerf_stream_t stream);
 
 /* profiling aid: restrict grid_encode_forward/backward to the levels whose bit is set (default all) */
 int enerf_debug_grid_level_mask(uint32_t mask);

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
     # every compute entry point has a ctypes signature in enerf_amd/_lib.py
     bound = set(_lib.SIGNATURES) | {"enerf_last_error", "enerf_workspace_generation"}
     assert set(names) <= bound, sorted(set(names) - bound)
-    assert _lib.lib().enerf_abi_version() == 1
+    assert _lib.lib().enerf_abi_version() == 2
 
 
 def test_backends_expose_reference_function_names():

@@ -81,22 +81,16 @@ def _rccl_worker(rank, world, port, out):
     try:
         from enerf_amd.trainer import TrainHarness
         data = _data(4, RAYS_PER_RANK)
-        # every tail twice: through the library's own communicator (csrc/dp_tail.hip, two C calls per step) and through
-        # torch.distributed (one round trip per piece)
-        for tag, dp, mode, native in (("single", 1, None, None), ("allreduce", 2, "allreduce", True),
-                                      ("sharded", 2, "sharded", True), ("allreduce_torch", 2, "allreduce", False),
-                                      ("sharded_torch", 2, "sharded", False), ("sharded_fused", 2, "sharded", False),
-                                      ("sharded_fused_native", 2, "sharded", True)):
+        # every tail of the harness on torch.distributed (the library's own RCCL tail of rounds 3 / 4 was retired in round 5:
+        # slower than this one in every measurement and untestable at world 2 on one GPU)
+        for tag, dp, mode in (("single", 1, None), ("allreduce_torch", 2, "allreduce"),
+                              ("sharded_torch", 2, "sharded"), ("sharded_fused", 2, "sharded")):
             model = _model()
             h = TrainHarness(model, lr=1e-2, occupancy="synthetic", world=dp)   # dp = 2: the data-parallel tail runs
             if mode:
                 h.comm_mode = mode
-                h.native_tail = None if native else False
-                h.fused_sharded = tag.startswith("sharded_fused")   # (the other sharded rows: the dense reduce-scatter tails;
-                #                                                     "_native": that whole tail inside the one-call step)
+                h.fused_sharded = tag.startswith("sharded_fused")   # (the other sharded row: the dense reduce-scatter tail)
             losses, counters = _run(h, data, 40)
-            if native:
-                assert h.native_tail is True, "the native tail did not come up on RCCL"
             out[tag] = (losses, counters, _params(model), int(model.mean_count))
     finally:
         dist.destroy_process_group()
@@ -111,7 +105,7 @@ def test_configs3_rank_shape_through_both_tails_on_rccl():
     mp.spawn(_rccl_worker, args=(1, _port(), out), nprocs=1, join=True)
     la, ca, pa, ma = out["single"]
     assert ca[:, 1].max() == RAYS_PER_RANK and ma > 0
-    for tag in ("allreduce", "sharded", "allreduce_torch", "sharded_torch", "sharded_fused", "sharded_fused_native"):
+    for tag in ("allreduce_torch", "sharded_torch", "sharded_fused"):
         lb, cb, pb, mb = out[tag]
         assert np.array_equal(ca, cb) and ma == mb, tag
         assert np.abs(np.array(la) - np.array(lb)).max() <= 1e-4 * np.abs(la).max(), tag

@@ -193,4 +193,3 @@ def test_harness_precision_switches_are_named_apart(cpu_oracle_backend):
         TrainHarness(model, occupancy="learned", amp="bf16")
     with pytest.raises(ValueError):
         TrainHarness(model, occupancy="learned", amp="fp8")
-    assert TrainHarness(model, occupancy="learned").native_tail is False          # the library's own RCCL tail is opt-in

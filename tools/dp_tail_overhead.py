@@ -3,7 +3,8 @@ to a local pass), step time with the tail against the plain single-process step:
 tail (launches per piece) and that its device side works on the real backend.  Caveat: with one rank RCCL runs
 `oneRankReduce<PreMulSum>` over the buffer for ReduceOp.AVG (~120 us for the 52 MB table) -- an artefact of the
 one-rank world that the ring kernels replace at N > 1, so the difference printed here is NOT the tail's fixed cost.
-python tools/dp_tail_overhead.py [--rays 4096] [--steps 96]"""
+python tools/dp_tail_overhead.py [--rays 4096] [--steps 96]
+(the library-side RCCL tail of rounds 3 / 4 -- csrc/dp_tail.hip -- lost every row of this table and was retired in round 5)"""
 import argparse
 import os
 import sys
@@ -33,26 +34,23 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1)
     dev = torch.device("cuda", 0)
     batches = bench.build_batches(8, a.rays, dev, 0, a.bound)
-    # (native: csrc/dp_tail.hip on the library's own communicator; torch: torch.distributed, one round trip per piece)
     # ("sharded, own slice fused": the default sharded tail -- this rank's slice of the table keeps its record lists for
     #  the optimizer pass, TrainHarness._finish_sharded_fused; "dense": every tile made dense first, _finish_sharded)
-    configs = (("single process", 1, 4, None, None, "allreduce", True),
-               ("torch tail, 1 piece", 2, 1, None, False, "allreduce", True),
-               ("torch tail, 4 pieces", 2, 4, None, False, "allreduce", True),
-               ("torch tail, 8 pieces", 2, 8, None, False, "allreduce", True),
-               ("torch tail, sharded, own slice fused", 2, 4, None, False, "sharded", True),
-               ("torch tail, sharded, dense", 2, 4, None, False, "sharded", False),
-               ("native tail, 1 piece", 2, 1, None, None, "allreduce", True),
-               ("native tail, 4 pieces", 2, 4, None, None, "allreduce", True),
-               ("native tail, 8 pieces", 2, 8, None, None, "allreduce", True),
-               ("native tail, sharded, dense", 2, 4, None, None, "sharded", False),
-               ("native, sharded, own slice fused (1 call)", 2, 4, None, None, "sharded", True),
-               ("torch tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16, False, "allreduce", True))
-    for tag, dp, chunks, dtype, native, mode, fused in (configs if a.only is None else configs[a.only:a.only + 1]):
+    # (last column: pretend_world -- this one rank owns 1 / N of the table and pays an N-rank world's dense route for the
+    #  rest: what a rank of N = 8 does between its backward and its optimizer pass, minus the wire)
+    configs = (("single process", 1, 4, None, None, "allreduce", True, 0),
+               ("torch tail, 1 piece", 2, 1, None, False, "allreduce", True, 0),
+               ("torch tail, 4 pieces", 2, 4, None, False, "allreduce", True, 0),
+               ("torch tail, sharded, own slice fused", 2, 4, None, False, "sharded", True, 0),
+               ("torch tail, sharded, dense", 2, 4, None, False, "sharded", False, 0),
+               ("sharded, own slice fused, owning 1/2", 2, 4, None, False, "sharded", True, 2),
+               ("sharded, own slice fused, owning 1/8", 2, 4, None, False, "sharded", True, 8),
+               ("torch tail, 4 pieces, bf16 wire", 2, 4, torch.bfloat16, False, "allreduce", True, 0))
+    for tag, dp, chunks, dtype, native, mode, fused, pretend in (configs if a.only is None else configs[a.only:a.only + 1]):
         torch.manual_seed(0)
         model = NeRFNetwork(encoding="hashgrid", bound=a.bound, cuda_ray=True, out_dim_color=3).to(dev)
         h = TrainHarness(model, occupancy="synthetic", world=dp)
-        h.comm_chunks, h.comm_dtype, h.native_tail, h.comm_mode, h.fused_sharded = chunks, dtype, native, mode, fused
+        h.comm_chunks, h.comm_dtype, h.comm_mode, h.fused_sharded, h.pretend_world = chunks, dtype, mode, fused, pretend
 
         def step(i):
             ro, rd, tg = batches[i % 8]
