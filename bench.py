@@ -678,7 +678,8 @@ def main():
                                                                ("fp16_autocast_rgb", "linear", "rgb", args.bound, "autocast", 0),
                                                                ("after_step_256_rgb", "linear", "rgb", args.bound, False, 16),
                                                                ("mlp32_fp32_exact_rgb", "linear", "rgb", args.bound, False, 0),
-                                                               ("dropin_route_rgb", "linear", "rgb", args.bound, False, 0)):
+                                                               ("dropin_route_rgb", "linear", "rgb", args.bound, False, 0),
+                                                               ("dropin_route_fusedadam_rgb", "linear", "rgb", args.bound, False, 0)):
             restore = []
             if args.only_legs and tag not in args.only_legs.split(","):
                 continue
@@ -688,7 +689,7 @@ def main():
                     # instead of the default split-bf16 products
                     prev_prec = _lib.lib().enerf_mlp32_precision(0)
                     restore.append(lambda p_=prev_prec: _lib.lib().enerf_mlp32_precision(p_))
-                if tag == "dropin_route_rgb":
+                if tag.startswith("dropin_route"):
                     # the boundary as the reference uses it: `_backend` of the reference-shaped wrappers = the pybind11
                     # modules _raymarching / _gridencoder / _shencoder (enerf_amd/ext), every fused route off, autograd,
                     # torch.optim.Adam -- what tests/test_gpu_ext.py checks against the oracle, timed
@@ -708,8 +709,11 @@ def main():
                     from enerf_amd.network import NeRFNetwork as LegNet
                 torch.manual_seed(0)
                 m2 = LegNet(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3).to(device)
-                if tag == "dropin_route_rgb":
-                    h2 = TrainHarness(m2, occupancy="synthetic", world=1, optimizer=torch.optim.Adam)
+                if tag.startswith("dropin_route"):
+                    # ("_fusedadam": the same route with the one-line optimizer swap of INTEGRATION.md -- enerf_amd.optim.FusedAdam
+                    #  in place of torch.optim.Adam: one launch over all parameters instead of torch's multi-tensor passes)
+                    h2 = TrainHarness(m2, occupancy="synthetic", world=1,
+                                      optimizer=None if tag.endswith("fusedadam_rgb") else torch.optim.Adam)
                     h2.native_step = h2.manual_mse = h2.fuse_table_adam = h2.prefetch = False
                 else:
                     h2 = TrainHarness(m2, occupancy="synthetic", world=1, fp16=fp16 if fp16 in (True, "autocast") else False,
@@ -917,8 +921,9 @@ def main():
             "data": "synthetic",
             "arithmetic": None if (args.net != "linear" or args.fp16 or args.fp16_autocast or args.fp16_true) else (
                 "fp32 storage and accumulation; products of the nn.Linear nets as three bf16 MFMA terms per fp32 product "
-                "(split-bf16: ~5e-6 relative forward error, profiles/r03_mlp32_accuracy.txt); the same step on the exact "
-                "fp32 MFMA is other_steps.mlp32_fp32_exact_rgb" if _lib.lib().enerf_mlp32_precision(-1) == 1 else
+                "(split-bf16: ~5e-6 relative forward error, profiles/r03_mlp32_accuracy.txt; both nets in one launch per "
+                "direction, csrc/nerf_mlp.hip); the same step on the exact fp32 MFMA is value_exact_fp32 / "
+                "other_steps.mlp32_fp32_exact_rgb" if _lib.lib().enerf_mlp32_precision(-1) == 1 else
                 "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
             "config": {"workload": (f"BASELINE configs[3]: {args.global_rays} rays/step ray-sharded over {world} rank(s), "
                                     if args.global_rays else "BASELINE configs[1]: ") +
@@ -929,6 +934,9 @@ def main():
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single"},
             "train_ray_samples_per_sec": total_samples / elapsed,
             "samples_per_step_per_gpu": total_samples / args.steps / world,
+            # the strictly-fp32 figure beside `value` (the same step on v_mfma_f32_32x32x2_f32, other_steps.mlp32_fp32_exact_rgb:
+            # 48 steps of its own after 20 warm-up steps -- three density-grid updates in the window, not one in twenty)
+            "value_exact_fp32": (other_steps or {}).get("mlp32_fp32_exact_rgb", {}).get("rays_per_sec"),
             "render": render,
             "step_split": split,
             "other_steps": other_steps,
