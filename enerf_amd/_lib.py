@@ -117,6 +117,7 @@ SIGNATURES = {
     "enerf_debug_step_timing": [_int, _c.POINTER(_c.c_double)],
     "enerf_abi_version": [],
     "enerf_nerf_mlp_available": [],
+    "enerf_amp_armed": [],
     "enerf_debug_nerf_mlp_fused": [_int],
     "enerf_nerf_mlp_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     "enerf_nerf_mlp_backward": [_vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp],

@@ -155,6 +155,9 @@ int enerf_amp_end(float growth_factor, float backoff_factor, int32_t growth_inte
 }
 
 // (an aborted step: disarm without an update)
+// 1 between enerf_amp_begin and enerf_amp_end / _cancel (callers whose optimizer path is not AMP-aware must refuse to run then)
+int enerf_amp_armed(void) { return g_amp.scale ? 1 : 0; }
+
 int enerf_amp_cancel(void) {
     g_amp = AmpState{nullptr, nullptr, nullptr};
     return 0;

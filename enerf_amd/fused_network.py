@@ -393,6 +393,14 @@ def _density_scratch(net, name, shape, dtype, dev):
     n = 1
     for d in shape:
         n *= int(d)
+    # the pool is not the caching allocator: nothing orders a new user's stream behind the previous user's.  Its buffers
+    # belong to ONE stream at a time; a call from another stream (a side-stream update, a capture) waits for everything the
+    # previous owner has queued before it reuses them.
+    cur = torch.cuda.current_stream(dev)
+    owner = pool.get("_stream")
+    if owner is not None and owner != cur:
+        cur.wait_stream(owner)
+    pool["_stream"] = cur
     buf = pool.get(name)
     if buf is None or buf.numel() < n or buf.dtype != dtype or buf.device != dev:
         buf = torch.empty(max(n, 1), dtype=dtype, device=dev)

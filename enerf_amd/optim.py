@@ -35,6 +35,9 @@ class FusedAdam(torch.optim.Optimizer):
         extra = [q for q in extra if q.grad is not None]
         if len(extra) > 8 or any(not (q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
                                       and q.grad.is_contiguous() and q.grad.dtype == torch.float32) for q in extra):
+            if L.lib().enerf_amp_armed():                   # step_now neither unscales nor skips
+                raise RuntimeError("FusedAdam.step_grid_table: under the device-side GradScaler (enerf_amp_begin) every extra "
+                                   "tensor must ride in the table launch: at most 8 contiguous fp32 CUDA tensors")
             self.step_now(only=extra)                       # (more / other tensors than the launch carries)
             extra = []
         group, st, args = self.grid_table_args(p, extra, [q.grad for q in extra])

@@ -45,6 +45,27 @@ class NeRFRenderer(nn.Module):
     def _zero_counters(self):
         self.mean_density = self.iter_density = self.mean_count = self.local_step = 0
 
+    # What the fused routes cache ON the module (scratch pools of update_extra_state -- up to 0.8 GB --, device pointers of the
+    # one-call steps, samples marched ahead, events): none of it is model state.  torch.save(model) / copy.deepcopy(model)
+    # see the module without it; the copy rebuilds what it needs on first use.
+    _TRANSIENT = ("_density_scratch", "_native_ctx", "_native_events_ctx", "_premarched", "_fused_kind",
+                  "_pending_density_stats", "_last_march_event")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._TRANSIENT:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def reset_extra_state(self):
         if self.cuda_ray:
             for state in (self.density_grid, self.step_counter):

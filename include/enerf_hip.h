@@ -525,6 +525,10 @@ int enerf_stream_wait_mlp32_signal(enerf_stream_t stream);
 int enerf_amp_begin(float* scale, int32_t* growth_tracker, uint32_t* found_inf, uint32_t* skipped);
 int enerf_amp_end(float growth_factor, float backoff_factor, int32_t growth_interval, enerf_stream_t stream);
 int enerf_amp_cancel(void);
+/* 1 while armed.  Only the kernels named above unscale and skip: the record-list Adam launch (table + up to 8 small tensors).
+ * The table's gradient itself is not inspected for non-finite values -- it is dL/dfeature (whose overflow the first layer's
+ * weight gradient, which IS inspected, shares) times trilinear weights <= 1. */
+int enerf_amp_armed(void);
 /* Tuning aid: number of workgroups (= partial weight-gradient sums) enerf_mlp32_backward launches; 0 restores the
  * default (768 for one hidden layer, 512 otherwise). */
 int enerf_debug_mlp32_wgrad_blocks(uint32_t blocks);
