@@ -31,8 +31,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
     using x8 = typename V<E>::x8;
     using x4 = typename V<E>::x4;
     constexpr int IN = 16 * IN_KB;
-    constexpr uint32_t NW = HID * (IN + HID * (NL - 1) + OUT);
-    __shared__ __attribute__((aligned(16))) E wl[NW];
+    constexpr int LD0 = IN + (int)kRowPad, LDH = HID + (int)kRowPad;      // padded rows of the LDS copy (ffmlp_common.h)
+    __shared__ __attribute__((aligned(16))) E wl[padded_size<IN, NL>()];
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     // Two 32-sample tiles (64 consecutive samples) per iteration: two independent MFMA dependency chains per layer,
     // and the next iteration's inputs are already in flight while this one computes (B % 128 == 0 => pairs are whole).
@@ -49,26 +49,26 @@ __global__ void __launch_bounds__(256) k_ffmlp_fwd(const E* __restrict__ X, cons
             for (int kb = 0; kb < IN_KB; kb++)
                 xn[t][kb] = *reinterpret_cast<const x8*>(X + ((size_t)(gw * T + t) * 32 + j) * IN + 16 * kb + 8 * h);
     }
-    stage_weights_n<NW>(wl, W);
+    stage_weights_padded<IN, NL>(wl, W);
 
     // weight fragments (A operands): lane = output neuron
     x8 w0[2][IN_KB], wh[NL - 1][2][4], wo[4];
 #pragma unroll
     for (int ob = 0; ob < 2; ob++)
 #pragma unroll
-        for (int kb = 0; kb < IN_KB; kb++) w0[ob][kb] = frag_row_nat<E>(wl, IN, 32 * ob + j, kb, h);
+        for (int kb = 0; kb < IN_KB; kb++) w0[ob][kb] = frag_row_nat<E>(wl, LD0, 32 * ob + j, kb, h);
 #pragma unroll
     for (int l = 0; l < NL - 1; l++)
 #pragma unroll
         for (int ob = 0; ob < 2; ob++)
 #pragma unroll
             for (int blk = 0; blk < 4; blk++)
-                wh[l][ob][blk] = frag_row_perm<E>(wl + HID * IN + l * HID * HID, HID, 32 * ob + j, blk, h);
+                wh[l][ob][blk] = frag_row_perm<E>(wl + padded_base<IN>(1 + l), LDH, 32 * ob + j, blk, h);
     {
-        const E* wout = wl + HID * IN + (NL - 1) * HID * HID;   // [16][64]; rows 16..31 of the MFMA tile are zero
+        const E* wout = wl + padded_base<IN>(NL);                // [16][64]; rows 16..31 of the MFMA tile are zero
 #pragma unroll
         for (int blk = 0; blk < 4; blk++) {
-            if (j < OUT) wo[blk] = frag_row_perm<E>(wout, HID, j, blk, h);
+            if (j < OUT) wo[blk] = frag_row_perm<E>(wout, LDH, j, blk, h);
             else
 #pragma unroll
                 for (int e = 0; e < 8; e++) wo[blk][e] = (E)0.0f;

@@ -259,6 +259,45 @@ __device__ __forceinline__ void stage_weights_n(E* wl, const E* __restrict__ w) 
     __syncthreads();
 }
 
+// The forward's copy: rows padded by 8 elements (16 B).  Its fragment builders read ROWS across lanes (lane = output
+// neuron): with the blob's own 128-byte rows every lane of a half-wave hit the same LDS bank -- a 32-way conflict on each of
+// the ~50 reads of the set-up, ~10 % of k_ffmlp_fwd's time at 2 M samples (round 5); 144-byte rows spread them over the banks.
+// Matrix m of the blob (W0 [64, IN] | Wh [64, 64] x (NL-1) | Wout [16, 64]) starts at padded_base<IN>(m).
+constexpr uint32_t kRowPad = 8;
+template <int IN>
+__host__ __device__ constexpr uint32_t padded_base(int m) {      // m = 0: W0, 1..: hidden matrices, then Wout
+    return m == 0 ? 0u : HID * (IN + kRowPad) + (uint32_t)(m - 1) * HID * (HID + kRowPad);
+}
+template <int IN, int NL>
+__host__ __device__ constexpr uint32_t padded_size() { return padded_base<IN>(NL) + OUT * (HID + kRowPad); }
+template <int IN, int NL, typename E>
+__device__ __forceinline__ void stage_weights_padded(E* wl, const E* __restrict__ w) {
+    constexpr uint32_t N = HID * (IN + HID * (NL - 1) + OUT);
+    constexpr uint32_t V = N / 8, PASSES = (V + 255u) / 256u;
+    constexpr uint32_t C0 = IN / 8, V0 = HID * C0;                 // 16-byte chunks per row / in all of W0
+    const uint4* src = reinterpret_cast<const uint4*>(w);
+    uint4 v[PASSES];
+#pragma unroll
+    for (uint32_t k = 0; k < PASSES; k++) {
+        const uint32_t i = threadIdx.x + k * 256u;
+        v[k] = src[i < V ? i : V - 1u];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PASSES; k++) {
+        const uint32_t i = threadIdx.x + k * 256u;
+        if (i < V) {
+            uint32_t at;                                           // element offset in the padded copy
+            if (i < V0) at = (i / C0) * (IN + kRowPad) + (i % C0) * 8u;
+            else {
+                const uint32_t r = (i - V0) / (HID / 8), c = (i - V0) % (HID / 8);      // rows of the 64-wide matrices, numbered through
+                at = HID * (IN + kRowPad) + r * (HID + kRowPad) + c * 8u;
+            }
+            *reinterpret_cast<uint4*>(wl + at) = v[k];
+        }
+    }
+    __syncthreads();
+}
+
 #define FFMLP_DISPATCH_ACT(E, CALL)                                                 \
     switch (act_class(act)) {                                                       \
         case 0: { constexpr int ACT = 0; FFMLP_DISPATCH(E, CALL); } break;          \

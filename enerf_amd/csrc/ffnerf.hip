@@ -65,6 +65,33 @@ __device__ __forceinline__ float frag_source(const float* __restrict__ Ws, const
     return j < OUT ? Wc[HID * 32 + 2 * HID * HID + j * HID + col_perm(f - F_CWO, h, e)] : 0.0f;
 }
 
+// the same as an address: -> pointer to read (always readable) and whether the element is a structural zero.  Branch-free
+// in the lane, so that the staging loop below can issue every load of a thread before its first LDS store.
+__device__ __forceinline__ const float* frag_address(const float* __restrict__ Ws, const float* __restrict__ Wc, int f, int lane,
+                                                     int e, bool& zero) {
+    const int j = lane & 31, h = lane >> 5;
+    const int jo = j < OUT ? j : 0;
+    zero = false;
+    if (f < F_SWH) return Ws + (32 * ((f - F_SW0) >> 1) + j) * 32 + col_nat((f - F_SW0) & 1, h, e);
+    if (f < F_SWO) return Ws + HID * 32 + (32 * ((f - F_SWH) >> 2) + j) * HID + col_perm((f - F_SWH) & 3, h, e);
+    if (f < F_CW0) {
+        zero = j >= OUT;
+        return Ws + HID * 32 + HID * HID + jo * HID + col_perm(f - F_SWO, h, e);
+    }
+    if (f < F_CWH) {
+        const int ob = (f - F_CW0) >> 1, kb = (f - F_CW0) & 1;
+        const int r = drow(h, e);
+        zero = kb == 1 && r == 0;
+        return Wc + (32 * ob + j) * 32 + (kb == 0 ? col_nat(0, h, e) : (r == 0 ? 0 : 16 + r - 1));
+    }
+    if (f < F_CWO) {
+        const int l = (f - F_CWH) >> 3, ob = ((f - F_CWH) >> 2) & 1, blk = (f - F_CWH) & 3;
+        return Wc + HID * 32 + l * HID * HID + (32 * ob + j) * HID + col_perm(blk, h, e);
+    }
+    zero = j >= OUT;
+    return Wc + HID * 32 + 2 * HID * HID + jo * HID + col_perm(f - F_CWO, h, e);
+}
+
 struct TileIn {
     float2 f[2][4];
     float dx, dy, dz;
@@ -89,8 +116,29 @@ __global__ void __launch_bounds__(256, 2) k_ffnerf_infer(const float* __restrict
                                                          float* __restrict__ rgb) {
     using x8 = typename V<E>::x8;
     __shared__ __attribute__((aligned(16))) E wl[kFrags * 64 * 8];
-    for (uint32_t i = threadIdx.x; i < kFrags * 64 * 8; i += blockDim.x)
-        wl[i] = (E)frag_source(Ws, Wc, (int)(i >> 9), (int)((i >> 3) & 63), (int)(i & 7));
+    {
+        // a thread builds whole 16-byte fragment pieces (fragment f, lane): 10 of them, 80 gathered floats, every load
+        // issued before the first store -- as the element-by-element loop it was one L2 round trip per element, 80 in a row
+        // (rocprofv3, round 5: ~10 % of the kernel's 0.5 ms per frame were this set-up); f is uniform in a wavefront
+        constexpr int PIECES = kFrags * 64 / 256;
+        static_assert(kFrags * 64 % 256 == 0, "pieces per thread");
+        float v[PIECES][8];
+        bool z[PIECES][8];
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) {
+            const int piece = (int)threadIdx.x + 256 * k;
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[k][e] = *frag_address(Ws, Wc, piece >> 6, piece & 63, e, z[k][e]);
+        }
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) {
+            const int piece = (int)threadIdx.x + 256 * k;
+            x8 q;
+#pragma unroll
+            for (int e = 0; e < 8; e++) q[e] = (E)(z[k][e] ? 0.0f : v[k][e]);
+            reinterpret_cast<x8*>(wl)[piece] = q;
+        }
+    }
     __syncthreads();
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const x8* fr = reinterpret_cast<const x8*>(wl) + lane;             // fragment f of this lane: fr[f * 64]
