@@ -157,7 +157,7 @@ __device__ __forceinline__ void copy_frags(u32x4n* __restrict__ fr, const uint32
 // Residency: ONE workgroup per CU and one wavefront per SIMD, by construction -- 84 KiB of LDS and more than half of the
 // register file per wave.  With two or three workgroups of this kernel on a CU the colour outputs of samples 16..31 of a
 // tile came out wrong in a few per cent of the tiles of the later-dispatched workgroups (10^-3 .. 10^-2 in rgb, different
-// rows every launch; sigma never; tools/dev/soak_old_mlp.py, profiles/r05_nerf_fwd_residency.txt), in VGPR- and AGPR-form
+// rows every launch; sigma never; tools/nerf_fwd_residency.sh -> profiles/r05_nerf_fwd_residency.txt), in VGPR- and AGPR-form
 // builds alike, while the one-net kernels of mlp32s.hip at the same residency and every build of this kernel at one
 // workgroup per CU are bit-stable over hundreds of launches.  The cause was not found in this round (it is not the operand
 // overlap of mfma_guard.h, which was fixed first and made the second workgroup safe but not the third); until it is, the
@@ -165,8 +165,14 @@ __device__ __forceinline__ void copy_frags(u32x4n* __restrict__ fr, const uint32
 // anyway).  tests/test_gpu_mlp32.py soaks both kernels for run-to-run bit-stability.
 // the wave's allocation is the SIMD's whole register file (256 + 256): no wavefront of ANY kernel shares the SIMD -- the
 // next batch's march runs on a second stream beside this library's step
+// (NERF_SHARED_CU: the experiment's build -- tools/nerf_fwd_residency.sh -- lets workgroups share a CU again)
+#ifdef NERF_SHARED_CU
+#define NERF_WHOLE_SIMD() do {} while (0)
+constexpr uint32_t kFwdLdsWords = 12 * 1024;              // 48 KiB: the fragments alone, three workgroups per CU
+#else
 #define NERF_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
 constexpr uint32_t kFwdLdsWords = 21 * 1024;              // 84 KiB: two workgroups do not fit a CU's 160 KiB
+#endif
 __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ X, const float* __restrict__ dirs,
                                                    const uint32_t* __restrict__ frags, float* __restrict__ sigma,
                                                    float* __restrict__ rgb, uint32_t B, uint32_t out_c, NerfRows rows,
