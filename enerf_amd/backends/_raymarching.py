@@ -79,6 +79,12 @@ def march_rays_train_ex(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, 
                                               L.stream_handle()), "march_rays_train_ex")
 
 
+def march_fuse_near_far(aabb, min_near):
+    """Arm the next march_rays_train(_ex / _count) call to compute near / far itself and write them into the nears / fars
+    arrays it is given (include/enerf_hip.h)."""
+    L.check(L.lib().enerf_march_fuse_near_far(_f32(aabb, "aabb"), float(min_near)), "march_fuse_near_far")
+
+
 def occupied_box_update(grid, C, H, bound):
     """(Re)compute the library's bounding box of the occupied cells of `grid` (include/enerf_hip.h)."""
     L.check(L.lib().enerf_occupied_box_update(_u8(grid, "grid"), int(C), int(H), float(bound), L.stream_handle()),

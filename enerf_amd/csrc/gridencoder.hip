@@ -438,28 +438,45 @@ __device__ __forceinline__ void scatter_add(__half* row, float w, const float (&
 //   load_sample     position + upstream gradient of sample b at one level; returns whether it contributes
 //   corner_contrib  cell coordinates and the 2^D * C per-corner contributions v[idx*C+c] = w_idx * g[c]
 //   aggregate_runs  in-wave run aggregation; returns whether this lane is the head of its run (only heads scatter)
+// A sample's position and gradient: requested (every load issued before anything is tested -- tested one coordinate at a
+// time, each load waited for the previous one: four memory latencies in a row at the head of both backward kernels) and,
+// separately, turned into the kernel's values, so that a persistent workgroup can request its next item's while it works
 template <typename T, int D, int C>
-__device__ __forceinline__ bool load_sample(uint32_t b, bool valid, const T* __restrict__ grad,
-                                            const float* __restrict__ inputs, uint32_t level, uint32_t B, uint32_t L,
-                                            int grad_layout, float in_add, float in_mul, float (&in)[D], float (&g)[C]) {
-    // every load is issued before anything is tested (clamped index, selections afterwards): tested one coordinate at
-    // a time, each load waited for the previous one -- four memory latencies in a row at the head of both backward
-    // kernels
+struct RawSample {
+    float raw[D];
+    Feat<T, C> gv;
+};
+template <typename T, int D, int C>
+__device__ __forceinline__ RawSample<T, D, C> request_sample(uint32_t b, const T* __restrict__ grad,
+                                                             const float* __restrict__ inputs, uint32_t level, uint32_t B,
+                                                             uint32_t L, int grad_layout) {
+    RawSample<T, D, C> r;
     const uint32_t bc = b < B ? b : B - 1u;
     const uint32_t Bp = (B + 31u) & ~31u;
-    float raw[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) raw[d] = inputs[(size_t)bc * D + d];
-    const Feat<T, C> gv = reinterpret_cast<const Feat<T, C>*>(
+    for (int d = 0; d < D; d++) r.raw[d] = inputs[(size_t)bc * D + d];
+    r.gv = reinterpret_cast<const Feat<T, C>*>(
         grad)[grad_layout == 0 ? (size_t)level * B + bc : grad_layout == 1 ? (size_t)bc * L + level : (size_t)level * Bp + bc];
+    return r;
+}
+template <typename T, int D, int C>
+__device__ __forceinline__ bool finish_sample(const RawSample<T, D, C>& r, bool valid, float in_add, float in_mul,
+                                              float (&in)[D], float (&g)[C]) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        in[d] = valid ? (raw[d] + in_add) * in_mul : 0.0f;
+        in[d] = valid ? (r.raw[d] + in_add) * in_mul : 0.0f;
         valid = valid && !(in[d] < 0 || in[d] > 1);   // out-of-range points contribute nothing
     }
 #pragma unroll
-    for (int c = 0; c < C; c++) g[c] = valid ? to_f(gv.v[c]) : 0.0f;
+    for (int c = 0; c < C; c++) g[c] = valid ? to_f(r.gv.v[c]) : 0.0f;
     return valid;
+}
+template <typename T, int D, int C>
+__device__ __forceinline__ bool load_sample(uint32_t b, bool valid, const T* __restrict__ grad, const float* __restrict__ inputs,
+                                            uint32_t level, uint32_t B, uint32_t L, int grad_layout, float in_add,
+                                            float in_mul, float (&in)[D], float (&g)[C]) {
+    const RawSample<T, D, C> r = request_sample<T, D, C>(b, grad, inputs, level, B, L, grad_layout);
+    return finish_sample<T, D, C>(r, valid, in_add, in_mul, in, g);
 }
 
 template <int D>
@@ -562,12 +579,55 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 // 64-KiB tiles (8192 fp64 accumulators), two tile workgroups per CU: against 128-KiB tiles with one workgroup per CU the
 // tile kernels gain ~8 % (finer-grained last round, two workgroups' phases interleave) at no cost to the binning pass
 #ifndef ENERF_TILE_ELEMS
-#define ENERF_TILE_ELEMS 8192
+#define ENERF_TILE_ELEMS 4096
+#endif
+#ifndef ENERF_TA_PAIRS
+#define ENERF_TA_PAIRS 10
+#endif
+#ifdef ENERF_TA_CAP
+#define ENERF_TA_REGS __attribute__((amdgpu_waves_per_eu(5, 8)))
+#else
+#define ENERF_TA_REGS __attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
+struct __attribute__((aligned(8))) f32x2g { float x, y; };
+// k_grid_tile_adam's m / v stream is marked non-temporal (every element is touched once per step; p is read again by the next
+// forward and keeps its place in the caches): the table's backward + Adam 120 -> 111 us stand-alone, 1 - 2 us in the step
+// (-DENERF_TA_TEMPORAL: plain loads and stores)
+typedef float ta_f4 __attribute__((ext_vector_type(4)));
+#ifndef ENERF_TA_TEMPORAL
+__device__ __forceinline__ float4 ta_load4(const float* p) {
+    const ta_f4 v = __builtin_nontemporal_load(reinterpret_cast<const ta_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ta_store4(float* p, const float4& v) {
+    ta_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<ta_f4*>(p));
+}
+#define TA_LOAD4(p) ta_load4(p)
+#define TA_STORE4(p, v) ta_store4(p, v)
+#else
+#define TA_LOAD4(p) (*reinterpret_cast<const float4*>(p))
+#define TA_STORE4(p, v) (*reinterpret_cast<float4*>(p) = (v))
+#endif
+#ifdef ENERF_TA_TIMING
+// development aid (tools/dev/ta_tiles.py): per tile of the last k_grid_tile_adam launch -- level, records, begin, end (100 MHz)
+__device__ uint32_t g_ta_log[4 * 4096];
+__device__ uint32_t g_ta_wg[2 * 2048];          // per workgroup: entry, exit
+__device__ unsigned long long g_bin_ph[32 * 8];      // binning pass: 100 MHz ticks per phase, summed over workgroups; [7] = workgroups
+#define BIN_PH(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_bin_ph[bin_lv * 8 + (k)], t_ - bin_t); bin_t = t_; } } while (0)
+#else
+#define BIN_PH(k)
 #endif
 constexpr uint32_t kTileElems = ENERF_TILE_ELEMS;
 constexpr uint32_t kTileThreads = ENERF_TILE_ELEMS / 16;
+constexpr uint32_t kTileAccBytes = ENERF_TILE_ELEMS * 8;         // k_grid_tile_adam's fp64 accumulators (dynamic LDS)
 constexpr uint32_t kTilesPerCu = 16384 / ENERF_TILE_ELEMS;     // resident tile workgroups per CU
-constexpr uint32_t kMaxBins = 256;           // record lists per level (256: the binning pass keeps 3 workgroups per CU)
+// record lists per level: a 2^19-row level cut into tiles of R rows, between 256 (C = 2: the binning pass's three LDS tables
+// of that many words leave room for 3 workgroups per CU) and kMaxBins (the stride of the cursor array)
+constexpr uint32_t kMaxBins = 512;
+__host__ __device__ constexpr uint32_t bins_limit(uint32_t R) {
+    return (1u << 19) / R <= 256u ? 256u : ((1u << 19) / R < kMaxBins ? (1u << 19) / R : kMaxBins);
+}
 struct BinPlan {
     uint32_t tiles, replicas, bins;          // bins = tiles * replicas (0: level not binned)
 };
@@ -576,9 +636,13 @@ __device__ __forceinline__ BinPlan bin_plan(const int32_t* __restrict__ offsets,
     BinPlan p;
     p.tiles = div_up((uint32_t)(offsets[level + 1] - offsets[level]), rows_per_tile);
     p.replicas = p.tiles >= min_tiles ? 1u : div_up(min_tiles, p.tiles);
-    p.bins = p.tiles * p.replicas <= kMaxBins ? p.tiles * p.replicas : 0u;
+    p.bins = p.tiles * p.replicas <= bins_limit(rows_per_tile) ? p.tiles * p.replicas : 0u;
     return p;
 }
+
+// records a list can hold: the level's region cut evenly, kept even so that two neighbouring records (one 4-byte pair of
+// keys, one 8-byte pair per value plane) can be fetched with one load each (k_grid_tile_adam)
+__device__ __forceinline__ uint32_t bin_cap(uint32_t region, uint32_t bins) { return (region / bins) & ~1u; }
 
 // One thread per (sample, level), global atomics from run heads.  binned_min_tiles != 0: skip the binned levels.
 template <typename T, int D, int C>
@@ -634,12 +698,13 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
                                                                uint32_t region, uint32_t* __restrict__ overflow) {
     constexpr uint32_t R = kTileElems / C;
     constexpr uint32_t NREC = PTS << D;
-    __shared__ uint32_t s_ofs[kMaxBins];         // records per list, then exclusive offset of the list in the staging area
+    constexpr uint32_t kBins = bins_limit(kTileElems / C);
+    __shared__ uint32_t s_ofs[kBins];            // records per list, then exclusive offset of the list in the staging area
     // where the staging area's record j of list t goes, in words from the level's first record: s_at[t] + j, valid
     // below s_end[t] (= the list's first word + its capacity); both are made once per list, so that the copy-out does
     // no multiplication and no 64-bit arithmetic per record
-    __shared__ uint32_t s_at[kMaxBins];
-    __shared__ uint32_t s_end[kMaxBins];
+    __shared__ uint32_t s_at[kBins];
+    __shared__ uint32_t s_end[kBins];
     __shared__ uint32_t s_key[NREC];             // row within tile | list << 16
     __shared__ float s_val[C][NREC];
     __shared__ uint32_t s_wave[PTS / 64 + 1];
@@ -672,11 +737,17 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
         }
         return;
     }
-    const uint32_t cap = region / plan.bins;
+    const uint32_t cap = bin_cap(region, plan.bins);
     const uint32_t replica = chunk % plan.replicas;
+#ifdef ENERF_TA_TIMING
+    unsigned long long bin_t = __builtin_amdgcn_s_memrealtime();
+    const uint32_t bin_lv = level;
+    if (threadIdx.x == 0) atomicAdd(&g_bin_ph[bin_lv * 8 + 7], 1ull);
+#endif
 
     for (uint32_t t = threadIdx.x; t < plan.bins; t += PTS) s_ofs[t] = 0;
     __syncthreads();
+    BIN_PH(0);
 
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -697,6 +768,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
         }
     }
     __syncthreads();
+    BIN_PH(1);
 
     // exclusive scan of the per-list counts (thread t owns `per` consecutive lists) + global reservation
     const uint32_t per = div_up(plan.bins, PTS);
@@ -711,19 +783,24 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     uint32_t before = incl - mine;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += s_wave[w];
     if (threadIdx.x == PTS - 1) s_wave[PTS / 64] = before + mine;      // total records
-    for (uint32_t k = 0; k < per; k++) {
+    // the reservation in the global lists (one returning atomic per list fed) is requested here and its answer is used
+    // only after the records have been staged: the round trip to the cursor runs beside the barrier and the staging
+    constexpr uint32_t PER_MAX = (kBins + PTS - 1) / PTS;
+    uint32_t got_[PER_MAX], bef_[PER_MAX];
+#pragma unroll
+    for (uint32_t k = 0; k < PER_MAX; k++) {
         const uint32_t t = threadIdx.x * per + k;
-        if (t < plan.bins) {
+        got_[k] = 0; bef_[k] = 0;
+        if (k < per && t < plan.bins) {
             const uint32_t n = s_ofs[t];
             s_ofs[t] = before;
-            const uint32_t first = t * cap * (1u + C);        // (< 2^32 words: a level's region is far smaller)
-            const uint32_t got = n ? atomicAdd(&cursors[level * kMaxBins + t], n) : 0u;
-            s_at[t] = first + got - before;
-            s_end[t] = first + cap;
+            bef_[k] = before;
+            got_[k] = n ? atomicAdd(&cursors[level * kMaxBins + t], n) : 0u;
             before += n;
         }
     }
     __syncthreads();
+    BIN_PH(2);
 
     if (head) {
 #pragma unroll
@@ -734,7 +811,17 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
             for (int c = 0; c < C; c++) s_val[c][p] = v[idx * C + c];
         }
     }
+#pragma unroll
+    for (uint32_t k = 0; k < PER_MAX; k++) {
+        const uint32_t t = threadIdx.x * per + k;
+        if (k < per && t < plan.bins) {
+            const uint32_t first = t * cap * (1u + C);        // (< 2^32 words: a level's region is far smaller)
+            s_at[t] = first + got_[k] - bef_[k];
+            s_end[t] = first + cap;
+        }
+    }
     __syncthreads();
+    BIN_PH(3);
 
     const uint32_t total = s_wave[PTS / 64];
     uint32_t* lrecs = recs + (size_t)level * region * (1 + C);
@@ -755,6 +842,10 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
             if (overflow) atomicAdd(overflow, 1u);          // (a deferred flush must then also read the dense gradient)
         }
     }
+#ifdef ENERF_TA_TIMING
+    __syncthreads();
+#endif
+    BIN_PH(4);
 }
 
 // Pass B: persistent workgroups (one per CU: the tile takes 128 KiB of LDS) walk the record lists, finest level
@@ -787,7 +878,7 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
             }
             rem -= plan.bins;
         }
-        const uint32_t cap = region / plan.bins;
+        const uint32_t cap = bin_cap(region, plan.bins);
         if (own_hi > own_lo) {
             const uint32_t o0 = (uint32_t)offsets[level], hs = (uint32_t)offsets[level + 1] - o0;
             const uint32_t r0 = (list / plan.replicas) * R, nr = hs - r0 < R ? hs - r0 : R;
@@ -914,8 +1005,10 @@ struct OwnerRange {
     float rec_scale;
 };
 
+// (registers: held to a fifth of a SIMD's file, so that the four workgroups a CU's LDS admits stay resident beside one
+//  wavefront per SIMD of the next batch's march, which runs on a second stream under this kernel)
 template <int C, bool AMP = false, bool RANGE = false>
-__global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* __restrict__ offsets, float* __restrict__ P,
+__global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(const int32_t* __restrict__ offsets, float* __restrict__ P,
                                                                  float* __restrict__ G, float* __restrict__ M,
                                                                  float* __restrict__ V, uint32_t L, uint32_t min_tiles,
                                                                  const uint32_t* __restrict__ recs,
@@ -924,10 +1017,17 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                                                                  uint32_t* __restrict__ other_overflow, AdamScalars ad,
                                                                  SmallAdam small, AmpAdam amp = AmpAdam{},
                                                                  OwnerRange own = OwnerRange{0, 0, 1.0f}) {
-    __shared__ __attribute__((aligned(16))) double acc[kTileElems];
+    // (dynamic: a static 32 KiB array tells the compiler that four workgroups fill the CU, and it then spends the registers
+    //  of a fifth wavefront per SIMD on scheduling freedom -- see the note above the kernel)
+    extern __shared__ __attribute__((aligned(16))) double acc[];
     __shared__ uint32_t s_n[64];
+#ifdef ENERF_TA_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     constexpr uint32_t R = kTileElems / C;
-    constexpr int U = 4;
+    // record pairs per thread and round (the AMP / RANGE forms hold more state: fewer, so that they fit the register cap)
+    constexpr int UP0 = (AMP || RANGE) ? ENERF_TA_PAIRS - 2 : ENERF_TA_PAIRS;
+    constexpr int UP = C <= 2 ? UP0 : (2 * UP0 / C > 0 ? 2 * UP0 / C : 1);
     float inv_scale = 1.0f;
     bool skip = false;
     uint32_t skipped = 0;
@@ -942,13 +1042,37 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
     if (other_overflow && blockIdx.x == 0 && threadIdx.x == 0) other_overflow[0] = 0;     // the next session's counter
     uint32_t total = 0;
     for (uint32_t lv = 0; lv < L; lv++) total += div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
-    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
-        uint32_t level = 0, tile = 0, rem = item;
-        for (uint32_t lv = L; lv-- > 0;) {                      // finest (fullest) levels first
+    auto decode = [&](uint32_t item, uint32_t& level, uint32_t& tile) {
+        uint32_t rem = item;
+        level = 0; tile = 0;
+        // coarsest levels first: their few tiles carry the longest lists (rays crowd into the same coarse cells: 41 k
+        // records on one tile of level 0 against 4 k on a tile of a hashed level, 33 us against 14) and must not be the
+        // kernel's tail; the hashed levels' tiles, all alike, fill the last round evenly
+        for (uint32_t lv = 0; lv < L; lv++) {
             const uint32_t t = div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
             if (rem < t) { level = lv; tile = rem; break; }
             rem -= t;
         }
+    };
+    // the record count of a tile's (first) list is requested one tile ahead: a tile's chain of dependent memory
+    // latencies is then records -> p / m / v, not cursor -> records -> p / m / v.  (Only this workgroup reads or
+    // resets the cursors of its tiles.)
+    auto first_cursor = [&](uint32_t item) -> uint32_t {
+        if (!have_records || item >= total) return 0u;
+        uint32_t lv, tl;
+        decode(item, lv, tl);
+        const BinPlan pl = bin_plan(offsets, lv, R, min_tiles);
+        return pl.bins != 0 ? cursors[lv * kMaxBins + tl * pl.replicas] : 0u;
+    };
+    uint32_t n_ahead = first_cursor(blockIdx.x);
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t level, tile;
+        decode(item, level, tile);
+        uint32_t n_first = n_ahead;
+#ifdef ENERF_TA_TIMING
+        const uint32_t ta_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        uint32_t ta_n = 0;
+#endif
         const uint32_t off0 = (uint32_t)offsets[level];
         const uint32_t rows = (uint32_t)offsets[level + 1] - off0;
         const uint32_t row0 = tile * R;
@@ -962,6 +1086,7 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
             if (t_hi <= own.lo || base >= own.hi) {             // not mine: the contributions held here are spent
                 for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTileThreads * 4)
                     *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                n_ahead = first_cursor(item + gridDim.x);
                 continue;
             }
             whole = base >= own.lo && t_hi <= own.hi;
@@ -972,84 +1097,109 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
         }
         const bool binned = have_records && plan.bins != 0 && whole;
         const bool dense = RANGE || !binned || spilled;
-        // the tile's p / m / v (and dense gradient) are requested first: they travel while the records are summed
+        if (binned) {
+            const uint32_t cap = bin_cap(region, plan.bins);
+            // Every thread holds the first list's count itself (n_first: a wave-uniform load issued one tile ago) instead of
+            // waiting for a load -> LDS -> barrier -> LDS round trip; replica lists (levels of few tiles) keep that
+            // route for the other counts.  Thread 0 resets the cursors after the barrier.
+            const uint32_t li0 = level * kMaxBins + tile * plan.replicas;
+            for (uint32_t i = threadIdx.x * 2; i < nrows * C; i += kTileThreads * 2)
+                *reinterpret_cast<double2*>(acc + i) = make_double2(0.0, 0.0);
+            if (plan.replicas > 1 && threadIdx.x < plan.replicas && threadIdx.x < 64) {
+                const uint32_t n = cursors[li0 + threadIdx.x];
+                s_n[threadIdx.x] = n < cap ? n : cap;
+            }
+            n_first = n_first < cap ? n_first : cap;
+            asm volatile("" :: "v"(n_first));       // (arrived: a wave's loads return in order, and the previous tile waited on younger ones)
+            __syncthreads();
+            if (threadIdx.x < plan.replicas && threadIdx.x < 64) cursors[li0 + threadIdx.x] = 0;
+            for (uint32_t rep = 0; rep < plan.replicas; rep++) {
+                const uint32_t n = plan.replicas == 1 ? n_first : s_n[rep < 64 ? rep : 63];
+#ifdef ENERF_TA_TIMING
+                ta_n += n;
+#endif
+                const uint32_t list = tile * plan.replicas + rep;
+                const uint32_t* r = recs + ((size_t)level * region + (size_t)list * cap) * (1 + C);
+                if (n == 0) continue;
+                // A round = UP record pairs per thread, ALL requested before the first is added: the list of a tile of a
+                // hashed level (~8.3 k records at the 4096-ray batch) is one round, i.e. one memory latency; the round
+                // loop only turns for longer lists.  (Before: 2048 records per round with the next round requested one
+                // round ahead -- five dependent latencies for the same list.)
+                const uint32_t npairs = (n + 1u) >> 1;
+                for (uint32_t p0 = threadIdx.x; p0 < npairs; p0 += kTileThreads * UP) {
+                    uint32_t key2[UP];
+                    f32x2g val2[UP][C];
+#pragma unroll
+                    for (int u = 0; u < UP; u++) {
+                        const uint32_t pi = p0 + u * kTileThreads;
+                        const uint32_t pc = pi < npairs ? pi : npairs - 1;
+                        key2[u] = r[pc];                                           // two 16-bit rows
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            val2[u][c] = *reinterpret_cast<const f32x2g*>(r + (size_t)(1 + c) * cap + 2 * pc);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UP; u++) {
+                        const uint32_t pi = p0 + u * kTileThreads;
+                        if (pi < npairs) {
+                            const uint32_t la = key2[u] & 0xffffu, lb = key2[u] >> 16;
+#pragma unroll
+                            for (int c = 0; c < C; c++) atomicAdd(acc + la * C + c, (double)val2[u][c].x);
+                            if (2 * pi + 1 < n) {
+#pragma unroll
+                                for (int c = 0; c < C; c++) atomicAdd(acc + lb * C + c, (double)val2[u][c].y);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // the tile's p / m / v (and dense gradient) are requested once the tile's LDS adds have been issued: they travel
+        // while the adds drain (and while the CU's other workgroup works); requested at the top of the tile they would
+        // have to be held in registers beside a whole round of records, which costs the second workgroup per CU
         constexpr int F = kTileElems / (4 * kTileThreads);
         // (no branch per piece: a short last tile re-requests its last piece, and the dense gradient is one
         // workgroup-uniform branch of its own -- conditional loads make the compiler wait between the pieces)
-        float4 p4[F], m4[F], v4[F], d4[F];
+        // the dense gradient is requested beside p / m / v only where every tile reads it (RANGE: the sharded tail); on one
+        // GPU it is read by the few tiles of levels too small to bin, piece by piece where it is used -- its 16 registers
+        // are what lets four of these workgroups share a CU with a marching wavefront on every SIMD
+        constexpr bool DENSE_AHEAD = RANGE;
+        float4 p4[F], m4[F], v4[F], d4[DENSE_AHEAD ? F : 1];
         const uint32_t last4 = nrows * C - 4u;                  // nrows is a multiple of 8
 #pragma unroll
         for (int f = 0; f < F; f++) {
             const uint32_t i = (threadIdx.x + f * kTileThreads) * 4, ic = i < nrows * C ? i : last4;
-            p4[f] = *reinterpret_cast<const float4*>(P + base + ic);
-            m4[f] = *reinterpret_cast<const float4*>(M + base + ic);
-            v4[f] = *reinterpret_cast<const float4*>(V + base + ic);
+            p4[f] = *reinterpret_cast<const float4*>(P + base + ic);      // (p is read again by the next forward: kept in the caches)
+            m4[f] = TA_LOAD4(M + base + ic);
+            v4[f] = TA_LOAD4(V + base + ic);
         }
-        if (dense) {
+        if constexpr (DENSE_AHEAD) {
+            if (dense) {
 #pragma unroll
-            for (int f = 0; f < F; f++) {
-                const uint32_t i = (threadIdx.x + f * kTileThreads) * 4, ic = i < nrows * C ? i : last4;
-                d4[f] = *reinterpret_cast<const float4*>(G + base + ic);
-            }
-        } else {
-#pragma unroll
-            for (int f = 0; f < F; f++) d4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (binned) {
-            const uint32_t cap = region / plan.bins;
-            if (threadIdx.x < plan.replicas && threadIdx.x < 64) {
-                const uint32_t li = level * kMaxBins + tile * plan.replicas + threadIdx.x;
-                const uint32_t n = cursors[li];
-                s_n[threadIdx.x] = n < cap ? n : cap;
-                cursors[li] = 0;
-            }
-            for (uint32_t i = threadIdx.x * 2; i < nrows * C; i += kTileThreads * 2)
-                *reinterpret_cast<double2*>(acc + i) = make_double2(0.0, 0.0);
-            __syncthreads();
-            for (uint32_t rep = 0; rep < plan.replicas; rep++) {
-                const uint32_t n = s_n[rep < 64 ? rep : 63];
-                const uint32_t list = tile * plan.replicas + rep;
-                const uint32_t* r = recs + ((size_t)level * region + (size_t)list * cap) * (1 + C);
-                if (n == 0) continue;
-                // U records per thread and round; the next round's records are requested before this round's are
-                // added, so a round costs max(memory latency, LDS adds) instead of their sum
-                uint32_t loc[U], nloc[U];
-                float val[U][C], nval[U][C];
-                auto fetch = [&](uint32_t i0, uint32_t (&lo)[U], float (&va)[U][C]) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t i = i0 + u * kTileThreads;
-                        const uint32_t ic = i < n ? i : n - 1;
-                        lo[u] = reinterpret_cast<const uint16_t*>(r)[ic];
-#pragma unroll
-                        for (int c = 0; c < C; c++) va[u][c] = __uint_as_float(r[(size_t)(1 + c) * cap + ic]);
-                    }
-                };
-                fetch(threadIdx.x, loc, val);
-                for (uint32_t i0 = threadIdx.x; i0 < n; i0 += kTileThreads * U) {
-                    fetch(i0 + kTileThreads * U, nloc, nval);           // (past the end: the last record again, unused)
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (i0 + u * kTileThreads < n) {
-#pragma unroll
-                            for (int c = 0; c < C; c++) atomicAdd(acc + loc[u] * C + c, (double)val[u][c]);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        loc[u] = nloc[u];
-#pragma unroll
-                        for (int c = 0; c < C; c++) val[u][c] = nval[u][c];
-                    }
+                for (int f = 0; f < F; f++) {
+                    const uint32_t i = (threadIdx.x + f * kTileThreads) * 4, ic = i < nrows * C ? i : last4;
+                    d4[f] = *reinterpret_cast<const float4*>(G + base + ic);
                 }
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; f++) d4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            __syncthreads();
         }
+        // (the next tile's count: requested here, behind p / m / v, so that no load is pending where the compiler drains the
+        //  queue -- at the record loop's entry and where registers of conditionally consumed loads are reused)
+        n_ahead = first_cursor(item + gridDim.x);
+        if (binned) __syncthreads();
 #pragma unroll
         for (int f = 0; f < F; f++) {
             const uint32_t i = (threadIdx.x + f * kTileThreads) * 4;
             if (i < nrows * C) {
-                float4 g4 = d4[f];
+                float4 g4;
+                if constexpr (DENSE_AHEAD) {
+                    g4 = d4[f];
+                } else {
+                    g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (dense) g4 = *reinterpret_cast<const float4*>(G + base + i);
+                }
                 if (binned) {
                     const double2 a0 = *reinterpret_cast<const double2*>(acc + i);
                     const double2 a1 = *reinterpret_cast<const double2*>(acc + i + 2);
@@ -1064,29 +1214,64 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_tile_adam(const int32_t* 
                     tile_adam1(p4[f].z, g4.z, m4[f].z, v4[f].z, ad);
                     tile_adam1(p4[f].w, g4.w, m4[f].w, v4[f].w, ad);
                     *reinterpret_cast<float4*>(P + base + i) = p4[f];
-                    *reinterpret_cast<float4*>(M + base + i) = m4[f];
-                    *reinterpret_cast<float4*>(V + base + i) = v4[f];
+                    TA_STORE4(M + base + i, m4[f]);
+                    TA_STORE4(V + base + i, v4[f]);
                 }
                 if (dense) *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         __syncthreads();
+#ifdef ENERF_TA_TIMING
+        if (threadIdx.x == 0 && item < 4096) {
+            g_ta_log[4 * item] = level; g_ta_log[4 * item + 1] = ta_n; g_ta_log[4 * item + 2] = ta_t0;
+            g_ta_log[4 * item + 3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
     }
-    // small parameters (MLP weights): workgroup k < small.count updates tensor k (dense gradient, not cleared)
-    if (blockIdx.x < small.count && (!AMP || !skip)) {
-        const uint32_t k = blockIdx.x;
-        AdamScalars a2 = ad;
-        a2.step_size = small.step_size[k];
-        a2.inv_bc2_sqrt = small.inv_bc2_sqrt[k];
-        if (AMP) amp_scalars(a2, amp.small_lr[k], amp.small_step[k], skipped);
-        for (uint32_t i = threadIdx.x; i < small.n[k]; i += kTileThreads) {
-            float pv = small.p[k][i], mv = small.m[k][i], vv = small.v[k][i];
-            tile_adam1(pv, AMP ? small.g[k][i] * inv_scale : small.g[k][i], mv, vv, a2);
-            small.p[k][i] = pv; small.m[k][i] = mv; small.v[k][i] = vv;
+    // small parameters (MLP weights; dense gradient, not cleared): their ~10 k elements are dealt over ALL workgroups, a
+    // slice of consecutive elements each, one element per thread -- one memory latency at the end of the kernel.  (One
+    // workgroup per tensor, looping, was a tail of sixteen dependent latencies behind that workgroup's tiles.)
+    if (small.count != 0 && (!AMP || !skip)) {
+        uint32_t total_small = 0;
+        for (uint32_t k = 0; k < small.count; k++) total_small += small.n[k];
+        const uint32_t chunk = div_up(total_small, gridDim.x);
+        for (uint32_t t = threadIdx.x; t < chunk; t += kTileThreads) {
+            uint32_t e = blockIdx.x * chunk + t;
+            if (e >= total_small) break;
+            uint32_t k = 0;
+            while (e >= small.n[k]) { e -= small.n[k]; k++; }
+            AdamScalars a2 = ad;
+            a2.step_size = small.step_size[k];
+            a2.inv_bc2_sqrt = small.inv_bc2_sqrt[k];
+            if (AMP) amp_scalars(a2, amp.small_lr[k], amp.small_step[k], skipped);
+            float pv = small.p[k][e], mv = small.m[k][e], vv = small.v[k][e];
+            tile_adam1(pv, AMP ? small.g[k][e] * inv_scale : small.g[k][e], mv, vv, a2);
+            small.p[k][e] = pv; small.m[k][e] = mv; small.v[k][e] = vv;
         }
     }
+#ifdef ENERF_TA_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
+#ifdef ENERF_TA_TIMING
+}  // namespace
+extern "C" int enerf_debug_ta_log(uint32_t* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ta_log), sizeof(uint32_t) * 4 * 4096) == hipSuccess ? 0 : -1;
+}
+extern "C" int enerf_debug_bin_ph(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[32 * 8] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_bin_ph), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_ph), sizeof(unsigned long long) * 32 * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int enerf_debug_ta_wg(uint32_t* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ta_wg), sizeof(uint32_t) * 2 * 2048) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (gridencoder.cu:314-340)
 template <typename T, int D, int C>
 __global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ grad, const T* __restrict__ dy_dx,
@@ -1442,7 +1627,7 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
         if (C != 2) ENERF_BADARG("grid_adam_from_records: an owner range serves C = 2 tables");
         if (amp_state().scale) ENERF_BADARG("grid_adam_from_records: owner range and loss scaling do not combine");
         if ((g_own_lo | g_own_hi) & 3u) ENERF_BADARG("grid_adam_from_records: owner range must be multiples of 4 elements");
-        k_grid_tile_adam<2, false, true><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(
+        k_grid_tile_adam<2, false, true><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(
             offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{},
             OwnerRange{g_own_lo, g_own_hi, g_own_scale});
         if (g_pending.region != 0) g_session++;
@@ -1458,7 +1643,7 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
         amp.lr = lr; amp.step = step;
         for (uint32_t k = 0; k < n_small; k++) { amp.small_lr[k] = slr[k]; amp.small_step[k] = sstep[k]; }
         if (C != 2) ENERF_BADARG("grid_adam_from_records: loss scaling serves C = 2 tables");
-        k_grid_tile_adam<2, true><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs,
+        k_grid_tile_adam<2, true><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs,
                                                                                     cursors, region, overflow, other, ad,
                                                                                     small, amp);
         if (g_pending.region != 0) g_session++;
@@ -1467,10 +1652,10 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
         return 0;
     }
     switch (C) {
-        case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
-        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
-        case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
-        case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, 0, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         default: ENERF_BADARG("grid_adam_from_records: C must be 1, 2, 4, or 8.");
     }
     if (g_pending.region != 0) g_session++;           // the next session counts overflows in the counter just cleared

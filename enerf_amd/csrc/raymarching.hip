@@ -184,27 +184,34 @@ __device__ __forceinline__ bool eval_cell_fixed(const RayCtx& c, const RayFixed&
 }
 
 // ------------------------------------------------------------------ small per-element kernels
+// near / far of one ray against the box (raymarching.cu:94-136); false: the ray misses it (both are FLT_MAX then)
+__device__ __forceinline__ bool near_far_of(float ox, float oy, float oz, float dx, float dy, float dz,
+                                            const float* __restrict__ aabb, float min_near, float& near, float& far) {
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float tmp;
+    near = (aabb[0] - ox) * rdx; far = (aabb[3] - ox) * rdx;
+    if (near > far) { tmp = near; near = far; far = tmp; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { tmp = near_y; near_y = far_y; far_y = tmp; }
+    if (near > far_y || near_y > far) { near = far = FLT_MAX; return false; }
+    if (near_y > near) near = near_y;
+    if (far_y < far) far = far_y;
+    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+    if (near_z > far_z) { tmp = near_z; near_z = far_z; far_z = tmp; }
+    if (near > far_z || near_z > far) { near = far = FLT_MAX; return false; }
+    if (near_z > near) near = near_z;
+    if (far_z < far) far = far_z;
+    if (near < min_near) near = min_near;
+    return true;
+}
 __global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                   const float* __restrict__ aabb, uint32_t N, float min_near,
                                                   float* nears, float* fars) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
-    if (near > far) { tmp = near; near = far; far = tmp; }
-    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
-    if (near_y > far_y) { tmp = near_y; near_y = far_y; far_y = tmp; }
-    if (near > far_y || near_y > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (near_y > near) near = near_y;
-    if (far_y < far) far = far_y;
-    float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
-    if (near_z > far_z) { tmp = near_z; near_z = far_z; far_z = tmp; }
-    if (near > far_z || near_z > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (near_z > near) near = near_z;
-    if (far_z < far) far = far_z;
-    if (near < min_near) near = min_near;
+    float near, far;
+    (void)near_far_of(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1],
+                      rays_d[n * 3 + 2], aabb, min_near, near, far);
     nears[n] = near;
     fars[n] = far;
 }
@@ -693,7 +700,9 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
                                                        const float* __restrict__ nears, const float* __restrict__ fars,
                                                        int32_t* rays, uint32_t perturb, ChunkEntry* __restrict__ log,
                                                        uint32_t* __restrict__ nlog,
-                                                       const int* __restrict__ occ_keys) {
+                                                       const int* __restrict__ occ_keys,
+                                                       const float* __restrict__ nf_aabb, float nf_min_near,
+                                                       float* nf_nears, float* nf_fars) {
     __shared__ float s_face[kTabH + 1];
     __shared__ uint32_t s_expand[kTabH];
     const bool fast = march_fast_ok(H);
@@ -705,9 +714,16 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
          n += nw) {
         RayCtx c;
         ray_ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, bound, 0.0f, max_steps, C, H);
-        float t0 = nears[n];
+        float t0, far;
+        if (nf_aabb) {
+            // near_far_from_aabb of this ray, here (enerf_march_fuse_near_far): k_near_far's own arithmetic, every lane the same
+            (void)near_far_of(c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, nf_aabb, nf_min_near, t0, far);
+            if (lane_id() == 0) { nf_nears[n] = t0; nf_fars[n] = far; }
+        } else {
+            t0 = nears[n];
+            far = fars[n];
+        }
         if (perturb) t0 = fmaf(c.dt_min, pcg_first_float((uint64_t)n, 1u), t0);   // contracted by the reference's compiler (:351)
-        float far = fars[n];
         uint32_t cnt = 0;
         if (occ_keys && !clip_to_occupied(c, occ_keys, far)) {
             if (lane_id() == 0) nlog[n] = 0;                                   // nothing to replay
@@ -1768,12 +1784,23 @@ static inline size_t march_log_bytes(uint32_t N, uint32_t H) {
     return march_uses_threads(N, H) ? (size_t)N * kRunCap * sizeof(RunEntry) : (size_t)N * kLogCap * sizeof(ChunkEntry);
 }
 
+// enerf_march_fuse_near_far: the next march_rays_train count pass computes near / far itself (written to the nears / fars
+// arrays it is given, for the write pass and the renderer) -- one launch less at the head of the side stream's chain
+static const float* g_nf_aabb = nullptr;
+static float g_nf_min_near = 0.0f;
+
 // count pass (+ scan): rays[n] = (n, offset, count), counter += (sum, N); the fixed-step marcher also fills the chunk log
 static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                              const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
                              bool use_box, bool fresh_counter, hipStream_t s) {
     if (int e = workspace_family_enter(0, s)) return e;
+    const float* nf_aabb = g_nf_aabb;
+    g_nf_aabb = nullptr;                                   // (armed for one call)
+    if (nf_aabb && !(march_uses_lattice(dt_gamma, max_steps, C, H) && !march_uses_threads(N, H))) {
+        k_near_far<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, nf_aabb, N, g_nf_min_near, (float*)nears, (float*)fars);
+        nf_aabb = nullptr;
+    }
     if (march_uses_lattice(dt_gamma, max_steps, C, H)) {
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
@@ -1809,7 +1836,8 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                                                            rays, perturb, (RunEntry*)ws, nlog, occ_keys);
         else
             k_march_count_w<<<background ? min(div_up(N, 4), count_blocks) : div_up(N, 4), 256, 0, s>>>(
-                rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys);
+                rays_o, rays_d, grid, bound, max_steps, N, C, H, nears, fars, rays, perturb, log, nlog, occ_keys, nf_aabb,
+                g_nf_min_near, (float*)nears, (float*)fars);
     } else {
         k_march_count<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears,
                                                    fars, rays, perturb);
@@ -1857,6 +1885,12 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
         k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
                                                    fars, xyzs, dirs, deltas, rays, perturb);
     }
+    return 0;
+}
+
+int enerf_march_fuse_near_far(const float* aabb, float min_near) {
+    g_nf_aabb = aabb;
+    g_nf_min_near = min_near;
     return 0;
 }
 

@@ -104,8 +104,8 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         signal_set = false;
         enerf_stream_t ss = a->side_stream;
         STEP(enerf_stream_wait_mlp32_signal(ss));
-        STEP(enerf_near_far_from_aabb(a->next_rays_o, a->next_rays_d, a->aabb, a->next_N, a->min_near, a->next_nears,
-                                      a->next_fars, ss));
+        // (near / far of the next batch inside the count pass: one launch less at the head of the chain the next step waits for)
+        STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));
         STEP(enerf_march_rays_train_ex(a->next_rays_o, a->next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
                                        a->next_N, a->cascade, a->grid_size, a->next_M, a->next_nears, a->next_fars,
                                        a->next_xyzs, a->next_dirs, a->next_deltas, a->next_rays, a->next_counter, a->perturb,
@@ -225,6 +225,8 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         signal_set = false;
         enerf_stream_t ss = a->side_stream;
         STEP(enerf_stream_wait_mlp32_signal(ss));
+        // (near / far of the next batch inside the count pass: one launch less at the head of the chain the next step waits for)
+        STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));
         for (int q = 0; q < 2; q++) {
             const enerf_step_render& n = a->r[q];
             if (!n.next_rays_o) continue;
@@ -342,6 +344,8 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
             signal_set = false;
             enerf_stream_t ss = a->side_stream;
             STEP(enerf_stream_wait_mlp32_signal(ss));
+        // (near / far of the next batch inside the count pass: one launch less at the head of the chain the next step waits for)
+        STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));
             for (int q = 0; q < 2; q++) {
                 const enerf_step_render& n = a->r[q];
                 if (!n.next_rays_o) continue;

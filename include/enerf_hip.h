@@ -136,6 +136,13 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
                               int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
                               enerf_stream_t stream);
 
+/* Arms the NEXT enerf_march_rays_train(_ex / _count) call: its count pass computes near / far of every ray against `aabb`
+ * itself (enerf_near_far_from_aabb's arithmetic, bit for bit) and WRITES them to the nears / fars arrays the call is
+ * given (they need not be initialised) -- the near_far launch at the head of a march that is prepared ahead of its step
+ * disappears.  Marchers that do not take the wave-per-ray route run the near_far kernel first, on the call's stream.
+ * `aabb` is read by that march's kernels, not here: it must stay valid until they have run. */
+int enerf_march_fuse_near_far(const float* aabb, float min_near);
+
 /* Bounding box of the occupied cells of a density bitfield, kept by the library for the fixed-step training marcher.
  * A sample can only be emitted inside an occupied cell's box, so a ray that misses the union's bounding box emits
  * nothing and a ray emits nothing after leaving it: with flag bit 2 (value 4) of enerf_march_rays_train_ex /

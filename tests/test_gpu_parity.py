@@ -203,6 +203,41 @@ def test_march_rays_train_background_mode_is_bit_identical(rm, scenes, overflow,
             assert np.array_equal(a, b), (name, perturb)
 
 
+@pytest.mark.parametrize("dt_gamma,flags", [(0.0, 0), (0.0, 3), (1.0 / 128, 0)])
+def test_march_with_near_far_inside_the_count_pass(rm, scenes, dt_gamma, flags, march_route):
+    """enerf_march_fuse_near_far: the armed march computes near / far in its count pass (or, on the routes that do not
+    take the wave-per-ray marcher, runs the near_far kernel itself) and writes them into the arrays it is given --
+    nears / fars == near_far_from_aabb, rays / counter / samples == the oracle's, bit for bit; the arming lasts one call."""
+    bound = 3
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(2500, 41, bound)
+    d[3] = [0, 0, 1]; o[4] = [7, 7, 7]                                  # axis-parallel; a ray that misses the box
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    N = len(o)
+    M = int(O.march_rays_train(o, d, bits, bound, dt_gamma, 1024, C, H, N * 1024, nears, fars, 1)[4][0]) + 500
+    M += 128 - M % 128
+    ref = O.march_rays_train(o, d, bits, bound, dt_gamma, 1024, C, H, M, nears, fars, 1)
+    g_n = torch.full((N,), float("nan"), device=DEV); g_f = torch.full((N,), float("nan"), device=DEV)
+    xyzs = torch.full((M, 3), float("nan"), device=DEV); dirs = torch.full((M, 3), float("nan"), device=DEV)
+    deltas = torch.full((M, 2), float("nan"), device=DEV)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    aabb_d = cu(aabb)                                                   # (the pointer is read by the march, not by the arming)
+    rm.march_fuse_near_far(aabb_d, 0.2)
+    rm.march_rays_train_ex(cu(o), cu(d), cu(bits), bound, dt_gamma, 1024, N, C, H, M, g_n, g_f, xyzs, dirs, deltas, rays,
+                           counter, 1, 1 | flags)
+    assert np.array_equal(g_n.cpu().numpy(), nears) and np.array_equal(g_f.cpu().numpy(), fars)
+    got = [x.cpu().numpy() for x in (xyzs, dirs, deltas, rays, counter)]
+    for a, b, name in zip(got, ref, ("xyzs", "dirs", "deltas", "rays", "counter")):
+        assert np.array_equal(a, b), name
+    # not armed any more: the next call reads the arrays it is given
+    counter.zero_()
+    bad = torch.full((N,), 3.4028234663852886e38, device=DEV)
+    rm.march_rays_train_ex(cu(o), cu(d), cu(bits), bound, dt_gamma, 1024, N, C, H, M, bad, bad.clone(), xyzs, dirs, deltas,
+                           rays, counter, 1, 1 | flags)
+    assert int(counter[0]) == 0
+
+
 @pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
 def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm, scenes, dt_gamma, march_route):
     """While no sample budget exists the reference allocates N * max_steps zero rows, marches, reads the count back and
