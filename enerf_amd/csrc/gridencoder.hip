@@ -195,6 +195,8 @@ __device__ __forceinline__ void corner_rows(const LevelGeom<D>& g, const uint32_
 
 // forward: XCD-pair groups.  Group g = XCDs (2g, 2g+1); round r deals levels L-1-4r .. L-4-4r to the groups in
 // alternating direction; the two members take alternate chunks of every level.
+// (Rounds walked in pairs -- a group's workgroups alternating between a gather-bound fine level and an instruction-bound
+//  coarse one -- are slower, not faster: profiles/r05_fwd_paired_rounds_rejected.txt.)
 constexpr uint32_t kGroupXcds = 2, kGroups = 8 / kGroupXcds;
 __device__ __forceinline__ bool decode_block_fwd(uint32_t nchunks, uint32_t L, uint32_t& level, uint32_t& chunk) {
     const uint32_t bid = blockIdx.x;
