@@ -35,6 +35,21 @@ using namespace enerf;
 
 namespace {
 
+#ifdef ENERF_TA_TIMING
+// development aid (tools/dev/ta_tiles.py): per tile of the last k_grid_tile_adam launch -- level, records, begin, end (100 MHz)
+__device__ uint32_t g_ta_log[4 * 4096];
+__device__ uint32_t g_ta_wg[2 * 2048];          // per workgroup: entry, exit
+__device__ unsigned long long g_ta_marks[8];    // last launch of grid_fwd / bin / tile_adam: first entry, last exit (100 MHz)
+#define TA_MARK_IN(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ta_marks[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TA_MARK_OUT(k) do { if (threadIdx.x == 0) atomicMax(&g_ta_marks[k], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+__device__ unsigned long long g_bin_ph[32 * 8];      // binning pass: 100 MHz ticks per phase, summed over workgroups; [7] = workgroups
+#define BIN_PH(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_bin_ph[bin_lv * 8 + (k)], t_ - bin_t); bin_t = t_; } } while (0)
+#else
+#define TA_MARK_IN(k)
+#define TA_MARK_OUT(k)
+#define BIN_PH(k)
+#endif
+
 constexpr int kMaxLevels = 32;
 constexpr int kPtsPerBlock = 256;
 // points per workgroup of the backward's binning pass (its LDS staging area grows with PTS * 2^D * (1 + C))
@@ -232,6 +247,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
                                                            uint32_t B, uint32_t L, LevelTab tab, bool calc_grad_inputs,
                                                            T* __restrict__ dy_dx, uint32_t gridtype, int out_layout,
                                                            uint32_t nchunks, SweepGen gen) {
+    TA_MARK_IN(0);
     uint32_t level, chunk;
     if (!decode_block_fwd(nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
@@ -360,6 +376,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
 #pragma unroll
     for (int c = 0; c < C; c++) o.v[c] = from_f<T>(res[c]);
     *out = o;
+    TA_MARK_OUT(1);
 
     if (jac) {
 #pragma unroll
@@ -593,7 +610,8 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 #endif
 struct __attribute__((aligned(8))) f32x2g { float x, y; };
 // k_grid_tile_adam's m / v stream is marked non-temporal (every element is touched once per step; p is read again by the next
-// forward and keeps its place in the caches): the table's backward + Adam 120 -> 111 us stand-alone, 1 - 2 us in the step
+// forward and keeps its place in the caches): the table's backward + Adam 120 -> 111 us stand-alone, 1 - 2 us in the step.
+// (Stores written through -- sc0 sc1 -- so that no dirty line waits for the end of the kernel: no change, 85.0 vs 85.7 us.)
 // (-DENERF_TA_TEMPORAL: plain loads and stores)
 typedef float ta_f4 __attribute__((ext_vector_type(4)));
 #ifndef ENERF_TA_TEMPORAL
@@ -610,15 +628,6 @@ __device__ __forceinline__ void ta_store4(float* p, const float4& v) {
 #else
 #define TA_LOAD4(p) (*reinterpret_cast<const float4*>(p))
 #define TA_STORE4(p, v) (*reinterpret_cast<float4*>(p) = (v))
-#endif
-#ifdef ENERF_TA_TIMING
-// development aid (tools/dev/ta_tiles.py): per tile of the last k_grid_tile_adam launch -- level, records, begin, end (100 MHz)
-__device__ uint32_t g_ta_log[4 * 4096];
-__device__ uint32_t g_ta_wg[2 * 2048];          // per workgroup: entry, exit
-__device__ unsigned long long g_bin_ph[32 * 8];      // binning pass: 100 MHz ticks per phase, summed over workgroups; [7] = workgroups
-#define BIN_PH(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_bin_ph[bin_lv * 8 + (k)], t_ - bin_t); bin_t = t_; } } while (0)
-#else
-#define BIN_PH(k)
 #endif
 constexpr uint32_t kTileElems = ENERF_TILE_ELEMS;
 constexpr uint32_t kTileThreads = ENERF_TILE_ELEMS / 16;
@@ -710,6 +719,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     __shared__ uint32_t s_key[NREC];             // row within tile | list << 16
     __shared__ float s_val[C][NREC];
     __shared__ uint32_t s_wave[PTS / 64 + 1];
+    TA_MARK_IN(2);
     uint32_t level, chunk;
     if (!decode_block(nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
@@ -848,6 +858,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     __syncthreads();
 #endif
     BIN_PH(4);
+    TA_MARK_OUT(3);
 }
 
 // Pass B: persistent workgroups (one per CU: the tile takes 128 KiB of LDS) walk the record lists, finest level
@@ -1026,6 +1037,7 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
 #ifdef ENERF_TA_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
+    TA_MARK_IN(4);
     constexpr uint32_t R = kTileElems / C;
     // record pairs per thread and round (the AMP / RANGE forms hold more state: fewer, so that they fit the register cap)
     constexpr int UP0 = (AMP || RANGE) ? ENERF_TA_PAIRS - 2 : ENERF_TA_PAIRS;
@@ -1255,6 +1267,7 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
+    TA_MARK_OUT(5);
 }
 
 #ifdef ENERF_TA_TIMING
@@ -1268,6 +1281,9 @@ extern "C" int enerf_debug_bin_ph(unsigned long long* out, int reset) {
         return hipMemcpyToSymbol(HIP_SYMBOL(g_bin_ph), z, sizeof(z)) == hipSuccess ? 0 : -1;
     }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_ph), sizeof(unsigned long long) * 32 * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int enerf_debug_ta_marks(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ta_marks), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
 }
 extern "C" int enerf_debug_ta_wg(uint32_t* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ta_wg), sizeof(uint32_t) * 2 * 2048) == hipSuccess ? 0 : -1;

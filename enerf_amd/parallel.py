@@ -26,7 +26,13 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver stack
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a rank that never arrives (or a collective that never completes) must end the job with an error on every rank,
+        # not hold the node: rendezvous and collectives time out (ENERF_DIST_TIMEOUT_S, default 5 minutes) and RCCL's
+        # watchdog tears the communicator down when they do
+        import datetime
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        timeout = datetime.timedelta(seconds=int(os.environ.get("ENERF_DIST_TIMEOUT_S", "300")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local_rank
 
 

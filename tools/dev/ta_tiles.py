@@ -40,3 +40,11 @@ for lv in range(16):
     n = max(1, ph[lv * 8 + 7])
     v = [ph[lv * 8 + k] / n / 100.0 for k in range(5)]
     print("  level %2d: %s  total %.2f   workgroups %d" % (lv, " ".join("%6.2f" % x for x in v), sum(v), ph[lv * 8 + 7]))
+
+mk = (ctypes.c_uint64 * 8)()
+assert lib.enerf_debug_ta_marks(mk) == 0
+m0 = mk[0]
+names = ["grid_fwd first entry", "grid_fwd last exit", "binning first entry", "binning last exit", "tile adam first entry", "tile adam last exit"]
+print("last step, shader-side marks (us after the grid forward's first workgroup):")
+for k in range(6):
+    print("   %-24s %8.1f" % (names[k], (mk[k] - m0) / 100.0))
