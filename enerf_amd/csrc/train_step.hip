@@ -225,13 +225,10 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         signal_set = false;
         enerf_stream_t ss = a->side_stream;
         STEP(enerf_stream_wait_mlp32_signal(ss));
-        // (near / far of the next batch inside the count pass: one launch less at the head of the chain the next step waits for)
-        STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));
         for (int q = 0; q < 2; q++) {
             const enerf_step_render& n = a->r[q];
             if (!n.next_rays_o) continue;
-            STEP(enerf_near_far_from_aabb(n.next_rays_o, n.next_rays_d, a->aabb, n.next_N, a->min_near, n.next_nears,
-                                          n.next_fars, ss));
+            STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));       // (near / far inside the march's count pass)
             STEP(enerf_march_rays_train_ex(n.next_rays_o, n.next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
                                            n.next_N, a->cascade, a->grid_size, n.next_M, n.next_nears, n.next_fars,
                                            n.next_xyzs, n.next_dirs, n.next_deltas, n.next_rays, n.next_counter, a->perturb,
@@ -344,13 +341,10 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
             signal_set = false;
             enerf_stream_t ss = a->side_stream;
             STEP(enerf_stream_wait_mlp32_signal(ss));
-        // (near / far of the next batch inside the count pass: one launch less at the head of the chain the next step waits for)
-        STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));
             for (int q = 0; q < 2; q++) {
                 const enerf_step_render& n = a->r[q];
                 if (!n.next_rays_o) continue;
-                STEP(enerf_near_far_from_aabb(n.next_rays_o, n.next_rays_d, a->aabb, n.next_N, a->min_near, n.next_nears,
-                                              n.next_fars, ss));
+                STEP(enerf_march_fuse_near_far(a->aabb, a->min_near));       // (near / far inside the march's count pass)
                 STEP(enerf_march_rays_train_ex(n.next_rays_o, n.next_rays_d, a->bitfield, a->bound, a->dt_gamma,
                                                a->max_steps, n.next_N, a->cascade, a->grid_size, n.next_M, n.next_nears,
                                                n.next_fars, n.next_xyzs, n.next_dirs, n.next_deltas, n.next_rays,
