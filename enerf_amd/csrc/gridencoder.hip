@@ -609,6 +609,9 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 #define ENERF_TA_REGS __attribute__((amdgpu_waves_per_eu(4, 8)))
 #endif
 struct __attribute__((aligned(8))) f32x2g { float x, y; };
+// k_grid_tile_adam's tiles are handed out on request: [0] the next tile nobody has taken, [1] workgroups that have left -- the
+// last one to leave clears [0] for the next launch ([1] wraps by itself); launches follow one another on one stream
+__device__ uint32_t g_ta_next[2];
 // k_grid_tile_adam's m / v stream is marked non-temporal (every element is touched once per step; p is read again by the next
 // forward and keeps its place in the caches): the table's backward + Adam 120 -> 111 us stand-alone, 1 - 2 us in the step.
 // (Stores written through -- sc0 sc1 -- so that no dirty line waits for the end of the kernel: no change, 85.0 vs 85.7 us.)
@@ -1078,8 +1081,16 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
         const BinPlan pl = bin_plan(offsets, lv, R, min_tiles);
         return pl.bins != 0 ? cursors[lv * kMaxBins + tl * pl.replicas] : 0u;
     };
-    uint32_t n_ahead = first_cursor(blockIdx.x);
-    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+    // Tiles on request: a workgroup's first tile is its own number, every further one the next nobody has taken (one
+    // atomic per tile, asked for at the tile's start and read at its end).  Dealt out in fixed strides, 107 of the 1024
+    // workgroups had a fourth tile of the 3179 and the kernel's last ~15 us ran at a tenth of the chip.
+    __shared__ uint32_t s_next;
+    uint32_t* next_counter = g_ta_next;
+    uint32_t item = blockIdx.x;
+    uint32_t n_ahead = first_cursor(item);
+    while (item < total) {
+        uint32_t pulled = 0;
+        if (threadIdx.x == 0) pulled = gridDim.x + atomicAdd(next_counter, 1u);
         uint32_t level, tile;
         decode(item, level, tile);
         uint32_t n_first = n_ahead;
@@ -1100,7 +1111,11 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
             if (t_hi <= own.lo || base >= own.hi) {             // not mine: the contributions held here are spent
                 for (uint32_t i = threadIdx.x * 4; i < nrows * C; i += kTileThreads * 4)
                     *reinterpret_cast<float4*>(G + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-                n_ahead = first_cursor(item + gridDim.x);
+                if (threadIdx.x == 0) s_next = pulled;
+                __syncthreads();
+                item = s_next;
+                __syncthreads();
+                n_ahead = first_cursor(item);
                 continue;
             }
             whole = base >= own.lo && t_hi <= own.hi;
@@ -1199,10 +1214,13 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
                 for (int f = 0; f < F; f++) d4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        // (the next tile's count: requested here, behind p / m / v, so that no load is pending where the compiler drains the
-        //  queue -- at the record loop's entry and where registers of conditionally consumed loads are reused)
-        n_ahead = first_cursor(item + gridDim.x);
-        if (binned) __syncthreads();
+        // (the next tile -- the answer to this tile's request -- and its count: requested here, behind p / m / v, so that no load
+        //  is pending where the compiler drains the queue -- at the record loop's entry and where registers of conditionally
+        //  consumed loads are reused)
+        if (threadIdx.x == 0) s_next = pulled;
+        __syncthreads();                            // (also: the tile's LDS adds are complete)
+        const uint32_t item_next = s_next;
+        n_ahead = first_cursor(item_next);
 #pragma unroll
         for (int f = 0; f < F; f++) {
             const uint32_t i = (threadIdx.x + f * kTileThreads) * 4;
@@ -1241,6 +1259,7 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
             g_ta_log[4 * item + 3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
         }
 #endif
+        item = item_next;
     }
     // small parameters (MLP weights; dense gradient, not cleared): their ~10 k elements are dealt over ALL workgroups, a
     // slice of consecutive elements each, one element per thread -- one memory latency at the end of the kernel.  (One
@@ -1268,6 +1287,8 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
     TA_MARK_OUT(5);
+    // (nobody asks for a tile any more once a workgroup is here: its own request came back >= total)
+    if (threadIdx.x == 0 && atomicInc(&g_ta_next[1], gridDim.x - 1u) == gridDim.x - 1u) g_ta_next[0] = 0;
 }
 
 #ifdef ENERF_TA_TIMING
@@ -1662,8 +1683,7 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
         for (uint32_t k = 0; k < n_small; k++) { amp.small_lr[k] = slr[k]; amp.small_step[k] = sstep[k]; }
         if (C != 2) ENERF_BADARG("grid_adam_from_records: loss scaling serves C = 2 tables");
         k_grid_tile_adam<2, true><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs,
-                                                                                    cursors, region, overflow, other, ad,
-                                                                                    small, amp);
+                                                                                    cursors, region, overflow, other, ad, small, amp);
         if (g_pending.region != 0) g_session++;
         g_pending = PendingRecords();
         ENERF_LAUNCH_CHECK("grid_adam_from_records(amp)");
