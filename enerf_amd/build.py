@@ -15,7 +15,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libenerf_hip.so")
 SOURCES = ["runtime.hip", "raymarching.hip", "gridencoder.hip", "shencoder.hip", "ffmlp.hip", "ffmlp_wgrad.hip",
-           "mlp32.hip", "mlp32s.hip", "mlp32s_f16.hip", "nerf_mlp.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "train_step.hip"]
+           "mlp32.hip", "mlp32s.hip", "mlp32s_f16.hip", "nerf_mlp.hip", "nerf_mlp_bwd.hip", "optim.hip", "density_update.hip", "ffnerf.hip", "event_pairs.hip", "train_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 # Per-file extras.  ffmlp.hip (forward + dgrad) keeps its MFMA accumulators in arch VGPRs: every accumulator is
@@ -24,7 +24,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # the AGPR half of the register file, so they live in their own translation unit without the flag.
 # (ENERF_MFMA_VGPR_FORM arms csrc/mfma_guard.h: that form lets a zero-initialised MFMA's result land on its operands)
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DENERF_MFMA_VGPR_FORM"]
-EXTRA = {"ffmlp.hip": _VGPR_FORM, "mlp32s.hip": _VGPR_FORM, "mlp32s_f16.hip": _VGPR_FORM, "nerf_mlp.hip": _VGPR_FORM}
+EXTRA = {"ffmlp.hip": _VGPR_FORM, "mlp32s.hip": _VGPR_FORM, "mlp32s_f16.hip": _VGPR_FORM, "nerf_mlp.hip": _VGPR_FORM,
+         "nerf_mlp_bwd.hip": _VGPR_FORM}
 # development aid: extra -D flags for every file (e.g. ENERF_DEFINES="-DENERF_BIN_TIMING" python -m enerf_amd.build --force)
 FLAGS += os.environ.get("ENERF_DEFINES", "").split()
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ffmlp_common.h"), os.path.join(CSRC, "mlp32_common.h"), os.path.join(CSRC, "mlp32s_ops.h"), os.path.join(CSRC, "mfma_guard.h"),
@@ -45,6 +46,8 @@ def _mtime(p):
 def _stale(obj, src):
     t = _mtime(obj)
     extra = [os.path.join(CSRC, "mlp32s.hip")] if src.endswith("mlp32s_f16.hip") else []     # (it #includes that file)
+    if src.endswith("nerf_mlp_bwd.hip"):
+        extra = [os.path.join(CSRC, "nerf_mlp.hip")]
     return t == 0.0 or _mtime(src) > t or any(_mtime(h) > t for h in HEADERS + extra) or _mtime(__file__) > t
 
 

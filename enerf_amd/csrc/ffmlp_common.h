@@ -136,6 +136,33 @@ __device__ __forceinline__ typename V<E>::x8 frag_col_perm(const E* m, int ld, i
     return f;
 }
 
+// A freshly converted pair of 16-bit operands against the MFMAs that read it: the barrier of mlp32s_ops.h (operand_ready,
+// where the hazard is described) -- every register of both fragments is written, in program order, before any reader, and
+// FFMLP_READY_NOPS + 1 idle cycles follow.  A translation unit asks for it with FFMLP_OPERAND_BARRIER: ffnerf.hip does (the
+// compiler put conversions two slots in front of their MFMAs there); ffmlp.hip's kernels keep the conversions of a tile
+// seven and more slots away from the MFMAs of the next layer as compiled, which tests/test_mfma_operand_overlap.py checks on
+// the assembly of every build -- the barrier would cost ffmlp_inference 8 % (0.437 -> 0.402 of the bf16 peak).
+#ifndef FFMLP_READY_NOPS
+#define FFMLP_READY_NOPS 1
+#endif
+#define FFMLP_STR2(x) #x
+#define FFMLP_STR(x) FFMLP_STR2(x)
+template <typename X8>
+__device__ __forceinline__ void operands_barrier(X8 (&out)[2]) {
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    i32x4_ a = __builtin_bit_cast(i32x4_, out[0]), b = __builtin_bit_cast(i32x4_, out[1]);
+    asm volatile("s_nop " FFMLP_STR(FFMLP_READY_NOPS) : "+v"(a), "+v"(b));
+    out[0] = __builtin_bit_cast(X8, a);
+    out[1] = __builtin_bit_cast(X8, b);
+}
+// (the ReLU path of act_to_frags -- the inference kernels' -- only where the translation unit asks: see above)
+template <typename X8>
+__device__ __forceinline__ void operands_ready(X8 (&out)[2]) {
+#ifdef FFMLP_OPERAND_BARRIER
+    operands_barrier(out);
+#endif
+}
+
 // D tile (fp32, lane = sample) -> two permuted-order K-blocks of 16-bit operands, with an elementwise map
 template <typename E>
 __device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::x8 (&out)[2]) {
@@ -143,6 +170,7 @@ __device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename V<E>::
     for (int kbb = 0; kbb < 2; kbb++)
 #pragma unroll
         for (int e = 0; e < 8; e++) out[kbb][e] = (E)acc[8 * kbb + e];
+    operands_barrier(out);                       // (plain conversions: the compiler does place them right in front of the MFMAs)
 }
 
 // activation + conversion of a hidden layer's D tile.  ReLU commutes with the (sign-symmetric, monotone) rounding to
@@ -174,6 +202,7 @@ __device__ __forceinline__ void act_to_frags(f32x16& acc, uint32_t a, typename V
             }
             out[kbb] = __builtin_bit_cast(typename V<E>::x8, r);
         }
+        operands_ready(out);
     } else {
         acc = apply_act_generic(acc, a);
         tile_to_frags<E>(acc, out);

@@ -16,6 +16,7 @@
 //  * weights are read as fp32 parameters and converted while they are staged into LDS (no per-call conversion launch).
 // Roundings follow the op-by-op route (16-bit net outputs, exp / sigmoid evaluated in fp32 on the rounded value and
 // rounded again), fp32 accumulation throughout.
+#define FFMLP_OPERAND_BARRIER          // (see ffmlp_common.h: operands_ready)
 #include "ffmlp_common.h"
 #include "sh_basis.h"
 
@@ -202,6 +203,7 @@ __global__ void __launch_bounds__(256, 2) k_ffnerf_infer(const float* __restrict
                     xb[t][kb][2 * q] = (E)in[t].f[kb][q].x;
                     xb[t][kb][2 * q + 1] = (E)in[t].f[kb][q].y;
                 }
+            operands_ready(xb[t]);                  // (the operand barrier of ffmlp_common.h / mlp32s_ops.h)
             dx[t] = in[t].dx; dy[t] = in[t].dy; dz[t] = in[t].dz;
         }
         if (grp + nw < ngroups) {                                  // next group's loads fly during this one's MFMAs
@@ -268,6 +270,11 @@ __global__ void __launch_bounds__(256, 2) k_ffnerf_infer(const float* __restrict
                 // scratch and indexes it by lane)
                 const uint32_t m = 0u - (uint32_t)h;
                 xsh[e] = (E)__uint_as_float((__float_as_uint(Y[e]) & ~m) | (__float_as_uint(Y[8 + e]) & m));
+            }
+            {
+                x8 pair[2] = {xsh, xsh};
+                operands_ready(pair);
+                xsh = pair[0];
             }
 #pragma unroll
             for (int ob = 0; ob < 2; ob++) {

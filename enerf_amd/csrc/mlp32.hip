@@ -1263,7 +1263,7 @@ int enerf_nerf_mlp_forward(const float* feats, const float* dirs, const float* c
     ProfScope prof(ENERF_K_FFMLP_FWD, s, true);
     prof.units((double)B);
     nerf_launch_fwd(feats, dirs, frags, sigma, rgb, B, out_c, g_valid_rows, g_valid_base, g_valid_cap,
-                    pgrid(B, g_fwd_blocks ? g_fwd_blocks : num_cus()), s, prof.start(), prof.stop());
+                    pgrid(B, g_fwd_blocks ? g_fwd_blocks : kNerfFwdPerCu * num_cus()), s, prof.start(), prof.stop());
     ENERF_LAUNCH_CHECK("nerf_mlp_forward");
     return 0;
 }

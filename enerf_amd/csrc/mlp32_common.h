@@ -286,6 +286,12 @@ void mlp32s_f16_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, con
 constexpr uint32_t kNerfFragBytes = 44 * 2048;
 constexpr uint32_t kNerfPartialStride = (HID * IN + 16 * HID) + (HID * IN + HID * HID + 16 * HID);
 constexpr uint32_t kNerfSigmaWords = HID * IN + 16 * HID;
+// workgroups of k_nerf_fwd per CU (its 48 KiB of LDS and ~136 registers admit three; -DNERF_FWD_ONE_PER_CU: one)
+#ifndef NERF_FWD_ONE_PER_CU
+constexpr uint32_t kNerfFwdPerCu = 3;
+#else
+constexpr uint32_t kNerfFwdPerCu = 1;
+#endif
 void nerf_launch_frags(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
                        uint32_t w0_cols, uint32_t out_c, uint32_t* frags, hipStream_t s);
 void nerf_launch_fwd(const float* X, const float* dirs, const uint32_t* frags, float* sigma, float* rgb, uint32_t B,

@@ -51,6 +51,31 @@ __device__ __forceinline__ f32x16 mmap(const FragT<1>& a, const FragT<1>& b, f32
 
 __device__ __forceinline__ float bf16r(float x) { return (float)(elem16)x; }      // round to nearest 16-bit operand value, back to fp32
 
+// The conversions that make a 16-bit MFMA operand (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 and the v_pk_add_f32 of the low
+// halves) against the MFMA that reads it: on gfx950 the matrix pipe can read the operand registers BEFORE a conversion
+// issued a few instructions earlier has written lanes 16..31 / 48..63 of them -- the compiler separates the two by the two
+// wait states of an ordinary VALU result, which holds while a SIMD runs one or two of these wavefronts and fails with
+// three (the wavefronts' conversions queue up in a unit they share): samples 16..31 of a 32-sample tile then saw a
+// stale operand, 10^-3..10^-2 in the output, in 5 % of the launches of the fused forward -- or in every launch, depending on
+// how the scheduler happened to place the conversions (profiles/r05_mfma_operand_hazard.txt).  The operand therefore passes
+// through this barrier: all of its registers are written, in program order, before anything that reads them, and four
+// idle cycles follow.  (Found with tools/nerf_fwd_residency.py: padded builds fail in 300 of 300 launches without it, 0
+// of 300 with it; the empty barrier alone already clears them, the wait states are the margin.)
+#ifndef MLP32S_READY_NOPS
+#define MLP32S_READY_NOPS 3
+#endif
+#define MLP32S_STR2(x) #x
+#define MLP32S_STR(x) MLP32S_STR2(x)
+#ifdef MLP32S_NO_OPERAND_BARRIER             // (the reproducer's build: tools/nerf_fwd_residency.sh)
+__device__ __forceinline__ void operand_ready(i32x4&) {}
+__device__ __forceinline__ void operand_ready(i32x4&, i32x4&) {}
+#else
+__device__ __forceinline__ void operand_ready(i32x4& r) { asm volatile("s_nop " MLP32S_STR(MLP32S_READY_NOPS) : "+v"(r)); }
+__device__ __forceinline__ void operand_ready(i32x4& r, i32x4& q) {
+    asm volatile("s_nop " MLP32S_STR(MLP32S_READY_NOPS) : "+v"(r), "+v"(q));
+}
+#endif
+
 template <int P>
 __device__ __forceinline__ FragT<P> split8(const float (&v)[8]) {
     i32x4 rh, rl;
@@ -64,6 +89,13 @@ __device__ __forceinline__ FragT<P> split8(const float (&v)[8]) {
             rl[p] = __builtin_bit_cast(int, __builtin_convertvector(rest, bf16x2));
         }
     }
+#ifdef MLP32S_READY_SPLIT
+    operand_ready(rh);                       // (the hi half on its own: the first product of a triple needs only it)
+    if constexpr (P == 3) operand_ready(rl);
+#else
+    if constexpr (P == 3) operand_ready(rh, rl);
+    else operand_ready(rh);
+#endif
     FragT<P> r;
     r.hi = __builtin_bit_cast(bf16x8, rh);
     if constexpr (P == 3) r.lo = __builtin_bit_cast(bf16x8, rl);
@@ -88,6 +120,7 @@ __device__ __forceinline__ bf16x8 exact8(const f32x16& d, int t) {
         const f32x2 f = {d[8 * t + 2 * p], d[8 * t + 2 * p + 1]};
         r[p] = __builtin_bit_cast(int, __builtin_convertvector(f, bf16x2));
     }
+    operand_ready(r);
     return __builtin_bit_cast(bf16x8, r);
 }
 // selection matrices B[k][c] of the flips, as B operands of lane (c, h): k = 8h + e

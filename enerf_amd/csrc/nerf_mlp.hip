@@ -58,6 +58,7 @@ __device__ __forceinline__ int c0_memcol(int c, uint32_t w0_cols) {
     return (uint32_t)m < w0_cols ? m : -1;
 }
 
+#ifndef NERF_MLP_BACKWARD_UNIT
 // One wavefront per fragment.  ws0 [64,32], ws1 [16,64], wc0 [64,w0_cols], wc1 [64,64], wc2 [out_c,64].
 __global__ void __launch_bounds__(64) k_nerf_frags(const float* __restrict__ ws0, const float* __restrict__ ws1,
                                                   const float* __restrict__ wc0, const float* __restrict__ wc1,
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(64) k_nerf_frags(const float* __restrict__ ws0
     dst[64 + lane] = __builtin_bit_cast(u32x4n, w.lo);
 }
 
+#endif
 struct NerfRows {                   // enerf_mlp32_valid_rows(_ex): see WSrc
     const int32_t* valid_rows;
     uint32_t valid_base, valid_cap;
@@ -153,33 +155,34 @@ __device__ __forceinline__ void copy_frags(u32x4n* __restrict__ fr, const uint32
     for (int k = 0; k < N; k++) dst[threadIdx.x + k * 256] = v[k];
 }
 
-// ---------------------------------------------------------------------------------------------------- forward
-// Residency: ONE workgroup per CU and one wavefront per SIMD, by construction -- 84 KiB of LDS and more than half of the
-// register file per wave.  With two or three workgroups of this kernel on a CU the colour outputs of samples 16..31 of a
-// tile came out wrong in a few per cent of the tiles of the later-dispatched workgroups (10^-3 .. 10^-2 in rgb, different
-// rows every launch; sigma never; tools/nerf_fwd_residency.sh -> profiles/r05_nerf_fwd_residency.txt), in VGPR- and AGPR-form
-// builds alike, while the one-net kernels of mlp32s.hip at the same residency and every build of this kernel at one
-// workgroup per CU are bit-stable over hundreds of launches.  The cause was not found in this round (it is not the operand
-// overlap of mfma_guard.h, which was fixed first and made the second workgroup safe but not the third); until it is, the
-// kernel does not share a SIMD with anything (NERF_WHOLE_SIMD below; the backward needs 149 KiB of LDS and ~480 registers
-// anyway).  tests/test_gpu_mlp32.py soaks both kernels for run-to-run bit-stability.
-// the wave's allocation is the SIMD's whole register file (256 + 256): no wavefront of ANY kernel shares the SIMD -- the
-// next batch's march runs on a second stream beside this library's step
-// (NERF_SHARED_CU: the experiment's build -- tools/nerf_fwd_residency.sh -- lets workgroups share a CU again)
-#ifdef NERF_SHARED_CU
-#define NERF_WHOLE_SIMD() do {} while (0)
+// Residency.  Rounds 4-5 shipped this kernel with ONE workgroup per CU (84 KiB of LDS, the SIMD's whole register file
+// claimed): with three workgroups per CU the colour outputs of samples 16..31 of a tile came out wrong in a few per cent
+// of the launches (10^-3..10^-2, different rows every launch, sigma never).  The cause is the operand hazard described in
+// mlp32s_ops.h (operand_ready): the conversions that make an MFMA's 16-bit operand were not yet complete in lanes 16..31
+// / 48..63 when the matrix pipe read it -- only when three wavefronts' conversions share a SIMD.  With the barrier in
+// split8 / exact8 the kernel is bit-stable at any residency (tools/nerf_fwd_residency.py: 0 of 400 launches at three
+// workgroups per CU, padded and unpadded builds; tests/test_gpu_mlp32.py soaks it), and the forward shares the CU again:
+// 48 KiB of LDS, ~136 registers, three workgroups per CU = three wavefronts per SIMD hiding each other's MFMA and LDS
+// latencies.  The backward keeps a CU to itself for what it needs (149 KiB of LDS, ~480 registers).
+// (-DNERF_FWD_ONE_PER_CU: the forward as shipped in round 5's first half, for A/B runs.)
+#ifndef NERF_FWD_ONE_PER_CU
+#define NERF_FWD_WHOLE_SIMD() do {} while (0)
 constexpr uint32_t kFwdLdsWords = 12 * 1024;              // 48 KiB: the fragments alone, three workgroups per CU
 #else
-#define NERF_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
+#define NERF_FWD_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
 constexpr uint32_t kFwdLdsWords = 21 * 1024;              // 84 KiB: two workgroups do not fit a CU's 160 KiB
 #endif
+// the backward's wave allocation is the SIMD's whole register file (256 + 256): it needs most of it anyway
+#define NERF_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
+#ifndef NERF_MLP_BACKWARD_UNIT
+// ---------------------------------------------------------------------------------------------------- forward
 __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ X, const float* __restrict__ dirs,
                                                    const uint32_t* __restrict__ frags, float* __restrict__ sigma,
                                                    float* __restrict__ rgb, uint32_t B, uint32_t out_c, NerfRows rows,
                                                    ShNorm4 nrm) {
     static_assert(NF_FWD * kFragWords <= kFwdLdsWords, "LDS");
     __shared__ __attribute__((aligned(16))) uint32_t lds[kFwdLdsWords];
-    NERF_WHOLE_SIMD();
+    NERF_FWD_WHOLE_SIMD();
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;
     const uint32_t Bp = (B + 31u) & ~31u;
     const uint32_t gw = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -282,6 +285,8 @@ __global__ void __launch_bounds__(256) k_nerf_fwd(const float* __restrict__ X, c
     }
 }
 
+#endif
+#ifdef NERF_MLP_BACKWARD_UNIT
 // ---------------------------------------------------------------------------------------------------- backward
 struct NerfBwdArgs {
     const float* X;            // [16, Bp, 2]
@@ -649,9 +654,14 @@ __global__ void __launch_bounds__(256) k_nerf_bwd(NerfBwdArgs a, const uint32_t*
     for (uint32_t i = threadIdx.x; i < NW_S + NW_C; i += blockDim.x) dst[i] = r0[i] + r0[P_STRIDE + i];
 }
 
+#endif
 // ---------------------------------------------------------------------------------------------------- launchers
+#ifdef NERF_MLP_BACKWARD_UNIT
+#define k_nerf_mark k_nerf_mark_bwd_unit          // (one marker kernel per translation unit)
+#endif
 __global__ void k_nerf_mark() {}
 
+#ifndef NERF_MLP_BACKWARD_UNIT
 void nerf_launch_frags(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
                        uint32_t w0_cols, uint32_t out_c, uint32_t* frags, hipStream_t s) {
     hipLaunchKernelGGL(k_nerf_frags, dim3(NF_ALL), dim3(64), 0, s, ws0, ws1, wc0, wc1, wc2, w0_cols, out_c, frags);
@@ -665,6 +675,7 @@ void nerf_launch_fwd(const float* X, const float* dirs, const uint32_t* frags, f
                           NerfRows{valid_rows, valid_base, valid_cap}, make_sh_norm4());
 }
 
+#else
 void nerf_launch_bwd(const float* X, const float* dirs, const float* g_rgb, const float* rgb, const float* g_sigma,
                      float sigma_scale, const uint32_t* frags, float* dX, float* partial, uint32_t B, uint32_t out_c,
                      const int32_t* valid_rows, uint32_t valid_base, uint32_t valid_cap, uint32_t grid, hipStream_t s,
@@ -676,5 +687,6 @@ void nerf_launch_bwd(const float* X, const float* dirs, const float* g_rgb, cons
     a.rows = NerfRows{valid_rows, valid_base, valid_cap};
     hipExtLaunchKernelGGL(k_nerf_bwd, dim3(grid), dim3(256), 0, s, nullptr, ev_stop, 0, a, frags, make_sh_norm4());
 }
+#endif
 
 }  // namespace enerf_mlp32

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-@pytest.mark.parametrize("src", ["nerf_mlp.hip", "mlp32s.hip", "mlp32s_f16.hip", "ffmlp.hip"])
+@pytest.mark.parametrize("src", ["nerf_mlp.hip", "nerf_mlp_bwd.hip", "mlp32s.hip", "mlp32s_f16.hip", "ffmlp.hip"])
 def test_no_mfma_result_lands_on_its_operands(src, tmp_path):
     from enerf_amd import build
     flags = [f for f in build.FLAGS if f not in ("-fPIC",)] + build.EXTRA.get(src, [])
@@ -27,3 +27,29 @@ def test_no_mfma_result_lands_on_its_operands(src, tmp_path):
     assert rows, "no MFMA found: the scan is looking at the wrong thing"
     bad = [ln for ln in rows if not ln.rstrip().endswith("overlapping 0")]
     assert not bad, "MFMA results overlapping SrcA / SrcB:\n" + "\n".join(bad[:10])
+
+
+# kernels that run two or more wavefronts per SIMD (nerf_mlp_bwd.hip runs one, by construction, and is compiled without the
+# barrier on purpose: see that file)
+@pytest.mark.parametrize("src", ["nerf_mlp.hip", "mlp32s.hip", "mlp32s_f16.hip", "ffmlp.hip", "ffnerf.hip"])
+def test_no_conversion_writes_an_operand_right_in_front_of_its_mfma(src, tmp_path):
+    """csrc/mlp32s_ops.h (operand_ready): a v_cvt_pk_* / v_pk_add_f32 that writes an MFMA's SrcA / SrcB must not sit within
+    four issue slots of it -- on gfx950 the matrix pipe otherwise reads lanes 16..31 / 48..63 of the operand before the
+    conversion has written them once several wavefronts share the SIMD.  Scanned on the compiled assembly by
+    tools/mfma_operand_distance.py."""
+    from enerf_amd import build
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_operand_distance", os.path.join(ROOT, "tools", "mfma_operand_distance.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    flags = [f for f in build.FLAGS if f not in ("-fPIC",)] + build.EXTRA.get(src, [])
+    out = tmp_path / (src + ".s")
+    subprocess.check_call([build._hipcc()] + flags + ["-S", "--cuda-device-only", os.path.join(build.CSRC, src), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    mfmas, close = 0, []
+    for name, ins in mod.functions(str(out)).items():
+        mfmas += sum(1 for s in ins if s.startswith("v_mfma"))
+        close += [(name[:60], d, w) for d, w, _ in mod.scan(ins)
+                  if d < 4 and w.startswith(("v_cvt_pk", "v_pk_add_f32", "v_cvt_"))]
+    assert mfmas, "no MFMA found: the scan is looking at the wrong thing"
+    assert not close, f"conversions within 4 slots of the MFMA that reads them: {close[:8]}"
