@@ -23,6 +23,7 @@ SIGNATURES = {
     "enerf_march_rays_train": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _u32, _vp],
     "enerf_march_fuse_near_far": [_vp, _f32],
+    "enerf_march_mirror_count": [_vp],
     "enerf_march_rays_train_ex": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _u32, _u32, _vp],
     "enerf_march_rays_train_count": [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32,

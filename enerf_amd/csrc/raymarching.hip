@@ -803,7 +803,8 @@ __global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ ra
 __device__ unsigned long long g_train_samples = 0ull;
 
 // `fresh`: the counter is taken as (0, 0) whatever it holds -- the caller's counter.zero_() without its launch
-__global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* counter, uint32_t N, uint32_t fresh) {
+__global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* counter, uint32_t N, uint32_t fresh,
+                                                     int32_t* mirror) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const int lane = lane_id();
@@ -831,7 +832,14 @@ __global__ void __launch_bounds__(1024) k_march_scan(int32_t* rays, int32_t* cou
     if (threadIdx.x == 0) {
         g_train_samples += (unsigned long long)(carry_s - c0);
         counter[0] = (int32_t)carry_s;
-        counter[1] = (fresh ? 0 : counter[1]) + (int32_t)N;
+        const int32_t n_rays = (fresh ? 0 : counter[1]) + (int32_t)N;
+        counter[1] = n_rays;
+        if (mirror) {
+            // enerf_march_mirror_count: the counter also goes straight into (pinned, device-visible) host memory -- the host
+            // that watches the two words sees the count without a copy queued behind this kernel
+            __hip_atomic_store(mirror, (int32_t)carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mirror + 1, n_rays, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -886,7 +894,8 @@ __global__ void __launch_bounds__(1024) k_march_scan_tiles(uint32_t* tile_sums, 
     if (threadIdx.x == 0) {
         g_train_samples += (unsigned long long)(carry_s - c0);
         counter[0] = (int32_t)carry_s;
-        counter[1] = (fresh ? 0 : counter[1]) + (int32_t)N;
+        const int32_t n_rays = (fresh ? 0 : counter[1]) + (int32_t)N;
+        counter[1] = n_rays;
     }
 }
 
@@ -1788,6 +1797,7 @@ static inline size_t march_log_bytes(uint32_t N, uint32_t H) {
 // arrays it is given, for the write pass and the renderer) -- one launch less at the head of the side stream's chain
 static const float* g_nf_aabb = nullptr;
 static float g_nf_min_near = 0.0f;
+static int32_t* g_count_mirror = nullptr;      // enerf_march_mirror_count (armed for one count pass)
 
 // count pass (+ scan): rays[n] = (n, offset, count), counter += (sum, N); the fixed-step marcher also fills the chunk log
 static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -1797,6 +1807,8 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
     if (int e = workspace_family_enter(0, s)) return e;
     const float* nf_aabb = g_nf_aabb;
     g_nf_aabb = nullptr;                                   // (armed for one call)
+    int32_t* mirror = g_count_mirror;
+    g_count_mirror = nullptr;
     if (nf_aabb && !(march_uses_lattice(dt_gamma, max_steps, C, H) && !march_uses_threads(N, H))) {
         k_near_far<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, nf_aabb, N, g_nf_min_near, (float*)nears, (float*)fars);
         nf_aabb = nullptr;
@@ -1843,7 +1855,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                                                    fars, rays, perturb);
     }
     if (N <= 16384u) {
-        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N, fresh_counter ? 1u : 0u);
+        k_march_scan<<<1, 1024, 0, s>>>(rays, counter, N, fresh_counter ? 1u : 0u, mirror);
     } else {
         const uint32_t ntiles = div_up(N, 1024);
         uint32_t* tiles = (uint32_t*)workspace(WS_SCAN, (size_t)ntiles * sizeof(uint32_t));
@@ -1851,6 +1863,8 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         k_march_scan_tile_sums<<<ntiles, 1024, 0, s>>>(rays, N, tiles);
         k_march_scan_tiles<<<1, 1024, 0, s>>>(tiles, ntiles, counter, N, fresh_counter ? 1u : 0u);
         k_march_scan_apply<<<ntiles, 1024, 0, s>>>(rays, N, tiles);
+        if (mirror && hipMemcpyAsync(mirror, counter, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+            ENERF_BADARG("march_rays_train: could not mirror the counter to the host");      // (large batches: a copy)
     }
     return 0;
 }
@@ -1885,6 +1899,11 @@ static int march_train_write(const float* rays_o, const float* rays_d, const uin
         k_march_write<<<div_up(N, 64), 64, 0, s>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears,
                                                    fars, xyzs, dirs, deltas, rays, perturb);
     }
+    return 0;
+}
+
+int enerf_march_mirror_count(int32_t* host_counter) {
+    g_count_mirror = host_counter;
     return 0;
 }
 

@@ -389,9 +389,19 @@ def _check_cold_stage(model, pre, rays_o, rays_d, perturb, dt_gamma, max_steps):
     count, scan and ray table do not depend on the rows (same counter slot, nothing marched since), so the write pass
     alone is repeated into buffers of the exact size -- what finish_march does for a speculative write pass that did not
     fit.  -> the stage to use."""
-    done, host, cap = pre.pop("cold_check")
-    done.synchronize()
-    m = int(host[0])
+    done, host, cap = pre.pop("cold_check")[:3]
+    # the count arrives in pinned memory behind the march (an 8-byte copy on its stream): the host watches the two words
+    # it pre-set to -1 instead of sleeping on the event -- the wake-up of an event wait is 10-20 us, in which the device,
+    # which has nothing queued yet, idles (the cold window's steps: 11 of the driver's 20)
+    hv = host.numpy()
+    if hv[0] < 0 or hv[1] < 0:
+        import time as _time
+        t_end = _time.perf_counter() + 0.05
+        while (hv[0] < 0 or hv[1] < 0) and _time.perf_counter() < t_end:
+            pass
+        if hv[0] < 0 or hv[1] < 0:
+            done.synchronize()
+    m = int(hv[0])
     N = rays_o.shape[0]
     rows = min(m + (128 - m % 128), N * int(max_steps))
     model._cold_rows = rows
@@ -434,6 +444,7 @@ def _take_premarched(model, rays_o, rays_d, perturb, dt_gamma, max_steps, defer_
 
 
 FUSED_COMPOSITE = True        # train_step_mse: compositing forward + MSE backward as one launch
+MIRROR_COUNT = True           # cold window: the march's count goes straight to pinned host memory (enerf_march_mirror_count)
 import os as _os
 SKIP_PADDING_ROWS = _os.environ.get("ENERF_SKIP_PADDING_ROWS", "1") != "0"      # raw renders: the MLP kernels skip the sample budget's unfilled rows (device-side count)
 
@@ -757,6 +768,15 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             ctx["flip"] = which ^ 1              # (the set the next call looks at first is the one this stage does not use)
         if not raw:
             a.lr, a.beta1, a.beta2, a.eps, a.table_step = ctx["plan"]()
+        cold_host = None
+        if nxt is not None and cold_next and MIRROR_COUNT:
+            # the cold window's next march writes its count straight into pinned host memory (enerf_march_mirror_count)
+            hosts = ctx.get("cold_hosts")
+            if hosts is None:
+                hosts = ctx["cold_hosts"] = [torch.empty(2, dtype=torch.int32, pin_memory=True) for _ in range(2)]
+            cold_host = hosts[which]
+            cold_host.fill_(-1)               # (what _check_cold_stage watches for: both words are >= 0 once the count has landed)
+            L.check(L.lib().enerf_march_mirror_count(cold_host.data_ptr()), "march_mirror_count")
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
         from .backends import _gridencoder as _gbk
@@ -774,7 +794,9 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                     hosts = ctx["cold_hosts"] = [torch.empty(2, dtype=torch.int32, pin_memory=True) for _ in range(2)]
                 host = hosts[which]
                 with torch.cuda.stream(side_stream):
-                    host.copy_(nxt["counter"], non_blocking=True)
+                    if cold_host is None:
+                        host.fill_(-1)            # (what _check_cold_stage watches for: both words are >= 0 once the copy has landed)
+                        host.copy_(nxt["counter"], non_blocking=True)
                     done = torch.cuda.Event()
                     done.record(side_stream)
                 nxt["cold_check"] = (done, host, Mn)

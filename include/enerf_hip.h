@@ -136,6 +136,12 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
                               int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
                               enerf_stream_t stream);
 
+/* Arms the NEXT enerf_march_rays_train(_ex / _count) call: the two words of `counter` it leaves on the device -- samples
+ * reserved, rays marched -- are also written to host_counter[0], [1] (pinned, device-visible host memory, e.g. a torch
+ * tensor with pin_memory=True), word 1 last: a host that pre-set both to -1 and watches them has the count without
+ * queueing a copy (and an event) behind the march.  Batches above 16 384 rays get the copy. */
+int enerf_march_mirror_count(int32_t* host_counter);
+
 /* Arms the NEXT enerf_march_rays_train(_ex / _count) call: its count pass computes near / far of every ray against `aabb`
  * itself (enerf_near_far_from_aabb's arithmetic, bit for bit) and WRITES them to the nears / fars arrays the call is
  * given (they need not be initialised) -- the near_far launch at the head of a march that is prepared ahead of its step

@@ -238,6 +238,28 @@ def test_march_with_near_far_inside_the_count_pass(rm, scenes, dt_gamma, flags, 
     assert int(counter[0]) == 0
 
 
+def test_march_count_mirrored_into_pinned_host_memory(rm, scenes):
+    """enerf_march_mirror_count: the armed count pass writes (samples reserved, rays marched) into pinned host memory too --
+    a host watching the two words it pre-set to -1 reads the device counter's values; the arming lasts one call."""
+    bound = 2
+    grid, bits, C = scenes[bound]
+    o, d, aabb = _rays(1500, 7, bound)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.2)
+    N = len(o)
+    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+    rays = torch.empty(N, 3, dtype=torch.int32, device=DEV)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    host.fill_(-1)
+    rm.march_mirror_count(host)
+    rm.march_rays_train_count(cu(o), cu(d), cu(bits), bound, 0.0, 1024, N, C, H, cu(nears), cu(fars), rays, counter, 1, 0)
+    torch.cuda.synchronize()
+    assert host.tolist() == counter.cpu().tolist() and host[1].item() == N and host[0].item() > 0
+    host.fill_(-1)
+    rm.march_rays_train_count(cu(o), cu(d), cu(bits), bound, 0.0, 1024, N, C, H, cu(nears), cu(fars), rays, counter, 1, 0)
+    torch.cuda.synchronize()
+    assert host.tolist() == [-1, -1]
+
+
 @pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
 def test_march_rays_train_count_then_write_equals_worst_case_buffers_cropped(rm, scenes, dt_gamma, march_route):
     """While no sample budget exists the reference allocates N * max_steps zero rows, marches, reads the count back and
