@@ -88,6 +88,7 @@ def march_fuse_near_far(aabb, min_near):
 def march_mirror_count(host_counter):
     """Arm the next march_rays_train(_ex / _count) call to write its two counter words into `host_counter` as well: a
     pinned int32 host tensor of 2 elements (include/enerf_hip.h)."""
+    import torch
     if host_counter.is_cuda or not host_counter.is_pinned() or host_counter.dtype != torch.int32 or host_counter.numel() < 2:
         raise ValueError("march_mirror_count: a pinned int32 host tensor of two elements")
     L.check(L.lib().enerf_march_mirror_count(host_counter.data_ptr()), "march_mirror_count")
