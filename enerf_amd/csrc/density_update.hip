@@ -14,7 +14,6 @@
 // scattered gathers is here ~10 launches, one read-back of 16 bytes, and coherent gathers: the sampled cells are sorted
 // (23-bit radix sort of (cascade, Morton index) keys) so neighbouring query points share hash-grid rows.  The sampling
 // is the same in distribution, not in its random numbers (torch's Philox stream is not reproduced): parity unpinned.
-#include <hipcub/hipcub.hpp>
 
 #include "common.h"
 #include "sweep_points.h"
@@ -121,8 +120,10 @@ __global__ void __launch_bounds__(256) k_occ_compact(const float* __restrict__ g
 // ---- partial update, step 2: (cascade << bits | Morton index) keys of the cells to evaluate
 __global__ void __launch_bounds__(256) k_select_keys(uint32_t C, uint32_t N, uint32_t bits, uint32_t H3, uint64_t seed,
                                                      const uint32_t* __restrict__ cas_counts,
-                                                     const uint32_t* __restrict__ list, uint32_t* __restrict__ keys) {
+                                                     const uint32_t* __restrict__ list, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ sort_counters, uint32_t n_counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_counters) sort_counters[i] = 0;                       // (bucket sizes and cursors of the sort that follows)
     if (i >= C * 2 * N) return;
     const uint32_t cas = i / (2 * N), j = i - cas * 2 * N;
     const Rand4 r = rand4(seed ^ 0x5bd1e995u, i);
@@ -130,6 +131,117 @@ __global__ void __launch_bounds__(256) k_select_keys(uint32_t C, uint32_t N, uin
     const uint32_t cnt = cas_counts[cas];
     if (j >= N && cnt) idx = list[(size_t)cas * H3 + (uint32_t)(((uint64_t)r.w[1] * cnt) >> 32)];   // occupied cell
     keys[i] = cas << bits | idx;
+}
+
+// ---- partial update, the sort between steps 2 and 3: ascending (cascade << bits | Morton index) keys, so that the encoder's
+// gathers of the 1 M scattered evaluations of the reference run in Morton order.  Keys only, values below C << bits:
+// a bucket sort by VALUE in four launches --
+//   k_sort_count    bucket = key >> low (4096 cells of one cascade in Morton order: a 16^3 block): per-workgroup LDS histogram,
+//                   one global atomic per (workgroup, bucket fed);
+//   k_sort_scan     exclusive scan of the <= 4096 bucket sizes;
+//   k_sort_scatter  the keys into their buckets' ranges, in any order (one reservation per (workgroup, bucket), LDS ranks);
+//   k_sort_buckets  one workgroup per bucket: an LDS histogram over the bucket's 2^low possible values, scanned, and every
+//                   value written out as often as it occurred -- which IS the sorted order (there is no payload).
+// (rounds 1-4: hipcub::DeviceRadixSort, the only library code on the path.)
+constexpr uint32_t kSortChunk = 8192;               // keys per workgroup of the count / scatter passes (256 threads x 32)
+constexpr uint32_t kSortMaxBuckets = 4096;
+constexpr uint32_t kSortMaxLow = 14;                // 2^14 counters of 4 bytes = 64 KiB of LDS in k_sort_buckets
+
+__global__ void __launch_bounds__(256) k_sort_count(const uint32_t* __restrict__ keys, uint32_t P, uint32_t low, uint32_t nb,
+                                                    uint32_t* __restrict__ bucket_count) {
+    __shared__ uint32_t hist[kSortMaxBuckets];
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortChunk;
+#pragma unroll 8
+    for (uint32_t k = 0; k < kSortChunk / 256; k++) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < P) atomicAdd(&hist[keys[i] >> low], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256)
+        if (hist[b]) atomicAdd(&bucket_count[b], hist[b]);
+}
+
+// bucket_base = exclusive scan of bucket_count (nb <= 4096: four per thread)
+__global__ void __launch_bounds__(1024) k_sort_scan(const uint32_t* __restrict__ bucket_count, uint32_t nb,
+                                                    uint32_t* __restrict__ bucket_base) {
+    __shared__ uint32_t wtot[16];
+    uint32_t v[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = threadIdx.x * 4 + k;
+        v[k] = b < nb ? bucket_count[b] : 0u;
+        mine += v[k];
+    }
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_add_u32(mine, lane);
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    uint32_t off = incl - mine;
+    for (int w = 0; w < wid; w++) off += wtot[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = threadIdx.x * 4 + k;
+        if (b < nb) bucket_base[b] = off;
+        off += v[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sort_scatter(const uint32_t* __restrict__ keys, uint32_t P, uint32_t low, uint32_t nb,
+                                                      const uint32_t* __restrict__ bucket_base,
+                                                      uint32_t* __restrict__ bucket_cursor, uint32_t* __restrict__ out) {
+    __shared__ uint32_t hist[kSortMaxBuckets];       // this chunk's keys per bucket, then the next free slot of its reservation
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortChunk;
+    uint32_t key[kSortChunk / 256];
+#pragma unroll
+    for (uint32_t k = 0; k < kSortChunk / 256; k++) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        key[k] = i < P ? keys[i] : 0xffffffffu;
+        if (i < P) atomicAdd(&hist[key[k] >> low], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+        const uint32_t n = hist[b];
+        hist[b] = n ? bucket_base[b] + atomicAdd(&bucket_cursor[b], n) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kSortChunk / 256; k++)
+        if (key[k] != 0xffffffffu) out[atomicAdd(&hist[key[k] >> low], 1u)] = key[k];
+}
+
+// one workgroup per bucket (any size): count its keys' low bits, scan, write every value out count[value] times
+__global__ void __launch_bounds__(256) k_sort_buckets(const uint32_t* __restrict__ scattered, uint32_t low,
+                                                      const uint32_t* __restrict__ bucket_count,
+                                                      const uint32_t* __restrict__ bucket_base, uint32_t* __restrict__ out) {
+    extern __shared__ uint32_t cnt[];                // 2^low
+    __shared__ uint32_t wtot[4];
+    const uint32_t b = blockIdx.x, n = bucket_count[b];
+    if (n == 0) return;
+    const uint32_t base = bucket_base[b], vals = 1u << low, mask = vals - 1u;
+    for (uint32_t v = threadIdx.x; v < vals; v += 256) cnt[v] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&cnt[scattered[base + i] & mask], 1u);
+    __syncthreads();
+    // thread t owns the values [t * per, (t + 1) * per): their total, an exclusive scan over the threads, then the writes
+    const uint32_t per = vals / 256;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; k++) mine += cnt[threadIdx.x * per + k];
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_add_u32(mine, lane);
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    uint32_t off = base + incl - mine;
+    for (int w = 0; w < wid; w++) off += wtot[w];
+    const uint32_t hi = b << low;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t v = threadIdx.x * per + k, c = cnt[v];
+        for (uint32_t j = 0; j < c; j++) out[off + j] = hi | v;
+        off += c;
+    }
 }
 
 // ---- partial update, step 3 (after the sort): keys -> Morton indices + jittered positions
@@ -280,14 +392,17 @@ int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, 
     if ((uint64_t)C * 2 * n_uniform > 0x7fffffffULL) ENERF_BADARG("density_grid_cells: too many samples");
     const uint32_t P = C * 2 * n_uniform;
     const uint32_t blocks_per_cas = H3 / kOccBlock, nblocks = C * blocks_per_cas;
-    const int end_bit = (int)(bits + log2u(C));
-    size_t sort_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0,
-                                          end_bit, s) != hipSuccess)
-        ENERF_BADARG("density_grid_cells: radix sort sizing failed");
+    // the sort's geometry: buckets of 2^low consecutive key values, at most kSortMaxBuckets of them
+    uint32_t key_bits = bits + log2u(C);
+    if ((1u << log2u(C)) < C) key_bits++;                                   // (C not a power of two)
+    const uint32_t low = key_bits > 24 ? key_bits - 12 : 12;
+    if (low > kSortMaxLow)
+        ENERF_BADARG("density_grid_cells: the partial update sorts keys of up to 26 bits (C * H^3 <= 2^26 cells), got %u bits", key_bits);
+    const uint32_t nb = div_up(C << bits, 1u << low);
     const size_t o_counts = 0, o_cas = o_counts + align256((size_t)nblocks * 4), o_list = o_cas + 256,
                  o_keys = o_list + align256((size_t)C * H3 * 4), o_sorted = o_keys + align256((size_t)P * 4),
-                 o_sort = o_sorted + align256((size_t)P * 4), total = o_sort + align256(sort_bytes);
+                 o_tmp = o_sorted + align256((size_t)P * 4), o_sort = o_tmp + align256((size_t)P * 4),
+                 total = o_sort + align256((size_t)3 * kSortMaxBuckets * 4);
     if (int ew = workspace_family_enter(1, s)) return ew;
     char* ws = (char*)workspace(WS_DENSITY, total);
     if (!ws) return ENERF_E_NOMEM;
@@ -299,9 +414,16 @@ int enerf_density_grid_cells(const float* density_grid, uint32_t C, uint32_t H, 
     k_occ_count<<<nblocks, 256, 0, s>>>(density_grid, block_counts);
     k_occ_scan<<<C, 1024, 0, s>>>(block_counts, blocks_per_cas, cas_counts);
     k_occ_compact<<<nblocks, 256, 0, s>>>(density_grid, block_counts, blocks_per_cas, H3, list);
-    k_select_keys<<<div_up(P, 256), 256, 0, s>>>(C, n_uniform, bits, H3, seed, cas_counts, list, keys);
-    if (hipcub::DeviceRadixSort::SortKeys(ws + o_sort, sort_bytes, keys, sorted, (int)P, 0, end_bit, s) != hipSuccess)
-        ENERF_BADARG("density_grid_cells: radix sort failed");
+    uint32_t* tmp = (uint32_t*)(ws + o_tmp);
+    uint32_t* bucket_count = (uint32_t*)(ws + o_sort);             // [nb] sizes | [nb] cursors | [nb] bases
+    uint32_t* bucket_cursor = bucket_count + kSortMaxBuckets;
+    uint32_t* bucket_base = bucket_cursor + kSortMaxBuckets;
+    k_select_keys<<<div_up(P > 2u * kSortMaxBuckets ? P : 2u * kSortMaxBuckets, 256), 256, 0, s>>>(
+        C, n_uniform, bits, H3, seed, cas_counts, list, keys, bucket_count, 2u * kSortMaxBuckets);
+    k_sort_count<<<div_up(P, kSortChunk), 256, 0, s>>>(keys, P, low, nb, bucket_count);
+    k_sort_scan<<<1, 1024, 0, s>>>(bucket_count, nb, bucket_base);
+    k_sort_scatter<<<div_up(P, kSortChunk), 256, 0, s>>>(keys, P, low, nb, bucket_base, bucket_cursor, tmp);
+    k_sort_buckets<<<nb, 256, sizeof(uint32_t) << low, s>>>(tmp, low, bucket_count, bucket_base, sorted);
     k_cells_from_keys<<<div_up(P, 256), 256, 0, s>>>(cs, P, H, bits, seed, sorted, indices, xyzs);
     ENERF_LAUNCH_CHECK("density_grid_cells(partial)");
     return 0;
