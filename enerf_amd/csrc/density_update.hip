@@ -237,10 +237,30 @@ __global__ void __launch_bounds__(256) k_sort_buckets(const uint32_t* __restrict
     uint32_t off = base + incl - mine;
     for (int w = 0; w < wid; w++) off += wtot[w];
     const uint32_t hi = b << low;
+    // a value drawn many times (few occupied cells: every draw of the cascade lands on them) is written by the whole
+    // workgroup, not by the one thread that owns it
+    __shared__ uint32_t heavy_n, heavy[64][3];
+    if (threadIdx.x == 0) heavy_n = 0;
+    __syncthreads();
     for (uint32_t k = 0; k < per; k++) {
         const uint32_t v = threadIdx.x * per + k, c = cnt[v];
-        for (uint32_t j = 0; j < c; j++) out[off + j] = hi | v;
+        bool mine_to_write = true;
+        if (c > 64u) {
+            const uint32_t slot = atomicAdd(&heavy_n, 1u);
+            if (slot < 64u) {
+                heavy[slot][0] = hi | v; heavy[slot][1] = c; heavy[slot][2] = off;
+                mine_to_write = false;
+            }
+        }
+        if (mine_to_write)
+            for (uint32_t j = 0; j < c; j++) out[off + j] = hi | v;
         off += c;
+    }
+    __syncthreads();
+    const uint32_t nh = heavy_n < 64u ? heavy_n : 64u;
+    for (uint32_t e = 0; e < nh; e++) {
+        const uint32_t key = heavy[e][0], c = heavy[e][1], at = heavy[e][2];
+        for (uint32_t j = threadIdx.x; j < c; j += 256) out[at + j] = key;
     }
 }
 
