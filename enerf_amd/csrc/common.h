@@ -75,6 +75,25 @@ enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, 
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// ---- a small job that another kernel's launch carries in a few extra workgroups ------------------------------------
+// Gather-and-split: thread t makes values 8t .. 8t+7, value i = src[map[i] >> 16][map[i] & 0xffff] (map 0xffffffff: 0.0f),
+// as bf16 hi (round to nearest even) and lo = bf16(value - hi); the 16 bytes of hi go to out + (t / 64) * 512 + (t % 64) * 4
+// (in 32-bit words), the 16 bytes of lo 256 words further.  (What csrc/nerf_mlp.hip's operand fragments are: the training
+// step's grid forward builds them beside its own work instead of a 5 us launch in front of the MLP forward.)
+struct SplitJob {
+    const float* src[5];
+    const uint32_t* map;
+    uint32_t* out;
+    uint32_t threads;
+};
+// gridencoder.hip: the next fp32 D = 3, C = 2 forward launch carries `job` (one-shot; nullptr disarms).  Returns whether a
+// job armed earlier was still waiting (= no launch took it).
+bool grid_fwd_carry(const SplitJob* job);
+// mlp32.hip: the job that builds the fragments enerf_nerf_mlp_forward / _backward would build for these weights, and the
+// promise that it runs before them on `s`: the calls that follow with flags bit 0 use the fragments as they are.
+int nerf_mlp_frag_job(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
+                      hipStream_t s, SplitJob* job);
+
 // ---- wave-level primitives (wave64) ----------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

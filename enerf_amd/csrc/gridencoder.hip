@@ -213,8 +213,8 @@ __device__ __forceinline__ void corner_rows(const LevelGeom<D>& g, const uint32_
 // (Rounds walked in pairs -- a group's workgroups alternating between a gather-bound fine level and an instruction-bound
 //  coarse one -- are slower, not faster: profiles/r05_fwd_paired_rounds_rejected.txt.)
 constexpr uint32_t kGroupXcds = 2, kGroups = 8 / kGroupXcds;
-__device__ __forceinline__ bool decode_block_fwd(uint32_t nchunks, uint32_t L, uint32_t& level, uint32_t& chunk) {
-    const uint32_t bid = blockIdx.x;
+__device__ __forceinline__ bool decode_block_fwd(uint32_t bid, uint32_t nchunks, uint32_t L, uint32_t& level,
+                                                 uint32_t& chunk) {
     const uint32_t xcd = bid & 7u, j = bid >> 3;
     const uint32_t group = xcd / kGroupXcds, member = xcd % kGroupXcds;
     const uint32_t per = div_up(nchunks, kGroupXcds);
@@ -241,15 +241,16 @@ __device__ __forceinline__ bool level_enabled(const LevelTab& tab, uint32_t leve
     return (tab.level_mask >> level) & 1u;
 }
 
+// (`bid`: the workgroup's index among the forward's own -- blockIdx.x, less the carried job's workgroups in front)
 template <typename T, int D, int C>
-__global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restrict__ inputs, const T* __restrict__ grid,
-                                                           const int32_t* __restrict__ offsets, T* __restrict__ outputs,
-                                                           uint32_t B, uint32_t L, LevelTab tab, bool calc_grad_inputs,
-                                                           T* __restrict__ dy_dx, uint32_t gridtype, int out_layout,
-                                                           uint32_t nchunks, SweepGen gen) {
+__device__ __forceinline__ void grid_fwd_block(uint32_t bid, const float* __restrict__ inputs, const T* __restrict__ grid,
+                                               const int32_t* __restrict__ offsets, T* __restrict__ outputs, uint32_t B,
+                                               uint32_t L, const LevelTab& tab, bool calc_grad_inputs,
+                                               T* __restrict__ dy_dx, uint32_t gridtype, int out_layout, uint32_t nchunks,
+                                               const SweepGen& gen) {
     TA_MARK_IN(0);
     uint32_t level, chunk;
-    if (!decode_block_fwd(nchunks, L, level, chunk)) return;
+    if (!decode_block_fwd(bid, nchunks, L, level, chunk)) return;
     if (!level_enabled(tab, level)) return;
     const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
     const uint32_t Bp = (B + 31u) & ~31u;
@@ -410,6 +411,57 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restri
             for (int c = 0; c < C; c++) jac[gd * C + c] = from_f<T>(rg[c]);
         }
     }
+}
+
+// common.h SplitJob: one workgroup's share (kPtsPerBlock threads of 8 values)
+typedef float cj_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cj_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_job_block(const float* s0, const float* s1, const float* s2, const float* s3,
+                                                const float* s4, const uint32_t* __restrict__ map,
+                                                uint32_t* __restrict__ out_words, uint32_t threads, uint32_t block) {
+    const uint32_t t = block * kPtsPerBlock + threadIdx.x;
+    if (t >= threads) return;
+    const uint4 m0 = reinterpret_cast<const uint4*>(map)[2 * t], m1 = reinterpret_cast<const uint4*>(map)[2 * t + 1];
+    const uint32_t m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const uint32_t k = m[e] >> 16;
+        const float* src = k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : k == 3 ? s3 : s4;
+        v[e] = m[e] == 0xffffffffu ? 0.0f : src[m[e] & 0xffffu];
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const cj_f32x2 f = {v[2 * p], v[2 * p + 1]};
+        const cj_bf16x2 h2 = __builtin_convertvector(f, cj_bf16x2);               // round to nearest even
+        const cj_f32x2 rest = f - __builtin_convertvector(h2, cj_f32x2);          // exact in fp32
+        hi[p] = __builtin_bit_cast(uint32_t, h2);
+        lo[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, cj_bf16x2));
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out_words + (size_t)(t >> 6) * 512u) + (t & 63u);
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+// (carry_blocks: the launch's first workgroups -- a multiple of 8, so that the forward's own keep their XCDs -- do `job`
+//  instead, enerf::grid_fwd_carry; 0 everywhere but in the training step's fp32 D = 3, C = 2 launch)
+constexpr uint32_t kCarryBlocks = 16;
+template <typename T, int D, int C>
+__global__ void __launch_bounds__(kPtsPerBlock) k_grid_fwd(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                           const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+                                                           uint32_t B, uint32_t L, LevelTab tab, bool calc_grad_inputs,
+                                                           T* __restrict__ dy_dx, uint32_t gridtype, int out_layout,
+                                                           uint32_t nchunks, SweepGen gen, SplitJob job,
+                                                           uint32_t carry_blocks) {
+    if constexpr (std::is_same<T, float>::value && D == 3 && C == 2) {
+        if (blockIdx.x < carry_blocks) {
+            split_job_block(job.src[0], job.src[1], job.src[2], job.src[3], job.src[4], job.map, job.out, job.threads,
+                            blockIdx.x);
+            return;
+        }
+    }
+    grid_fwd_block<T, D, C>(blockIdx.x - carry_blocks, inputs, grid, offsets, outputs, B, L, tab, calc_grad_inputs, dy_dx,
+                            gridtype, out_layout, nchunks, gen);
 }
 
 template <int C>
@@ -1357,12 +1409,22 @@ int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H, float in_add,
 
 __global__ void k_prof_mark() {}
 
+static SplitJob g_carry;              // enerf::grid_fwd_carry
+static bool g_carry_armed = false;
+
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
                const LevelTab& tab, bool calc, T* dy_dx, uint32_t gridtype, int layout, hipStream_t s,
                hipEvent_t ev_start, hipEvent_t ev_stop, const SweepGen& gen = SweepGen{}) {
     const uint32_t nchunks = div_up(layout == 2 ? ((B + 31u) & ~31u) : B, kPtsPerBlock);
     const uint32_t nblocks = fwd_blocks(nchunks, L);
+    SplitJob job{};
+    uint32_t carry = 0;
+    if (std::is_same<T, float>::value && D == 3 && C == 2 && g_carry_armed) {      // enerf::grid_fwd_carry: a job rides along
+        g_carry_armed = false;
+        job = g_carry;
+        carry = kCarryBlocks;
+    }
 #define ENERF_GF(CC)                                                                                               \
     do {                                                                                                           \
         if (ev_start) {                                                                                            \
@@ -1370,13 +1432,13 @@ int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* out
                which cost the stream nothing, where a start event on the kernel itself costs it ~10 us of idle    \
                queue around the launch (tools/launch_chain.hip; the marker's end is the kernel's dispatch) */     \
             hipExtLaunchKernelGGL(k_prof_mark, dim3(1), dim3(64), 0, s, nullptr, ev_start, 0);                     \
-            hipExtLaunchKernelGGL((k_grid_fwd<T, D, CC>), dim3(nblocks), dim3(kPtsPerBlock), 0, s, nullptr,        \
+            hipExtLaunchKernelGGL((k_grid_fwd<T, D, CC>), dim3(nblocks + carry), dim3(kPtsPerBlock), 0, s, nullptr, \
                                   ev_stop, 0, inputs, emb, offsets, outputs, B, L, tab, calc, dy_dx, gridtype,     \
-                                  layout, nchunks, gen);                                                                \
+                                  layout, nchunks, gen, job, carry);                                               \
         }                                                                                                          \
         else                                                                                                       \
-            k_grid_fwd<T, D, CC><<<nblocks, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc,  \
-                                                                  dy_dx, gridtype, layout, nchunks, gen);               \
+            k_grid_fwd<T, D, CC><<<nblocks + carry, kPtsPerBlock, 0, s>>>(inputs, emb, offsets, outputs, B, L, tab, calc, \
+                                                                          dy_dx, gridtype, layout, nchunks, gen, job, carry); \
     } while (0)
     switch (C) {
         case 1: ENERF_GF(1); break;
@@ -1488,6 +1550,13 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
 }
 
 }  // namespace
+
+bool enerf::grid_fwd_carry(const SplitJob* job) {
+    const bool waiting = g_carry_armed;
+    g_carry_armed = job != nullptr && job->threads <= kCarryBlocks * kPtsPerBlock;
+    if (g_carry_armed) g_carry = *job;
+    return waiting;
+}
 
 extern "C" {
 

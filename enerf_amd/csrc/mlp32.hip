@@ -1196,6 +1196,8 @@ static bool g_nerf_fused = true;                 // enerf_debug_nerf_mlp_fused
 static const float* g_nerf_built[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 static uint32_t g_nerf_built_cols = 0, g_nerf_built_out = 0;
 static uint64_t g_nerf_built_gen = 0;
+static uint32_t g_nerf_map_cols = 0, g_nerf_map_out = 0;      // geometry nerf_launch_frag_map's table was made for
+static uint64_t g_nerf_map_gen = ~0ull;
 
 // 1 when enerf_nerf_mlp_forward / _backward serve the process's current arithmetic (split-bf16, recomputing backward)
 int enerf_nerf_mlp_available(void) { return (g_nerf_fused && g_precision == 1 && g_recompute && g_fused_bwd) ? 1 : 0; }
@@ -1231,7 +1233,7 @@ static int nerf_args_ok(const float* const* wseg_s, const float* const* wseg_c, 
 // weights -- same pointers, values unchanged since -- by an earlier call; anything else rebuilds them: one 44-wave launch)
 static uint32_t* nerf_frags(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
                             uint32_t flags, hipStream_t s) {
-    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfFragBytes);
+    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfFragBytes + kNerfMapBytes);
     if (!frags) return nullptr;
     const float* w[5] = {wseg_s[0], wseg_s[3], wseg_c[0], wseg_c[1], wseg_c[3]};
     bool same = (flags & 1u) && g_nerf_built_cols == w0_cols_c && g_nerf_built_out == out_c &&
@@ -1381,6 +1383,45 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
 }
 
 }  // extern "C"
+
+// testing aid: the 90 112 bytes of operand fragments as the last build left them, copied to `dst` (device memory) on `stream`
+extern "C" int enerf_debug_nerf_frags_copy(void* dst, enerf_stream_t stream) {
+    if (!dst) ENERF_BADARG("debug_nerf_frags_copy: dst is required");
+    if (g_nerf_built_gen != workspace_generation() || !g_nerf_built[0]) ENERF_BADARG("debug_nerf_frags_copy: no fragments built");
+    const void* frags = workspace(WS_NERF_FRAGS, kNerfFragBytes + kNerfMapBytes);
+    if (!frags) return ENERF_E_NOMEM;
+    if (hipMemcpyAsync(dst, frags, kNerfFragBytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        ENERF_BADARG("debug_nerf_frags_copy: copy failed");
+    return 0;
+}
+
+// common.h: the fragments' build handed to a launch that runs before the MLP forward on `s`
+int enerf::nerf_mlp_frag_job(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
+                             hipStream_t s, SplitJob* job) {
+    if (int e = nerf_args_ok(wseg_s, wseg_c, w0_cols_c, out_c, "nerf_mlp_frag_job")) return e;
+    if (int ew = workspace_family_enter(1, s)) return ew;
+    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfFragBytes + kNerfMapBytes);
+    if (!frags) return ENERF_E_NOMEM;
+    uint32_t* map = frags + kNerfFragBytes / 4;
+    if (g_nerf_map_cols != w0_cols_c || g_nerf_map_out != out_c || g_nerf_map_gen != workspace_generation()) {
+        nerf_launch_frag_map(w0_cols_c, out_c, map, s);
+        g_nerf_map_cols = w0_cols_c;
+        g_nerf_map_out = out_c;
+        g_nerf_map_gen = workspace_generation();
+    }
+    const float* w[5] = {wseg_s[0], wseg_s[3], wseg_c[0], wseg_c[1], wseg_c[3]};
+    for (int k = 0; k < 5; k++) {
+        job->src[k] = w[k];
+        g_nerf_built[k] = w[k];
+    }
+    g_nerf_built_cols = w0_cols_c;
+    g_nerf_built_out = out_c;
+    g_nerf_built_gen = workspace_generation();
+    job->map = map;
+    job->out = frags;
+    job->threads = kNerfFragBytes / 2048 * 64;
+    return 0;
+}
 
 namespace enerf_mlp32 {
 

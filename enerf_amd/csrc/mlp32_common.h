@@ -284,6 +284,7 @@ void mlp32s_f16_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, con
 // fragments of 2 KiB built by nerf_launch_frags from the five weight matrices; `partial`: grid x kNerfPartialStride floats
 // of per-workgroup weight-gradient sums, [sigma blob 3072 | colour blob 6144 + 64 out_c] each.
 constexpr uint32_t kNerfFragBytes = 44 * 2048;
+constexpr uint32_t kNerfMapBytes = 44 * 512 * 4;      // nerf_launch_frag_map's table, kept behind the fragments
 constexpr uint32_t kNerfPartialStride = (HID * IN + 16 * HID) + (HID * IN + HID * HID + 16 * HID);
 constexpr uint32_t kNerfSigmaWords = HID * IN + 16 * HID;
 // workgroups of k_nerf_fwd per CU (its 48 KiB of LDS and ~136 registers admit three; -DNERF_FWD_ONE_PER_CU: one)
@@ -294,6 +295,7 @@ constexpr uint32_t kNerfFwdPerCu = 1;
 #endif
 void nerf_launch_frags(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
                        uint32_t w0_cols, uint32_t out_c, uint32_t* frags, hipStream_t s);
+void nerf_launch_frag_map(uint32_t w0_cols, uint32_t out_c, uint32_t* map, hipStream_t s);
 void nerf_launch_fwd(const float* X, const float* dirs, const uint32_t* frags, float* sigma, float* rgb, uint32_t B,
                      uint32_t out_c, const int32_t* valid_rows, uint32_t valid_base, uint32_t valid_cap, uint32_t grid,
                      hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

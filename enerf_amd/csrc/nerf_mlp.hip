@@ -59,7 +59,46 @@ __device__ __forceinline__ int c0_memcol(int c, uint32_t w0_cols) {
 }
 
 #ifndef NERF_MLP_BACKWARD_UNIT
-// One wavefront per fragment.  ws0 [64,32], ws1 [16,64], wc0 [64,w0_cols], wc1 [64,64], wc2 [out_c,64].
+// Where value e of lane (j, h) of fragment f comes from: tensor k = {ws0 [64,32], ws1 [16,64], wc0 [64,w0_cols], wc1 [64,64],
+// wc2 [out_c,64]} in the upper half-word, the element's flat index in the lower; kFragZero = a padding zero.
+constexpr uint32_t kFragZero = 0xffffffffu;
+__device__ __forceinline__ uint32_t frag_source(int f, int j, int h, int e, uint32_t w0_cols, uint32_t out_c) {
+    auto at = [](uint32_t k, int idx) { return (k << 16) | (uint32_t)idx; };
+    if (f < F_SO) {
+        const int ob = (f - F_S0) >> 1, t = f & 1;
+        return at(0, (32 * ob + j) * IN + kmap<1>(8 * t + e, h));
+    } else if (f < F_C0) {
+        const int ib = (f - F_SO) >> 1, t = f & 1;
+        return j < 16 ? at(1, j * HID + 32 * ib + nrow(8 * t + e, h)) : kFragZero;
+    } else if (f < F_CH) {
+        const int ob = (f - F_C0) >> 1, t = f & 1;
+        const int m = c0_memcol(16 * t + nrow(e, h), w0_cols);
+        return m < 0 ? kFragZero : at(2, (32 * ob + j) * (int)w0_cols + m);
+    } else if (f < F_CO) {
+        const int q = f - F_CH, ob = q >> 2, ib = (q >> 1) & 1, t = q & 1;
+        return at(3, (32 * ob + j) * HID + 32 * ib + nrow(8 * t + e, h));
+    } else if (f < B_COT) {
+        const int ib = (f - F_CO) >> 1, t = f & 1;
+        return (uint32_t)j < out_c ? at(4, j * HID + 32 * ib + nrow(8 * t + e, h)) : kFragZero;
+    } else if (f < B_CHT) {
+        const int ib = f - B_COT, o = 8 * h + e;
+        return (uint32_t)o < out_c ? at(4, o * HID + 32 * ib + j) : kFragZero;
+    } else if (f < B_C0T) {
+        const int q = f - B_CHT, ib = q >> 2, ob = (q >> 1) & 1, t = q & 1;
+        return at(3, (32 * ob + nrow(8 * t + e, h)) * HID + 32 * ib + j);
+    } else if (f < B_SOT) {
+        const int ob = (f - B_C0T) >> 1, t = f & 1;
+        const int m = c0_memcol(j, w0_cols);
+        return m < 0 ? kFragZero : at(2, (32 * ob + nrow(8 * t + e, h)) * (int)w0_cols + m);
+    } else if (f < B_S0T) {
+        const int ib = f - B_SOT;
+        return at(1, nrow(e, h) * HID + 32 * ib + j);
+    }
+    const int ob = (f - B_S0T) >> 1, t = f & 1;
+    return at(0, (32 * ob + nrow(8 * t + e, h)) * IN + j);
+}
+
+// One wavefront per fragment.
 __global__ void __launch_bounds__(64) k_nerf_frags(const float* __restrict__ ws0, const float* __restrict__ ws1,
                                                   const float* __restrict__ wc0, const float* __restrict__ wc1,
                                                   const float* __restrict__ wc2, uint32_t w0_cols, uint32_t out_c,
@@ -68,46 +107,23 @@ __global__ void __launch_bounds__(64) k_nerf_frags(const float* __restrict__ ws0
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        float x = 0.0f;
-        if (f < F_SO) {
-            const int ob = (f - F_S0) >> 1, t = f & 1;
-            x = ws0[(32 * ob + j) * IN + kmap<1>(8 * t + e, h)];
-        } else if (f < F_C0) {
-            const int ib = (f - F_SO) >> 1, t = f & 1;
-            x = j < 16 ? ws1[j * HID + 32 * ib + nrow(8 * t + e, h)] : 0.0f;
-        } else if (f < F_CH) {
-            const int ob = (f - F_C0) >> 1, t = f & 1;
-            const int m = c0_memcol(16 * t + nrow(e, h), w0_cols);
-            x = m < 0 ? 0.0f : wc0[(32 * ob + j) * w0_cols + m];
-        } else if (f < F_CO) {
-            const int q = f - F_CH, ob = q >> 2, ib = (q >> 1) & 1, t = q & 1;
-            x = wc1[(32 * ob + j) * HID + 32 * ib + nrow(8 * t + e, h)];
-        } else if (f < B_COT) {
-            const int ib = (f - F_CO) >> 1, t = f & 1;
-            x = (uint32_t)j < out_c ? wc2[j * HID + 32 * ib + nrow(8 * t + e, h)] : 0.0f;
-        } else if (f < B_CHT) {
-            const int ib = f - B_COT, o = 8 * h + e;
-            x = (uint32_t)o < out_c ? wc2[o * HID + 32 * ib + j] : 0.0f;
-        } else if (f < B_C0T) {
-            const int q = f - B_CHT, ib = q >> 2, ob = (q >> 1) & 1, t = q & 1;
-            x = wc1[(32 * ob + nrow(8 * t + e, h)) * HID + 32 * ib + j];
-        } else if (f < B_SOT) {
-            const int ob = (f - B_C0T) >> 1, t = f & 1;
-            const int m = c0_memcol(j, w0_cols);
-            x = m < 0 ? 0.0f : wc0[(32 * ob + nrow(8 * t + e, h)) * w0_cols + m];
-        } else if (f < B_S0T) {
-            const int ib = f - B_SOT;
-            x = ws1[nrow(e, h) * HID + 32 * ib + j];
-        } else {
-            const int ob = (f - B_S0T) >> 1, t = f & 1;
-            x = ws0[(32 * ob + nrow(8 * t + e, h)) * IN + j];
-        }
-        v[e] = x;
+        const uint32_t src = frag_source(f, j, h, e, w0_cols, out_c);
+        const uint32_t k = src >> 16, idx = src & 0xffffu;
+        const float* w = k == 0 ? ws0 : k == 1 ? ws1 : k == 2 ? wc0 : k == 3 ? wc1 : wc2;
+        v[e] = src == kFragZero ? 0.0f : w[idx];
     }
     const FragT<3> w = split8<3>(v);
     u32x4n* dst = reinterpret_cast<u32x4n*>(frags + (size_t)f * kFragWords);
     dst[lane] = __builtin_bit_cast(u32x4n, w.hi);
     dst[64 + lane] = __builtin_bit_cast(u32x4n, w.lo);
+}
+
+// The same as a table: map[(f * 64 + lane) * 8 + e] = frag_source(...) -- what a kernel that knows nothing of the layout
+// needs to build the fragments (enerf_nerf_mlp_frag_job: the grid forward of the one-call training step carries the build).
+__global__ void __launch_bounds__(64) k_nerf_frag_map(uint32_t w0_cols, uint32_t out_c, uint32_t* __restrict__ map) {
+    const int f = blockIdx.x, lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; e++) map[((size_t)f * 64 + lane) * 8 + e] = frag_source(f, j, h, e, w0_cols, out_c);
 }
 
 #endif
@@ -665,6 +681,10 @@ __global__ void k_nerf_mark() {}
 void nerf_launch_frags(const float* ws0, const float* ws1, const float* wc0, const float* wc1, const float* wc2,
                        uint32_t w0_cols, uint32_t out_c, uint32_t* frags, hipStream_t s) {
     hipLaunchKernelGGL(k_nerf_frags, dim3(NF_ALL), dim3(64), 0, s, ws0, ws1, wc0, wc1, wc2, w0_cols, out_c, frags);
+}
+
+void nerf_launch_frag_map(uint32_t w0_cols, uint32_t out_c, uint32_t* map, hipStream_t s) {
+    hipLaunchKernelGGL(k_nerf_frag_map, dim3(NF_ALL), dim3(64), 0, s, w0_cols, out_c, map);
 }
 
 void nerf_launch_fwd(const float* X, const float* dirs, const uint32_t* frags, float* sigma, float* rgb, uint32_t B,

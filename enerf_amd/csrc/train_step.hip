@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -25,6 +26,8 @@ using namespace enerf;
 static double g_host_us[16];
 static uint64_t g_host_steps = 0;
 static bool g_host_timing = false;
+// the fused MLP's operand fragments built inside the grid forward's launch (ENERF_NO_CARRY_FRAGS: by their own launch)
+static bool g_carry_frags = getenv("ENERF_NO_CARRY_FRAGS") == nullptr;      // enerf_debug_carry_frags
 
 extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     if (!a) ENERF_BADARG("train_step_mse: null arguments");
@@ -38,7 +41,8 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     int prev_prec = -1;
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
-    bool rows_set = false, defer_set = false, signal_set = false, fused_mlp = false;
+    bool rows_set = false, defer_set = false, signal_set = false, fused_mlp = false, carry_set = false;
+    uint32_t frags_built = 0;
     int slot = 0;
     auto t_prev = std::chrono::steady_clock::now();
     if (g_host_timing) g_host_steps++;
@@ -54,16 +58,29 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         if (rc) goto done;                                                               \
     } while (0)
     // ---- forward
+    // (both nets as one launch each way when the arithmetic is the split-bf16 default: csrc/nerf_mlp.hip; their operand
+    //  fragments are then built by sixteen extra workgroups of the grid forward's launch -- common.h SplitJob)
+    fused_mlp = a->nh_s == 1 && a->nh_c == 2 && enerf_nerf_mlp_available() != 0;
+    if (fused_mlp && g_carry_frags) {
+        SplitJob job;
+        STEP(nerf_mlp_frag_job(a->wseg_s, a->wseg_c, a->w0_cols_c, a->out_c, (hipStream_t)s, &job));
+        if (g_host_timing) slot--;
+        grid_fwd_carry(&job);
+        carry_set = true;
+    }
     STEP(enerf_grid_encode_forward(a->xyzs, a->embeddings, a->offsets, a->feats, M, 3, 2, 16, a->level_scale_log2,
                                    a->base_resolution, 0, a->feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
+    if (carry_set) {
+        frags_built = grid_fwd_carry(nullptr) ? 0u : 1u;      // (taken along: the MLP calls are told so)
+        carry_set = false;
+    }
     if (a->counter) {
         enerf_mlp32_valid_rows(a->counter);
         rows_set = true;
     }
-    // (both nets as one launch each way when the arithmetic is the split-bf16 default: csrc/nerf_mlp.hip)
-    fused_mlp = a->nh_s == 1 && a->nh_c == 2 && enerf_nerf_mlp_available() != 0;
     if (fused_mlp) {
-        STEP(enerf_nerf_mlp_forward(a->feats, a->dirs, a->wseg_s, a->wseg_c, a->w0_cols_c, M, a->out_c, a->sigma, a->rgb, 0, s));
+        STEP(enerf_nerf_mlp_forward(a->feats, a->dirs, a->wseg_s, a->wseg_c, a->w0_cols_c, M, a->out_c, a->sigma, a->rgb,
+                                    frags_built, s));
         if (g_host_timing) slot++;
     } else {
         STEP(enerf_mlp32_forward_p(a->feats, a->wseg_s, 32, 0, M, 32, 16, a->nh_s, 0, 6, a->fb_s, a->h32, 1, 32, a->sigma,
@@ -130,6 +147,7 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
                                          a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step, s));
 done:
 #undef STEP
+    if (carry_set) grid_fwd_carry(nullptr);
     if (defer_set) enerf_mlp32_defer_reduce(0);
     if (signal_set) enerf_mlp32_signal_next_reduce(0);
     if (rows_set) enerf_mlp32_valid_rows(nullptr);
@@ -369,6 +387,12 @@ done:
 
 // development aid: on != 0 starts (and clears) the per-call host timers of enerf_train_step_mse; out (16 doubles, may
 // be NULL) receives the microseconds per call slot, in call order, averaged over the steps since the last start
+extern "C" int enerf_debug_carry_frags(int on) {
+    const int prev = g_carry_frags ? 1 : 0;
+    if (on >= 0) g_carry_frags = on != 0;
+    return prev;
+}
+
 extern "C" int enerf_debug_step_timing(int on, double* out) {
     if (out)
         for (int k = 0; k < 16; k++) out[k] = g_host_steps ? g_host_us[k] / (double)g_host_steps : 0.0;

@@ -452,6 +452,8 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
  * optimizer step since) -- skips the 44-wavefront rebuild. */
 int enerf_nerf_mlp_available(void);
 int enerf_debug_nerf_mlp_fused(int on);
+/* Testing aid: the operand fragments (44 x 2048 bytes) as the last build left them, copied to device memory `dst`. */
+int enerf_debug_nerf_frags_copy(void* dst, enerf_stream_t stream);
 int enerf_nerf_mlp_forward(const float* feats, const float* dirs, const float* const* wseg_s, const float* const* wseg_c,
                            uint32_t w0_cols_c, uint32_t B, uint32_t out_c, float* sigma, float* rgb, uint32_t flags,
                            enerf_stream_t stream);
@@ -672,6 +674,10 @@ int enerf_train_step_mse(const enerf_train_step_args* args);
 /* Development aid: host microseconds enerf_train_step_mse spends in each of its calls (in call order, 16 slots, averaged
  * over the steps since timing was switched on); on >= 0 switches the timers (and clears them), on < 0 only reads. */
 int enerf_debug_step_timing(int on, double* out16);
+/* enerf_train_step_mse builds the fused MLP's operand fragments inside its grid forward's launch (sixteen extra
+ * workgroups) instead of a launch of their own; on = 0 switches that off (testing aid; < 0 only reads).  Returns the
+ * previous setting. */
+int enerf_debug_carry_frags(int on);
 
 /* The event-only step (Trainer.train_step_events, nerf/utils.py:482-546, event_only = 1, C_thres != -1) the same way: TWO
  * renders -- the event pairs' rays at the two poses -- blended with one background colour, the event loss on the two

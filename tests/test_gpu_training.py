@@ -986,3 +986,64 @@ def test_native_event_step_call_equals_the_python_driven_event_step():
     for n, a in pa.items():
         assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
     assert ga == gb
+
+
+def test_fragments_built_inside_the_grid_forward_equal_their_own_launch():
+    """enerf_train_step_mse has the fused MLP's operand fragments built by sixteen extra workgroups of its grid forward's
+    launch (csrc/common.h SplitJob, from csrc/nerf_mlp.hip's table of sources) instead of k_nerf_frags: the 90 112 bytes
+    must be the same, bit for bit, for the weights every step starts with; and a run with the carried build switched off
+    (enerf_debug_carry_frags) sees the same counters and losses."""
+    from enerf_amd import _lib as L, fused_network as fnet, fused_render
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    lib = L.lib()
+    data = _batches(4, 4096, 2)
+    stream = lambda: torch.cuda.current_stream().cuda_stream
+    runs = {}
+    for carry in (1, 0):
+        prev = lib.enerf_debug_carry_frags(carry)
+        try:
+            torch.manual_seed(0)
+            model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+            h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+            weights = fnet.network_params(model)[1:]
+            checked = []
+            orig = fused_render.train_step_native
+
+            def spy(*a, **k):
+                before = [w.detach().clone() for w in weights]
+                out = orig(*a, **k)
+                if not carry or len(checked) >= 6:
+                    return out
+                carried = torch.empty(44 * 2048, dtype=torch.uint8, device=DEV)
+                L.check(lib.enerf_debug_nerf_frags_copy(carried.data_ptr(), stream()), "frags_copy")
+                # the same from k_nerf_frags: a forward over 32 rows with the step's starting weights, nothing vouched for
+                seg_s, seg_c = fnet._weight_segments("linear", before)
+                B = 32
+                feats = torch.zeros(16, B, 2, device=DEV)
+                dirs = torch.zeros(B, 3, device=DEV)
+                dirs[:, 2] = 1
+                sigma, rgb = torch.empty(B, device=DEV), torch.empty(B, 3, device=DEV)
+                L.check(lib.enerf_nerf_mlp_forward(feats.data_ptr(), dirs.data_ptr(), seg_s, seg_c,
+                                                   fnet._ARCH["linear"]["w0c"], B, 3, sigma.data_ptr(), rgb.data_ptr(), 0,
+                                                   stream()), "nerf_mlp_forward")
+                own = torch.empty_like(carried)
+                L.check(lib.enerf_debug_nerf_frags_copy(own.data_ptr(), stream()), "frags_copy")
+                checked.append(bool(torch.equal(carried, own)) and bool(carried.any()))
+                return out
+            fused_render.train_step_native = spy
+            try:
+                losses, counters = [], []
+                for i in range(24):
+                    nxt = data[(i + 1) % 4]
+                    losses.append(float(h.step_rgb(*data[i % 4], next_rays=(nxt[0], nxt[1]))))
+                    counters.append(model.step_counter[model.rendered_counter_slot].cpu().clone())
+            finally:
+                fused_render.train_step_native = orig
+            torch.cuda.synchronize()
+            runs[carry] = (losses, torch.stack(counters), checked)
+        finally:
+            lib.enerf_debug_carry_frags(prev)
+    assert len(runs[1][2]) == 6 and all(runs[1][2]), runs[1][2]
+    assert torch.equal(runs[1][1], runs[0][1])
+    assert np.abs(np.array(runs[1][0]) - np.array(runs[0][0])).max() <= 1e-5 * np.abs(runs[0][0]).max()
