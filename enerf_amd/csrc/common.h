@@ -93,6 +93,23 @@ bool grid_fwd_carry(const SplitJob* job);
 // promise that it runs before them on `s`: the calls that follow with flags bit 0 use the fragments as they are.
 int nerf_mlp_frag_job(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
                       hipStream_t s, SplitJob* job);
+// Per-workgroup partial sums that the table optimizer's launch reduces on the fly: value i (< n) = sum over b < parts of
+// partial[b * stride + i], the gradient of element map[i] & 0xffffff of that launch's small tensor map[i] >> 24
+// (0xffffffff: of nobody).  (The fused MLP backward's weight gradients: k_mlp32_reduce_w2 and its 5 us leave the chain.)
+struct PartialSums {
+    const float* partial;
+    const uint32_t* map;
+    uint32_t parts, stride, n;
+};
+// gridencoder.hip: the next enerf_grid_adam_from_records(_ex) call sums `job` for its small tensors' gradients (and
+// stores them where it would have read them) -- one-shot; nullptr disarms.  Returns whether a job was still waiting.
+bool grid_adam_partial_sums(const PartialSums* job);
+// mlp32.hip: the job for the enerf_nerf_mlp_backward call that follows on `s` with flags bit 1 (B rows, same gradient
+// segments); small_g / small_n: the optimizer call's small tensors.  0: `job` is set; 1: does not apply (the small tensors
+// are not exactly the five gradient matrices, or loss scaling is armed); < 0: error.
+int nerf_mlp_partial_job(float* const* dwseg_s, float* const* dwseg_c, uint32_t w0_cols_c, uint32_t out_c,
+                         const float* const* small_g, const uint32_t* small_n, uint32_t n_small, uint32_t B, hipStream_t s,
+                         PartialSums* job);
 
 // ---- wave-level primitives (wave64) ----------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -1084,7 +1084,8 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
                                                                  uint32_t* __restrict__ overflow,
                                                                  uint32_t* __restrict__ other_overflow, AdamScalars ad,
                                                                  SmallAdam small, AmpAdam amp = AmpAdam{},
-                                                                 OwnerRange own = OwnerRange{0, 0, 1.0f}) {
+                                                                 OwnerRange own = OwnerRange{0, 0, 1.0f},
+                                                                 PartialSums ps = PartialSums{nullptr, nullptr, 0, 0, 0}) {
     // (dynamic: a static 32 KiB array tells the compiler that four workgroups fill the CU, and it then spends the registers
     //  of a fifth wavefront per SIMD on scheduling freedom -- see the note above the kernel)
     extern __shared__ __attribute__((aligned(16))) double acc[];
@@ -1316,7 +1317,50 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     // small parameters (MLP weights; dense gradient, not cleared): their ~10 k elements are dealt over ALL workgroups, a
     // slice of consecutive elements each, one element per thread -- one memory latency at the end of the kernel.  (One
     // workgroup per tensor, looping, was a tail of sixteen dependent latencies behind that workgroup's tiles.)
-    if (small.count != 0 && (!AMP || !skip)) {
+    if (!AMP && !RANGE && ps.n != 0) {
+        // common.h PartialSums: the small tensors' gradients arrive as per-workgroup partial sums (the fused MLP backward's)
+        // and are summed here -- 16 values at a time, 16 threads a value (each 1/16 of the partial sums, four independent
+        // chains, fixed order), combined through the tile sums' LDS, which nobody uses any more; the sum is stored as the
+        // gradient and goes straight into the element's update
+        float* red = reinterpret_cast<float*>(acc);
+        const uint32_t chunk = div_up(ps.n, gridDim.x);
+        const uint32_t j = threadIdx.x & 15u, q = threadIdx.x >> 4;
+        for (uint32_t c0 = 0; c0 < chunk; c0 += 16u) {
+            const uint32_t i = blockIdx.x * chunk + c0 + j;
+            const bool live = c0 + j < chunk && i < ps.n;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            if (live) {
+                const float* col = ps.partial + i;
+                uint32_t b = q;
+                for (; b + 48u < ps.parts; b += 64u) {
+                    s0 += col[(size_t)b * ps.stride];
+                    s1 += col[(size_t)(b + 16u) * ps.stride];
+                    s2 += col[(size_t)(b + 32u) * ps.stride];
+                    s3 += col[(size_t)(b + 48u) * ps.stride];
+                }
+                for (; b < ps.parts; b += 16u) s0 += col[(size_t)b * ps.stride];
+            }
+            red[q * 16u + j] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            if (q == 0 && live) {
+                float gsum = 0.0f;
+#pragma unroll
+                for (uint32_t w = 0; w < kTileThreads / 16u; w++) gsum += red[w * 16u + j];
+                const uint32_t code = ps.map[i];
+                if (code != 0xffffffffu) {
+                    const uint32_t k = code >> 24, e = code & 0xffffffu;
+                    AdamScalars a2 = ad;
+                    a2.step_size = small.step_size[k];
+                    a2.inv_bc2_sqrt = small.inv_bc2_sqrt[k];
+                    float pv = small.p[k][e], mv = small.m[k][e], vv = small.v[k][e];
+                    tile_adam1(pv, gsum, mv, vv, a2);
+                    small.p[k][e] = pv; small.m[k][e] = mv; small.v[k][e] = vv;
+                    const_cast<float*>(small.g[k])[e] = gsum;
+                }
+            }
+            __syncthreads();
+        }
+    } else if (small.count != 0 && (!AMP || !skip)) {
         uint32_t total_small = 0;
         for (uint32_t k = 0; k < small.count; k++) total_small += small.n[k];
         const uint32_t chunk = div_up(total_small, gridDim.x);
@@ -1411,6 +1455,8 @@ __global__ void k_prof_mark() {}
 
 static SplitJob g_carry;              // enerf::grid_fwd_carry
 static bool g_carry_armed = false;
+static PartialSums g_partial_sums;     // enerf::grid_adam_partial_sums
+static bool g_partial_armed = false;
 
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
@@ -1550,6 +1596,13 @@ int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gr
 }
 
 }  // namespace
+
+bool enerf::grid_adam_partial_sums(const PartialSums* job) {
+    const bool waiting = g_partial_armed;
+    g_partial_armed = job != nullptr && job->n != 0;
+    if (g_partial_armed) g_partial_sums = *job;
+    return waiting;
+}
 
 bool enerf::grid_fwd_carry(const SplitJob* job) {
     const bool waiting = g_carry_armed;
@@ -1758,9 +1811,14 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
         ENERF_LAUNCH_CHECK("grid_adam_from_records(amp)");
         return 0;
     }
+    PartialSums ps{nullptr, nullptr, 0, 0, 0};
+    if (g_partial_armed && C == 2 && n_small == 5) {      // enerf::grid_adam_partial_sums: the small gradients are summed here
+        g_partial_armed = false;
+        ps = g_partial_sums;
+    }
     switch (C) {
         case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
-        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
+        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{}, OwnerRange{0, 0, 1.0f}, ps); break;
         case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         default: ENERF_BADARG("grid_adam_from_records: C must be 1, 2, 4, or 8.");

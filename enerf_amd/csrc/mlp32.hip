@@ -773,6 +773,28 @@ __global__ void __launch_bounds__(256) k_mlp32_bwd_fused(DySource dys, const flo
 #endif
 }
 
+__global__ void k_signal_mark() {}
+
+// common.h PartialSums.map for the two gradient blobs of csrc/nerf_mlp.hip's backward: whose element the reduce pass would
+// write sum i to
+struct SmallDst {
+    const float* g[5];
+    uint32_t n[5];
+};
+__global__ void __launch_bounds__(256) k_nerf_partial_map(WDst ds, WDst dc, uint32_t nw_s, uint32_t nw_c, SmallDst sm,
+                                                          uint32_t* __restrict__ map) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nw_s + nw_c) return;
+    const float* dst = i < nw_s ? wdst_at(ds, i) : wdst_at(dc, i - nw_s);
+    uint32_t code = 0xffffffffu;
+    if (dst) {
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++)
+            if (dst >= sm.g[k] && dst < sm.g[k] + sm.n[k]) code = (k << 24) | (uint32_t)(dst - sm.g[k]);
+    }
+    map[i] = code;
+}
+
 struct ReduceJob {
     const float* partial;
     uint32_t nblocks, NW;
@@ -829,6 +851,12 @@ static uint32_t g_valid_base = 0, g_valid_cap = 0;  // enerf_mlp32_valid_rows_ex
 static bool g_signal_armed = false;      // enerf_mlp32_signal_next_reduce
 static bool g_signal_recorded = false;
 static hipEvent_t g_signal_event = nullptr;
+// (device-scope release: what waits for it is another stream of this device, never the host)
+#ifndef ENERF_SIGNAL_SYSTEM_RELEASE
+constexpr unsigned kSignalEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+#else
+constexpr unsigned kSignalEventFlags = hipEventDisableTiming;
+#endif
 static bool g_defer_next = false;        // one-shot: set by enerf_mlp32_defer_reduce
 static bool g_have_pending = false;
 static ReduceJob g_pending;
@@ -1172,7 +1200,7 @@ static int mlp32_backward_impl(const float* dY, const float* X, WSrc W, const fl
             // (tried and dropped, tools/step_timeline.py: a device-scope release event -- same ~6 us before the next
             // kernel of this stream; a generation number published by the reduce launch's last workgroup + a sleeping
             // wait kernel on the other stream -- the gap goes, the reduce launch grows by 3 us, the step does not move)
-            if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming) != hipSuccess)
+            if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, kSignalEventFlags) != hipSuccess)
                 g_signal_event = nullptr;
             sig = g_signal_event;
             g_signal_recorded = sig != nullptr;
@@ -1233,7 +1261,7 @@ static int nerf_args_ok(const float* const* wseg_s, const float* const* wseg_c, 
 // weights -- same pointers, values unchanged since -- by an earlier call; anything else rebuilds them: one 44-wave launch)
 static uint32_t* nerf_frags(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
                             uint32_t flags, hipStream_t s) {
-    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfFragBytes + kNerfMapBytes);
+    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfWsBytes);
     if (!frags) return nullptr;
     const float* w[5] = {wseg_s[0], wseg_s[3], wseg_c[0], wseg_c[1], wseg_c[3]};
     bool same = (flags & 1u) && g_nerf_built_cols == w0_cols_c && g_nerf_built_out == out_c &&
@@ -1291,11 +1319,27 @@ int enerf_nerf_mlp_backward(const float* g_rgb, const float* g_sigma, float sigm
     const uint32_t grid = pgrid(B, g_bwd_blocks ? g_bwd_blocks : 256);
     float* partial = (float*)workspace(WS_NERF_PART, sizeof(float) * (size_t)grid * kNerfPartialStride);
     if (!partial) return ENERF_E_NOMEM;
+    hipEvent_t sig = nullptr;
+    bool sig_sent = false;
+    if (g_signal_armed) {
+        g_signal_armed = false;
+        if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, kSignalEventFlags) != hipSuccess)
+            g_signal_event = nullptr;
+        sig = g_signal_event;
+        g_signal_recorded = sig != nullptr;
+    }
     {
         ProfScope prof(ENERF_K_FFMLP_BWD, s, true);
         prof.units((double)B);
+        // (flags bit 1: no reduce launch follows to carry the signal -- it leaves with this launch, unless a timed interval
+        //  needs the launch's stop event)
+        hipEvent_t stop = prof.stop();
+        if ((flags & 2u) && sig && !stop) {
+            stop = sig;
+            sig_sent = true;
+        }
         nerf_launch_bwd(feats, dirs, g_rgb, rgb, g_sigma, sigma_scale, frags, dfeat, partial, B, out_c, g_valid_rows,
-                        g_valid_base, g_valid_cap, grid, s, prof.start(), prof.stop());
+                        g_valid_base, g_valid_cap, grid, s, prof.start(), stop);
     }
     WDst ds, dc;
     for (int k = 0; k < 4; k++) {
@@ -1304,13 +1348,13 @@ int enerf_nerf_mlp_backward(const float* g_rgb, const float* g_sigma, float sigm
     }
     ds.w0_cols = IN; ds.nerf_perm = 0; ds.overwrite = overwrite;
     dc.w0_cols = w0_cols_c; dc.nerf_perm = 1; dc.overwrite = overwrite;
-    hipEvent_t sig = nullptr;
-    if (g_signal_armed) {
-        g_signal_armed = false;
-        if (!g_signal_event && hipEventCreateWithFlags(&g_signal_event, hipEventDisableTiming) != hipSuccess)
-            g_signal_event = nullptr;
-        sig = g_signal_event;
-        g_signal_recorded = sig != nullptr;
+    if (flags & 2u) {
+        // the caller sums the partial sums itself (enerf::nerf_mlp_partial_job): no reduce launch; the signal leaves on a
+        // marker of its own
+        if (!overwrite) ENERF_BADARG("nerf_mlp_backward: flags bit 1 serves overwrite != 0");
+        if (sig && !sig_sent) hipExtLaunchKernelGGL(k_signal_mark, dim3(1), dim3(64), 0, s, nullptr, sig, 0);
+        ENERF_LAUNCH_CHECK("nerf_mlp_backward");
+        return 0;
     }
     const uint32_t nw_c = HID * IN + HID * HID + out_c * HID;
     ProfScope prof_reduce(ENERF_K_MLP_REDUCE, s);
@@ -1388,10 +1432,62 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
 extern "C" int enerf_debug_nerf_frags_copy(void* dst, enerf_stream_t stream) {
     if (!dst) ENERF_BADARG("debug_nerf_frags_copy: dst is required");
     if (g_nerf_built_gen != workspace_generation() || !g_nerf_built[0]) ENERF_BADARG("debug_nerf_frags_copy: no fragments built");
-    const void* frags = workspace(WS_NERF_FRAGS, kNerfFragBytes + kNerfMapBytes);
+    const void* frags = workspace(WS_NERF_FRAGS, kNerfWsBytes);
     if (!frags) return ENERF_E_NOMEM;
     if (hipMemcpyAsync(dst, frags, kNerfFragBytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
         ENERF_BADARG("debug_nerf_frags_copy: copy failed");
+    return 0;
+}
+
+// common.h: the weight-gradient sums of the backward call that follows, left to the optimizer's launch
+static const void* g_part_key[12] = {};
+static uint64_t g_part_gen = ~0ull;
+int enerf::nerf_mlp_partial_job(float* const* dwseg_s, float* const* dwseg_c, uint32_t w0_cols_c, uint32_t out_c,
+                                const float* const* small_g, const uint32_t* small_n, uint32_t n_small, uint32_t B,
+                                hipStream_t s, PartialSums* job) {
+    if (n_small != 5 || !small_g || !small_n || !dwseg_s || !dwseg_c || amp_state().scale || B == 0) return 1;
+    if ((w0_cols_c != 31 && w0_cols_c != 32) || out_c == 0 || out_c > 16) return 1;
+    // the five gradient matrices must be the optimizer's five small tensors, whole (then every element gets exactly one sum)
+    const float* seg[5] = {dwseg_s[0], dwseg_s[3], dwseg_c[0], dwseg_c[1], dwseg_c[3]};
+    const uint32_t len[5] = {HID * IN, 16 * HID, HID * w0_cols_c, HID * HID, out_c * HID};
+    uint32_t seen = 0;
+    for (int k = 0; k < 5; k++) {
+        if (!seg[k]) return 1;
+        for (uint32_t j = 0; j < 5; j++)
+            if (small_g[j] == seg[k] && small_n[j] == len[k]) seen |= 1u << j;
+    }
+    if (seen != 31u) return 1;
+    if (int ew = workspace_family_enter(1, s)) return ew;
+    uint32_t* ws = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfWsBytes);
+    const uint32_t grid = pgrid(B, g_bwd_blocks ? g_bwd_blocks : 256);
+    float* partial = (float*)workspace(WS_NERF_PART, sizeof(float) * (size_t)grid * kNerfPartialStride);
+    if (!ws || !partial) return ENERF_E_NOMEM;
+    uint32_t* map = ws + (kNerfFragBytes + kNerfMapBytes) / 4;
+    const uint32_t nw_c = HID * IN + HID * HID + out_c * HID;
+    const void* key[12] = {seg[0], seg[1], seg[2], seg[3], seg[4], small_g[0], small_g[1], small_g[2], small_g[3], small_g[4],
+                           (const void*)(uintptr_t)w0_cols_c, (const void*)(uintptr_t)out_c};
+    bool same = g_part_gen == workspace_generation();
+    for (int k = 0; k < 12; k++) same = same && g_part_key[k] == key[k];
+    if (!same) {
+        WDst ds, dc;
+        for (int k = 0; k < 4; k++) {
+            ds.seg[k] = (k == 0 || k == 3) ? dwseg_s[k] : nullptr;
+            dc.seg[k] = (k == 0 || k == 1 || k == 3) ? dwseg_c[k] : nullptr;
+        }
+        ds.w0_cols = IN; ds.nerf_perm = 0; ds.overwrite = 1;
+        dc.w0_cols = w0_cols_c; dc.nerf_perm = 1; dc.overwrite = 1;
+        SmallDst sm;
+        for (int k = 0; k < 5; k++) { sm.g[k] = small_g[k]; sm.n[k] = small_n[k]; }
+        hipLaunchKernelGGL(k_nerf_partial_map, dim3(div_up(kNerfSigmaWords + nw_c, 256)), dim3(256), 0, s, ds, dc,
+                           kNerfSigmaWords, nw_c, sm, map);
+        for (int k = 0; k < 12; k++) g_part_key[k] = key[k];
+        g_part_gen = workspace_generation();
+    }
+    job->partial = partial;
+    job->map = map;
+    job->parts = grid;
+    job->stride = kNerfPartialStride;
+    job->n = kNerfSigmaWords + nw_c;
     return 0;
 }
 
@@ -1400,7 +1496,7 @@ int enerf::nerf_mlp_frag_job(const float* const* wseg_s, const float* const* wse
                              hipStream_t s, SplitJob* job) {
     if (int e = nerf_args_ok(wseg_s, wseg_c, w0_cols_c, out_c, "nerf_mlp_frag_job")) return e;
     if (int ew = workspace_family_enter(1, s)) return ew;
-    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfFragBytes + kNerfMapBytes);
+    uint32_t* frags = (uint32_t*)workspace(WS_NERF_FRAGS, kNerfWsBytes);
     if (!frags) return ENERF_E_NOMEM;
     uint32_t* map = frags + kNerfFragBytes / 4;
     if (g_nerf_map_cols != w0_cols_c || g_nerf_map_out != out_c || g_nerf_map_gen != workspace_generation()) {

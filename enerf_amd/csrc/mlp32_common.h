@@ -285,6 +285,8 @@ void mlp32s_f16_launch_bwd(int prec, uint32_t num_hidden, uint32_t x_layout, con
 // of per-workgroup weight-gradient sums, [sigma blob 3072 | colour blob 6144 + 64 out_c] each.
 constexpr uint32_t kNerfFragBytes = 44 * 2048;
 constexpr uint32_t kNerfMapBytes = 44 * 512 * 4;      // nerf_launch_frag_map's table, kept behind the fragments
+constexpr uint32_t kNerfPartMapBytes = ((HID * IN + 16 * HID) + (HID * IN + HID * HID + 16 * HID)) * 4;   // PartialSums.map
+constexpr uint32_t kNerfWsBytes = kNerfFragBytes + kNerfMapBytes + kNerfPartMapBytes;
 constexpr uint32_t kNerfPartialStride = (HID * IN + 16 * HID) + (HID * IN + HID * HID + 16 * HID);
 constexpr uint32_t kNerfSigmaWords = HID * IN + 16 * HID;
 // workgroups of k_nerf_fwd per CU (its 48 KiB of LDS and ~136 registers admit three; -DNERF_FWD_ONE_PER_CU: one)

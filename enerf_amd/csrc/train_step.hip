@@ -28,6 +28,8 @@ static uint64_t g_host_steps = 0;
 static bool g_host_timing = false;
 // the fused MLP's operand fragments built inside the grid forward's launch (ENERF_NO_CARRY_FRAGS: by their own launch)
 static bool g_carry_frags = getenv("ENERF_NO_CARRY_FRAGS") == nullptr;      // enerf_debug_carry_frags
+// the fused MLP's weight-gradient partial sums summed by the optimizer's launch (ENERF_NO_FOLD_REDUCE: by k_mlp32_reduce_w2)
+static bool g_fold_reduce = getenv("ENERF_NO_FOLD_REDUCE") == nullptr;      // enerf_debug_fold_reduce
 
 extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     if (!a) ENERF_BADARG("train_step_mse: null arguments");
@@ -41,8 +43,9 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     int prev_prec = -1;
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
-    bool rows_set = false, defer_set = false, signal_set = false, fused_mlp = false, carry_set = false;
+    bool rows_set = false, defer_set = false, signal_set = false, fused_mlp = false, carry_set = false, own_sums = false;
     uint32_t frags_built = 0;
+    PartialSums sums{nullptr, nullptr, 0, 0, 0};
     int slot = 0;
     auto t_prev = std::chrono::steady_clock::now();
     if (g_host_timing) g_host_steps++;
@@ -98,8 +101,13 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         signal_set = true;
     }
     if (fused_mlp) {
+        // (the weight gradients' partial sums are summed by the optimizer's launch when it follows in this call and its small
+        //  tensors are those gradients: no reduce launch in between -- common.h PartialSums)
+        if (g_fold_reduce && !(a->flags & 1u))
+            own_sums = nerf_mlp_partial_job(a->dwseg_s, a->dwseg_c, a->w0_cols_c, a->out_c, a->small_g, a->small_n, a->n_small,
+                                            M, (hipStream_t)s, &sums) == 0;
         STEP(enerf_nerf_mlp_backward(a->g_rgbs, a->g_sigmas, 1.0f, a->feats, a->dirs, a->rgb, a->wseg_s, a->wseg_c,
-                                     a->dwseg_s, a->dwseg_c, a->w0_cols_c, 1, M, a->out_c, a->dfeat, 1, s));
+                                     a->dwseg_s, a->dwseg_c, a->w0_cols_c, 1, M, a->out_c, a->dfeat, own_sums ? 3u : 1u, s));
         if (g_host_timing) slot++;
     } else {
         enerf_mlp32_defer_reduce(1);
@@ -142,11 +150,18 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     STEP(enerf_grid_encode_backward_ex(a->dfeat, a->xyzs, a->embeddings, a->offsets, a->table_grad, M, 3, 2, 16,
                                        a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
                                        ENERF_F32, 2, in_add, in_mul, 1, M, s));
+    if (own_sums) grid_adam_partial_sums(&sums);
     STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr,
                                          a->beta1, a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g,
                                          a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step, s));
+    if (own_sums && grid_adam_partial_sums(nullptr)) {
+        set_error("train_step_mse: the optimizer launch did not take the weight gradients' partial sums");
+        rc = ENERF_E_BADARG;
+    }
+    own_sums = false;
 done:
 #undef STEP
+    if (own_sums) grid_adam_partial_sums(nullptr);
     if (carry_set) grid_fwd_carry(nullptr);
     if (defer_set) enerf_mlp32_defer_reduce(0);
     if (signal_set) enerf_mlp32_signal_next_reduce(0);
@@ -385,14 +400,20 @@ done:
     return rc;
 }
 
-// development aid: on != 0 starts (and clears) the per-call host timers of enerf_train_step_mse; out (16 doubles, may
-// be NULL) receives the microseconds per call slot, in call order, averaged over the steps since the last start
+extern "C" int enerf_debug_fold_reduce(int on) {
+    const int prev = g_fold_reduce ? 1 : 0;
+    if (on >= 0) g_fold_reduce = on != 0;
+    return prev;
+}
+
 extern "C" int enerf_debug_carry_frags(int on) {
     const int prev = g_carry_frags ? 1 : 0;
     if (on >= 0) g_carry_frags = on != 0;
     return prev;
 }
 
+// development aid: on != 0 starts (and clears) the per-call host timers of enerf_train_step_mse; out (16 doubles, may
+// be NULL) receives the microseconds per call slot, in call order, averaged over the steps since the last start
 extern "C" int enerf_debug_step_timing(int on, double* out) {
     if (out)
         for (int k = 0; k < 16; k++) out[k] = g_host_steps ? g_host_us[k] / (double)g_host_steps : 0.0;

@@ -449,7 +449,9 @@ int enerf_mlp32_backward_p(const float* dY, const float* X, const float* const* 
  * gradients through dwseg_* (same shapes as wseg_*), the feature gradient level-major into dfeat [16, Bp, 2] (pad rows
  * zero: ready for enerf_grid_encode_backward with grad_layout 2).  g_sigma is multiplied by sigma_scale on the fly.
  * flags bit 0: the operand fragments an earlier call built from these very weight tensors are still current (no
- * optimizer step since) -- skips the 44-wavefront rebuild. */
+ * optimizer step since) -- skips the 44-wavefront rebuild.  Backward, flags bit 1 (library-internal: enerf_train_step_mse
+ * sets it): the weight gradients stay per-workgroup partial sums in the library's workspace for the optimizer launch that
+ * follows; dwseg_* are not written by this call. */
 int enerf_nerf_mlp_available(void);
 int enerf_debug_nerf_mlp_fused(int on);
 /* Testing aid: the operand fragments (44 x 2048 bytes) as the last build left them, copied to device memory `dst`. */
@@ -678,6 +680,10 @@ int enerf_debug_step_timing(int on, double* out16);
  * workgroups) instead of a launch of their own; on = 0 switches that off (testing aid; < 0 only reads).  Returns the
  * previous setting. */
 int enerf_debug_carry_frags(int on);
+/* ... and leaves the fused MLP backward's weight-gradient partial sums to the optimizer's launch, which sums them for its
+ * small tensors (no k_mlp32_reduce_w2 launch in between; the sums land in the gradient tensors all the same); on = 0
+ * switches that off (testing aid; < 0 only reads).  Returns the previous setting. */
+int enerf_debug_fold_reduce(int on);
 
 /* The event-only step (Trainer.train_step_events, nerf/utils.py:482-546, event_only = 1, C_thres != -1) the same way: TWO
  * renders -- the event pairs' rays at the two poses -- blended with one background colour, the event loss on the two

@@ -1047,3 +1047,40 @@ def test_fragments_built_inside_the_grid_forward_equal_their_own_launch():
     assert len(runs[1][2]) == 6 and all(runs[1][2]), runs[1][2]
     assert torch.equal(runs[1][1], runs[0][1])
     assert np.abs(np.array(runs[1][0]) - np.array(runs[0][0])).max() <= 1e-5 * np.abs(runs[0][0]).max()
+
+
+def test_weight_gradients_summed_by_the_optimizer_launch_equal_the_reduce_launch():
+    """enerf_train_step_mse leaves the fused MLP backward's per-workgroup weight-gradient sums to k_grid_tile_adam's small-
+    tensor section (csrc/common.h PartialSums) instead of launching k_mlp32_reduce_w2: same counters, same losses, the
+    same gradients in p.grad and the same weights, to the order of the fp32 sums (enerf_debug_fold_reduce switches back)."""
+    from enerf_amd import _lib as L
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    lib = L.lib()
+    data = _batches(4, 4096, 2)
+    runs = {}
+    for fold in (1, 0):
+        prev = lib.enerf_debug_fold_reduce(fold)
+        try:
+            torch.manual_seed(0)
+            model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+            h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+            losses, counters = [], []
+            for i in range(24):
+                nxt = data[(i + 1) % 4]
+                losses.append(float(h.step_rgb(*data[i % 4], next_rays=(nxt[0], nxt[1]))))
+                counters.append(model.step_counter[model.rendered_counter_slot].cpu().clone())
+            torch.cuda.synchronize()
+            named = {n: p for n, p in model.named_parameters() if "encoder" not in n}
+            runs[fold] = (losses, torch.stack(counters), {n: p.detach().clone() for n, p in named.items()},
+                          {n: p.grad.detach().clone() for n, p in named.items()})
+        finally:
+            lib.enerf_debug_fold_reduce(prev)
+    (la, ca, pa, ga), (lb, cb, pb, gb) = runs[1], runs[0]
+    assert torch.equal(ca, cb)
+    assert np.abs(np.array(la) - np.array(lb)).max() <= 1e-5 * np.abs(lb).max()
+    assert len(ga) == 5
+    for n in ga:
+        assert float(gb[n].abs().max()) > 0
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-4 * float(gb[n].abs().max()), n
+        assert float((pa[n] - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
