@@ -184,7 +184,9 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     int prev_prec = -1;
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
-    bool rows_set = false, defer_set = false, signal_set = false;
+    bool rows_set = false, defer_set = false, signal_set = false, carry_set = false, own_sums = false;
+    uint32_t frags_built = 0;
+    PartialSums sums{nullptr, nullptr, 0, 0, 0};
     const bool march_next = r0.next_rays_o != nullptr || r1.next_rays_o != nullptr;
     const bool skip = r0.counter != nullptr && r1.counter != nullptr;
     const bool fused_mlp = a->nh_s == 1 && a->nh_c == 2 && enerf_nerf_mlp_available() != 0;
@@ -193,15 +195,27 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         rc = (call);         \
         if (rc) goto done;   \
     } while (0)
+    // (as in enerf_train_step_mse: the operand fragments' build rides in the grid forward's launch, the weight gradients'
+    //  partial sums are summed by the optimizer's launch)
+    if (fused_mlp && g_carry_frags) {
+        SplitJob job;
+        STEP(nerf_mlp_frag_job(a->wseg_s, a->wseg_c, a->w0_cols_c, a->out_c, (hipStream_t)s, &job));
+        grid_fwd_carry(&job);
+        carry_set = true;
+    }
     STEP(enerf_grid_encode_forward(r0.xyzs, a->embeddings, a->offsets, a->m_feats, M2, 3, 2, 16, a->level_scale_log2,
                                    a->base_resolution, 0, a->m_feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
+    if (carry_set) {
+        frags_built = grid_fwd_carry(nullptr) ? 0u : 1u;
+        carry_set = false;
+    }
     if (skip) {
         enerf_mlp32_valid_rows_ex(r1.counter, M, M);         // real rows: the first render's M + min(counter_2, M)
         rows_set = true;
     }
     if (fused_mlp) {
         STEP(enerf_nerf_mlp_forward(a->m_feats, r0.dirs, a->wseg_s, a->wseg_c, a->w0_cols_c, M2, a->out_c, a->m_sigma,
-                                    a->m_rgb, 0, s));
+                                    a->m_rgb, frags_built, s));
     } else {
         STEP(enerf_mlp32_forward_p(a->m_feats, a->wseg_s, 32, 0, M2, 32, 16, a->nh_s, 0, 6, a->m_fb_s, a->m_h32, 1, 32,
                                    a->m_sigma, r0.dirs, s));
@@ -237,8 +251,11 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         signal_set = true;
     }
     if (fused_mlp) {
+        if (g_fold_reduce)
+            own_sums = nerf_mlp_partial_job(a->dwseg_s, a->dwseg_c, a->w0_cols_c, a->out_c, a->small_g, a->small_n, a->n_small,
+                                            M2, (hipStream_t)s, &sums) == 0;
         STEP(enerf_nerf_mlp_backward(a->m_g_rgbs, a->m_g_sigmas, 1.0f, a->m_feats, r0.dirs, a->m_rgb, a->wseg_s, a->wseg_c,
-                                     a->dwseg_s, a->dwseg_c, a->w0_cols_c, 1u, M2, a->out_c, a->m_dfeat, 1, s));
+                                     a->dwseg_s, a->dwseg_c, a->w0_cols_c, 1u, M2, a->out_c, a->m_dfeat, own_sums ? 3u : 1u, s));
     } else {
         enerf_mlp32_defer_reduce(1);
         defer_set = true;
@@ -271,11 +288,19 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     STEP(enerf_grid_encode_backward_ex(a->m_dfeat, r0.xyzs, a->embeddings, a->offsets, a->table_grad, M2, 3, 2, 16,
                                        a->level_scale_log2, a->base_resolution, 0, a->m_dfeat, a->m_dfeat, a->gridtype,
                                        ENERF_F32, 2, in_add, in_mul, 1, M2, s));
+    if (own_sums) grid_adam_partial_sums(&sums);
     STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr, a->beta1,
                                          a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g, a->small_m,
                                          a->small_v, a->small_n, a->small_lr, a->small_step, s));
+    if (own_sums && grid_adam_partial_sums(nullptr)) {
+        set_error("train_step_events: the optimizer launch did not take the weight gradients' partial sums");
+        rc = ENERF_E_BADARG;
+    }
+    own_sums = false;
 done:
 #undef STEP
+    if (own_sums) grid_adam_partial_sums(nullptr);
+    if (carry_set) grid_fwd_carry(nullptr);
     if (defer_set) enerf_mlp32_defer_reduce(0);
     if (signal_set) enerf_mlp32_signal_next_reduce(0);
     if (rows_set) enerf_mlp32_valid_rows(nullptr);
