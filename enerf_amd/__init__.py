@@ -3,7 +3,8 @@
 Layout
   csrc/        hand-written HIP kernels + the C ABI (include/enerf_hip.h) -> lib/libenerf_hip.so
   backends/    ctypes shims with the reference's pybind module/function names (_raymarching, _gridencoder, ...)
-  dropin/      the same four modules as top-level names, for the reference's untouched Python wrappers
+  ext/         pybind11 modules of the same four names over the C ABI, importable as top-level `_raymarching` ... by the
+               reference's untouched Python wrappers
   raymarching, gridencoder, shencoder, ffmlp      host-side mirror of the reference's autograd wrappers
   encoding, activation, renderer, network, network_ff, events   the callers re-stated for the bench harness
   optim, parallel                                  fused optimizer + ray-sharded data parallel step

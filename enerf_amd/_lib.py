@@ -130,6 +130,18 @@ SIGNATURES = {
 
 F32, F16, BF16 = 0, 1, 2
 
+HEADER_PATH = os.path.join(_HERE, "..", "include", "enerf_hip.h")
+
+
+def header_abi_version():
+    """ENERF_ABI_VERSION as include/enerf_hip.h states it (the one place the number is written)."""
+    import re
+    with open(HEADER_PATH) as f:
+        m = re.search(r"^#define\s+ENERF_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise RuntimeError(f"enerf_amd: no ENERF_ABI_VERSION in {HEADER_PATH}")
+    return int(m.group(1))
+
 _lib = None
 
 
@@ -154,6 +166,10 @@ def lib():
         l.enerf_last_error.argtypes = []
         l.enerf_workspace_generation.restype = _c.c_uint64
         l.enerf_workspace_generation.argtypes = []
+        want, got = header_abi_version(), l.enerf_abi_version()
+        if got != want:
+            raise RuntimeError(f"enerf_amd: {LIB_PATH} answers ABI {got}, include/enerf_hip.h says {want}: "
+                               "stale build, run `python -m enerf_amd.build --force`")
         if os.environ.get("ENERF_TRACE_CALLS"):
             l = _TracedLib(l, os.environ["ENERF_TRACE_CALLS"])
         _lib = l

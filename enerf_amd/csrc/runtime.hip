@@ -187,7 +187,7 @@ int enerf_debug_workspace_ordering(int on) {
 }
 
 const char* enerf_last_error(void) { return enerf::g_err; }
-int enerf_abi_version(void) { return 2; }      // 2: enerf_train_step_args lost its RCCL-tail fields, enerf_dp_* retired, enerf_nerf_mlp_* added
+int enerf_abi_version(void) { return ENERF_ABI_VERSION; }      // include/enerf_hip.h
 uint64_t enerf_workspace_generation(void) { return enerf::workspace_generation(); }
 
 int enerf_prof_enable(int on) {

@@ -48,7 +48,11 @@ typedef void* enerf_stream_t; /* hipStream_t */
 #define ENERF_BF16 2
 
 const char* enerf_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change.  This #define is the ONE place the number lives:
+ * the library returns it (csrc/runtime.hip), enerf_amd/_lib.py parses it and refuses a library that answers differently,
+ * __graft_entry__.build() and tests/test_abi.py compare against the parsed value.
+ * 2: enerf_train_step_args lost its RCCL-tail fields, enerf_dp_* retired, enerf_nerf_mlp_* added. */
+#define ENERF_ABI_VERSION 2
 int enerf_abi_version(void);
 /* The library keeps grow-only scratch buffers per device (march chunk log, grid-backward record lists, ...).  Growing one
  * frees the old allocation; the counter returned here moves every time that happens.  A caller that captured library
