@@ -316,6 +316,7 @@ def launch_check(args):
 
 def main():
     args = parse()
+    os.environ.setdefault("ENERF_DIST_TIMEOUT_S", "300")    # (this program's phases are seconds long: a missing rank ends it)
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
@@ -467,7 +468,7 @@ def main():
     sync()
 
     samples_acc = torch.zeros((), dtype=torch.int64, device=device)
-    gb.STATS.update(fwd_points=0, fwd_calls=0, bwd_points=0, bwd_calls=0)
+    gb.STATS.update(fwd_points=0, fwd_calls=0, bwd_points=0, bwd_calls=0, budget_rows=0)
     _lib.prof.reset()
     # live hipEvent timing of the roofline kernel (and its backward) over the timed region; the other kernel families
     # are in profiles/ (rocprofv3) -- timing all of them costs ~25 event records per step, 5 % of a 1 ms step.
@@ -543,6 +544,13 @@ def main():
         sel = [r for r in runs if r[0] == name]
         n = sum(r[1] for r in sel)
         split[name] = {"ms_per_step": sum(r[2].elapsed_time(r[3]) for r in sel) / n if n else None, "steps": n}
+    # The training launches carry a sample BUDGET (rows) of which the grid kernels encode / bin only what the marcher filled
+    # (a device-side count: csrc/common.h grid_valid_rows): real points = rows x this rank's samples / its budget rows
+    local_samples = int(samples_acc.item())
+    fill = None
+    if gb.STATS.get("budget_rows"):
+        f = local_samples / gb.STATS["budget_rows"]
+        fill = f if 0.0 < f <= 1.0 else None
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -566,7 +574,11 @@ def main():
     if "grid_fwd" in kernels and gb.STATS["fwd_calls"]:
         # points per launch of the launches that were TIMED (the region mixes 133 k-point training batches with
         # 6.3 M-point density sweeps: time and points must come from the same launches)
-        pts = kernels["grid_fwd"].get("units_per_timed_launch", gb.STATS["fwd_points"] / gb.STATS["fwd_calls"])
+        rows = kernels["grid_fwd"].get("units_per_timed_launch", gb.STATS["fwd_points"] / gb.STATS["fwd_calls"])
+        # rows -> real points for training-batch launches (a density sweep's 6.3 M rows are all real; the region's timed
+        # launches are one kind or the other when one launch in --time-every is timed)
+        train_launches = fill is not None and rows < 1.0e6
+        pts = rows * fill if train_launches else rows
         # (--fp16: the timed launches mix half-table training batches, 588 B/point, with fp32 density sweeps; the
         # fp32 figure is kept so that the fraction is a lower bound)
         achieved = pts * GRID_FWD_BYTES_PER_POINT / (kernels["grid_fwd"]["avg_ms"] * 1e-3) / 1e9
@@ -576,7 +588,10 @@ def main():
                     "traffic_source": None if traffic is None else
                     f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run), "
                     f"bytes per point x this run's points per launch",
-                    "points_per_launch": pts, "avg_launch_ms": kernels["grid_fwd"]["avg_ms"],
+                    "points_per_launch": pts, "rows_per_launch": rows,
+                    "points_are": ("real samples: the launch's budget rows x (device-side sample total / budget rows of "
+                                   "the region); the kernel skips the unfilled rows" if train_launches else "rows launched"),
+                    "avg_launch_ms": kernels["grid_fwd"]["avg_ms"],
                     "timed_launches": kernels["grid_fwd"]["launches"],
                     "launches_in_region": kernels["grid_fwd"]["launches_in_region"],
                     "points_per_launch_all_region": gb.STATS["fwd_points"] / gb.STATS["fwd_calls"],
@@ -620,6 +635,8 @@ def main():
             gb_calls = gb.STATS["bwd_calls"] - bwd_before[1]
             if roofline is not None and gb_n and gb_calls:
                 ptsb = (gb.STATS["bwd_points"] - bwd_before[0]) / gb_calls
+                if fill is not None and 0 < probe_samples < ptsb:
+                    ptsb = probe_samples              # (real samples of the probe steps, not their budget rows)
                 kernels["grid_bwd"] = {"avg_ms": gb_ms / gb_n, "launches": int(gb_n), "timed_in": "probe steps"}
                 if ta_n:
                     kernels["table_adam"] = {"avg_ms": ta_ms / ta_n, "launches": int(ta_n), "timed_in": "probe steps"}

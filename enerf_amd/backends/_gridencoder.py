@@ -4,7 +4,10 @@
 from .. import _lib as L
 
 # points processed per entry point since the last reset (bench.py: algorithmic bytes = 1164 B/point)
-STATS = {"fwd_points": 0, "fwd_calls": 0, "bwd_points": 0, "bwd_calls": 0}
+# (budget_rows: rows of the whole-step entry points' launches, which carry a sample BUDGET of which the kernels encode and bin
+#  only the rows the marcher filled -- csrc/common.h grid_valid_rows; bench.py turns rows into real points with the device-side
+#  sample total)
+STATS = {"fwd_points": 0, "fwd_calls": 0, "bwd_points": 0, "bwd_calls": 0, "budget_rows": 0}
 # the same forward counts from process start, never reset: the denominator of per-dispatch counter averages taken over a
 # whole profiled process (tools/profile_round.sh)
 LIFETIME = {"fwd_points": 0, "fwd_calls": 0}

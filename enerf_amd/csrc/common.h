@@ -89,10 +89,18 @@ struct SplitJob {
 // gridencoder.hip: the next fp32 D = 3, C = 2 forward launch carries `job` (one-shot; nullptr disarms).  Returns whether a
 // job armed earlier was still waiting (= no launch took it).
 bool grid_fwd_carry(const SplitJob* job);
+// gridencoder.hip: while set (device_count != nullptr), enerf_grid_encode_forward / _backward(_ex) treat their B rows as a
+// budget of which only base + min(*device_count, cap) (cap == 0: *device_count), rounded up to 32, are real -- the
+// convention of enerf_mlp32_valid_rows(_ex), whose kernels sit between the two and skip the same rows.  Results for real
+// rows are unchanged; the rest is neither encoded nor binned.  Set and cleared by the whole-step entry points only.
+void grid_valid_rows(const int32_t* device_count, uint32_t base, uint32_t cap);
 // mlp32.hip: the job that builds the fragments enerf_nerf_mlp_forward / _backward would build for these weights, and the
 // promise that it runs before them on `s`: the calls that follow with flags bit 0 use the fragments as they are.
 int nerf_mlp_frag_job(const float* const* wseg_s, const float* const* wseg_c, uint32_t w0_cols_c, uint32_t out_c,
                       hipStream_t s, SplitJob* job);
+// ... and the promise withdrawn: no launch took the job (or the launch that should have failed), the book-keeping of
+// "fragments current for these weight pointers" is void and the next MLP call rebuilds them whatever its flags say.
+void nerf_mlp_frags_invalidate();
 // Per-workgroup partial sums that the table optimizer's launch reduces on the fly: value i (< n) = sum over b < parts of
 // partial[b * stride + i], the gradient of element map[i] & 0xffffff of that launch's small tensor map[i] >> 24
 // (0xffffffff: of nobody).  (The fused MLP backward's weight gradients: k_mlp32_reduce_w2 and its 5 us leave the chain.)

@@ -63,7 +63,21 @@ struct LevelTab {
     float in_add, in_mul;  // inputs are read as (x + in_add) * in_mul: (0, 1) = as given; (bound, 1/(2 bound)) folds
                            // the wrapper's normalisation (grid.py:150) into the kernels, rounded exactly as torch's
                            // two elementwise kernels round it
+    // enerf::grid_valid_rows (the training step): the batch is a budget of B rows of which the marcher filled
+    // base + min(*valid_rows, cap) (cap == 0: *valid_rows) -- enerf_mlp32_valid_rows' convention, the MLP kernels between
+    // this file's forward and backward skip the same rows.  Rows from that count rounded up to the MLP kernels' 32-row
+    // tile onwards are neither encoded (nobody reads their features) nor binned (their gradient is zero).
+    const int32_t* valid_rows;
+    uint32_t valid_base, valid_cap;
 };
+__device__ __forceinline__ uint32_t grid_row_limit(const LevelTab& tab, uint32_t B) {
+    if (!tab.valid_rows) return B;
+    int32_t v = tab.valid_rows[0];
+    if (tab.valid_cap) v = (int32_t)tab.valid_base + (v <= 0 ? 0 : (v < (int32_t)tab.valid_cap ? v : (int32_t)tab.valid_cap));
+    const uint32_t rows = v <= 0 ? 0u : ((uint32_t)v < B ? (uint32_t)v : B);
+    const uint32_t up = (rows + 31u) & ~31u;
+    return up < B ? up : B;
+}
 
 uint32_t g_level_mask = 0xffffffffu;
 uint32_t g_binned_min_batch = 16384;     // enerf_debug_grid_bwd_binned
@@ -254,6 +268,7 @@ __device__ __forceinline__ void grid_fwd_block(uint32_t bid, const float* __rest
     if (!level_enabled(tab, level)) return;
     const uint32_t b = chunk * kPtsPerBlock + threadIdx.x;
     const uint32_t Bp = (B + 31u) & ~31u;
+    if (tab.valid_rows && b >= grid_row_limit(tab, B)) return;      // (the budget's unfilled rows: nobody reads them)
     if (b >= B) {
         if (out_layout == 2 && b < Bp) {     // zeroed pad rows of the [L,Bp,C] layout
             Feat<T, C> z;
@@ -730,7 +745,7 @@ __global__ void __launch_bounds__(kPtsPerBlock) k_grid_bwd(const T* __restrict__
 
     float in[D], g[C], pos[D], v[(1 << D) * C];
     uint32_t pos_grid[D];
-    const bool valid = load_sample<T, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, tab.in_add, tab.in_mul, in, g);
+    const bool valid = load_sample<T, D, C>(b, b < grid_row_limit(tab, B), grad, inputs, level, B, L, grad_layout, tab.in_add, tab.in_mul, in, g);
     cell_of<D>(in, tab.scale[level], pos_grid, pos);
     corner_contrib<D, C>(pos, g, v);
     if (!aggregate_runs<D, C>(valid, lane, pos_grid, v)) return;
@@ -789,7 +804,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
         float* rows = grad_grid + (size_t)off0 * C;
         float in[D], g[C], pos[D], v[(1 << D) * C];
         uint32_t pos_grid[D], cr[1 << D];
-        const bool valid = load_sample<float, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, tab.in_add,
+        const bool valid = load_sample<float, D, C>(b, b < grid_row_limit(tab, B), grad, inputs, level, B, L, grad_layout, tab.in_add,
                                                     tab.in_mul, in, g);
         cell_of<D>(in, tab.scale[level], pos_grid, pos);
         corner_contrib<D, C>(pos, g, v);
@@ -822,7 +837,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
 
     float in[D], g[C], pos[D], v[(1 << D) * C];
     uint32_t pos_grid[D], cr[1 << D], bin[1 << D], rank[1 << D];
-    const bool valid = load_sample<float, D, C>(b, b < B, grad, inputs, level, B, L, grad_layout, tab.in_add, tab.in_mul, in, g);
+    const bool valid = load_sample<float, D, C>(b, b < grid_row_limit(tab, B), grad, inputs, level, B, L, grad_layout, tab.in_add, tab.in_mul, in, g);
     cell_of<D>(in, tab.scale[level], pos_grid, pos);
     corner_contrib<D, C>(pos, g, v);
     const bool head = aggregate_runs<D, C>(valid, lane, pos_grid, v);
@@ -1448,7 +1463,18 @@ int fill_level_tab(LevelTab& tab, uint32_t L, float S, uint32_t H, float in_add,
         tab.resolution[l] = (uint32_t)ceil(scale) + 1;
     }
     tab.level_mask = g_level_mask;
+    tab.valid_rows = nullptr;
+    tab.valid_base = tab.valid_cap = 0;
     return 0;
+}
+
+// enerf::grid_valid_rows (common.h): set by the whole-step entry points around their forward .. backward
+static const int32_t* g_grid_valid_rows = nullptr;
+static uint32_t g_grid_valid_base = 0, g_grid_valid_cap = 0;
+static inline void apply_valid_rows(LevelTab& tab) {
+    tab.valid_rows = g_grid_valid_rows;
+    tab.valid_base = g_grid_valid_base;
+    tab.valid_cap = g_grid_valid_cap;
 }
 
 __global__ void k_prof_mark() {}
@@ -1604,6 +1630,12 @@ bool enerf::grid_adam_partial_sums(const PartialSums* job) {
     return waiting;
 }
 
+void enerf::grid_valid_rows(const int32_t* device_count, uint32_t base, uint32_t cap) {
+    g_grid_valid_rows = device_count;
+    g_grid_valid_base = device_count ? base : 0u;
+    g_grid_valid_cap = device_count ? cap : 0u;
+}
+
 bool enerf::grid_fwd_carry(const SplitJob* job) {
     const bool waiting = g_carry_armed;
     g_carry_armed = job != nullptr && job->threads <= kCarryBlocks * kPtsPerBlock;
@@ -1637,6 +1669,7 @@ int enerf_grid_encode_forward(const float* inputs, const void* embeddings, const
     if (fill_level_tab(tab, L, S, H, in_add, in_mul)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
     if (out_layout < 0 || out_layout > 2) ENERF_BADARG("GridEncoding: out_layout must be 0, 1 or 2, got %d", out_layout);
+    apply_valid_rows(tab);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_FWD, s, true);   // timed with the kernel's own begin / end stamps
     prof.units((double)B);
@@ -1694,6 +1727,7 @@ int enerf_grid_encode_backward_ex(const void* grad, const float* inputs, const v
     if (fill_level_tab(tab, L, S, H, in_add, in_mul)) ENERF_BADARG("GridEncoding: L must be in [1, %d], got %u", kMaxLevels, L);
     if (dtype != ENERF_F32 && dtype != ENERF_F16) ENERF_BADARG("GridEncoding: dtype must be f32 or f16");
     if (grad_layout < 0 || grad_layout > 2) ENERF_BADARG("GridEncoding: grad_layout must be 0, 1 or 2, got %d", grad_layout);
+    apply_valid_rows(tab);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_GRID_BWD, s);
     prof.units((double)B);

@@ -1519,6 +1519,11 @@ int enerf::nerf_mlp_frag_job(const float* const* wseg_s, const float* const* wse
     return 0;
 }
 
+void enerf::nerf_mlp_frags_invalidate() {
+    for (int k = 0; k < 5; k++) g_nerf_built[k] = nullptr;
+    g_nerf_built_gen = 0;
+}
+
 namespace enerf_mlp32 {
 
 // The reference's FFMLP entry points on this file's data flow (mlp32_common.h).  The arithmetic mode and the 16-bit I/O

@@ -344,6 +344,11 @@ __global__ void __launch_bounds__(256) k_nerf_bwd(NerfBwdArgs a, const uint32_t*
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBwdLdsWords];       // operands (then the dW sums), selectors, stashes
     static_assert(NF_BWD * kFragWords >= 2 * P_STRIDE, "the two sum regions reuse the operand area");
     static_assert(kBwdLdsWords * 4 <= 160 * 1024, "LDS");
+#if defined(MLP32S_NO_OPERAND_BARRIER)
+    // nerf_mlp_bwd.hip compiles this kernel without the operand barrier: sound only while ONE workgroup of it fits a CU,
+    // i.e. one wavefront per SIMD (mlp32s_ops.h: operand_ready).  More than half of the CU's 160 KiB of LDS guarantees it.
+    static_assert(kBwdLdsWords * 4 > 80 * 1024, "k_nerf_bwd without the operand barrier must stay at one workgroup per CU");
+#endif
     NERF_WHOLE_SIMD();
     typedef FragT<3> Frag;
     const int lane = lane_id(), j = lane & 31, h = lane >> 5;

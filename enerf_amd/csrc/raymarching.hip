@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(256) k_march_count_w(const float* __restrict__
                                                        const float* __restrict__ rays_d,
                                                        const uint8_t* __restrict__ grid, float bound, uint32_t max_steps,
                                                        uint32_t N, uint32_t C, uint32_t H,
-                                                       const float* __restrict__ nears, const float* __restrict__ fars,
+                                                       const float* nears, const float* fars,   // (no __restrict__: nf_nears / nf_fars alias them)
                                                        int32_t* rays, uint32_t perturb, ChunkEntry* __restrict__ log,
                                                        uint32_t* __restrict__ nlog,
                                                        const int* __restrict__ occ_keys,
@@ -1798,17 +1798,31 @@ static inline size_t march_log_bytes(uint32_t N, uint32_t H) {
 static const float* g_nf_aabb = nullptr;
 static float g_nf_min_near = 0.0f;
 static int32_t* g_count_mirror = nullptr;      // enerf_march_mirror_count (armed for one count pass)
+// Both are one-shot requests for "the next march".  Every public march entry point takes them -- consumes AND disarms --
+// as its first statement, before any early return (N == 0, bad arguments, a workspace failure), so that a request can never
+// outlive the call it was made for and reach an unrelated march with a stale aabb / host pointer.  The whole-step entry
+// points disarm again on their way out (train_step.hip `done:`) in case they failed between arming and marching.
+struct MarchOneShot {
+    const float* nf_aabb;
+    float nf_min_near;
+    int32_t* mirror;
+};
+static inline MarchOneShot march_take_oneshot() {
+    MarchOneShot o = {g_nf_aabb, g_nf_min_near, g_count_mirror};
+    g_nf_aabb = nullptr;
+    g_count_mirror = nullptr;
+    return o;
+}
 
 // count pass (+ scan): rays[n] = (n, offset, count), counter += (sum, N); the fixed-step marcher also fills the chunk log
 static int march_train_count(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                              const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
-                             bool use_box, bool fresh_counter, hipStream_t s) {
+                             bool use_box, bool fresh_counter, const MarchOneShot& once, hipStream_t s) {
     if (int e = workspace_family_enter(0, s)) return e;
-    const float* nf_aabb = g_nf_aabb;
-    g_nf_aabb = nullptr;                                   // (armed for one call)
-    int32_t* mirror = g_count_mirror;
-    g_count_mirror = nullptr;
+    const float* nf_aabb = once.nf_aabb;
+    const float g_nf_min_near = once.nf_min_near;
+    int32_t* mirror = once.mirror;
     if (nf_aabb && !(march_uses_lattice(dt_gamma, max_steps, C, H) && !march_uses_threads(N, H))) {
         k_near_far<<<div_up(N, 256), 256, 0, s>>>(rays_o, rays_d, nf_aabb, N, g_nf_min_near, (float*)nears, (float*)fars);
         nf_aabb = nullptr;
@@ -1918,6 +1932,7 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
                               const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                               int32_t* rays, int32_t* counter, uint32_t perturb, uint32_t zero_unwritten,
                               enerf_stream_t stream) {
+    const MarchOneShot once = march_take_oneshot();
     if (N == 0) {
         if (zero_unwritten && M) {
             (void)hipMemsetAsync(xyzs, 0, (size_t)M * 12, (hipStream_t)stream);
@@ -1931,7 +1946,7 @@ int enerf_march_rays_train_ex(const float* rays_o, const float* rays_d, const ui
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
                                perturb, (zero_unwritten & 2u) != 0, (zero_unwritten & 4u) != 0, (zero_unwritten & 8u) != 0,
-                               s);
+                               once, s);
     if (rc) return rc;
     rc = march_train_write(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                            rays, counter, perturb, zero_unwritten & 1u, s);
@@ -1944,13 +1959,14 @@ int enerf_march_rays_train_count(const float* rays_o, const float* rays_d, const
                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                  const float* nears, const float* fars, int32_t* rays, int32_t* counter,
                                  uint32_t perturb, uint32_t flags, enerf_stream_t stream) {
+    const MarchOneShot once = march_take_oneshot();
     if (N == 0) return 0;
     if (C == 0 || H < 2 || max_steps == 0)
         ENERF_BADARG("march_rays_train_count: bad C=%u H=%u max_steps=%u", C, H, max_steps);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
     const int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
-                                     perturb, (flags & 2u) != 0, (flags & 4u) != 0, (flags & 8u) != 0, s);
+                                     perturb, (flags & 2u) != 0, (flags & 4u) != 0, (flags & 8u) != 0, once, s);
     if (rc) return rc;
     ENERF_LAUNCH_CHECK("march_rays_train_count");
     return 0;

@@ -71,10 +71,12 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         grid_fwd_carry(&job);
         carry_set = true;
     }
+    if (a->counter) grid_valid_rows(a->counter, 0, 0);      // (forward .. backward: the budget's unfilled rows are skipped)
     STEP(enerf_grid_encode_forward(a->xyzs, a->embeddings, a->offsets, a->feats, M, 3, 2, 16, a->level_scale_log2,
                                    a->base_resolution, 0, a->feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
     if (carry_set) {
         frags_built = grid_fwd_carry(nullptr) ? 0u : 1u;      // (taken along: the MLP calls are told so)
+        if (!frags_built) nerf_mlp_frags_invalidate();
         carry_set = false;
     }
     if (a->counter) {
@@ -161,8 +163,15 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     own_sums = false;
 done:
 #undef STEP
+    // (one-shot march requests never outlive the step they were armed for -- csrc/raymarching.hip: MarchOneShot)
+    enerf_march_fuse_near_far(nullptr, 0.0f);
+    enerf_march_mirror_count(nullptr);
+    grid_valid_rows(nullptr, 0, 0);
     if (own_sums) grid_adam_partial_sums(nullptr);
-    if (carry_set) grid_fwd_carry(nullptr);
+    if (carry_set) {                       // (the launch that should have carried the fragments' build never ran)
+        grid_fwd_carry(nullptr);
+        nerf_mlp_frags_invalidate();
+    }
     if (defer_set) enerf_mlp32_defer_reduce(0);
     if (signal_set) enerf_mlp32_signal_next_reduce(0);
     if (rows_set) enerf_mlp32_valid_rows(nullptr);
@@ -203,10 +212,12 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         grid_fwd_carry(&job);
         carry_set = true;
     }
+    if (skip) grid_valid_rows(r1.counter, M, M);            // (real rows: the first render's M + min(counter_2, M))
     STEP(enerf_grid_encode_forward(r0.xyzs, a->embeddings, a->offsets, a->m_feats, M2, 3, 2, 16, a->level_scale_log2,
                                    a->base_resolution, 0, a->m_feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
     if (carry_set) {
         frags_built = grid_fwd_carry(nullptr) ? 0u : 1u;
+        if (!frags_built) nerf_mlp_frags_invalidate();
         carry_set = false;
     }
     if (skip) {
@@ -299,8 +310,15 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     own_sums = false;
 done:
 #undef STEP
+    // (one-shot march requests never outlive the step they were armed for -- csrc/raymarching.hip: MarchOneShot)
+    enerf_march_fuse_near_far(nullptr, 0.0f);
+    enerf_march_mirror_count(nullptr);
+    grid_valid_rows(nullptr, 0, 0);
     if (own_sums) grid_adam_partial_sums(nullptr);
-    if (carry_set) grid_fwd_carry(nullptr);
+    if (carry_set) {                       // (the launch that should have carried the fragments' build never ran)
+        grid_fwd_carry(nullptr);
+        nerf_mlp_frags_invalidate();
+    }
     if (defer_set) enerf_mlp32_defer_reduce(0);
     if (signal_set) enerf_mlp32_signal_next_reduce(0);
     if (rows_set) enerf_mlp32_valid_rows(nullptr);
@@ -336,6 +354,7 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
     // ---- the two renders' forward
     for (int k = 0; k < 2; k++) {
         const enerf_step_render& r = a->r[k];
+        grid_valid_rows(r.counter, 0, 0);
         STEP(enerf_grid_encode_forward(r.xyzs, a->embeddings, a->offsets, r.feats, r.M, 3, 2, 16, a->level_scale_log2,
                                        a->base_resolution, 0, r.feats, a->gridtype, ENERF_F32, 2, in_add, in_mul, s));
         if (r.counter) {
@@ -409,6 +428,7 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
                                                n.next_counter, a->perturb, a->march_flags, ss));
             }
         }
+        grid_valid_rows(r.counter, 0, 0);
         STEP(enerf_grid_encode_backward_ex(r.dfeat, r.xyzs, a->embeddings, a->offsets, a->table_grad, r.M, 3, 2, 16,
                                            a->level_scale_log2, a->base_resolution, 0, r.dfeat, r.dfeat, a->gridtype,
                                            ENERF_F32, 2, in_add, in_mul, 1, total, s));
@@ -418,6 +438,10 @@ extern "C" int enerf_train_step_events(const enerf_event_step_args* a) {
                                          a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step, s));
 done:
 #undef STEP
+    // (one-shot march requests never outlive the step they were armed for -- csrc/raymarching.hip: MarchOneShot)
+    enerf_march_fuse_near_far(nullptr, 0.0f);
+    enerf_march_mirror_count(nullptr);
+    grid_valid_rows(nullptr, 0, 0);
     if (defer_set) enerf_mlp32_defer_reduce(0);
     if (signal_set) enerf_mlp32_signal_next_reduce(0);
     if (rows_set) enerf_mlp32_valid_rows(nullptr);

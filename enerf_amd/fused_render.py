@@ -393,12 +393,19 @@ def _check_cold_stage(model, pre, rays_o, rays_d, perturb, dt_gamma, max_steps):
     # the count arrives in pinned memory behind the march (an 8-byte copy on its stream): the host watches the two words
     # it pre-set to -1 instead of sleeping on the event -- the wake-up of an event wait is 10-20 us, in which the device,
     # which has nothing queued yet, idles (the cold window's steps: 11 of the driver's 20)
+    # The watch is bounded by a few march times (2 ms; a 4096-ray march is ~0.13 ms) and only tried where the count is
+    # stored by the kernel itself (MIRROR_COUNT): a count that arrives by an asynchronous copy is ordered by the event
+    # anyway.  A watch that runs out -- pinned memory that is not host-coherent while the kernel runs
+    # (HIP_HOST_COHERENT=0) -- is remembered on the model and every later step goes straight to the event.
     hv = host.numpy()
     if hv[0] < 0 or hv[1] < 0:
-        import time as _time
-        t_end = _time.perf_counter() + 0.05
-        while (hv[0] < 0 or hv[1] < 0) and _time.perf_counter() < t_end:
-            pass
+        if MIRROR_COUNT and not getattr(model, "_cold_watch_failed", False):
+            import time as _time
+            t_end = _time.perf_counter() + 0.002
+            while (hv[0] < 0 or hv[1] < 0) and _time.perf_counter() < t_end:
+                pass
+            if hv[0] < 0 or hv[1] < 0:
+                model._cold_watch_failed = True
         if hv[0] < 0 or hv[1] < 0:
             done.synchronize()
     m = int(hv[0])
@@ -781,6 +788,7 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
         from .backends import _gridencoder as _gbk
         _gbk.STATS["fwd_points"] += M
+        _gbk.STATS["budget_rows"] += M
         _gbk.STATS["fwd_calls"] += 1
         _gbk.STATS["bwd_points"] += M
         _gbk.STATS["bwd_calls"] += 1
@@ -1051,6 +1059,7 @@ def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_st
         # (the launch counters bench.py reads: merged, the library issued ONE grid_encode_forward / backward over 2 M points)
         for points in ([pres[0]["M"] + pres[1]["M"]] if merged else [pre["M"] for pre in pres]):
             _gbk.STATS["fwd_points"] += points
+            _gbk.STATS["budget_rows"] += points
             _gbk.STATS["fwd_calls"] += 1
             _gbk.STATS["bwd_points"] += points
             _gbk.STATS["bwd_calls"] += 1

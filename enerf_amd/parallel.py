@@ -27,12 +27,16 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver stack
         # a rank that never arrives (or a collective that never completes) must end the job with an error on every rank,
-        # not hold the node: rendezvous and collectives time out (ENERF_DIST_TIMEOUT_S, default 5 minutes) and RCCL's
-        # watchdog tears the communicator down when they do
+        # not hold the node: RCCL's watchdog tears the communicator down when a collective times out.  The timeout itself
+        # is torch's default (10 min nccl / 30 min gloo: long single-rank phases -- full-resolution evaluation, an export
+        # on rank 0, a first build -- must not kill a training job) unless ENERF_DIST_TIMEOUT_S says otherwise; bench.py,
+        # whose phases are seconds long, sets it to 300 for its own run.
         import datetime
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
-        timeout = datetime.timedelta(seconds=int(os.environ.get("ENERF_DIST_TIMEOUT_S", "300")))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        kw = {}
+        if os.environ.get("ENERF_DIST_TIMEOUT_S"):
+            kw["timeout"] = datetime.timedelta(seconds=int(os.environ["ENERF_DIST_TIMEOUT_S"]))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
 
