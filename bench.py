@@ -921,12 +921,26 @@ def main():
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         cpu = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-400:]}
 
+    # who took part: RCCL's own view of the world and the device every rank ran on, so that a multi-GPU line is
+    # self-evidently N ranks on N distinct GPUs
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "device_name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
+          "pid": os.getpid()}
+    if world > 1:
+        members = [None] * world
+        dist.all_gather_object(members, me)
+        world_obj = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": members,
+                     "distinct_devices": len({(m["device_index"], m["pci_bus_id"], m["uuid"]) for m in members})}
+    else:
+        world_obj = {"backend": None, "world_size": 1, "ranks": [me], "distinct_devices": 1}
     if rank == 0:
         out = {
             "metric": "train_rays_per_sec",
             "value": total_rays / elapsed,
             "unit": "rays/s",
             "n_gpus": world,
+            "world": world_obj,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -667,6 +667,12 @@ __device__ __forceinline__ bool aggregate_runs(bool valid, int lane, const uint3
 #ifndef ENERF_TILE_ELEMS
 #define ENERF_TILE_ELEMS 4096
 #endif
+// how k_grid_bwd_bin ranks a head's records within their lists: 0 = one returning LDS atomic per record (shipped), 1 = one
+// per corner pair / cell when the records share a list, 2 = 1 + one per wavefront and list on the coarse levels (ballot).
+// Both alternatives were measured SLOWER (profiles/r06_bin_ranks_rejected.txt) and are kept for the record only.
+#ifndef ENERF_BIN_RANKS
+#define ENERF_BIN_RANKS 0
+#endif
 #ifndef ENERF_TA_PAIRS
 #define ENERF_TA_PAIRS 10
 #endif
@@ -842,6 +848,62 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
     corner_contrib<D, C>(pos, g, v);
     const bool head = aggregate_runs<D, C>(valid, lane, pos_grid, v);
     corner_rows<D>(geom, pos_grid, cr);
+    // Ranks of the records within their lists.  A returning LDS atomic per record (eight per run head) was 2-4 of this
+    // workgroup's ~7 us; records that share a list are ranked together instead:
+    //  * the two x-neighbours of a corner pair sit in adjacent rows (dense levels; hashed levels with x even) or in rows that
+    //    differ in a few low bits (x odd): one list almost always -> one atomic of 2;
+    //  * on the coarse levels all eight corners of a cell -- and those of every head of the wavefront -- fall into one or
+    //    two lists: the wavefront's heads are counted with a ballot and ONE lane reserves for all of them (what serialised
+    //    64 same-address atomics per instruction before).
+    // The order of a list's records changes with this, nothing else: k_grid_tile_adam sums them in fp64 and rounds once.
+#if ENERF_BIN_RANKS >= 1
+    bool all8 = head, ranked = false;
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        bin[idx] = __umul24(cr[idx] / R, plan.replicas) + replica;          // (R is a power of two; both factors < 2^24)
+        rank[idx] = 0;
+        all8 = all8 && bin[idx] == bin[0];
+    }
+    {
+        unsigned long long m = ENERF_BIN_RANKS >= 2 ? __ballot(all8) : 0ull;
+        if (__popcll(m) >= 8) {                                              // (wave-uniform)
+            for (int round = 0; round < 4 && m != 0ull; round++) {
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)bin[0], leader);
+                const bool in = all8 && !ranked && bin[0] == bl;
+                const unsigned long long mm = __ballot(in);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&s_ofs[bl], (uint32_t)__popcll(mm) << D);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                if (in) {
+                    const uint32_t before_me = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+#pragma unroll
+                    for (int idx = 0; idx < (1 << D); idx++) rank[idx] = base + (before_me << D) + (uint32_t)idx;
+                    ranked = true;
+                }
+                m &= ~mm;
+            }
+        }
+    }
+    if (head && all8 && !ranked) {                                           // one list, not ranked by the wavefront
+        const uint32_t r = atomicAdd(&s_ofs[bin[0]], 1u << D);
+#pragma unroll
+        for (int idx = 0; idx < (1 << D); idx++) rank[idx] = r + (uint32_t)idx;
+    } else if (head && !ranked) {
+#pragma unroll
+        for (int k = 0; k < (1 << (D - 1)); k++) {
+            if (bin[2 * k] == bin[2 * k + 1]) {
+                const uint32_t r = atomicAdd(&s_ofs[bin[2 * k]], 2u);
+                rank[2 * k] = r;
+                rank[2 * k + 1] = r + 1u;
+            } else {
+                rank[2 * k] = atomicAdd(&s_ofs[bin[2 * k]], 1u);
+                rank[2 * k + 1] = atomicAdd(&s_ofs[bin[2 * k + 1]], 1u);
+            }
+        }
+    }
+#else
     if (head) {
 #pragma unroll
         for (int idx = 0; idx < (1 << D); idx++) {
@@ -849,6 +911,7 @@ __global__ void __launch_bounds__(PTS) k_grid_bwd_bin(const float* __restrict__ 
             rank[idx] = atomicAdd(&s_ofs[bin[idx]], 1u);
         }
     }
+#endif
     __syncthreads();
     BIN_PH(1);
 

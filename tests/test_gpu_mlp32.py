@@ -542,3 +542,63 @@ def test_both_nets_in_one_launch_are_bit_stable_from_run_to_run(precision):
         again = step()
         for a, b, what in zip(again, first, ("sigma", "rgb", "dW")):
             assert torch.equal(a, b), (it, what, int((a != b).sum()))
+
+
+def test_backward_is_bit_stable_beside_a_marching_stream():
+    """k_nerf_bwd is the one 16-bit MFMA kernel compiled without the operand barrier (csrc/nerf_mlp_bwd.hip: one wavefront of it
+    per SIMD, nothing of ITS kind shares the matrix pipe).  In the training step it does not run alone, though: the next
+    batch's march sits on a second stream and its wavefronts -- plain VALU code, 66 registers -- may be co-resident wherever
+    registers and LDS allow.  The same batch through forward and backward 40 times while a second stream marches rays
+    back to back: every output bit-identical to the run made on an idle device."""
+    from enerf_amd import _lib, fused_network as fn, scene
+    from enerf_amd.backends import _raymarching as rb
+    from enerf_amd.network import NeRFNetwork
+    lib = _lib.lib()
+    if not lib.enerf_nerf_mlp_available():
+        pytest.skip("split-bf16 only")
+    N = 133000
+    torch.manual_seed(3)
+    m = NeRFNetwork(encoding="hashgrid", bound=3, cuda_ray=True, out_dim_color=3).to(DEV)
+    m.encoder.embeddings.data.uniform_(-1, 1)
+    scene.install_occupancy(m)
+    x = torch.rand(N, 3, device=DEV) * 6 - 3
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=DEV), dim=-1)
+    gs, gc = torch.randn(N, device=DEV), torch.randn(N, 3, device=DEV)
+    params = fn.network_params(m)
+    cfg, offs = fn.network_cfg(m), fn.encoder_offsets(m)
+
+    def step():
+        s, c, sv = fn.nerf_forward(x, d, cfg, True, params[0], offs, *params[1:])
+        assert sv["fused"]
+        g_emb, dw = fn.nerf_backward(sv, gs, gc, raw=True)
+        return s, c, dw
+
+    first = step()
+    torch.cuda.synchronize()
+    # the neighbour: 4096-ray training marches (count + scan + write), queued back to back on a stream of their own
+    (ro, rd), _ = scene.training_batch(0, 4096, DEV)
+    ro, rd = ro.view(-1, 3).contiguous(), rd.view(-1, 3).contiguous()
+    n = ro.shape[0]
+    aabb = m.aabb_train if hasattr(m, "aabb_train") else torch.tensor([-3.0] * 3 + [3.0] * 3, device=DEV)
+    nears, fars = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    rb.near_far_from_aabb(ro, rd, aabb, n, 0.2, nears, fars)
+    M = 160000
+    xyzs, dirs, deltas = (torch.empty(M, 3, device=DEV), torch.empty(M, 3, device=DEV), torch.empty(M, 2, device=DEV))
+    rays = torch.empty(n, 3, dtype=torch.int32, device=DEV)
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+
+    def neighbour(k):
+        with torch.cuda.stream(side):
+            for _ in range(k):
+                counter.zero_()
+                rb.march_rays_train(ro, rd, m.density_bitfield, m.bound, 0.0, 1024, n, m.cascade, m.grid_size, M, nears,
+                                    fars, xyzs, dirs, deltas, rays, counter, True)
+    for it in range(40):
+        neighbour(3)                                   # (~0.15 ms of marching queued beside each ~0.07 ms forward + backward)
+        again = step()
+        for a, b, what in zip(again, first, ("sigma", "rgb", "dW")):
+            assert torch.equal(a, b), (it, what, int((a != b).sum()))
+    torch.cuda.synchronize()
+    assert int(counter[0]) > 0                         # (the neighbour really marched)
