@@ -123,6 +123,8 @@ SIGNATURES = {
     "enerf_debug_nerf_mlp_fused": [_int],
     "enerf_debug_nerf_frags_copy": [_vp, _vp],
     "enerf_debug_carry_frags": [_int],
+    "enerf_debug_carry_count": [_int],
+    "enerf_debug_march_carry_blocks": [_u32],
     "enerf_debug_fold_reduce": [_int],
     "enerf_nerf_mlp_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     "enerf_nerf_mlp_backward": [_vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _u32, _vp],

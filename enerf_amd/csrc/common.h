@@ -119,6 +119,45 @@ int nerf_mlp_partial_job(float* const* dwseg_s, float* const* dwseg_c, uint32_t 
                          const float* const* small_g, const uint32_t* small_n, uint32_t n_small, uint32_t B, hipStream_t s,
                          PartialSums* job);
 
+// The count pass of the wave-per-ray lattice marcher as data (csrc/march_lattice.h: march_count_block runs it as workgroup
+// `bid` of `blocks` workgroups of 256 threads).  In the one-call training step the NEXT batch's count pass rides in the
+// table optimizer's launch -- one queue, no second stream, none of the two cross-stream hand-overs (a signal behind the MLP
+// backward, an event wait at the head of the next step: ~17 us of idle queue per step) -- and one small launch behind the
+// optimizer scans the counts and writes the samples.
+struct MarchCountJob {
+    const float* rays_o;
+    const float* rays_d;
+    const uint8_t* grid;
+    float bound;
+    uint32_t max_steps, N, C, H;
+    const float* nears;          // (nf_nears / nf_fars alias them when near / far are computed in the count pass)
+    const float* fars;
+    int32_t* rays;
+    uint32_t perturb;
+    void* log;                   // ChunkEntry[N][kLogCap]
+    uint32_t* nlog;
+    const int* occ_keys;
+    const float* nf_aabb;
+    float nf_min_near;
+    float* nf_nears;
+    float* nf_fars;
+    uint32_t blocks;
+};
+// gridencoder.hip: the next enerf_grid_adam_from_records(_ex) launch of the plain fp32 C = 2 form carries `job` in
+// job->blocks extra workgroups (one-shot; nullptr disarms).  Returns whether a job armed earlier was still waiting.
+bool tile_adam_carry_count(const MarchCountJob* job);
+// raymarching.hip: march_rays_train_ex(...) split around a carrying launch.  begin: 0 = *job is the call's count pass (the
+// workspace is prepared, the one-shot near / far request consumed) and the call's scan + write are remembered for
+// march_carry_end; 1 = this call cannot be served that way (another marcher, a count mirror armed, a kept counter ...):
+// nothing consumed, make the ordinary call; < 0 = error.  end: scan + write on `s` (behind the launch that carried the job).
+int march_carry_begin(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                      const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                      uint32_t perturb, uint32_t flags, hipStream_t s, MarchCountJob* job);
+int march_carry_end(hipStream_t s);
+int march_carry_count_now(const MarchCountJob* job, hipStream_t s);     // (the carrying launch did not take the job)
+void march_carry_abort();                                               // (a step failed between begin and end)
+
 // ---- wave-level primitives (wave64) ----------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

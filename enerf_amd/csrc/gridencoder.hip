@@ -1103,6 +1103,9 @@ __global__ void __launch_bounds__(kTileThreads) k_grid_bwd_tile(const int32_t* _
 struct AdamScalars {
     float b1, b2, eps, step_size, inv_bc2_sqrt;
 };
+// (the next batch's count pass rides in this kernel's launch: common.h MarchCountJob)
+#include "march_lattice.h"
+
 // the model's other (small) parameters ride along in the same launch: one workgroup each, after its tiles
 constexpr int kMaxSmallAdam = 8;
 struct SmallAdam {
@@ -1153,7 +1156,7 @@ struct OwnerRange {
 
 // (registers: held to a fifth of a SIMD's file, so that the four workgroups a CU's LDS admits stay resident beside one
 //  wavefront per SIMD of the next batch's march, which runs on a second stream under this kernel)
-template <int C, bool AMP = false, bool RANGE = false>
+template <int C, bool AMP = false, bool RANGE = false, bool COUNT = false>
 __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(const int32_t* __restrict__ offsets, float* __restrict__ P,
                                                                  float* __restrict__ G, float* __restrict__ M,
                                                                  float* __restrict__ V, uint32_t L, uint32_t min_tiles,
@@ -1163,13 +1166,27 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
                                                                  uint32_t* __restrict__ other_overflow, AdamScalars ad,
                                                                  SmallAdam small, AmpAdam amp = AmpAdam{},
                                                                  OwnerRange own = OwnerRange{0, 0, 1.0f},
-                                                                 PartialSums ps = PartialSums{nullptr, nullptr, 0, 0, 0}) {
+                                                                 PartialSums ps = PartialSums{nullptr, nullptr, 0, 0, 0},
+                                                                 MarchCountJob cj = MarchCountJob{}) {
     // (dynamic: a static 32 KiB array tells the compiler that four workgroups fill the CU, and it then spends the registers
     //  of a fifth wavefront per SIMD on scheduling freedom -- see the note above the kernel)
     extern __shared__ __attribute__((aligned(16))) double acc[];
     __shared__ uint32_t s_n[64];
+    // COUNT: the launch's first cj.blocks workgroups are the next batch's march count pass (march_lattice.h; its two
+    // lookup tables live in the accumulators' LDS); the rest see themselves as workgroup `bid` of `nb`
+    uint32_t bid = blockIdx.x, nb = gridDim.x;
+    if constexpr (COUNT) {
+        static_assert(kTileThreads == 256 && kTileAccBytes >= (2 * kTabH + 1) * 4, "the count pass runs in 256-thread workgroups");
+        if (blockIdx.x < cj.blocks) {
+            float* s_face = reinterpret_cast<float*>(acc);
+            march_count_block(cj, blockIdx.x, cj.blocks, s_face, reinterpret_cast<uint32_t*>(s_face + kTabH + 1));
+            return;
+        }
+        bid -= cj.blocks;
+        nb -= cj.blocks;
+    }
 #ifdef ENERF_TA_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && bid < 2048) g_ta_wg[2 * bid] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
     TA_MARK_IN(4);
     constexpr uint32_t R = kTileElems / C;
@@ -1187,7 +1204,7 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     }
     const bool have_records = region != 0;
     const bool spilled = have_records && overflow[0] != 0;
-    if (other_overflow && blockIdx.x == 0 && threadIdx.x == 0) other_overflow[0] = 0;     // the next session's counter
+    if (other_overflow && bid == 0 && threadIdx.x == 0) other_overflow[0] = 0;     // the next session's counter
     uint32_t total = 0;
     for (uint32_t lv = 0; lv < L; lv++) total += div_up((uint32_t)(offsets[lv + 1] - offsets[lv]), R);
     auto decode = [&](uint32_t item, uint32_t& level, uint32_t& tile) {
@@ -1217,11 +1234,11 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     // workgroups had a fourth tile of the 3179 and the kernel's last ~15 us ran at a tenth of the chip.
     __shared__ uint32_t s_next;
     uint32_t* next_counter = g_ta_next;
-    uint32_t item = blockIdx.x;
+    uint32_t item = bid;
     uint32_t n_ahead = first_cursor(item);
     while (item < total) {
         uint32_t pulled = 0;
-        if (threadIdx.x == 0) pulled = gridDim.x + atomicAdd(next_counter, 1u);
+        if (threadIdx.x == 0) pulled = nb + atomicAdd(next_counter, 1u);
         uint32_t level, tile;
         decode(item, level, tile);
         uint32_t n_first = n_ahead;
@@ -1401,10 +1418,10 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
         // chains, fixed order), combined through the tile sums' LDS, which nobody uses any more; the sum is stored as the
         // gradient and goes straight into the element's update
         float* red = reinterpret_cast<float*>(acc);
-        const uint32_t chunk = div_up(ps.n, gridDim.x);
+        const uint32_t chunk = div_up(ps.n, nb);
         const uint32_t j = threadIdx.x & 15u, q = threadIdx.x >> 4;
         for (uint32_t c0 = 0; c0 < chunk; c0 += 16u) {
-            const uint32_t i = blockIdx.x * chunk + c0 + j;
+            const uint32_t i = bid * chunk + c0 + j;
             const bool live = c0 + j < chunk && i < ps.n;
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
             if (live) {
@@ -1441,9 +1458,9 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     } else if (small.count != 0 && (!AMP || !skip)) {
         uint32_t total_small = 0;
         for (uint32_t k = 0; k < small.count; k++) total_small += small.n[k];
-        const uint32_t chunk = div_up(total_small, gridDim.x);
+        const uint32_t chunk = div_up(total_small, nb);
         for (uint32_t t = threadIdx.x; t < chunk; t += kTileThreads) {
-            uint32_t e = blockIdx.x * chunk + t;
+            uint32_t e = bid * chunk + t;
             if (e >= total_small) break;
             uint32_t k = 0;
             while (e >= small.n[k]) { e -= small.n[k]; k++; }
@@ -1458,11 +1475,11 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     }
 #ifdef ENERF_TA_TIMING
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x < 2048) g_ta_wg[2 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && bid < 2048) g_ta_wg[2 * bid + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
     TA_MARK_OUT(5);
     // (nobody asks for a tile any more once a workgroup is here: its own request came back >= total)
-    if (threadIdx.x == 0 && atomicInc(&g_ta_next[1], gridDim.x - 1u) == gridDim.x - 1u) g_ta_next[0] = 0;
+    if (threadIdx.x == 0 && atomicInc(&g_ta_next[1], nb - 1u) == nb - 1u) g_ta_next[0] = 0;
 }
 
 #ifdef ENERF_TA_TIMING
@@ -1546,6 +1563,8 @@ static SplitJob g_carry;              // enerf::grid_fwd_carry
 static bool g_carry_armed = false;
 static PartialSums g_partial_sums;     // enerf::grid_adam_partial_sums
 static bool g_partial_armed = false;
+static MarchCountJob g_count_job;       // enerf::tile_adam_carry_count
+static bool g_count_armed = false;
 
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
@@ -1697,6 +1716,13 @@ void enerf::grid_valid_rows(const int32_t* device_count, uint32_t base, uint32_t
     g_grid_valid_rows = device_count;
     g_grid_valid_base = device_count ? base : 0u;
     g_grid_valid_cap = device_count ? cap : 0u;
+}
+
+bool enerf::tile_adam_carry_count(const MarchCountJob* job) {
+    const bool waiting = g_count_armed;
+    g_count_armed = job != nullptr && job->blocks != 0 && job->N != 0;
+    if (g_count_armed) g_count_job = *job;
+    return waiting;
 }
 
 bool enerf::grid_fwd_carry(const SplitJob* job) {
@@ -1915,7 +1941,16 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
     }
     switch (C) {
         case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
-        case 2: k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{}, OwnerRange{0, 0, 1.0f}, ps); break;
+        case 2:
+            if (g_count_armed) {                     // enerf::tile_adam_carry_count: the next batch's march count pass rides along
+                g_count_armed = false;
+                k_grid_tile_adam<2, false, false, true><<<kTilesPerCu * num_cus() + g_count_job.blocks, kTileThreads, kTileAccBytes, s>>>(
+                    offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{},
+                    OwnerRange{0, 0, 1.0f}, ps, g_count_job);
+            } else {
+                k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{}, OwnerRange{0, 0, 1.0f}, ps);
+            }
+            break;
         case 4: k_grid_tile_adam<4><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         case 8: k_grid_tile_adam<8><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         default: ENERF_BADARG("grid_adam_from_records: C must be 1, 2, 4, or 8.");

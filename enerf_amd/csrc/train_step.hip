@@ -30,6 +30,16 @@ static bool g_host_timing = false;
 static bool g_carry_frags = getenv("ENERF_NO_CARRY_FRAGS") == nullptr;      // enerf_debug_carry_frags
 // the fused MLP's weight-gradient partial sums summed by the optimizer's launch (ENERF_NO_FOLD_REDUCE: by k_mlp32_reduce_w2)
 static bool g_fold_reduce = getenv("ENERF_NO_FOLD_REDUCE") == nullptr;      // enerf_debug_fold_reduce
+// the next batch's march without a second stream: its count pass rides in the table optimizer's launch, scan + write are one
+// launch behind it (common.h MarchCountJob; ENERF_NO_CARRY_COUNT / enerf_debug_carry_count(0): the side-stream march)
+static bool g_carry_count = getenv("ENERF_NO_CARRY_COUNT") == nullptr;
+static int g_carried_steps = 0;          // steps whose next batch was marched that way so far (enerf_debug_carry_count(-2))
+extern "C" int enerf_debug_carry_count(int on) {
+    if (on == -2) return g_carried_steps;
+    const int prev = g_carry_count ? 1 : 0;
+    if (on >= 0) g_carry_count = on != 0;
+    return prev;
+}
 
 extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     if (!a) ENERF_BADARG("train_step_mse: null arguments");
@@ -44,6 +54,8 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
     bool rows_set = false, defer_set = false, signal_set = false, fused_mlp = false, carry_set = false, own_sums = false;
+    bool count_carried = false;
+    MarchCountJob count_job{};
     uint32_t frags_built = 0;
     PartialSums sums{nullptr, nullptr, 0, 0, 0};
     int slot = 0;
@@ -97,8 +109,20 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
     STEP(enerf_composite_rays_train_fwd_bwd_mse(a->sigma, a->rgb, a->deltas, a->rays, M, N, a->weights_sum, a->image,
                                                 nullptr, 0, a->bg_scalar, a->out_image, a->target, a->grad_scale,
                                                 a->counter, a->g_sigmas, a->g_rgbs, a->loss, s));
+    // ---- the next batch's march: carried by the optimizer's launch where that applies (decided here, because the
+    //      side-stream form needs its signal armed on the MLP backward)
+    if (a->next_rays_o && g_carry_count && !(a->flags & 1u)) {
+        enerf_march_fuse_near_far(a->aabb, a->min_near);           // (near / far inside the count pass)
+        const int b = march_carry_begin(a->next_rays_o, a->next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
+                                        a->next_N, a->cascade, a->grid_size, a->next_M, a->next_nears, a->next_fars,
+                                        a->next_xyzs, a->next_dirs, a->next_deltas, a->next_rays, a->next_counter,
+                                        a->perturb, a->march_flags, (hipStream_t)s, &count_job);
+        if (b < 0) { rc = b; goto done; }
+        count_carried = b == 0;
+        if (!count_carried) enerf_march_fuse_near_far(nullptr, 0.0f);    // (nothing consumed: the ordinary call arms it again)
+    }
     // ---- MLP backward (the colour net's partial sums wait for the sigma net's reduce launch)
-    if (a->next_rays_o) {
+    if (a->next_rays_o && !count_carried) {
         enerf_mlp32_signal_next_reduce(1);
         signal_set = true;
     }
@@ -126,7 +150,7 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         rows_set = false;
     }
     // ---- the next batch's march, on the side stream, behind the MLP backward (it reads no parameter)
-    if (a->next_rays_o) {
+    if (a->next_rays_o && !count_carried) {
         enerf_mlp32_signal_next_reduce(0);
         signal_set = false;
         enerf_stream_t ss = a->side_stream;
@@ -153,6 +177,7 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
                                        a->level_scale_log2, a->base_resolution, 0, a->dfeat, a->dfeat, a->gridtype,
                                        ENERF_F32, 2, in_add, in_mul, 1, M, s));
     if (own_sums) grid_adam_partial_sums(&sums);
+    if (count_carried) tile_adam_carry_count(&count_job);
     STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr,
                                          a->beta1, a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g,
                                          a->small_m, a->small_v, a->small_n, a->small_lr, a->small_step, s));
@@ -161,12 +186,23 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
         rc = ENERF_E_BADARG;
     }
     own_sums = false;
+    if (count_carried && !rc) {
+        // (an optimizer form that carries nothing -- loss scaling armed -- leaves the job waiting: counted by its own launch)
+        if (tile_adam_carry_count(nullptr)) STEP(march_carry_count_now(&count_job, (hipStream_t)s));
+        STEP(march_carry_end((hipStream_t)s));
+        count_carried = false;
+        g_carried_steps++;
+    }
 done:
 #undef STEP
     // (one-shot march requests never outlive the step they were armed for -- csrc/raymarching.hip: MarchOneShot)
     enerf_march_fuse_near_far(nullptr, 0.0f);
     enerf_march_mirror_count(nullptr);
     grid_valid_rows(nullptr, 0, 0);
+    if (count_carried) {                   // (failed between march_carry_begin and march_carry_end)
+        tile_adam_carry_count(nullptr);
+        march_carry_abort();
+    }
     if (own_sums) grid_adam_partial_sums(nullptr);
     if (carry_set) {                       // (the launch that should have carried the fragments' build never ran)
         grid_fwd_carry(nullptr);

@@ -688,6 +688,14 @@ int enerf_debug_carry_frags(int on);
  * small tensors (no k_mlp32_reduce_w2 launch in between; the sums land in the gradient tensors all the same); on = 0
  * switches that off (testing aid; < 0 only reads).  Returns the previous setting. */
 int enerf_debug_fold_reduce(int on);
+/* ... and marches the NEXT batch without a second stream: the march's count pass rides in the table optimizer's launch
+ * (extra workgroups; enerf_debug_march_carry_blocks sets how many, 0 = two per compute unit), its scan + write are one launch
+ * behind it on the step's own stream -- no cross-stream signal behind the MLP backward, no event wait at the head of the next
+ * step.  Same samples, same offsets.  Served where the wave-per-ray fixed-step marcher is (dt_gamma = 0, at most 16384 rays)
+ * and no count mirror is armed; everything else keeps the side-stream march.  on = 0 switches it off (-1 only reads).
+ * Returns the previous setting; on = -2 returns the number of steps marched that way so far. */
+int enerf_debug_carry_count(int on);
+int enerf_debug_march_carry_blocks(uint32_t blocks);
 
 /* The event-only step (Trainer.train_step_events, nerf/utils.py:482-546, event_only = 1, C_thres != -1) the same way: TWO
  * renders -- the event pairs' rays at the two poses -- blended with one background colour, the event loss on the two
