@@ -111,7 +111,7 @@ extern "C" int enerf_train_step_mse(const enerf_train_step_args* a) {
                                                 a->counter, a->g_sigmas, a->g_rgbs, a->loss, s));
     // ---- the next batch's march: carried by the optimizer's launch where that applies (decided here, because the
     //      side-stream form needs its signal armed on the MLP backward)
-    if (a->next_rays_o && g_carry_count && !(a->flags & 1u)) {
+    if (a->next_rays_o && g_carry_count && !(a->flags & 1u) && !(a->march_flags & 16u)) {
         enerf_march_fuse_near_far(a->aabb, a->min_near);           // (near / far inside the count pass)
         const int b = march_carry_begin(a->next_rays_o, a->next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
                                         a->next_N, a->cascade, a->grid_size, a->next_M, a->next_nears, a->next_fars,

@@ -271,6 +271,13 @@ def early_mean_count(model):
     total_step = min(16, int(model.local_step))
     if total_step == 0:
         return (None, 0)                           # nothing to average: mean_count keeps its value
+    staged = model.__dict__.pop("_ring_copy", None)
+    if staged is not None and staged[1] == int(model.local_step) and not getattr(model, "_premarched", None):
+        # stage_ring_copy: the ring was copied on the training stream in front of the window's last step (whose march-free
+        # call has long been queued behind it); nothing has marched since
+        staged[0].synchronize()
+        counted = int(model._ring_host[:total_step, 0].to(torch.int64).sum())
+        return (int(counted / total_step), total_step)
     last = getattr(model, "_last_march_event", None)
     stash = getattr(model, "_premarched", None)
     if last is None or stash:                      # the last march ran on the training stream / an unconsumed stage
@@ -286,6 +293,20 @@ def early_mean_count(model):
     done.synchronize()
     counted = int(host[:total_step, 0].to(torch.int64).sum())
     return (int(counted / total_step), total_step)
+
+
+def stage_ring_copy(model):
+    """The window's step counters to pinned host memory, on the CURRENT stream, now.  Where the marches run on the training
+    stream itself (the one-call step carries the next batch's march in its optimizer launch: csrc/train_step.hip), early_mean_count
+    has no side stream to read the ring behind: TrainHarness calls this in front of the window's LAST step -- which marches
+    nothing, the update that follows voids any stage -- so that the copy is complete a whole step before the update needs it."""
+    host = getattr(model, "_ring_host", None)
+    if host is None:
+        host = model._ring_host = torch.empty(16, 2, dtype=torch.int32, pin_memory=True)
+    host.copy_(model._buffers["step_counter"], non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    model._ring_copy = (done, int(model.local_step))
 
 
 def prefetch_march(model, rays_o, rays_d, perturb=True, dt_gamma=0, max_steps=1024, stream=None, background=True,
@@ -738,7 +759,8 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                 a.dt_gamma = float(dt_gamma)
                 a.next_N, a.next_M, a.max_steps = Nn, Mn, int(max_steps)
                 a.perturb = 1 if perturb else 0
-                a.march_flags = occupied_box_flag(model) | 3 | 8
+                # (bit 4: this march stays on the side stream -- the cold window reads its count back behind it there)
+                a.march_flags = occupied_box_flag(model) | 3 | 8 | (16 if cold_next else 0)
                 for name in ("nears", "fars", "xyzs", "dirs", "deltas", "rays", "counter"):
                     setattr(a, "next_" + name, nxt[name].data_ptr())
                 key = (no.data_ptr(), nd.data_ptr(), Nn, bool(perturb), float(dt_gamma), int(max_steps))
@@ -784,7 +806,10 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
             cold_host = hosts[which]
             cold_host.fill_(-1)               # (what _check_cold_stage watches for: both words are >= 0 once the count has landed)
             L.check(L.lib().enerf_march_mirror_count(cold_host.data_ptr()), "march_mirror_count")
+        carried_before = L.lib().enerf_debug_carry_count(-2) if nxt is not None else 0
         L.check(L.lib().enerf_train_step_mse(_ct.byref(a)), "train_step_mse")
+        # (the next batch's march may have ridden in this call's own launches, on this stream: no event to wait for then)
+        march_carried = nxt is not None and L.lib().enerf_debug_carry_count(-2) != carried_before
         # (the launch counters bench.py reads: the library issued one grid_encode_forward / backward over M points)
         from .backends import _gridencoder as _gbk
         _gbk.STATS["fwd_points"] += M
@@ -809,11 +834,13 @@ def train_step_native(model, rays_o, rays_d, target, opt, next_rays=None, side_s
                     done.record(side_stream)
                 nxt["cold_check"] = (done, host, Mn)
                 nxt["ready"] = done
+            elif march_carried:
+                nxt["ready"] = None                  # (marched on this very stream)
             else:
                 nxt["ready"] = torch.cuda.Event()
                 nxt["ready"].record(side_stream)
             stash[key] = nxt
-            model._last_march_event = (nxt["ready"], side_stream)
+            model._last_march_event = None if march_carried else (nxt["ready"], side_stream)
         if not raw:
             views = ctx.get("grad_views")
             if views is None:

@@ -782,6 +782,11 @@ class TrainHarness:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             nxt = next_rays
+        if (nxt is None and self.early_budget and self.prefetch and self.global_step % self.update_interval == 0
+                and getattr(m, "_last_march_event", None) is None and not data_parallel):
+            # the window's last step (the next call starts with update_extra_state): where the marches ride on this
+            # stream, the ring of step counters is copied out here, a whole step before the update wants the budget
+            fused_render.stage_ring_copy(m)
         loss = self._loss_slot()
         own = self._owner_range() if data_parallel else None
         if own is not None:

@@ -648,7 +648,9 @@ typedef struct enerf_train_step_args {
      * rgb [M,out_c], weights_sum [N], image [N,3], out_image [N,3], g_sigmas [M], g_rgbs [M,3], dx32 [M,32],
      * dfeat [16,Mp,2] (Mp = M rounded up to 32) */
     float *feats, *h32, *fb_s, *fb_c, *sigma, *rgb, *weights_sum, *image, *out_image, *g_sigmas, *g_rgbs, *dx32, *dfeat;
-    /* next batch's march (next_rays_o == NULL: none) */
+    /* next batch's march (next_rays_o == NULL: none).  march_flags: enerf_march_rays_train_ex's zero_unwritten bits 0-3,
+     * plus bit 4 = keep this march on side_stream (the caller reads its counter back behind it there); without bit 4 the
+     * march may ride in this call's own launches on `stream` (enerf_debug_carry_count) and side_stream sees nothing */
     const float *next_rays_o, *next_rays_d, *aabb;
     const uint8_t* bitfield;
     float min_near, dt_gamma;
