@@ -7,6 +7,7 @@
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
 #include <float.h>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -1731,7 +1732,7 @@ struct CarriedMarch {
 CarriedMarch g_carried;
 }  // namespace
 // workgroups of the carrying launch that count (enerf_debug_march_carry_blocks; 0 = two per compute unit)
-static uint32_t g_march_carry_blocks = 0;
+static uint32_t g_march_carry_blocks = getenv("ENERF_MARCH_CARRY_BLOCKS") ? (uint32_t)atoi(getenv("ENERF_MARCH_CARRY_BLOCKS")) : 0u;
 extern "C" int enerf_debug_march_carry_blocks(uint32_t blocks) {
     g_march_carry_blocks = blocks;
     return 0;
