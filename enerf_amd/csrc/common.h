@@ -71,7 +71,7 @@ uint32_t num_cus();                    // compute units of the current device (2
 int workspace_family_enter(int family, hipStream_t s);
 // process-wide session state belongs to the first device that used it: != 0 (error set) when another device is current
 int single_device_guard(const char* what);
-enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_AABB = 7, WS_AABB_CALL = 8, WS_FFMLP_W = 9, WS_NERF_FRAGS = 10, WS_NERF_PART = 11, WS_SLOTS = 12 };
+enum { WS_SCAN = 0, WS_COMPACT = 1, WS_FFMLP = 2, WS_GRIDBWD = 3, WS_MARCH = 4, WS_DENSITY = 5, WS_MLP32_DEFER = 6, WS_AABB = 7, WS_AABB_CALL = 8, WS_FFMLP_W = 9, WS_NERF_FRAGS = 10, WS_NERF_PART = 11, WS_MARCH2 = 12, WS_SLOTS = 13 };
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -144,16 +144,19 @@ struct MarchCountJob {
     uint32_t blocks;
 };
 // gridencoder.hip: the next enerf_grid_adam_from_records(_ex) launch of the plain fp32 C = 2 form carries `job` in
-// job->blocks extra workgroups (one-shot; nullptr disarms).  Returns whether a job armed earlier was still waiting.
+// job->blocks extra workgroups.  Up to TWO jobs may wait (the event step's two renders): each call with a job appends;
+// nullptr disarms.  Returns whether a job armed earlier was still waiting.
 bool tile_adam_carry_count(const MarchCountJob* job);
 // raymarching.hip: march_rays_train_ex(...) split around a carrying launch.  begin: 0 = *job is the call's count pass (the
 // workspace is prepared, the one-shot near / far request consumed) and the call's scan + write are remembered for
 // march_carry_end; 1 = this call cannot be served that way (another marcher, a count mirror armed, a kept counter ...):
 // nothing consumed, make the ordinary call; < 0 = error.  end: scan + write on `s` (behind the launch that carried the job).
+// Up to two marches may be pending (begun one after the other: the second uses a chunk log of its own, WS_MARCH2); end
+// finishes all of them in the order they were begun.  `share`: how many marches will ride in the launch (splits the workgroups).
 int march_carry_begin(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                       const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
-                      uint32_t perturb, uint32_t flags, hipStream_t s, MarchCountJob* job);
+                      uint32_t perturb, uint32_t flags, hipStream_t s, MarchCountJob* job, uint32_t share = 1);
 int march_carry_end(hipStream_t s);
 int march_carry_count_now(const MarchCountJob* job, hipStream_t s);     // (the carrying launch did not take the job)
 void march_carry_abort();                                               // (a step failed between begin and end)

@@ -1167,7 +1167,8 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
                                                                  SmallAdam small, AmpAdam amp = AmpAdam{},
                                                                  OwnerRange own = OwnerRange{0, 0, 1.0f},
                                                                  PartialSums ps = PartialSums{nullptr, nullptr, 0, 0, 0},
-                                                                 MarchCountJob cj = MarchCountJob{}) {
+                                                                 MarchCountJob cj = MarchCountJob{},
+                                                                 MarchCountJob cj2 = MarchCountJob{}) {
     // (dynamic: a static 32 KiB array tells the compiler that four workgroups fill the CU, and it then spends the registers
     //  of a fifth wavefront per SIMD on scheduling freedom -- see the note above the kernel)
     extern __shared__ __attribute__((aligned(16))) double acc[];
@@ -1177,13 +1178,16 @@ __global__ void __launch_bounds__(kTileThreads) ENERF_TA_REGS k_grid_tile_adam(c
     uint32_t bid = blockIdx.x, nb = gridDim.x;
     if constexpr (COUNT) {
         static_assert(kTileThreads == 256 && kTileAccBytes >= (2 * kTabH + 1) * 4, "the count pass runs in 256-thread workgroups");
-        if (blockIdx.x < cj.blocks) {
+        const uint32_t ncount = cj.blocks + cj2.blocks;      // (the event step's two renders: two jobs, one after the other)
+        if (blockIdx.x < ncount) {
             float* s_face = reinterpret_cast<float*>(acc);
-            march_count_block(cj, blockIdx.x, cj.blocks, s_face, reinterpret_cast<uint32_t*>(s_face + kTabH + 1));
+            uint32_t* s_expand = reinterpret_cast<uint32_t*>(s_face + kTabH + 1);
+            if (blockIdx.x < cj.blocks) march_count_block(cj, blockIdx.x, cj.blocks, s_face, s_expand);
+            else march_count_block(cj2, blockIdx.x - cj.blocks, cj2.blocks, s_face, s_expand);
             return;
         }
-        bid -= cj.blocks;
-        nb -= cj.blocks;
+        bid -= ncount;
+        nb -= ncount;
     }
 #ifdef ENERF_TA_TIMING
     if (threadIdx.x == 0 && bid < 2048) g_ta_wg[2 * bid] = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -1563,8 +1567,8 @@ static SplitJob g_carry;              // enerf::grid_fwd_carry
 static bool g_carry_armed = false;
 static PartialSums g_partial_sums;     // enerf::grid_adam_partial_sums
 static bool g_partial_armed = false;
-static MarchCountJob g_count_job;       // enerf::tile_adam_carry_count
-static bool g_count_armed = false;
+static MarchCountJob g_count_job[2];    // enerf::tile_adam_carry_count
+static uint32_t g_count_armed = 0;      // jobs waiting
 
 template <typename T, int D>
 int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
@@ -1719,9 +1723,13 @@ void enerf::grid_valid_rows(const int32_t* device_count, uint32_t base, uint32_t
 }
 
 bool enerf::tile_adam_carry_count(const MarchCountJob* job) {
-    const bool waiting = g_count_armed;
-    g_count_armed = job != nullptr && job->blocks != 0 && job->N != 0;
-    if (g_count_armed) g_count_job = *job;
+    const bool waiting = g_count_armed != 0;
+    if (job == nullptr || job->blocks == 0 || job->N == 0) {
+        g_count_armed = 0;
+        return waiting;
+    }
+    if (g_count_armed >= 2u) g_count_armed = 0;      // (never more than two: a third starts over)
+    g_count_job[g_count_armed++] = *job;
     return waiting;
 }
 
@@ -1942,11 +1950,12 @@ int enerf_grid_adam_from_records_ex(float* p, float* g, float* m, float* v, cons
     switch (C) {
         case 1: k_grid_tile_adam<1><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small); break;
         case 2:
-            if (g_count_armed) {                     // enerf::tile_adam_carry_count: the next batch's march count pass rides along
-                g_count_armed = false;
-                k_grid_tile_adam<2, false, false, true><<<kTilesPerCu * num_cus() + g_count_job.blocks, kTileThreads, kTileAccBytes, s>>>(
+            if (g_count_armed) {                     // enerf::tile_adam_carry_count: the next batch's march count pass(es) ride along
+                const MarchCountJob j0 = g_count_job[0], j1 = g_count_armed > 1u ? g_count_job[1] : MarchCountJob{};
+                g_count_armed = 0;
+                k_grid_tile_adam<2, false, false, true><<<kTilesPerCu * num_cus() + j0.blocks + j1.blocks, kTileThreads, kTileAccBytes, s>>>(
                     offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{},
-                    OwnerRange{0, 0, 1.0f}, ps, g_count_job);
+                    OwnerRange{0, 0, 1.0f}, ps, j0, j1);
             } else {
                 k_grid_tile_adam<2><<<kTilesPerCu * num_cus(), kTileThreads, kTileAccBytes, s>>>(offsets, p, g, m, v, L, min_tiles, recs, cursors, region, overflow, other, ad, small, AmpAdam{}, OwnerRange{0, 0, 1.0f}, ps);
             }

@@ -1283,7 +1283,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* nears,
                              const float* fars, int32_t* rays, int32_t* counter, uint32_t perturb, bool background,
                              bool use_box, bool fresh_counter, const MarchOneShot& once, hipStream_t s,
-                             MarchCountJob* carry_job = nullptr) {
+                             MarchCountJob* carry_job = nullptr, int ws_slot = WS_MARCH) {
     if (int e = workspace_family_enter(0, s)) return e;
     const float* nf_aabb = once.nf_aabb;
     const float g_nf_min_near = once.nf_min_near;
@@ -1296,7 +1296,7 @@ static int march_train_count(const float* rays_o, const float* rays_d, const uin
         // fixed step: wave-per-ray lattice marcher (bit-identical results, 64 lattice points per ray in flight)
         // the count pass logs every emitting chunk; the write pass replays the log
         const size_t log_bytes = march_log_bytes(N, H);
-        char* ws = (char*)workspace(WS_MARCH, log_bytes + (size_t)N * sizeof(uint32_t) + 512);
+        char* ws = (char*)workspace(ws_slot, log_bytes + (size_t)N * sizeof(uint32_t) + 512);
         if (!ws) return ENERF_E_NOMEM;
         ChunkEntry* log = (ChunkEntry*)ws;
         uint32_t* nlog = (uint32_t*)(ws + log_bytes);
@@ -1729,7 +1729,8 @@ struct CarriedMarch {
     const ChunkEntry* log = nullptr;
     const uint32_t* nlog = nullptr;
 };
-CarriedMarch g_carried;
+CarriedMarch g_carried[2];
+uint32_t g_carried_n = 0;
 }  // namespace
 // workgroups of the carrying launch that count (enerf_debug_march_carry_blocks; 0 = two per compute unit)
 static uint32_t g_march_carry_blocks = getenv("ENERF_MARCH_CARRY_BLOCKS") ? (uint32_t)atoi(getenv("ENERF_MARCH_CARRY_BLOCKS")) : 0u;
@@ -1741,32 +1742,34 @@ extern "C" int enerf_debug_march_carry_blocks(uint32_t blocks) {
 int enerf::march_carry_begin(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                              const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
-                             uint32_t perturb, uint32_t flags, hipStream_t s, MarchCountJob* job) {
+                             uint32_t perturb, uint32_t flags, hipStream_t s, MarchCountJob* job, uint32_t share) {
     // what the carried form serves: the wave-per-ray lattice marcher, one-launch scan sizes, a counter taken as (0, 0)
     // (flags bit 3), no count mirror waiting (the cold window's host watches for k_march_scan's store)
     if (N == 0 || N > 16384u || C == 0 || H < 2 || max_steps == 0 || !(flags & 8u) || g_count_mirror != nullptr ||
-        g_carried.pending || !march_uses_lattice(dt_gamma, max_steps, C, H) || march_uses_threads(N, H))
+        g_carried_n >= 2u || !march_uses_lattice(dt_gamma, max_steps, C, H) || march_uses_threads(N, H))
         return 1;
     const MarchOneShot once = march_take_oneshot();
     MarchCountJob j{};
+    // (a second pending march logs into a workspace of its own: the first's log waits for its write pass)
     const int rc = march_train_count(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, counter,
-                                     perturb, true, (flags & 4u) != 0, true, once, s, &j);
+                                     perturb, true, (flags & 4u) != 0, true, once, s, &j, g_carried_n == 0 ? WS_MARCH : WS_MARCH2);
     if (rc) return rc;
     if (!j.log) {
         set_error("march_carry_begin: the count pass was not handed over");
         return ENERF_E_BADARG;
     }
-    const uint32_t want = g_march_carry_blocks ? g_march_carry_blocks : 2u * num_cus();
-    j.blocks = min(div_up(N, 4), want);
+    const uint32_t want = (g_march_carry_blocks ? g_march_carry_blocks : 2u * num_cus()) / (share ? share : 1u);
+    j.blocks = min(div_up(N, 4), want ? want : 1u);
     *job = j;
-    g_carried = CarriedMarch();
-    g_carried.pending = true;
-    g_carried.rays_o = rays_o; g_carried.rays_d = rays_d; g_carried.grid = grid; g_carried.bound = bound;
-    g_carried.max_steps = max_steps; g_carried.N = N; g_carried.C = C; g_carried.H = H; g_carried.M = M;
-    g_carried.nears = nears; g_carried.fars = fars; g_carried.xyzs = xyzs; g_carried.dirs = dirs; g_carried.deltas = deltas;
-    g_carried.rays = rays; g_carried.counter = counter; g_carried.perturb = perturb; g_carried.zero_unwritten = flags & 1u;
-    g_carried.log = static_cast<const ChunkEntry*>(j.log);
-    g_carried.nlog = j.nlog;
+    CarriedMarch& c = g_carried[g_carried_n++];
+    c = CarriedMarch();
+    c.pending = true;
+    c.rays_o = rays_o; c.rays_d = rays_d; c.grid = grid; c.bound = bound;
+    c.max_steps = max_steps; c.N = N; c.C = C; c.H = H; c.M = M;
+    c.nears = nears; c.fars = fars; c.xyzs = xyzs; c.dirs = dirs; c.deltas = deltas;
+    c.rays = rays; c.counter = counter; c.perturb = perturb; c.zero_unwritten = flags & 1u;
+    c.log = static_cast<const ChunkEntry*>(j.log);
+    c.nlog = j.nlog;
     return 0;
 }
 
@@ -1778,21 +1781,24 @@ int enerf::march_carry_count_now(const MarchCountJob* job, hipStream_t s) {
     return 0;
 }
 // a step that failed between begin and end
-void enerf::march_carry_abort() { g_carried = CarriedMarch(); }
+void enerf::march_carry_abort() { g_carried_n = 0; }
 
 int enerf::march_carry_end(hipStream_t s) {
-    if (!g_carried.pending) {
+    if (g_carried_n == 0) {
         set_error("march_carry_end: no carried march is pending");
         return ENERF_E_BADARG;
     }
-    const CarriedMarch m = g_carried;
-    g_carried = CarriedMarch();
+    const uint32_t n = g_carried_n;
+    g_carried_n = 0;
     if (int e = workspace_family_enter(0, s)) return e;
     ProfScope prof(ENERF_K_MARCH_TRAIN, s);
-    const uint32_t ray_blocks = div_up(m.N, 4);
-    k_march_scan_write_w<<<ray_blocks + (m.zero_unwritten ? 128u : 0u), 256, 0, s>>>(
-        m.rays_o, m.rays_d, m.grid, m.bound, m.max_steps, m.N, m.C, m.H, m.M, m.nears, m.fars, m.xyzs, m.dirs, m.deltas,
-        m.rays, m.perturb, m.log, m.nlog, m.counter, m.zero_unwritten, ray_blocks);
+    for (uint32_t k = 0; k < n; k++) {
+        const CarriedMarch m = g_carried[k];
+        const uint32_t ray_blocks = div_up(m.N, 4);
+        k_march_scan_write_w<<<ray_blocks + (m.zero_unwritten ? 128u : 0u), 256, 0, s>>>(
+            m.rays_o, m.rays_d, m.grid, m.bound, m.max_steps, m.N, m.C, m.H, m.M, m.nears, m.fars, m.xyzs, m.dirs, m.deltas,
+            m.rays, m.perturb, m.log, m.nlog, m.counter, m.zero_unwritten, ray_blocks);
+    }
     ENERF_LAUNCH_CHECK("march_rays_train (carried)");
     return 0;
 }

@@ -230,6 +230,8 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
     if (a->mlp_precision >= 0) prev_prec = enerf_mlp32_precision(a->mlp_precision);
     int rc = 0;
     bool rows_set = false, defer_set = false, signal_set = false, carry_set = false, own_sums = false;
+    uint32_t counts_carried = 0;           // the next step's marches riding in this step's optimizer launch
+    MarchCountJob count_jobs[2] = {};
     uint32_t frags_built = 0;
     PartialSums sums{nullptr, nullptr, 0, 0, 0};
     const bool march_next = r0.next_rays_o != nullptr || r1.next_rays_o != nullptr;
@@ -293,7 +295,29 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         enerf_mlp32_valid_rows_ex(r1.counter, M, M);
         rows_set = true;
     }
-    if (march_next) {
+    // ---- the next step's two marches: carried by the optimizer's launch where that applies (both or neither; decided here,
+    //      because the side-stream form needs its signal armed on the MLP backward)
+    if (march_next && g_carry_count && !(a->march_flags & 16u)) {
+        const uint32_t want = (r0.next_rays_o ? 1u : 0u) + (r1.next_rays_o ? 1u : 0u);
+        for (int q = 0; q < 2; q++) {
+            const enerf_step_render& n = a->r[q];
+            if (!n.next_rays_o) continue;
+            enerf_march_fuse_near_far(a->aabb, a->min_near);       // (near / far inside the count pass)
+            const int b = march_carry_begin(n.next_rays_o, n.next_rays_d, a->bitfield, a->bound, a->dt_gamma, a->max_steps,
+                                            n.next_N, a->cascade, a->grid_size, n.next_M, n.next_nears, n.next_fars,
+                                            n.next_xyzs, n.next_dirs, n.next_deltas, n.next_rays, n.next_counter, a->perturb,
+                                            a->march_flags, (hipStream_t)s, &count_jobs[counts_carried], want);
+            if (b < 0) { rc = b; goto done; }
+            if (b != 0) {                                           // not this way: both marches take the side stream
+                enerf_march_fuse_near_far(nullptr, 0.0f);
+                march_carry_abort();
+                counts_carried = 0;
+                break;
+            }
+            counts_carried++;
+        }
+    }
+    if (march_next && !counts_carried) {
         enerf_mlp32_signal_next_reduce(1);
         signal_set = true;
     }
@@ -317,7 +341,7 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         enerf_mlp32_valid_rows(nullptr);
         rows_set = false;
     }
-    if (march_next) {
+    if (march_next && !counts_carried) {
         enerf_mlp32_signal_next_reduce(0);
         signal_set = false;
         enerf_stream_t ss = a->side_stream;
@@ -336,6 +360,7 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
                                        a->level_scale_log2, a->base_resolution, 0, a->m_dfeat, a->m_dfeat, a->gridtype,
                                        ENERF_F32, 2, in_add, in_mul, 1, M2, s));
     if (own_sums) grid_adam_partial_sums(&sums);
+    for (uint32_t q = 0; q < counts_carried; q++) tile_adam_carry_count(&count_jobs[q]);
     STEP(enerf_grid_adam_from_records_ex(a->table, a->table_grad, a->table_m, a->table_v, a->offsets, 16, 2, a->lr, a->beta1,
                                          a->beta2, a->eps, a->table_step, a->n_small, a->small_p, a->small_g, a->small_m,
                                          a->small_v, a->small_n, a->small_lr, a->small_step, s));
@@ -344,12 +369,24 @@ static int train_step_events_merged(const enerf_event_step_args* a) {
         rc = ENERF_E_BADARG;
     }
     own_sums = false;
+    if (counts_carried && !rc) {
+        // (an optimizer form that carries nothing leaves the jobs waiting: counted by launches of their own)
+        if (tile_adam_carry_count(nullptr))
+            for (uint32_t q = 0; q < counts_carried; q++) STEP(march_carry_count_now(&count_jobs[q], (hipStream_t)s));
+        STEP(march_carry_end((hipStream_t)s));
+        counts_carried = 0;
+        g_carried_steps++;
+    }
 done:
 #undef STEP
     // (one-shot march requests never outlive the step they were armed for -- csrc/raymarching.hip: MarchOneShot)
     enerf_march_fuse_near_far(nullptr, 0.0f);
     enerf_march_mirror_count(nullptr);
     grid_valid_rows(nullptr, 0, 0);
+    if (counts_carried) {                  // (failed between march_carry_begin and march_carry_end)
+        tile_adam_carry_count(nullptr);
+        march_carry_abort();
+    }
     if (own_sums) grid_adam_partial_sums(nullptr);
     if (carry_set) {                       // (the launch that should have carried the fragments' build never ran)
         grid_fwd_carry(nullptr);

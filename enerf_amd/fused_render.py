@@ -1081,7 +1081,10 @@ def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_st
             for name, arr in zip(("small_p", "small_g", "small_m", "small_v", "small_n", "small_lr", "small_step"), small[1:]):
                 setattr(a, name, _ct.cast(arr, _vp) if arr is not None else None)
         a.lr, a.beta1, a.beta2, a.eps, a.table_step = plan()
+        carried_before = L.lib().enerf_debug_carry_count(-2) if staged else 0
         L.check(L.lib().enerf_train_step_events(_ct.byref(a)), "train_step_events")
+        # (the next step's marches may have ridden in this call's own launches, on this stream: no event to wait for then)
+        march_carried = bool(staged) and L.lib().enerf_debug_carry_count(-2) != carried_before
         from .backends import _gridencoder as _gbk
         # (the launch counters bench.py reads: merged, the library issued ONE grid_encode_forward / backward over 2 M points)
         for points in ([pres[0]["M"] + pres[1]["M"]] if merged else [pre["M"] for pre in pres]):
@@ -1093,12 +1096,14 @@ def train_step_events_native(model, data, loss_opt, opt, next_data=None, side_st
             _gbk.LIFETIME["fwd_points"] += points
             _gbk.LIFETIME["fwd_calls"] += 1
         if staged:
-            ready = torch.cuda.Event()
-            ready.record(side_stream)
+            ready = None
+            if not march_carried:
+                ready = torch.cuda.Event()
+                ready.record(side_stream)
             for key, nxt in staged:
                 nxt["ready"] = ready
                 stash[key] = nxt
-            model._last_march_event = (ready, side_stream)
+            model._last_march_event = None if march_carried else (ready, side_stream)
         views = ctx.get("grad_views")
         if views is None:
             views = ctx["grad_views"] = [g.view_as(p) for p, g in zip(weights, grads)]

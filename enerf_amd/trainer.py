@@ -1051,6 +1051,9 @@ class TrainHarness:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             nxt = next_data
+        if (nxt is None and self.early_budget and self.prefetch and self.global_step % self.update_interval == 0
+                and getattr(m, "_last_march_event", None) is None):
+            fused_render.stage_ring_copy(m)     # (the window's last step, marches on this stream: see _step_rgb_native)
         try:
             loss, _ = fused_render.train_step_events_native(m, data, opt, self.opt, next_data=nxt, side_stream=self._side)
         except BaseException:

@@ -1124,3 +1124,46 @@ def test_march_carried_by_the_optimizer_launch_equals_the_side_stream_march():
     assert float((la - lb).abs().max()) <= 1e-5 * float(lb.abs().max())
     for n, a in pa.items():
         assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
+
+
+def test_event_marches_carried_by_the_optimizer_launch_equal_the_side_stream_marches():
+    """The event-only step's TWO next marches ride in its optimizer launch as two count jobs (the second logs into a chunk log
+    of its own, WS_MARCH2) and are scanned + written by two launches behind it: same counters as with the side-stream marches,
+    losses and parameters to the last bits the table's float atomics leave open."""
+    from enerf_amd import _lib
+    from enerf_amd.events import EventOptions
+    from enerf_amd.network import NeRFNetwork
+    from enerf_amd.trainer import TrainHarness
+    lib = _lib.lib()
+    data = _batches(4, 4096, 2)
+    opt = EventOptions(C_thres=0.2, use_luma=True, linlog=True, event_only=True)
+
+    def batch(i):
+        ro, rd, tg = data[i % len(data)]
+        ro2, rd2, _ = data[(i + 1) % len(data)]
+        return {"images": tg.view(1, -1, 3), "rays_evs_o1": ro.view(1, -1, 3), "rays_evs_d1": rd.view(1, -1, 3),
+                "rays_evs_o2": ro2.view(1, -1, 3), "rays_evs_d2": rd2.view(1, -1, 3),
+                "pols": torch.sign(tg[..., 0] - 0.5).view(1, -1)}
+    runs = {}
+    prev = lib.enerf_debug_carry_count(-1)
+    try:
+        for carried in (1, 0):
+            lib.enerf_debug_carry_count(carried)
+            taken0 = lib.enerf_debug_carry_count(-2)
+            torch.manual_seed(0)
+            model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+            h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
+            torch.manual_seed(3)                               # the step draws a random background colour
+            losses = [h.step_events(batch(i), opt, next_data=batch(i + 1)).clone() for i in range(40)]
+            torch.cuda.synchronize()
+            runs[carried] = (torch.stack(losses).cpu(), model.step_counter.clone().cpu(),
+                             {n: p.detach().clone() for n, p in model.named_parameters()},
+                             lib.enerf_debug_carry_count(-2) - taken0)
+    finally:
+        lib.enerf_debug_carry_count(prev)
+    (la, ca, pa, na), (lb, cb, pb, nb) = runs[1], runs[0]
+    assert na >= 20 and nb == 0, (na, nb)
+    assert torch.equal(ca, cb)
+    assert float(((la - lb).abs() / lb.abs().clamp(min=1e-9)).max()) <= 1e-5
+    for n, a in pa.items():
+        assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
