@@ -47,7 +47,7 @@ MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 MFMA
 MLP_LINEAR_FLOP_FWD = 18688       # nn.Linear nets, sigma 6144 + colour 12544 FLOP/sample forward
 MLP_LINEAR_FLOP_STEP = 56064      # forward + dgrad + wgrad = 3 x forward
 FFMLP_FLOP_FWD = 36864            # FFMLP nets (padded dims), sigma 14336 + colour 22528
-PMC_FILE = "profiles/r05_pmc_hbm_bench.json"
+PMC_FILE = "profiles/r06_pmc_hbm_bench.json"
 REF_ROUTE_FILE = "profiles/r04_ref_route_speed.txt"
 
 
@@ -170,7 +170,7 @@ def pmc_traffic(points_per_launch):
     try:
         path = os.path.join(ROOT, PMC_FILE)
         if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r04_pmc_hbm_bench.json")
+            path = os.path.join(ROOT, "profiles", "r05_pmc_hbm_bench.json")
         with open(path) as f:
             j = json.load(f)
         d = j["k_grid_fwd<float, 3, 2>"]
