@@ -1086,7 +1086,8 @@ def test_weight_gradients_summed_by_the_optimizer_launch_equal_the_reduce_launch
         assert float((pa[n] - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
 
 
-def test_march_carried_by_the_optimizer_launch_equals_the_side_stream_march():
+@pytest.mark.parametrize("n_rays,bound,steps", [(4096, 2, 40), (1000, 3, 36), (16384, 2, 36), (64, 2, 36)])
+def test_march_carried_by_the_optimizer_launch_equals_the_side_stream_march(n_rays, bound, steps):
     """csrc/train_step.hip: in the steady state the next batch's march rides in the table optimizer's launch (count pass) and
     one launch behind it (scan + write) instead of a second stream.  Same rays table, same counter, same samples -- bit for
     bit -- hence the same training run: 40 steps with the carried march against 40 with the side-stream march, sample
@@ -1095,7 +1096,7 @@ def test_march_carried_by_the_optimizer_launch_equals_the_side_stream_march():
     from enerf_amd.network import NeRFNetwork
     from enerf_amd.trainer import TrainHarness
     lib = _lib.lib()
-    data = _batches(4, 4096, 2)
+    data = _batches(4, n_rays, bound)
     runs = {}
     prev = lib.enerf_debug_carry_count(-1)
     try:
@@ -1103,10 +1104,10 @@ def test_march_carried_by_the_optimizer_launch_equals_the_side_stream_march():
             lib.enerf_debug_carry_count(carried)
             taken0 = lib.enerf_debug_carry_count(-2)
             torch.manual_seed(0)
-            model = NeRFNetwork(encoding="hashgrid", bound=2, cuda_ray=True, out_dim_color=3).to(DEV)
+            model = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True, out_dim_color=3).to(DEV)
             h = TrainHarness(model, lr=1e-2, occupancy="synthetic")
             losses, counters = [], []
-            for i in range(40):
+            for i in range(steps):
                 nxt = data[(i + 1) % 4]
                 losses.append(h.step_rgb(*data[i % 4], next_rays=(nxt[0], nxt[1])).detach().clone())
                 counters.append(model.step_counter[model.rendered_counter_slot].clone())
@@ -1117,11 +1118,13 @@ def test_march_carried_by_the_optimizer_launch_equals_the_side_stream_march():
     finally:
         lib.enerf_debug_carry_count(prev)
     (la, ca, pa, na), (lb, cb, pb, nb) = runs[1], runs[0]
-    assert na >= 20 and nb == 0, (na, nb)         # (the steady-state steps; the cold window mirrors its count and keeps the side stream)
+    # (the steady-state steps that have a successor to march: the cold window mirrors its count and keeps the side stream)
+    assert na >= steps // 2 - 2 and nb == 0, (na, nb)
     assert torch.equal(ca, cb)
     # (the table's smallest levels are scattered with float atomics, whose order moves last bits from run to run: the bars
     #  are those of the native-call test above)
-    assert float((la - lb).abs().max()) <= 1e-5 * float(lb.abs().max())
+    #  (small batches scatter EVERY level with atomics: 7e-7 of a 0.06 loss between two runs of the 64-ray case)
+    assert float((la - lb).abs().max()) <= (1e-5 if n_rays >= 4096 else 5e-5) * float(lb.abs().max())
     for n, a in pa.items():
         assert float((a - pb[n]).abs().mean()) <= 1e-4 * float(pb[n].abs().mean()) + 1e-9, n
 
