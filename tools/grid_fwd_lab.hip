@@ -102,6 +102,92 @@ __device__ __forceinline__ void point_level(const float* __restrict__ in, const 
     }
 }
 
+// Round 6: P points per thread (paired loads), every point's gathers requested before the first is used -- more loads in
+// flight per wavefront at the price of registers (occupancy).  Points b, b + 256, ... of a P * 256-point chunk.
+template <int P>
+__device__ __forceinline__ void point_level_multi(const float* __restrict__ in, const float2* __restrict__ grid, float2* outp,
+                                                  size_t ostride, const Tab& tab, uint32_t level, uint32_t b0, uint32_t B) {
+    const uint32_t off0 = tab.off[level], size = tab.off[level + 1] - off0, res = tab.res[level];
+    const float scale = tab.scale[level];
+    const float2* rows = grid + off0;
+    float x[P][3];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const uint32_t b = b0 + 256u * p < B ? b0 + 256u * p : B - 1;
+#pragma unroll
+        for (int d = 0; d < 3; d++) x[p][d] = in[(size_t)b * 3 + d];
+    }
+    float pos[P][3];
+    uint32_t r0[P][4], r1[P][4];
+    bool adj[P][4];
+    F4u q[P][4];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        uint32_t pg[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            pos[p][d] = fmaf(x[p][d], scale, 0.5f);
+            const float fl = floorf(pos[p][d]);
+            pg[d] = (uint32_t)fl;
+            pos[p][d] -= (float)pg[d];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r0[p][k] = row_of(size, res, pg[0], pg[1] + (k & 1), pg[2] + (k >> 1));
+            r1[p][k] = row_of(size, res, pg[0] + 1, pg[1] + (k & 1), pg[2] + (k >> 1));
+            const uint32_t lo = r0[p][k] < r1[p][k] ? r0[p][k] : r1[p][k];
+            adj[p][k] = (r0[p][k] ^ r1[p][k]) == 1u || r1[p][k] == r0[p][k] + 1u;
+            q[p][k] = *reinterpret_cast<const F4u*>(rows + (adj[p][k] ? lo : (r0[p][k] & ~1u)));
+        }
+    }
+    float2 e[P][4];
+#pragma unroll
+    for (int p = 0; p < P; p++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            e[p][k] = make_float2(0.f, 0.f);
+            if (!adj[p][k]) e[p][k] = rows[r1[p][k]];
+        }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        float2 f[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool first = adj[p][k] ? (r0[p][k] < r1[p][k]) : ((r0[p][k] & 1u) == 0u);
+            const float2 a = make_float2(q[p][k].v[0], q[p][k].v[1]), c = make_float2(q[p][k].v[2], q[p][k].v[3]);
+            f[2 * k] = first ? a : c;
+            f[2 * k + 1] = adj[p][k] ? (first ? c : a) : e[p][k];
+        }
+        float r[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float w = 1;
+#pragma unroll
+            for (int d = 0; d < 3; d++) w *= ((i >> d) & 1) ? pos[p][d] : 1 - pos[p][d];
+            r[0] = fmaf(w, f[i].x, r[0]);
+            r[1] = fmaf(w, f[i].y, r[1]);
+        }
+        if (b0 + 256u * p < B) outp[(size_t)p * 256 * ostride] = make_float2(r[0], r[1]);
+    }
+}
+template <int P, int GX>
+__global__ void __launch_bounds__(256) k_group_multi(const float* __restrict__ in, const float2* __restrict__ grid,
+                                                     float2* __restrict__ out, uint32_t B, Tab tab, int layout, uint32_t nchunks) {
+    constexpr uint32_t NG = 8 / GX;
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, j = bid >> 3;
+    const uint32_t group = xcd / GX, member = xcd % GX;
+    const uint32_t per = (nchunks + GX - 1) / GX;      // chunks (of P * 256 points) per member per level
+    const uint32_t li = j / per;
+    const uint32_t chunk = (j % per) * GX + member;
+    const uint32_t round = li, posn = (round & 1u) ? (NG - 1 - group) : group;
+    const int level = (int)L - 1 - (int)(round * NG + posn);
+    if (level < 0 || chunk >= nchunks) return;
+    const uint32_t b = chunk * 256 * P + threadIdx.x;
+    if (b >= B) return;
+    float2* o = out + (layout == 0 ? (size_t)level * B + b : (size_t)b * L + level);
+    point_level_multi<P>(in, grid, o, layout == 0 ? 1 : L, tab, (uint32_t)level, b, B);
+}
+
 template <int VAR, bool NT>
 __global__ void __launch_bounds__(256) k_static(const float* __restrict__ in, const float2* __restrict__ grid,
                                                 float2* __restrict__ out, uint32_t B, Tab tab, int layout, uint32_t nchunks) {
@@ -229,7 +315,7 @@ int main() {
             k_static<0, false><<<nblocks, 256>>>(in, grid, ref, B, tab, layout, nchunks);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
-            for (int var = 0; var < 8; var++) {
+            for (int var = 0; var < 10; var++) {
                 auto launch = [&]() {
                     switch (var) {
                         case 0: k_static<0, false><<<nblocks, 256>>>(in, grid, out, B, tab, layout, nchunks); break;
@@ -240,6 +326,8 @@ int main() {
                         case 5: k_group<1, false, 4><<<8 * ((nchunks + 3) / 4) * 8, 256>>>(in, grid, out, B, tab, layout, nchunks); break;
                         case 6: k_group<1, false, 8><<<8 * ((nchunks + 7) / 8) * 16, 256>>>(in, grid, out, B, tab, layout, nchunks); break;
                         case 7: k_group<0, false, 2><<<8 * ((nchunks + 1) / 2) * 4, 256>>>(in, grid, out, B, tab, layout, nchunks); break;
+                        case 8: { const uint32_t nc2 = (B + 511) / 512; k_group_multi<2, 2><<<8 * ((nc2 + 1) / 2) * 4, 256>>>(in, grid, out, B, tab, layout, nc2); } break;
+                        case 9: { const uint32_t nc3 = (B + 1023) / 1024; k_group_multi<4, 2><<<8 * ((nc3 + 1) / 2) * 4, 256>>>(in, grid, out, B, tab, layout, nc3); } break;
                     }
                 };
                 CK(hipMemset(out, 0xff, (size_t)B * L * 8));
@@ -256,7 +344,8 @@ int main() {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 ms /= reps;
                 static const char* names[] = {"static 8x8B", "static 8x8B nt", "static paired", "static paired nt",
-                                              "group2 paired", "group4 paired", "group8 paired", "group2 8x8B"};
+                                              "group2 paired", "group4 paired", "group8 paired", "group2 8x8B",
+                                              "group2 paired x2pts", "group2 paired x4pts"};
                 printf("[%s] layout %d %-22s %8.4f ms  %7.0f GB/s alg  %s\n", st.name, layout, names[var], ms,
                        B * 1164.0 / ms / 1e6, same ? "bit-exact" : "MISMATCH");
             }
